@@ -1,0 +1,274 @@
+"""
+Generates the golden fixtures in this directory by IMPORTING THE REFERENCE from
+/root/reference (through tools/refshim, which only supplies what the build container
+lacks: the removed ``np.float_`` alias, an empty ``k3d`` and a stand-in for numba's CUDA
+simulator API).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The outputs (*.npz) are plain data — inputs and the reference's outputs — and are
+committed; the reference itself never enters the repository and does not exist on the
+GPU box.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "tools", "refshim"))
+import refshim  # noqa: E402
+
+refshim.install()
+
+from octreelib.grid import Grid, GridConfig  # noqa: E402
+from octreelib.octree import Octree, OctreeConfig  # noqa: E402
+from octreelib.octree_manager import OctreeManager  # noqa: E402
+from octreelib.ransac import CudaRansac  # noqa: E402
+
+
+def _index_of(points):
+    """bytes(row) -> original index (points are distinct)."""
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    d = {pts[i].tobytes(): i for i in range(len(pts))}
+    assert len(d) == len(pts), "fixture points must be distinct"
+    return d
+
+
+def _leaf_table(leaves, index):
+    """list of reference leaf objects -> corners, edges, sizes, concatenated indices
+    (within a leaf sorted ascending: the reference's within-leaf order is an artefact of
+    an unstable argsort and is not part of the contract)."""
+    corners = np.array(
+        [np.asarray(v.corner_min, dtype=np.float64) for v in leaves], dtype=np.float64
+    ).reshape(-1, 3)
+    edges = np.array([np.float64(v.edge_length) for v in leaves], dtype=np.float64)
+    sizes, idx = [], []
+    for v in leaves:
+        p = np.ascontiguousarray(v.get_points(), dtype=np.float64)
+        ii = sorted(index[p[i].tobytes()] for i in range(len(p)))
+        sizes.append(len(ii))
+        idx.extend(ii)
+    return corners, edges, np.array(sizes, dtype=np.int64), np.array(idx, dtype=np.int64)
+
+
+def _save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def crit(k):
+    return [lambda pts: len(pts) > k]
+
+
+# --------------------------------------------------------------------------------------
+# G2a: bare Octree, edge 1, uniform points
+# --------------------------------------------------------------------------------------
+def gen_octree():
+    for n, seed in ((2000, 11), (20000, 12)):
+        pts = np.random.default_rng(seed).random((n, 3))
+        index = _index_of(pts)
+        out = {"points": pts, "corner": np.zeros(3), "edge": np.float64(1.0)}
+        for k in (8, 32, 256):
+            oc = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+            oc.insert_points(pts)
+            oc.subdivide(crit(k))
+            c, e, s, i = _leaf_table(oc.get_leaf_points(), index)
+            out[f"k{k}_corners"], out[f"k{k}_edges"] = c, e
+            out[f"k{k}_sizes"], out[f"k{k}_idx"] = s, i
+            ca, ea, _, _ = _leaf_table(oc.get_leaf_points(non_empty=False), index)
+            out[f"k{k}_all_corners"], out[f"k{k}_all_edges"] = ca, ea
+            out[f"k{k}_counts"] = np.array([oc.n_nodes, oc.n_leaves, oc.n_points])
+        _save(f"octree_uniform_{n}.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
+# G2b: Grid, L=1 with negative coordinates, boundary-adjacent points and tight clusters
+# G2c: Grid, L=5 (non power-of-two edge), two poses
+# --------------------------------------------------------------------------------------
+def _grid_points(rng, n, lo, hi):
+    pts = rng.random((n, 3)) * (hi - lo) + lo
+    # points one ulp either side of voxel faces and of octant planes
+    faces = np.array([-1.0, 0.0, 1.0, 0.5, -0.5, 0.25, 1.75])
+    extra = []
+    for f in faces:
+        for _ in range(6):
+            p = rng.random(3) * (hi - lo) + lo
+            ax = rng.integers(0, 3)
+            p[ax] = f
+            extra.append(p.copy())
+            p[ax] = np.nextafter(f, np.inf)
+            extra.append(p.copy())
+            if f != 0.0:  # -tiny + 1 rounds to 1.0: IndexError upstream
+                p[ax] = np.nextafter(f, -np.inf)
+                extra.append(p.copy())
+    # tight clusters (force deep subdivision)
+    for _ in range(6):
+        c = rng.random(3) * (hi - lo - 0.2) + lo + 0.1
+        extra.extend(c + rng.random((40, 3)) * 1e-6)
+    pts = np.vstack([pts, np.array(extra)])
+    pts = np.unique(pts, axis=0)
+    rng.shuffle(pts)
+    return pts
+
+
+def gen_grid():
+    rng = np.random.default_rng(21)
+    pts = _grid_points(rng, 30000, -2.0, 2.0)
+    index = _index_of(pts)
+    g = Grid(GridConfig(voxel_edge_length=1))
+    g.insert_points(0, pts)
+    out = {"points": pts, "L": np.float64(1)}
+    c, e, s, i = _leaf_table(g.get_leaf_points(0), index)
+    out["pre_corners"], out["pre_edges"], out["pre_sizes"], out["pre_idx"] = c, e, s, i
+    out["pre_counts"] = np.array([g.n_nodes(0), g.n_leaves(0), g.n_points(0)])
+    g.subdivide(crit(16))
+    c, e, s, i = _leaf_table(g.get_leaf_points(0), index)
+    out["k16_corners"], out["k16_edges"], out["k16_sizes"], out["k16_idx"] = c, e, s, i
+    out["k16_counts"] = np.array([g.n_nodes(0), g.n_leaves(0), g.n_points(0)])
+    _save("grid_L1_mixed.npz", **out)
+
+    rng = np.random.default_rng(22)
+    poses = [rng.random((4000, 3)) * 20.0 - 5.0, rng.random((3000, 3)) * 20.0 - 5.0]
+    g = Grid(GridConfig(voxel_edge_length=5))
+    out = {"L": np.float64(5), "n_poses": np.int64(2)}
+    for p, pts in enumerate(poses):
+        g.insert_points(p, pts)
+        out[f"points{p}"] = pts
+    g.subdivide(crit(24))
+    for p, pts in enumerate(poses):
+        index = _index_of(pts)
+        c, e, s, i = _leaf_table(g.get_leaf_points(p), index)
+        out[f"p{p}_corners"], out[f"p{p}_edges"] = c, e
+        out[f"p{p}_sizes"], out[f"p{p}_idx"] = s, i
+        out[f"p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+    # second subdivide restricted to pose 1 with a finer criterion (refinement)
+    g.subdivide(crit(6), [1])
+    for p, pts in enumerate(poses):
+        index = _index_of(pts)
+        c, e, s, i = _leaf_table(g.get_leaf_points(p), index)
+        out[f"r_p{p}_corners"], out[f"r_p{p}_edges"] = c, e
+        out[f"r_p{p}_sizes"], out[f"r_p{p}_idx"] = s, i
+        out[f"r_p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+    _save("grid_L5_two_poses.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
+# G2d: OctreeManager, 4 poses: subdivide on a pose subset, then a late-inserted pose
+# --------------------------------------------------------------------------------------
+def gen_manager():
+    rng = np.random.default_rng(31)
+    poses = [rng.random((n, 3)) * 2.0 for n in (900, 700, 1100, 500)]
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 2.0)
+    out = {"edge": np.float64(2.0), "n_poses": np.int64(4)}
+    for p in range(3):
+        m.insert_points(p, poses[p])
+    for p in range(4):
+        out[f"points{p}"] = poses[p]
+    m.subdivide(crit(40), [0, 2])
+    m.insert_points(3, poses[3])  # inherits the scheme
+    for p in range(4):
+        index = _index_of(poses[p])
+        c, e, s, i = _leaf_table(m.get_leaf_points(True, p), index)
+        out[f"p{p}_corners"], out[f"p{p}_edges"] = c, e
+        out[f"p{p}_sizes"], out[f"p{p}_idx"] = s, i
+        out[f"p{p}_counts"] = np.array([m.n_nodes(p), m.n_leaves(p), m.n_points(p)])
+    m.subdivide(crit(25))  # all four poses, finer
+    for p in range(4):
+        index = _index_of(poses[p])
+        c, e, s, i = _leaf_table(m.get_leaf_points(True, p), index)
+        out[f"r_p{p}_corners"], out[f"r_p{p}_edges"] = c, e
+        out[f"r_p{p}_sizes"], out[f"r_p{p}_idx"] = s, i
+        out[f"r_p{p}_counts"] = np.array([m.n_nodes(p), m.n_leaves(p), m.n_points(p)])
+    _save("manager_four_poses.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
+# G3: RANSAC operator, CudaRansac.evaluate on explicit inputs (reference kernel source run
+#     under the simulator stand-in)
+# --------------------------------------------------------------------------------------
+def _planar_block(rng, n, sigma, corner, edge=1.0):
+    a, b = rng.uniform(-0.4, 0.4, 2)
+    xy = rng.random((n, 2)) * edge
+    z = 0.5 * edge + a * (xy[:, 0] - 0.5 * edge) + b * (xy[:, 1] - 0.5 * edge)
+    z = z + rng.normal(0, sigma, n)
+    return np.column_stack([xy, z]) + corner
+
+
+def gen_ransac():
+    rng = np.random.default_rng(41)
+    for name, H, k, thr in (("h64", 64, 6, 0.01), ("h1024", 1024, 6, 0.01), ("h32k3", 32, 3, 0.02)):
+        blocks = [
+            _planar_block(rng, 40, 0.01, np.array([3.0, 1.0, 7.0])),
+            _planar_block(rng, 17, 0.02, np.array([0.0, 0.0, 0.0])),
+            rng.random((4, 3)) + 5.0,  # fewer than k=6 points (n < k -> all False)
+            rng.random((30, 3)) * 0.5 + np.array([10.0, 20.0, 30.0]),  # pure noise
+            np.tile(np.array([[1.5, 2.5, 3.5]]), (7, 1)),  # zero-norm plane (util.py:77-78)
+            _planar_block(rng, 64, 0.005, np.array([31.0, 31.0, 31.0])),
+        ]
+        if name == "h1024":
+            blocks = blocks[:3] + blocks[4:5]
+        cloud = np.vstack(blocks)
+        sizes = np.array([len(b) for b in blocks], dtype=np.int32)
+        np.random.seed(1000 + H)
+        table_probe = np.random.random((min(H, 1024), k))
+        np.random.seed(1000 + H)
+        r = CudaRansac(threshold=thr, hypotheses_number=H, initial_points_number=k)
+        mask = r.evaluate(cloud, sizes)
+        _save(
+            f"ransac_{name}.npz",
+            cloud=cloud,
+            block_sizes=sizes,
+            hypotheses=table_probe,
+            threshold=np.float64(thr),
+            mask=mask,
+        )
+
+
+# --------------------------------------------------------------------------------------
+# G4: Grid.map_leaf_points_cuda_ransac end to end.  Exactly planar inliers + gross
+#     outliers, so the surviving set does not depend on the within-leaf order.
+# --------------------------------------------------------------------------------------
+def gen_grid_ransac():
+    rng = np.random.default_rng(51)
+    poses = []
+    for p in range(2):
+        parts = []
+        for corner in ([0, 0, 0], [5, 0, 5], [5, 5, 0]):
+            corner = np.array(corner, dtype=float)
+            n_in, n_out = 14, 3
+            xy = rng.random((n_in, 2)) * 4.0 + 0.5
+            a, b = rng.uniform(-0.3, 0.3, 2)
+            z = 2.5 + a * (xy[:, 0] - 2.5) + b * (xy[:, 1] - 2.5)
+            inl = np.column_stack([xy, z]) + corner
+            outl = rng.random((n_out, 3)) * 0.4 + corner + np.array([0.2, 0.2, 4.4])
+            parts.append(np.vstack([inl, outl]))
+        pts = np.vstack(parts)
+        rng.shuffle(pts)
+        poses.append(pts)
+    g = Grid(GridConfig(voxel_edge_length=5))
+    out = {"L": np.float64(5), "n_poses": np.int64(2), "seed": np.int64(7)}
+    for p, pts in enumerate(poses):
+        g.insert_points(p, pts)
+        out[f"points{p}"] = pts
+    np.random.seed(7)
+    g.map_leaf_points_cuda_ransac(
+        poses_per_batch=10, threshold=0.01, hypotheses_number=256, initial_points_number=6
+    )
+    for p, pts in enumerate(poses):
+        index = _index_of(pts)
+        c, e, s, i = _leaf_table(g.get_leaf_points(p), index)
+        out[f"p{p}_corners"], out[f"p{p}_edges"] = c, e
+        out[f"p{p}_sizes"], out[f"p{p}_idx"] = s, i
+        out[f"p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+    _save("grid_ransac_e2e.npz", **out)
+
+
+if __name__ == "__main__":
+    gen_octree()
+    gen_grid()
+    gen_manager()
+    gen_ransac()
+    gen_grid_ransac()

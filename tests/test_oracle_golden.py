@@ -1,0 +1,165 @@
+"""The oracle (oracle/octree_np.py, oracle/ransac_np.py) against the golden vectors that
+were produced by the reference itself (tests/golden/make_golden.py) and against the
+hand-written known answers of the reference's own tests."""
+
+import numpy as np
+import pytest
+
+from oracle import octree_np as onp
+from oracle import ransac_np as rnp
+from tests._util import assert_same_leaves, canon_from_list, golden_canon, load_golden
+
+
+@pytest.mark.parametrize("n", [2000, 20000])
+@pytest.mark.parametrize("k", [8, 32, 256])
+def test_octree_uniform(n, k):
+    g = load_golden(f"octree_uniform_{n}.npz")
+    t = onp.OTree(np.array([0.0, 0.0, 0.0]), np.float64(1))
+    t.insert_points(g["points"])
+    t.subdivide(k)
+    assert_same_leaves(canon_from_list(onp.tree_leaf_table(t)), golden_canon(g, f"k{k}"))
+    assert [t.n_nodes, t.n_leaves, t.n_points] == list(g[f"k{k}_counts"])
+    # full cached-leaf list incl. empty leaves, order included
+    all_leaves = onp.tree_leaf_table(t, non_empty=False)
+    assert np.array_equal(np.array([c for c, _, _ in all_leaves]), g[f"k{k}_all_corners"])
+    assert np.array_equal(np.array([e for _, e, _ in all_leaves]), g[f"k{k}_all_edges"])
+
+
+def test_grid_L1_mixed():
+    g = load_golden("grid_L1_mixed.npz")
+    og = onp.OGrid(1)
+    og.insert_points(0, g["points"])
+    assert_same_leaves(canon_from_list(og.leaf_table(0)), golden_canon(g, "pre"))
+    assert [og.n_nodes(0), og.n_leaves(0), og.n_points(0)] == list(g["pre_counts"])
+    og.subdivide(16)
+    assert_same_leaves(canon_from_list(og.leaf_table(0)), golden_canon(g, "k16"))
+    assert [og.n_nodes(0), og.n_leaves(0), og.n_points(0)] == list(g["k16_counts"])
+
+
+def test_grid_L5_two_poses():
+    g = load_golden("grid_L5_two_poses.npz")
+    og = onp.OGrid(5)
+    for p in range(2):
+        og.insert_points(p, g[f"points{p}"])
+    og.subdivide(24)
+    for p in range(2):
+        assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"p{p}"))
+        assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"p{p}_counts"])
+    og.subdivide(6, [1])
+    for p in range(2):
+        assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"r_p{p}"))
+        assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"r_p{p}_counts"])
+
+
+def test_manager_four_poses():
+    g = load_golden("manager_four_poses.npz")
+    m = onp.OManager(np.array([0.0, 0.0, 0.0]), 2.0)
+    for p in range(3):
+        m.insert_points(p, g[f"points{p}"])
+    m.subdivide(40, [0, 2])
+    m.insert_points(3, g["points3"])
+    for p in range(4):
+        got = canon_from_list(onp.tree_leaf_table(m.octrees[p]))
+        assert_same_leaves(got, golden_canon(g, f"p{p}"))
+        assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == list(g[f"p{p}_counts"])
+    m.subdivide(25)
+    for p in range(4):
+        got = canon_from_list(onp.tree_leaf_table(m.octrees[p]))
+        assert_same_leaves(got, golden_canon(g, f"r_p{p}"))
+        assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == list(g[f"r_p{p}_counts"])
+
+
+@pytest.mark.parametrize("name", ["h64", "h1024", "h32k3"])
+def test_ransac_operator(name):
+    """Reference kernel source (run under the simulator stand-in) vs the restatement.
+    The reference's winner among tied hypotheses is a race: its mask must equal the mask
+    of one of the tied planes, and its popcount must equal the maximal inlier count."""
+    g = load_golden(f"ransac_{name}.npz")
+    cloud, sizes, hyp, thr = g["cloud"], g["block_sizes"], g["hypotheses"], float(g["threshold"])
+    mask, best_count, best_plane, best_index, tied = rnp.evaluate(cloud, sizes, hyp, thr, details=True)
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    k = hyp.shape[1]
+    for b in range(len(sizes)):
+        s, e = starts[b], starts[b + 1]
+        ref = g["mask"][s:e]
+        if sizes[b] < k:
+            assert not ref.any() and not mask[s:e].any()
+            continue
+        assert int(ref.sum()) == int(best_count[b])
+        blk = cloud[s:e]
+        ok = False
+        for pl in tied[b]:
+            p = pl.astype(np.float64)
+            d = np.abs(((p[0] * blk[:, 0] + p[1] * blk[:, 1]) + p[2] * blk[:, 2]) + p[3])
+            if np.array_equal(d < thr, ref):
+                ok = True
+                break
+        assert ok, f"block {b}: reference mask matches none of the tied planes"
+    # the restatement's own choice (lowest tied index) is one of the legal outcomes too
+    for b in range(len(sizes)):
+        assert int(mask[starts[b] : starts[b + 1]].sum()) == int(best_count[b])
+
+
+def test_ransac_degenerate_block_all_inliers():
+    g = load_golden("ransac_h64.npz")
+    sizes = g["block_sizes"]
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    b = 4  # seven identical points: zero-norm plane -> every point is an inlier
+    assert g["mask"][starts[b] : starts[b + 1]].all()
+
+
+def test_reference_known_answers_octree():
+    # test/octree/test_octree.py:33-62
+    pc = np.array([[0, 0, 1], [0, 0, 2], [0, 0, 3], [9, 9, 8], [9, 9, 9]], dtype=float)
+    t = onp.OTree(np.array([0, 0, 0]), np.float64(10))
+    t.insert_points(pc)
+    assert (t.get_points() == pc).all()
+    t.subdivide(2)
+    assert t.n_leaves == 3 and t.n_points == 5
+    assert len(t.cached) == 15  # test_octree.py:30
+
+
+def test_reference_known_answers_multi_pose():
+    # test/octree/test_multi_pose.py:45-68, 93-164
+    def make():
+        m = onp.OManager(np.array([0, 0, 0]), 5)
+        m.insert_points(0, np.array([[0, 0, 1], [0, 0, 2], [0, 0, 3]], dtype=float))
+        m.insert_points(1, np.array([[1, 0, 1], [4, 0, 2], [0, 2, 3]], dtype=float))
+        return m
+
+    m = make()
+    m.subdivide(2, [0])
+    assert [m.n_nodes(0), m.n_nodes(1)] == [9, 9]
+    assert [m.n_leaves(0), m.n_leaves(1)] == [2, 3]
+    leaves0 = {(tuple(v.corner), float(v.edge)) for v in m.octrees[0].leaves()}
+    assert leaves0 == {((0, 0, 0), 2.5), ((0, 0, 2.5), 2.5)}
+    m = make()
+    m.subdivide(1, None)
+    assert [m.n_nodes(0), m.n_nodes(1)] == [33, 33]
+    assert [m.n_leaves(0), m.n_leaves(1)] == [3, 3]
+    leaves0 = {(tuple(v.corner), float(v.edge)) for v in m.octrees[0].leaves()}
+    assert leaves0 == {((0, 0, 0.625), 0.625), ((0, 0, 1.25), 1.25), ((0, 0, 2.5), 1.25)}
+    leaves1 = {(tuple(v.corner), float(v.edge)) for v in m.octrees[1].leaves()}
+    assert leaves1 == {((0.625, 0, 0.625), 0.625), ((0, 1.25, 2.5), 1.25), ((2.5, 0, 0), 2.5)}
+
+
+def test_reference_known_answers_grid():
+    # test/grid/test_grid.py:14-93
+    def make():
+        g = onp.OGrid(5)
+        g.insert_points(0, np.array([[0, 0, 1], [0, 0, 2], [0, 0, 3], [9, 9, 8], [9, 9, 9]], dtype=float))
+        g.insert_points(1, np.array([[1, 0, 1], [4, 0, 2], [0, 2, 3], [5, 9, 9], [9, 3, 8]], dtype=float))
+        return g
+
+    g = make()
+    assert [g.n_leaves(0), g.n_leaves(1)] == [2, 3]
+    assert [g.n_nodes(0), g.n_nodes(1)] == [2, 3]
+    g.subdivide(2)
+    assert [g.n_leaves(0), g.n_leaves(1)] == [4, 5]
+    assert [g.n_nodes(0), g.n_nodes(1)] == [26, 27]
+    assert [g.n_points(0), g.n_points(1)] == [5, 5]
+    g = make()
+    g.subdivide(3)
+    assert [g.n_leaves(0), g.n_leaves(1)] == [3, 5]
+    with pytest.raises(ValueError, match="Cannot insert points to existing pose 0"):
+        g.insert_points(0, np.zeros((1, 3)))
