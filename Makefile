@@ -1,0 +1,28 @@
+# Builds liboctree_hip.so (gfx950 only) and the C oracle.  No cmake: plain hipcc / gcc.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+# -ffp-contract=off: the parity contract forbids fusing the reference's separate mul/add
+HIPFLAGS = -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall -Wno-unused-function -Iinclude
+SRCS = $(wildcard octreelib_amd/csrc/*.hip)
+HDRS = $(wildcard octreelib_amd/csrc/*.h) include/octreelib_hip.h
+OBJS = $(patsubst octreelib_amd/csrc/%.hip,build/%.o,$(SRCS))
+LIB  = octreelib_amd/lib/liboctree_hip.so
+
+all: $(LIB) oracle
+
+build/%.o: octreelib_amd/csrc/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p octreelib_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -ldl
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,238 @@
+/*
+ * octreelib_hip.h — C ABI of liboctree_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for octreelib's point-cloud -> octree-grid build-and-query
+ * path.  The reference (prime-slam/octreelib, /root/reference) has no FFI of its own: its
+ * boundary is the Python class surface plus ONE device operator.  Every entry point below
+ * names the reference interface it replaces (paths relative to /root/reference):
+ *
+ *   octl_forest_*            Grid / OctreeManager / Octree state
+ *                            grid/grid.py:49-56, octree_manager/octree_manager.py:21-34,
+ *                            octree/octree_base.py:143-158
+ *   octl_forest_add_pose     Grid.insert_points                grid/grid.py:58-109
+ *                            OctreeManager.insert_points       octree_manager.py:161-171
+ *                            Octree.insert_points              octree/octree.py:235-239
+ *   octl_forest_build        Grid.subdivide                    grid/grid.py:244-258
+ *                            OctreeManager.subdivide           octree_manager.py:36-66
+ *                            OctreeNode.subdivide/_as          octree/octree.py:20-53
+ *                            OctreeNode.insert_points          octree/octree.py:67-100
+ *                            OctreeNode._generate_children     octree/octree.py:177-191
+ *   octl_forest_ransac       Grid.map_leaf_points_cuda_ransac  grid/grid.py:124-215
+ *   octl_forest_apply_mask   OctreeManager/Octree.apply_mask   octree_manager.py:173-180,
+ *                                                              octree/octree.py:265-274
+ *   octl_ransac_evaluate     CudaRansac.evaluate               ransac/cuda_ransac.py:43-81
+ *                            kernel                            ransac/cuda_ransac.py:85-155
+ *                            get_plane_from_points             ransac/util.py:27-84
+ *                            measure_distance                  ransac/util.py:12-24
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative OCTL_E_* code on failure; the text of
+ *     the last failure on a context is octl_last_error(ctx).  No exception crosses the ABI.
+ *   - host buffers belong to the caller and are only touched during the call; all device
+ *     memory belongs to the context / forest.  Calls are blocking with respect to host
+ *     buffers.  A context is bound to one device and one HIP stream and is not thread safe
+ *     (one context per GPU; multi-GPU = one process per rank).
+ *   - "pose slot" = index of a pose in insertion order (0..P-1); the Python layer maps the
+ *     user's pose numbers to slots.
+ *   - coordinates are float64 row-major (n,3), exactly as the reference stores them
+ *     (internal/voxel.py:81-83).
+ */
+#ifndef OCTREELIB_HIP_H
+#define OCTREELIB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCTL_ABI_VERSION 1
+
+enum {
+  OCTL_OK = 0,
+  OCTL_E_INVALID = -1,    /* bad argument                                              */
+  OCTL_E_HIP = -2,        /* HIP runtime error (message has the hipError string)        */
+  OCTL_E_NOMEM = -3,      /* device or host allocation failed                           */
+  OCTL_E_DOMAIN = -4,     /* input outside the parity domain (point outside its cube,
+                             non-finite coordinate, voxel index out of range)            */
+  OCTL_E_DEPTH = -5,      /* max_depth exceeded (duplicate points with a count criterion
+                             recurse forever in the reference)                           */
+  OCTL_E_STATE = -6,      /* call out of order (e.g. ransac before build)               */
+  OCTL_E_COMM = -7        /* RCCL error                                                  */
+};
+
+typedef struct octl_ctx octl_ctx;
+typedef struct octl_forest octl_forest;
+
+/* ---- context ------------------------------------------------------------------------ */
+int octl_abi_version(void);
+int octl_device_count(int* count);
+int octl_ctx_create(int device_id, octl_ctx** out);
+void octl_ctx_destroy(octl_ctx* ctx);
+const char* octl_last_error(const octl_ctx* ctx);
+/* synchronise the context's stream */
+int octl_ctx_sync(octl_ctx* ctx);
+/* timing of the kernels launched by the last build / ransac call, by name; fills up to cap
+ * entries, returns the number available through *n.  Milliseconds from hipEvents on the
+ * context's stream; only recorded when profiling was enabled with octl_ctx_set_profiling */
+int octl_ctx_set_profiling(octl_ctx* ctx, int enabled);
+int octl_ctx_get_timings(octl_ctx* ctx, char* names, int name_stride, float* ms,
+                         int64_t* launches, int cap, int* n);
+
+/* ---- forest: a Grid (many top-level voxels) or one cube (Octree / OctreeManager) ------ */
+
+/* mode 0: grid of top-level voxels of edge L anchored at grid_corner (GridConfig.
+ *         voxel_edge_length / corner, grid/grid_base.py:70-71).  L must be integer valued
+ *         (the reference truncates voxel coordinates with astype(int), grid.py:72-76).
+ * mode 1: a single cube [corner, corner+edge)^3 (Octree(config, corner_min, edge_length) /
+ *         OctreeManager(..., corner_min, edge_length)).                                    */
+int octl_forest_create(octl_ctx* ctx, int mode, const double corner[3], double edge,
+                       octl_forest** out);
+void octl_forest_destroy(octl_forest* f);
+
+/* Append the cloud of a new pose slot (host pointer, copied to the device).  Returns the
+ * slot through *slot.  Replaces Grid.insert_points' storage step.                        */
+int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* slot);
+/* Same, from a device pointer (device-to-device copy; no PCIe).                           */
+int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n,
+                                int32_t* slot);
+/* Append more points to an EXISTING pose slot (only meaningful in mode 1, where the
+ * reference allows OctreeManager.insert_points twice for one pose).                       */
+int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n);
+
+typedef struct octl_build_info {
+  int64_t n_points;     /* alive points that were placed                                   */
+  int64_t n_voxels;     /* top-level voxels (roots)                                        */
+  int64_t n_nodes;      /* all scheme nodes: roots + 8 per internal node                   */
+  int64_t n_internal;   /* internal scheme nodes                                           */
+  int64_t n_blocks;     /* non-empty (leaf, pose) blocks                                   */
+  int32_t max_depth;    /* deepest leaf                                                    */
+  int32_t n_levels;     /* subdivision levels executed                                     */
+} octl_build_info;
+
+/* Build the scheme for the count criterion len(points) > K over the union of the poses
+ * whose scheme_mask[slot] != 0 (NULL = all poses), then place every alive point of every
+ * pose in its scheme leaf.  keep_scheme != 0 re-places the points in the EXISTING scheme
+ * (a pose inserted after a subdivide inherits it, octree_manager.py:161-171) and ignores
+ * K / scheme_mask.  K < 0 means "never split" (the state right after insert_points).
+ * max_depth guards the recursion the reference does not bound (<= 0: default 63).         */
+int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
+                      int32_t keep_scheme, int32_t max_depth, octl_build_info* info);
+
+/* ---- results of the last build (host copies; size-query = pass NULL outputs) ---------- */
+
+/* Scheme nodes.  For node i: voxel (root) index, depth, parent (-1 for roots), first child
+ * (-1 for leaves; children are first_child..first_child+7 in child_id order, child_id =
+ * 4*ix+2*iy+iz as octree.py:94-97), corner_min[3] and edge_length computed with the
+ * reference's arithmetic (octree.py:181-191), epoch = build call at which the node became
+ * internal (0 for leaves).  Any output pointer may be NULL.                                */
+int octl_forest_get_nodes(octl_forest* f, int64_t cap, int32_t* voxel, int32_t* depth,
+                          int32_t* parent, int32_t* first_child, double* corner,
+                          double* edge, int32_t* epoch, int64_t* n_nodes);
+/* Integer coordinates of the top-level voxels, (V,3) int64, lexicographically sorted — the
+ * order of np.unique(axis=0) at grid.py:79-81.                                            */
+int octl_forest_get_voxels(octl_forest* f, int64_t cap, int64_t* coords, int64_t* n_voxels);
+/* Non-empty (leaf, pose) blocks in storage order (voxel, leaf path, pose): scheme node id of
+ * the leaf, pose slot, start and size in the leaf-ordered arrays.                          */
+int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* slot,
+                           int64_t* start, int32_t* size, int64_t* n_blocks);
+/* Leaf-ordered point permutation: perm[i] = index of the point at storage position i in
+ * the concatenation of all pose clouds in slot order (pose-local index = perm - offset of
+ * its slot).  Within a block the order is ascending (stable).                              */
+int octl_forest_get_perm(octl_forest* f, int64_t cap, int64_t* perm, int64_t* n);
+/* Leaf-ordered coordinates (n,3) f64 for storage positions [start, start+count).           */
+int octl_forest_get_points(octl_forest* f, int64_t start, int64_t count, double* xyz);
+
+/* ---- RANSAC on the forest (device resident) ------------------------------------------- */
+
+/* Per-leaf RANSAC plane fit over the blocks listed in block_order (indices into the block
+ * table, in the order the reference would concatenate them: grid.py:173-191) — the list is
+ * one "batch"; virtual start indices are the running sum of the block sizes in that order
+ * (cuda_ransac.py:64-66) and enter the sampling arithmetic exactly as in the reference
+ * (cuda_ransac.py:103-107).  hypotheses: (H,k) f64 table (cuda_ransac.py:39-41), H <= 1024.
+ * Outputs (any may be NULL), all indexed like block_order: plane (nb,4) f32, best_count
+ * (nb) i32, best_index (nb) i32 (lowest hypothesis index attaining the maximum; the
+ * reference lets any tied hypothesis win, cuda_ransac.py:140-145).  The inlier mask stays
+ * on the device (octl_forest_get_mask / octl_forest_apply_mask).                           */
+int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
+                       const double* hypotheses, int32_t H, int32_t k, double threshold,
+                       float* plane, int32_t* best_count, int32_t* best_index);
+/* All non-empty (leaf, pose) blocks in the order in which the reference lists them: pose
+ * slot major, then top-level voxel (lexicographic), then the octree's cached-leaf list
+ * (octree_base.py:152-158, octree.py:183-191,256-263), computed on the device.  e0[slot]
+ * (nullable = 0) is the build epoch at which the pose's octrees were created: the cached
+ * list is history dependent (a pose inserted after a subdivide inherits the whole scheme at
+ * once, octree_manager.py:161-171).  order (n_blocks) i32 = indices into the block table.   */
+int octl_forest_reference_order(octl_forest* f, const int32_t* e0, int32_t n_e0, int64_t cap,
+                                int32_t* order, int64_t* n_blocks);
+/* RANSAC over ALL blocks in that order, one reference "batch" per poses_per_batch consecutive
+ * slots (grid.py:126,149-157,194); order, virtual starts and the kernel all stay on the device,
+ * nothing but the (H,k) table crosses PCIe.  The async launches are NOT synchronised: follow
+ * with octl_ctx_sync / get_mask / apply_mask.                                               */
+int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, const int32_t* e0,
+                           int32_t n_e0, const double* hypotheses, int32_t H, int32_t k,
+                           double threshold);
+/* Inlier mask of the last ransac call(s), uint8 per storage position.                      */
+int octl_forest_get_mask(octl_forest* f, int64_t cap, uint8_t* mask, int64_t* n);
+/* Drop the points whose mask byte is 0 from the blocks that were evaluated (apply_mask,
+ * octree.py:137-142): compacts the leaf-ordered arrays, updates the block table and marks
+ * the points dead for later builds.  Returns the surviving point count.                    */
+int octl_forest_apply_mask(octl_forest* f, int64_t* n_alive);
+/* Drop points by an explicit host mask over storage positions (filter / map_leaf_points
+ * paths of the Python layer).                                                              */
+int octl_forest_apply_host_mask(octl_forest* f, const uint8_t* mask, int64_t n,
+                                int64_t* n_alive);
+
+/* ---- the reference's operator, stand-alone ------------------------------------------- */
+
+/* CudaRansac(threshold, H, k).evaluate(point_cloud, block_sizes) -> mask
+ * (ransac/cuda_ransac.py:43-81).  point_cloud (M,3) f64 leaf-major, block_sizes (B) i32,
+ * hypotheses (H,k) f64.  mask_out (M) uint8.  Extensions (nullable): planes_out (B,4) f32,
+ * best_count_out (B) i32, best_index_out (B) i32.                                          */
+int octl_ransac_evaluate(octl_ctx* ctx, const double* point_cloud, int64_t M,
+                         const int32_t* block_sizes, int64_t B, const double* hypotheses,
+                         int32_t H, int32_t k, double threshold, uint8_t* mask_out,
+                         float* planes_out, int32_t* best_count_out, int32_t* best_index_out);
+
+/* ---- multi-GPU: shard the grid by top-level voxel, route points to their owner --------- */
+
+/* Owner rank of a top-level voxel (pure function, also used by the CPU tests).             */
+int32_t octl_voxel_owner(int64_t qx, int64_t qy, int64_t qz, int32_t n_ranks);
+#define OCTL_UNIQUE_ID_BYTES 128
+/* rank 0 creates the RCCL unique id; the caller distributes the bytes to all ranks.        */
+int octl_comm_unique_id(uint8_t id[OCTL_UNIQUE_ID_BYTES]);
+int octl_comm_init(octl_ctx* ctx, int32_t n_ranks, int32_t rank,
+                   const uint8_t id[OCTL_UNIQUE_ID_BYTES]);
+int octl_comm_destroy(octl_ctx* ctx);
+/* Route a device-resident cloud (n,3) f64 with global indices gidx (n) i64 (may be NULL:
+ * then index_base + i) to the ranks that own the points' top-level voxels (edge L, grid
+ * corner c): key + count per destination, 8x8 count exchange, one grouped ncclSend/ncclRecv
+ * all-to-all over xGMI.  The received cloud stays on the device inside ctx; its size is
+ * returned through *n_recv and it is handed to a forest with octl_forest_add_pose_routed.   */
+int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_dev,
+                      int64_t n, int64_t index_base, const double corner[3], double L,
+                      int64_t* n_recv, int64_t* send_counts /* [n_ranks], nullable */);
+int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot);
+/* global indices of the routed cloud of the last octl_route_points call (n_recv) i64        */
+int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n);
+/* sum-all-reduce of small int64 vectors (counters) over the communicator                   */
+int octl_comm_allreduce_i64(octl_ctx* ctx, int64_t* inout_host, int32_t n);
+
+/* ---- small device utilities used by bench.py (inputs resident in HBM) ------------------ */
+int octl_dev_alloc(octl_ctx* ctx, int64_t bytes, void** dptr);
+int octl_dev_free(octl_ctx* ctx, void* dptr);
+int octl_dev_upload(octl_ctx* ctx, void* dptr, const void* src, int64_t bytes);
+int octl_dev_download(octl_ctx* ctx, void* dst, const void* dptr, int64_t bytes);
+/* measured device copy bandwidth (bytes/s) over `bytes`, for the roofline report           */
+int octl_dev_copy_bandwidth(octl_ctx* ctx, int64_t bytes, int iters, double* bytes_per_s);
+
+/* ---- test hooks for the device-wide primitives (host in / host out) ----------------------- */
+int octl_debug_exclusive_scan(octl_ctx* ctx, const uint32_t* in, int64_t n, uint32_t* out,
+                              uint32_t* total);
+int octl_debug_radix_sort(octl_ctx* ctx, uint64_t* keys, uint32_t* vals, int64_t n,
+                          int key_bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCTREELIB_HIP_H */

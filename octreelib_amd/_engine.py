@@ -1,0 +1,367 @@
+"""
+Host-side view of one device-resident forest (include/octreelib_hip.h `octl_forest`): the flat
+tables behind Grid / OctreeManager / Octree.  Everything heavy (bucketing, subdivision, leaf
+ordering, RANSAC, compaction) happens in HIP kernels; this module only keeps NumPy mirrors of
+the small result tables and turns them into the reference's API objects lazily.
+"""
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from octreelib_amd import _native as nat
+
+
+class Forest:
+    """mode 0 = Grid (top-level voxels of edge `edge`), mode 1 = one cube (Octree / Manager)."""
+
+    def __init__(self, mode: int, corner, edge, ctx: Optional[nat.Context] = None):
+        self.ctx = ctx if ctx is not None else nat.get_context()
+        self.lib = self.ctx.lib
+        self.mode = mode
+        corner = np.ascontiguousarray(np.asarray(corner, dtype=np.float64).reshape(3))
+        h = C.c_void_p()
+        self.ctx.check(
+            self.lib.octl_forest_create(self.ctx.handle, mode, nat.ptr(corner), float(edge), C.byref(h))
+        )
+        self.handle = h
+        self.n_slots = 0
+        self.slot_sizes: List[int] = []      # points ever inserted per slot
+        self.slot_epoch: List[int] = []      # build epoch at which the slot's octrees were created
+        self.epoch = 0                       # number of subdivide() calls so far
+        self.has_scheme = False              # a K-driven scheme exists
+        self._dirty = True                   # points were added since the last build
+        self.info = None
+        self.n_ord = 0
+        self._invalidate()
+        # grid bookkeeping that must survive rebuilds: voxels each pose was inserted into and
+        # the order in which voxels were first created (Grid.__octrees dict order, grid.py:56)
+        self.slot_voxel_keys: List[Optional[np.ndarray]] = []
+        self.voxel_creation: Dict[tuple, int] = {}
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.octl_forest_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _invalidate(self):
+        self._nodes = None
+        self._voxels = None
+        self._blocks = None
+        self._order = None
+        self._xyz = None
+        self._perm = None
+        self._slot_blocks = None
+
+    # -- points -----------------------------------------------------------------------------
+    def add_pose(self, points) -> int:
+        pts = nat.as_points(points)
+        slot = C.c_int32(-1)
+        self.ctx.check(self.lib.octl_forest_add_pose(self.handle, nat.ptr(pts), len(pts), C.byref(slot)))
+        self._register_slot(len(pts))
+        return slot.value
+
+    def add_pose_device(self, dptr, n: int) -> int:
+        slot = C.c_int32(-1)
+        self.ctx.check(self.lib.octl_forest_add_pose_device(self.handle, dptr, int(n), C.byref(slot)))
+        self._register_slot(int(n))
+        return slot.value
+
+    def add_pose_routed(self, n: int) -> int:
+        slot = C.c_int32(-1)
+        self.ctx.check(self.lib.octl_forest_add_pose_routed(self.handle, C.byref(slot)))
+        self._register_slot(int(n))
+        return slot.value
+
+    def _register_slot(self, n: int):
+        self.n_slots += 1
+        self.slot_sizes.append(n)
+        self.slot_epoch.append(self.epoch)
+        self.slot_voxel_keys.append(None)
+        self._dirty = True
+        self._invalidate()
+
+    def extend_pose(self, slot: int, points):
+        pts = nat.as_points(points)
+        self.ctx.check(self.lib.octl_forest_extend_pose(self.handle, slot, nat.ptr(pts), len(pts)))
+        self.slot_sizes[slot] += len(pts)
+        self._dirty = True
+        self._invalidate()
+
+    # -- build ------------------------------------------------------------------------------
+    def build(self, K: int, scheme_slots=None, keep_scheme=False, max_depth=0):
+        mask = None
+        if scheme_slots is not None and not keep_scheme:
+            mask = np.zeros(self.n_slots, dtype=np.uint8)
+            mask[list(scheme_slots)] = 1
+        info = nat.BuildInfo()
+        self.ctx.check(
+            self.lib.octl_forest_build(
+                self.handle, int(K), nat.ptr(mask), self.n_slots if mask is not None else 0,
+                1 if keep_scheme else 0, int(max_depth), C.byref(info),
+            )
+        )
+        self.info = info
+        self.n_ord = int(info.n_points)
+        self._dirty = False
+        self._invalidate()
+        if not keep_scheme:
+            self.epoch += 1
+            self.has_scheme = True
+        self._update_membership()
+
+    def subdivide(self, K: int, scheme_slots=None, max_depth=0):
+        self.build(K, scheme_slots, False, max_depth)
+
+    def ensure_built(self):
+        """Bring the device structure up to date after insertions: a new pose inherits the
+        current scheme (octree_manager.py:161-171); before any subdivide the scheme is just
+        the top-level voxels."""
+        if not self._dirty and self.info is not None:
+            return
+        if self.has_scheme:
+            self.build(0, None, keep_scheme=True)
+        else:
+            # K < 0: never split.  Not a subdivide call: the epoch does not advance.
+            info = nat.BuildInfo()
+            self.ctx.check(self.lib.octl_forest_build(self.handle, -1, None, 0, 0, 0, C.byref(info)))
+            self.info = info
+            self.n_ord = int(info.n_points)
+            self._dirty = False
+            self._invalidate()
+            self.epoch += 1  # mirrors the library's counter of non-keep builds
+            self._update_membership()
+
+    def _update_membership(self):
+        """Record, for slots seen for the first time, the voxels they were inserted into
+        (Grid.__pose_voxel_coordinates, grid.py:53,108) and the voxel creation order."""
+        if all(k is not None for k in self.slot_voxel_keys):
+            return
+        vox = self.voxels
+        blk = self.blocks
+        node_vox = self.nodes["voxel"]
+        for s in range(self.n_slots):
+            if self.slot_voxel_keys[s] is not None:
+                continue
+            sel = blk["slot"] == s
+            vids = np.unique(node_vox[blk["node"][sel]])
+            keys = vox[vids]
+            self.slot_voxel_keys[s] = keys
+            for k in map(tuple, keys.tolist()):
+                if k not in self.voxel_creation:
+                    self.voxel_creation[k] = len(self.voxel_creation)
+
+    # -- tables -----------------------------------------------------------------------------
+    @property
+    def nodes(self):
+        if self._nodes is None:
+            self.ensure_built()
+            n = C.c_int64(0)
+            self.ctx.check(
+                self.lib.octl_forest_get_nodes(self.handle, 0, None, None, None, None, None, None, None, C.byref(n))
+            )
+            n = n.value
+            t = {
+                "voxel": np.empty(n, dtype=np.int32),
+                "depth": np.empty(n, dtype=np.int32),
+                "parent": np.empty(n, dtype=np.int32),
+                "first_child": np.empty(n, dtype=np.int32),
+                "corner": np.empty((n, 3), dtype=np.float64),
+                "edge": np.empty(n, dtype=np.float64),
+                "epoch": np.empty(n, dtype=np.int32),
+            }
+            m = C.c_int64(0)
+            self.ctx.check(
+                self.lib.octl_forest_get_nodes(
+                    self.handle, n, nat.ptr(t["voxel"]), nat.ptr(t["depth"]), nat.ptr(t["parent"]),
+                    nat.ptr(t["first_child"]), nat.ptr(t["corner"]), nat.ptr(t["edge"]),
+                    nat.ptr(t["epoch"]), C.byref(m),
+                )
+            )
+            self._nodes = t
+        return self._nodes
+
+    @property
+    def voxels(self) -> np.ndarray:
+        """(V,3) int64 voxel coordinates (= corners), lexicographic order."""
+        if self._voxels is None:
+            self.ensure_built()
+            n = C.c_int64(0)
+            self.ctx.check(self.lib.octl_forest_get_voxels(self.handle, 0, None, C.byref(n)))
+            v = np.empty((n.value, 3), dtype=np.int64)
+            self.ctx.check(self.lib.octl_forest_get_voxels(self.handle, n.value, nat.ptr(v), C.byref(n)))
+            self._voxels = v
+        return self._voxels
+
+    @property
+    def blocks(self):
+        if self._blocks is None:
+            self.ensure_built()
+            n = C.c_int64(0)
+            self.ctx.check(self.lib.octl_forest_get_blocks(self.handle, 0, None, None, None, None, C.byref(n)))
+            n = n.value
+            b = {
+                "node": np.empty(n, dtype=np.int32),
+                "slot": np.empty(n, dtype=np.int32),
+                "start": np.empty(n, dtype=np.int64),
+                "size": np.empty(n, dtype=np.int32),
+            }
+            m = C.c_int64(0)
+            self.ctx.check(
+                self.lib.octl_forest_get_blocks(
+                    self.handle, n, nat.ptr(b["node"]), nat.ptr(b["slot"]), nat.ptr(b["start"]),
+                    nat.ptr(b["size"]), C.byref(m),
+                )
+            )
+            self._blocks = b
+        return self._blocks
+
+    @property
+    def order(self) -> np.ndarray:
+        """All non-empty (leaf, pose) blocks in the reference's listing order (slot major,
+        voxel lexicographic, cached-leaf order) - computed on the device."""
+        if self._order is None:
+            self.ensure_built()
+            nb = len(self.blocks["node"])
+            e0 = np.ascontiguousarray(np.asarray(self.slot_epoch, dtype=np.int32))
+            out = np.empty(nb, dtype=np.int32)
+            n = C.c_int64(0)
+            self.ctx.check(
+                self.lib.octl_forest_reference_order(
+                    self.handle, nat.ptr(e0) if self.n_slots else None, self.n_slots, nb,
+                    nat.ptr(out), C.byref(n),
+                )
+            )
+            self._order = out
+        return self._order
+
+    def slot_blocks(self, slot: int) -> np.ndarray:
+        """Block ids of a slot in the reference's order (= its non-empty leaves)."""
+        if self._slot_blocks is None:
+            order = self.order
+            slots = self.blocks["slot"][order]
+            # order is slot-major: split at the slot boundaries
+            bounds = np.searchsorted(slots, np.arange(self.n_slots + 1))
+            self._slot_blocks = [order[bounds[s] : bounds[s + 1]] for s in range(self.n_slots)]
+        return self._slot_blocks[slot]
+
+    @property
+    def xyz(self) -> np.ndarray:
+        """Leaf-ordered coordinates (n,3) f64 (host copy, fetched on first use)."""
+        if self._xyz is None:
+            self.ensure_built()
+            n = self.n_ord
+            a = np.empty((n, 3), dtype=np.float64)
+            if n:
+                self.ctx.check(self.lib.octl_forest_get_points(self.handle, 0, n, nat.ptr(a)))
+            self._xyz = a
+        return self._xyz
+
+    @property
+    def perm(self) -> np.ndarray:
+        """perm[i] = index (in the concatenation of all pose clouds, slot order) of the point at
+        storage position i."""
+        if self._perm is None:
+            self.ensure_built()
+            n = C.c_int64(0)
+            self.ctx.check(self.lib.octl_forest_get_perm(self.handle, 0, None, C.byref(n)))
+            p = np.empty(n.value, dtype=np.int64)
+            self.ctx.check(self.lib.octl_forest_get_perm(self.handle, n.value, nat.ptr(p), C.byref(n)))
+            self._perm = p
+        return self._perm
+
+    # -- counters (reference: octree.py:144-175, octree_manager.py:132-159, grid.py:343-362) ---
+    def n_points(self, slot: int) -> int:
+        b = self.blocks
+        return int(b["size"][b["slot"] == slot].sum())
+
+    def n_leaves(self, slot: int) -> int:
+        return int((self.blocks["slot"] == slot).sum())
+
+    def internal_per_voxel(self) -> np.ndarray:
+        nd = self.nodes
+        internal = nd["first_child"] >= 0
+        return np.bincount(nd["voxel"][internal], minlength=len(self.voxels))
+
+    def slot_voxel_ranks(self, slot: int) -> np.ndarray:
+        """Current voxel ranks of the voxels the slot was inserted into (lexicographic)."""
+        self.ensure_built()
+        keys = self.slot_voxel_keys[slot]
+        if keys is None or len(keys) == 0:
+            return np.empty(0, dtype=np.int64)
+        return _rank_rows(self.voxels, keys)
+
+    def n_nodes(self, slot: int) -> int:
+        ranks = self.slot_voxel_ranks(slot)
+        if len(ranks) == 0:
+            return 0
+        return int((1 + 8 * self.internal_per_voxel()[ranks]).sum())
+
+    # -- masks ------------------------------------------------------------------------------
+    def apply_host_mask(self, mask: np.ndarray):
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.octl_forest_apply_host_mask(self.handle, nat.ptr(mask), len(mask), C.byref(n)))
+        self.n_ord = n.value
+        self._invalidate()
+
+    def apply_device_mask(self):
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.octl_forest_apply_mask(self.handle, C.byref(n)))
+        self.n_ord = n.value
+        self._invalidate()
+
+    def device_mask(self) -> np.ndarray:
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.octl_forest_get_mask(self.handle, 0, None, C.byref(n)))
+        m = np.empty(n.value, dtype=np.uint8)
+        self.ctx.check(self.lib.octl_forest_get_mask(self.handle, n.value, nat.ptr(m), C.byref(n)))
+        return m
+
+    # -- RANSAC -----------------------------------------------------------------------------
+    def ransac_all(self, poses_per_batch: int, hypotheses: np.ndarray, threshold: float):
+        self.ensure_built()
+        hyp = np.ascontiguousarray(hypotheses, dtype=np.float64)
+        e0 = np.ascontiguousarray(np.asarray(self.slot_epoch, dtype=np.int32))
+        self.ctx.check(
+            self.lib.octl_forest_ransac_all(
+                self.handle, int(poses_per_batch), nat.ptr(e0), self.n_slots, nat.ptr(hyp),
+                hyp.shape[0], hyp.shape[1], float(threshold),
+            )
+        )
+
+    def ransac_blocks(self, block_order: np.ndarray, hypotheses: np.ndarray, threshold: float,
+                      details=False):
+        self.ensure_built()
+        order = np.ascontiguousarray(block_order, dtype=np.int32)
+        hyp = np.ascontiguousarray(hypotheses, dtype=np.float64)
+        nb = len(order)
+        plane = np.empty((nb, 4), dtype=np.float32) if details else None
+        count = np.empty(nb, dtype=np.int32) if details else None
+        index = np.empty(nb, dtype=np.int32) if details else None
+        self.ctx.check(
+            self.lib.octl_forest_ransac(
+                self.handle, nat.ptr(order), nb, nat.ptr(hyp), hyp.shape[0], hyp.shape[1],
+                float(threshold), nat.ptr(plane), nat.ptr(count), nat.ptr(index),
+            )
+        )
+        return plane, count, index
+
+
+def _rank_rows(table: np.ndarray, rows: np.ndarray) -> np.ndarray:
+    """Index in the lexicographically sorted (V,3) int64 `table` of every row of `rows`."""
+    if len(rows) == 0:
+        return np.empty(0, dtype=np.int64)
+    dt = np.dtype([("x", np.int64), ("y", np.int64), ("z", np.int64)])
+    t = np.ascontiguousarray(table).view(dt).reshape(-1)
+    r = np.ascontiguousarray(rows).view(dt).reshape(-1)
+    idx = np.searchsorted(t, r)
+    return idx.astype(np.int64)

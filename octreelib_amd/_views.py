@@ -1,0 +1,189 @@
+"""
+Lazy API objects over the flat device tables: leaf views (what get_leaf_points returns) and the
+host-side helpers shared by Octree / OctreeManager / Grid for the callable-driven operations
+(filter, map_leaf_points, apply_mask), which the reference defines on arbitrary Python
+callables (octree/octree.py:102-142) and which therefore run on the host over device-produced
+leaf arrays.
+"""
+
+from typing import Callable, Iterable, List, Sequence
+
+import numpy as np
+
+from octreelib_amd.internal.voxel import Voxel
+
+
+class LeafView(Voxel):
+    """One octree leaf: same duck type as the reference's cached OctreeNode / Voxel
+    (corner_min, edge_length, id, n_points, get_points(), corner_max, all_corners).
+    A snapshot: it keeps the coordinates array of the build it was created from."""
+
+    __slots__ = ("_xyz", "_start", "_size", "node")
+
+    def __init__(self, corner_min, edge_length, xyz, start, size, node):
+        self._corner_min = corner_min
+        self._edge_length = edge_length
+        self._lazy_id = None
+        self._points = None
+        self._xyz = xyz
+        self._start = int(start)
+        self._size = int(size)
+        self.node = int(node)
+
+    def get_points(self):
+        if self._size == 0:
+            return np.empty((0, 3), dtype=float)
+        return self._xyz[self._start : self._start + self._size].copy()
+
+    @property
+    def n_points(self):
+        return self._size
+
+    def __repr__(self):
+        return f"LeafView(corner_min={self._corner_min!r}, edge_length={self._edge_length!r}, n_points={self._size})"
+
+
+def _node_corner(forest, node):
+    nd = forest.nodes
+    c = nd["corner"][node]
+    if nd["depth"][node] == 0 and forest.mode == 0:
+        # Grid managers are created with np.array(voxel_coordinates): an int64 corner
+        # (grid/grid.py:100-106); children get float corners (octree.py:186)
+        return forest.voxels[nd["voxel"][node]].copy()
+    return c.copy()
+
+
+def leaf_views(forest, slot: int, non_empty: bool = True) -> List[LeafView]:
+    """Leaves of one pose in the reference's order (voxel lexicographic, cached-leaf order)."""
+    nd = forest.nodes
+    blk = forest.blocks
+    if non_empty:
+        ids = forest.slot_blocks(slot)
+        if len(ids) == 0:
+            return []
+        xyz = forest.xyz
+        return [
+            LeafView(_node_corner(forest, n), nd["edge"][n], xyz, s, z, n)
+            for n, s, z in zip(blk["node"][ids].tolist(), blk["start"][ids].tolist(), blk["size"][ids].tolist())
+        ]
+    # all leaves, empty ones included: host-side ordering from the node table
+    order = all_leaves_order(forest, slot)
+    xyz = forest.xyz
+    ids = forest.slot_blocks(slot)
+    by_node = {int(n): (int(s), int(z)) for n, s, z in zip(blk["node"][ids], blk["start"][ids], blk["size"][ids])}
+    out = []
+    for n in order.tolist():
+        s, z = by_node.get(n, (0, 0))
+        out.append(LeafView(_node_corner(forest, n), nd["edge"][n], xyz, s, z, n))
+    return out
+
+
+def preorder_rank(nd) -> np.ndarray:
+    """DFS-preorder rank of every internal node among the internal nodes of its voxel
+    (level-synchronous, vectorised): the order in which the reference splits nodes inside one
+    subdivide / subdivide_as call (octree.py:20-53)."""
+    n = len(nd["depth"])
+    fc = nd["first_child"]
+    depth = nd["depth"]
+    internal = fc >= 0
+    nint = np.zeros(n, dtype=np.int64)
+    max_d = int(depth.max()) if n else 0
+    for d in range(max_d, -1, -1):
+        ids = np.nonzero(internal & (depth == d))[0]
+        if len(ids) == 0:
+            continue
+        kids = fc[ids][:, None] + np.arange(8)[None, :]
+        nint[ids] = 1 + nint[kids].sum(axis=1)
+    rank = np.zeros(n, dtype=np.int64)
+    for d in range(0, max_d + 1):
+        ids = np.nonzero(internal & (depth == d))[0]
+        if len(ids) == 0:
+            continue
+        kids = fc[ids][:, None] + np.arange(8)[None, :]
+        sub = nint[kids]
+        offs = np.cumsum(sub, axis=1) - sub
+        rank[kids] = rank[ids][:, None] + 1 + offs
+    return rank
+
+
+def all_leaves_order(forest, slot: int) -> np.ndarray:
+    """Node ids of ALL leaves (empty ones too) of the voxels a pose lives in, in the order of
+    the reference's cached-leaf list (octree_base.py:152-158, octree.py:183-191)."""
+    nd = forest.nodes
+    ranks = forest.slot_voxel_ranks(slot) if forest.mode == 0 else np.array([0])
+    leaves = np.nonzero(nd["first_child"] < 0)[0]
+    leaves = leaves[np.isin(nd["voxel"][leaves], ranks)]
+    if len(leaves) == 0:
+        return leaves
+    prank = preorder_rank(nd)
+    par = nd["parent"][leaves]
+    has_par = par >= 0
+    p = np.where(has_par, par, 0)
+    e0 = forest.slot_epoch[slot]
+    eff = np.where(has_par, np.maximum(nd["epoch"][p], e0), 0)
+    pr = np.where(has_par, prank[p], 0)
+    digit = np.where(has_par, leaves - nd["first_child"][p], 0)
+    key = np.lexsort((digit, pr, eff, nd["voxel"][leaves]))
+    return leaves[key]
+
+
+def positions_of_slot(forest, slot: int):
+    """(starts, sizes) of the slot's non-empty leaves in cached-leaf order."""
+    blk = forest.blocks
+    ids = forest.slot_blocks(slot)
+    return blk["start"][ids], blk["size"][ids]
+
+
+def apply_mask_slot(forest, slot: int, mask):
+    """Octree.apply_mask (octree.py:265-274): the mask runs over the pose's non-empty leaves in
+    cached-leaf order."""
+    mask = np.asarray(mask).astype(bool).reshape(-1)
+    starts, sizes = positions_of_slot(forest, slot)
+    keep = np.ones(forest.n_ord, dtype=np.uint8)
+    off = 0
+    for s, z in zip(starts.tolist(), sizes.tolist()):
+        keep[s : s + z] = mask[off : off + z]
+        off += z
+    forest.apply_host_mask(keep)
+
+
+def filter_slots(forest, slots: Iterable[int], criteria: Sequence[Callable]):
+    """OctreeNode.filter (octree.py:102-112): a leaf whose points fail any criterion is emptied."""
+    xyz = forest.xyz
+    keep = np.ones(forest.n_ord, dtype=np.uint8)
+    changed = False
+    for slot in slots:
+        starts, sizes = positions_of_slot(forest, slot)
+        for s, z in zip(starts.tolist(), sizes.tolist()):
+            pts = xyz[s : s + z]
+            if not all([c(pts) for c in criteria]):
+                keep[s : s + z] = 0
+                changed = True
+    if changed:
+        forest.apply_host_mask(keep)
+
+
+def map_slots(forest, slots: Iterable[int], function: Callable):
+    """OctreeNode.map_leaf_points (octree.py:114-123).  The reference stores whatever the
+    function returns as the leaf's new cloud; here the result must be a selection of the
+    leaf's own points (the RANSAC-like use), which becomes a device compaction."""
+    xyz = forest.xyz
+    keep = np.ones(forest.n_ord, dtype=np.uint8)
+    for slot in slots:
+        starts, sizes = positions_of_slot(forest, slot)
+        for s, z in zip(starts.tolist(), sizes.tolist()):
+            pts = xyz[s : s + z]
+            res = np.asarray(function(pts.copy()), dtype=float).reshape(-1, 3)
+            sel = np.zeros(z, dtype=np.uint8)
+            used = np.zeros(z, dtype=bool)
+            for row in res:
+                hit = np.nonzero((pts == row).all(axis=1) & ~used)[0]
+                if len(hit) == 0:
+                    raise NotImplementedError(
+                        "map_leaf_points: the function returned a point that is not one of the "
+                        "leaf's points; only selections of the leaf's own points are supported"
+                    )
+                used[hit[0]] = True
+                sel[hit[0]] = 1
+            keep[s : s + z] = sel
+    forest.apply_host_mask(keep)

@@ -1,0 +1,123 @@
+"""
+Subdivision criteria.
+
+The reference takes arbitrary Python callables ``points -> bool`` (octree/octree.py:26); a
+callable cannot run inside a HIP kernel.  The device path understands the one criterion the
+library is used with - the point count, ``len(points) > K`` - given either as ``MaxPoints(K)``
+or as a plain lambda/def of exactly that shape, which is recognised from its bytecode and
+double-checked by probing.  Anything else is refused loudly (no silent CPU fallback).
+"""
+
+import dis
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+__all__ = ["MaxPoints", "count_threshold", "UnsupportedCriterion"]
+
+
+class UnsupportedCriterion(NotImplementedError):
+    pass
+
+
+class MaxPoints:
+    """Subdivide a node while it holds more than `k` points: ``len(points) > k``."""
+
+    def __init__(self, k: int):
+        self.k = int(k)
+
+    def __call__(self, points) -> bool:
+        return len(points) > self.k
+
+    def __repr__(self):
+        return f"MaxPoints({self.k})"
+
+
+def _resolve(fn, ins):
+    """Value loaded by a LOAD_CONST / LOAD_DEREF / LOAD_GLOBAL / LOAD_FAST-less instruction."""
+    if ins.opname == "LOAD_CONST":
+        return ins.argval
+    if ins.opname in ("LOAD_DEREF", "LOAD_CLOSURE"):
+        names = fn.__code__.co_cellvars + fn.__code__.co_freevars
+        idx = names.index(ins.argval) - len(fn.__code__.co_cellvars)
+        return fn.__closure__[idx].cell_contents
+    if ins.opname in ("LOAD_GLOBAL", "LOAD_NAME"):
+        return fn.__globals__[ins.argval]
+    raise KeyError(ins.opname)
+
+
+def _match_len_compare(fn) -> Optional[int]:
+    """K if `fn` is `lambda p: len(p) > c` / `len(p) >= c` / `c < len(p)` / `c <= len(p)`."""
+    code = getattr(fn, "__code__", None)
+    if code is None or code.co_argcount != 1:
+        return None
+    skip = {"RESUME", "PRECALL", "PUSH_NULL", "CACHE", "COPY_FREE_VARS", "NOP"}
+    ins = [i for i in dis.get_instructions(fn) if i.opname not in skip]
+    arg = code.co_varnames[0]
+
+    def is_len_call(seq):
+        return (
+            len(seq) == 3
+            and seq[0].opname == "LOAD_GLOBAL"
+            and seq[0].argval == "len"
+            and seq[1].opname == "LOAD_FAST"
+            and seq[1].argval == arg
+            and seq[2].opname in ("CALL_FUNCTION", "CALL")
+        )
+
+    if len(ins) != 6 or ins[-1].opname != "RETURN_VALUE" or ins[-2].opname != "COMPARE_OP":
+        return None
+    op = ins[-2].argval
+    try:
+        if is_len_call(ins[0:3]):
+            c = _resolve(fn, ins[3])
+            if op == ">":
+                return int(c) if float(c) == int(c) else int(np.floor(c))
+            if op == ">=":
+                return int(np.ceil(c)) - 1
+        elif is_len_call(ins[1:4]):
+            c = _resolve(fn, ins[0])
+            if op == "<":
+                return int(c) if float(c) == int(c) else int(np.floor(c))
+            if op == "<=":
+                return int(np.ceil(c)) - 1
+    except Exception:
+        return None
+    return None
+
+
+def _probe(fn, k: int) -> bool:
+    """fn must behave like len(points) > k around k."""
+    try:
+        for n in {0, max(k, 0), max(k, 0) + 1, max(k, 0) + 2}:
+            if bool(fn(np.zeros((n, 3)))) != (n > k):
+                return False
+    except Exception:
+        return False
+    return True
+
+
+def count_threshold(criteria: Sequence[Callable]) -> int:
+    """K such that any(criterion(points)) == len(points) > K, or raise UnsupportedCriterion.
+    An empty list never subdivides (any([]) is False): K = -1 means 'never'."""
+    if criteria is None:
+        raise TypeError("subdivision_criteria must be a list of callables")
+    ks = []
+    for c in criteria:
+        if isinstance(c, MaxPoints):
+            ks.append(c.k)
+            continue
+        k = _match_len_compare(c)
+        if k is None or not _probe(c, k):
+            raise UnsupportedCriterion(
+                "only point-count criteria (octreelib_amd.MaxPoints(K) or `lambda points: "
+                "len(points) > K`) run on the device; arbitrary Python callables cannot be "
+                "evaluated inside a HIP kernel and there is no CPU fallback"
+            )
+        ks.append(k)
+    if not ks:
+        return -1
+    if min(ks) < 0:
+        # len(points) > K with K < 0 is true for empty nodes: the reference recurses forever
+        raise RecursionError("the criterion is true for empty nodes: subdivision never terminates")
+    return min(ks)  # any(): the smallest threshold decides

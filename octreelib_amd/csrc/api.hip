@@ -1,0 +1,525 @@
+// extern "C" surface of the forest (Grid / OctreeManager / Octree state) and of the stand-alone
+// RANSAC operator.  See include/octreelib_hip.h for the reference interfaces each entry point
+// replaces.
+#include "forest.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_fill_u8(uint8_t* p, int64_t n, uint8_t v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_mask_to_flags(const uint8_t* __restrict__ mask, int64_t n,
+                                                       uint32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = mask[i] ? 1u : 0u;
+}
+
+// stream compaction of the leaf-ordered arrays by the mask; dropped points die in the store
+__global__ __launch_bounds__(256) void k_compact_ord(
+    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ scanned, int64_t n,
+    const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
+    const int32_t* __restrict__ pos_node, uint32_t* __restrict__ ord_idx2,
+    double* __restrict__ xyz_ord2, int32_t* __restrict__ pos_node2, uint8_t* __restrict__ alive) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t v = ord_idx[i];
+  if (mask[i]) {
+    const uint32_t d = scanned[i];
+    ord_idx2[d] = v;
+    xyz_ord2[3 * (int64_t)d] = xyz_ord[3 * i];
+    xyz_ord2[3 * (int64_t)d + 1] = xyz_ord[3 * i + 1];
+    xyz_ord2[3 * (int64_t)d + 2] = xyz_ord[3 * i + 2];
+    pos_node2[d] = pos_node[i];
+  } else {
+    alive[v] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_widen_u32_i64(const uint32_t* __restrict__ in, int64_t n,
+                                                       int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int64_t)in[i];
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
+
+int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device) {
+  octl_ctx* ctx = f->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n < 0 || (n > 0 && !xyz)) return octl_set_error(ctx, OCTL_E_INVALID, "bad point buffer");
+  const int64_t total = f->n_store + n;
+  if (total >= ((int64_t)1 << 31))
+    return octl_set_error(ctx, OCTL_E_INVALID, "more than 2^31-1 points in one forest");
+  OCTL_TRY(devbuf_reserve(ctx, f->xyz, (size_t)std::max<int64_t>(total, 1) * 24, 1));
+  OCTL_TRY(devbuf_reserve(ctx, f->alive, (size_t)std::max<int64_t>(total, 1), 1));
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(f->xyz.as<double>() + 3 * f->n_store, xyz, (size_t)n * 24,
+                                from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(f->alive.as<uint8_t>() + f->n_store, 1, (size_t)n, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return OCTL_OK;
+}
+
+int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
+  octl_ctx* ctx = f->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t n = f->n_ord;
+  if (n > 0) {
+    KTimer t(ctx, "apply_mask");
+    OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n + 8) * 4));
+    uint32_t* flags = f->flags.as<uint32_t>();
+    uint32_t* small = ctx->small.as<uint32_t>();
+    hipLaunchKernelGGL(k_mask_to_flags, dim3(grid_for(n)), dim3(256), 0, st,
+                       (const uint8_t*)f->mask.as<uint8_t>(), n, flags);
+    HIP_TRY(ctx, hipGetLastError());
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n, small + 20));
+    OCTL_TRY(devbuf_reserve(ctx, f->ord_idx2, (size_t)n * 4));
+    OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord2, (size_t)n * 24));
+    OCTL_TRY(devbuf_reserve(ctx, f->pos_node2, (size_t)n * 4));
+    hipLaunchKernelGGL(k_compact_ord, dim3(grid_for(n)), dim3(256), 0, st,
+                       (const uint8_t*)f->mask.as<uint8_t>(), (const uint32_t*)flags, n,
+                       (const uint32_t*)f->ord_idx.as<uint32_t>(),
+                       (const double*)f->xyz_ord.as<double>(),
+                       (const int32_t*)f->pos_node.as<int32_t>(), f->ord_idx2.as<uint32_t>(),
+                       f->xyz_ord2.as<double>(), f->pos_node2.as<int32_t>(),
+                       f->alive.as<uint8_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small + 20, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    uint32_t kept;
+    std::memcpy(&kept, ctx->small_host, 4);
+    std::swap(f->ord_idx, f->ord_idx2);
+    std::swap(f->xyz_ord, f->xyz_ord2);
+    std::swap(f->pos_node, f->pos_node2);
+    f->n_alive -= (n - (int64_t)kept);
+    f->n_ord = kept;
+  }
+  f->mask_valid = false;
+  OCTL_TRY(forest_make_blocks(f));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (n_alive_out) *n_alive_out = f->n_ord;
+  return OCTL_OK;
+}
+
+int ensure_mask(octl_forest* f) {
+  octl_ctx* ctx = f->ctx;
+  if (f->mask_valid) return OCTL_OK;
+  OCTL_TRY(devbuf_reserve(ctx, f->mask, (size_t)std::max<int64_t>(f->n_ord, 1)));
+  if (f->n_ord > 0)
+    HIP_TRY(ctx, hipMemsetAsync(f->mask.p, 1, (size_t)f->n_ord, ctx->stream));
+  f->mask_valid = true;
+  return OCTL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int octl_forest_create(octl_ctx* ctx, int mode, const double corner[3], double edge,
+                       octl_forest** out) {
+  if (!ctx || !out || !corner) return OCTL_E_INVALID;
+  *out = nullptr;
+  if (mode != 0 && mode != 1) return octl_set_error(ctx, OCTL_E_INVALID, "mode must be 0 or 1");
+  if (!(edge > 0.0)) return octl_set_error(ctx, OCTL_E_INVALID, "edge length must be positive");
+  if (mode == 0) {
+    if (corner[0] != 0.0 || corner[1] != 0.0 || corner[2] != 0.0)
+      return octl_set_error(ctx, OCTL_E_INVALID,
+                            "a non-zero grid corner is outside the parity domain: the reference "
+                            "places its octrees relative to the corner but subtracts absolute "
+                            "points (grid.py:96-105 vs octree.py:74)");
+    if (edge != (double)(int64_t)edge)
+      return octl_set_error(ctx, OCTL_E_INVALID,
+                            "voxel_edge_length must be integer valued: the reference truncates "
+                            "voxel coordinates with astype(int) (grid.py:72-76)");
+  }
+  octl_forest* f = new octl_forest();
+  f->ctx = ctx;
+  f->mode = mode;
+  for (int a = 0; a < 3; ++a) f->corner[a] = corner[a];
+  f->edge = edge;
+  *out = f;
+  return OCTL_OK;
+}
+
+void octl_forest_destroy(octl_forest* f) {
+  if (!f) return;
+  (void)hipSetDevice(f->ctx->device);
+  (void)hipStreamSynchronize(f->ctx->stream);
+  nodes_free(f->nodes[0]);
+  nodes_free(f->nodes[1]);
+  for (DevBuf* b :
+       {&f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
+        &f->blk_start, &f->blk_size, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order,
+        &f->rs_hyp, &f->rs_plane, &f->rs_count, &f->rs_index, &f->ord_idx2, &f->xyz_ord2,
+        &f->pos_node2, &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
+        &f->hist, &f->idxbuf[0], &f->idxbuf[1], &f->pathbuf[0], &f->pathbuf[1], &f->flags,
+        &f->entries, &f->split[0], &f->split[1], &f->split_tiles[0], &f->split_tiles[1],
+        &f->child_sc, &f->pose_off_dev, &f->scheme_dev, &f->root_up})
+    devbuf_free(*b);
+  delete f;
+}
+
+int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* slot) {
+  if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(store_append(f, xyz, n, false));
+  if (slot) *slot = (int32_t)f->pose_off.size() - 1;
+  f->n_store += n;
+  f->n_alive += n;
+  f->pose_off.push_back(f->n_store);
+  f->store_dirty = true;
+  return OCTL_OK;
+}
+
+int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n, int32_t* slot) {
+  if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(store_append(f, xyz_dev, n, true));
+  if (slot) *slot = (int32_t)f->pose_off.size() - 1;
+  f->n_store += n;
+  f->n_alive += n;
+  f->pose_off.push_back(f->n_store);
+  f->store_dirty = true;
+  return OCTL_OK;
+}
+
+int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n) {
+  if (!f) return OCTL_E_INVALID;
+  const int n_poses = (int)f->pose_off.size() - 1;
+  if (slot != n_poses - 1)
+    return octl_set_error(f->ctx, OCTL_E_INVALID,
+                          "only the most recently added pose can be extended (pose-major store)");
+  OCTL_TRY(store_append(f, xyz, n, false));
+  f->n_store += n;
+  f->n_alive += n;
+  f->pose_off.back() = f->n_store;
+  f->store_dirty = true;
+  return OCTL_OK;
+}
+
+int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
+                      int32_t keep_scheme, int32_t max_depth, octl_build_info* info) {
+  if (!f) return OCTL_E_INVALID;
+  return forest_build(f, K, scheme_mask, n_mask, keep_scheme, max_depth, info);
+}
+
+int octl_forest_get_nodes(octl_forest* f, int64_t cap, int32_t* voxel, int32_t* depth,
+                          int32_t* parent, int32_t* first_child, double* corner, double* edge,
+                          int32_t* epoch, int64_t* n_nodes) {
+  if (!f || !n_nodes) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  NodeTable& t = f->nodes[f->cur];
+  *n_nodes = t.n;
+  const int64_t n = std::min<int64_t>(cap, t.n);
+  if (n <= 0) return OCTL_OK;
+  hipStream_t st = ctx->stream;
+  auto dl = [&](void* dst, const DevBuf& src, size_t bytes) {
+    return dst ? hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, st) : hipSuccess;
+  };
+  HIP_TRY(ctx, dl(voxel, t.voxel, (size_t)n * 4));
+  HIP_TRY(ctx, dl(depth, t.depth, (size_t)n * 4));
+  HIP_TRY(ctx, dl(parent, t.parent, (size_t)n * 4));
+  HIP_TRY(ctx, dl(first_child, t.first_child, (size_t)n * 4));
+  HIP_TRY(ctx, dl(corner, t.corner, (size_t)n * 24));
+  HIP_TRY(ctx, dl(edge, t.edge, (size_t)n * 8));
+  HIP_TRY(ctx, dl(epoch, t.epoch, (size_t)n * 4));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return OCTL_OK;
+}
+
+int octl_forest_get_voxels(octl_forest* f, int64_t cap, int64_t* coords, int64_t* n_voxels) {
+  if (!f || !n_voxels) return OCTL_E_INVALID;
+  if (!f->built) return octl_set_error(f->ctx, OCTL_E_STATE, "no scheme has been built");
+  *n_voxels = (int64_t)f->vkeys.size();
+  if (!coords) return OCTL_OK;
+  const int64_t n = std::min<int64_t>(cap, *n_voxels);
+  for (int64_t v = 0; v < n; ++v) {
+    int64_t q[3];
+    vkey_decode(f->vkeys[v], q);
+    // the reference's voxel coordinates are int(q * L): the corner, not the index
+    for (int a = 0; a < 3; ++a)
+      coords[3 * v + a] = f->mode == 0 ? (int64_t)((double)q[a] * f->edge) : 0;
+  }
+  return OCTL_OK;
+}
+
+int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* slot,
+                           int64_t* start, int32_t* size, int64_t* n_blocks) {
+  if (!f || !n_blocks) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  *n_blocks = f->n_blocks;
+  const int64_t n = std::min<int64_t>(cap, f->n_blocks);
+  if (n <= 0) return OCTL_OK;
+  hipStream_t st = ctx->stream;
+  if (node) HIP_TRY(ctx, hipMemcpyAsync(node, f->blk_node.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (slot) HIP_TRY(ctx, hipMemcpyAsync(slot, f->blk_slot.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (size) HIP_TRY(ctx, hipMemcpyAsync(size, f->blk_size.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (start) {
+    OCTL_TRY(devbuf_reserve(ctx, f->rs_scratch, (size_t)n * 8));
+    hipLaunchKernelGGL(k_widen_u32_i64, dim3(grid_for(n)), dim3(256), 0, st,
+                       (const uint32_t*)f->blk_start.as<uint32_t>(), n,
+                       f->rs_scratch.as<int64_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(start, f->rs_scratch.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return OCTL_OK;
+}
+
+int octl_forest_get_perm(octl_forest* f, int64_t cap, int64_t* perm, int64_t* n_out) {
+  if (!f || !n_out) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  *n_out = f->n_ord;
+  const int64_t n = std::min<int64_t>(cap, f->n_ord);
+  if (n <= 0 || !perm) return OCTL_OK;
+  hipStream_t st = ctx->stream;
+  OCTL_TRY(devbuf_reserve(ctx, f->rs_scratch, (size_t)n * 8));
+  hipLaunchKernelGGL(k_widen_u32_i64, dim3(grid_for(n)), dim3(256), 0, st,
+                     (const uint32_t*)f->ord_idx.as<uint32_t>(), n, f->rs_scratch.as<int64_t>());
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(perm, f->rs_scratch.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return OCTL_OK;
+}
+
+int octl_forest_get_points(octl_forest* f, int64_t start, int64_t count, double* xyz) {
+  if (!f) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  if (start < 0 || count < 0 || start + count > f->n_ord)
+    return octl_set_error(ctx, OCTL_E_INVALID, "point range out of bounds");
+  if (count == 0) return OCTL_OK;
+  if (!xyz) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipMemcpyAsync(xyz, f->xyz_ord.as<double>() + 3 * start, (size_t)count * 24,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
+                       const double* hypotheses, int32_t H, int32_t k, double threshold,
+                       float* plane, int32_t* best_count, int32_t* best_index) {
+  if (!f) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "ransac before build");
+  if (nb < 0 || (nb > 0 && !block_order) || !hypotheses)
+    return octl_set_error(ctx, OCTL_E_INVALID, "bad ransac arguments");
+  if (H < 1 || H > 1024 || k < 1) return octl_set_error(ctx, OCTL_E_INVALID, "bad H or k");
+  for (int64_t b = 0; b < nb; ++b)
+    if (block_order[b] < 0 || block_order[b] >= f->n_blocks)
+      return octl_set_error(ctx, OCTL_E_INVALID, "block index out of range");
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  OCTL_TRY(ensure_mask(f));
+  if (nb == 0) return OCTL_OK;
+  OCTL_TRY(devbuf_reserve(ctx, f->rs_order, (size_t)nb * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(f->rs_order.p, block_order, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  float* plane_d = nullptr;
+  int32_t *count_d = nullptr, *index_d = nullptr;
+  if (plane) {
+    OCTL_TRY(devbuf_reserve(ctx, f->rs_plane, (size_t)nb * 16));
+    plane_d = f->rs_plane.as<float>();
+  }
+  if (best_count) {
+    OCTL_TRY(devbuf_reserve(ctx, f->rs_count, (size_t)nb * 4));
+    count_d = f->rs_count.as<int32_t>();
+  }
+  if (best_index) {
+    OCTL_TRY(devbuf_reserve(ctx, f->rs_index, (size_t)nb * 4));
+    index_d = f->rs_index.as<int32_t>();
+  }
+  OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
+                         f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>(), nb,
+                         f->rs_hyp.as<double>(), H, k, threshold, f->mask.as<uint8_t>(), plane_d,
+                         count_d, index_d, nullptr, f->rs_scratch));
+  if (plane) HIP_TRY(ctx, hipMemcpyAsync(plane, plane_d, (size_t)nb * 16, hipMemcpyDeviceToHost, st));
+  if (best_count) HIP_TRY(ctx, hipMemcpyAsync(best_count, count_d, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+  if (best_index) HIP_TRY(ctx, hipMemcpyAsync(best_index, index_d, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return OCTL_OK;
+}
+
+int octl_forest_get_mask(octl_forest* f, int64_t cap, uint8_t* mask, int64_t* n_out) {
+  if (!f || !n_out) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  *n_out = f->n_ord;
+  const int64_t n = std::min<int64_t>(cap, f->n_ord);
+  if (n <= 0 || !mask) return OCTL_OK;
+  OCTL_TRY(ensure_mask(f));
+  HIP_TRY(ctx, hipMemcpyAsync(mask, f->mask.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+int octl_forest_apply_mask(octl_forest* f, int64_t* n_alive) {
+  if (!f) return OCTL_E_INVALID;
+  if (!f->built) return octl_set_error(f->ctx, OCTL_E_STATE, "apply_mask before build");
+  OCTL_TRY(ensure_mask(f));
+  return apply_device_mask(f, n_alive);
+}
+
+int octl_forest_apply_host_mask(octl_forest* f, const uint8_t* mask, int64_t n, int64_t* n_alive) {
+  if (!f) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "apply_mask before build");
+  if (n != f->n_ord || (n > 0 && !mask))
+    return octl_set_error(ctx, OCTL_E_INVALID, "mask has %lld entries for %lld points",
+                          (long long)n, (long long)f->n_ord);
+  OCTL_TRY(devbuf_reserve(ctx, f->mask, (size_t)std::max<int64_t>(n, 1)));
+  if (n > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(f->mask.p, mask, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  f->mask_valid = true;
+  return apply_device_mask(f, n_alive);
+}
+
+int octl_ransac_evaluate(octl_ctx* ctx, const double* point_cloud, int64_t M,
+                         const int32_t* block_sizes, int64_t B, const double* hypotheses,
+                         int32_t H, int32_t k, double threshold, uint8_t* mask_out,
+                         float* planes_out, int32_t* best_count_out, int32_t* best_index_out) {
+  if (!ctx) return OCTL_E_INVALID;
+  if (M < 0 || B < 0 || (M > 0 && !point_cloud) || (B > 0 && !block_sizes) || !hypotheses ||
+      (M > 0 && !mask_out))
+    return octl_set_error(ctx, OCTL_E_INVALID, "bad ransac_evaluate arguments");
+  if (H < 1 || H > 1024 || k < 1) return octl_set_error(ctx, OCTL_E_INVALID, "bad H or k");
+  if (M >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "cloud too large");
+  int64_t total = 0;
+  std::vector<uint32_t> starts((size_t)std::max<int64_t>(B, 1));
+  for (int64_t b = 0; b < B; ++b) {
+    if (block_sizes[b] < 0) return octl_set_error(ctx, OCTL_E_INVALID, "negative block size");
+    starts[b] = (uint32_t)total;  // np.cumsum([0] + sizes[:-1]) (cuda_ransac.py:64-66)
+    total += block_sizes[b];
+  }
+  if (total > M)
+    return octl_set_error(ctx, OCTL_E_INVALID, "block sizes add up to %lld > %lld points",
+                          (long long)total, (long long)M);
+  if (M == 0) return OCTL_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf xyz, sizes, starts_d, hyp, mask, plane, count, index, scratch;
+  int rc = OCTL_OK;
+  auto cleanup = [&]() {
+    for (DevBuf* b : {&xyz, &sizes, &starts_d, &hyp, &mask, &plane, &count, &index, &scratch})
+      devbuf_free(*b);
+  };
+#define EV_TRY(expr)            \
+  do {                          \
+    rc = (expr);                \
+    if (rc != OCTL_OK) {        \
+      cleanup();                \
+      return rc;                \
+    }                           \
+  } while (0)
+#define EV_HIP(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      cleanup();                                                                            \
+      return octl_set_error(ctx, OCTL_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    }                                                                                       \
+  } while (0)
+  EV_TRY(devbuf_reserve(ctx, xyz, (size_t)M * 24));
+  EV_TRY(devbuf_reserve(ctx, mask, (size_t)M));
+  EV_TRY(devbuf_reserve(ctx, hyp, (size_t)H * k * 8));
+  EV_HIP(hipMemcpyAsync(xyz.p, point_cloud, (size_t)M * 24, hipMemcpyHostToDevice, st));
+  EV_HIP(hipMemcpyAsync(hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+  EV_HIP(hipMemsetAsync(mask.p, 0, (size_t)M, st));  // np.zeros (cuda_ransac.py:57)
+  if (B > 0) {
+    EV_TRY(devbuf_reserve(ctx, sizes, (size_t)B * 4));
+    EV_TRY(devbuf_reserve(ctx, starts_d, (size_t)B * 4));
+    EV_HIP(hipMemcpyAsync(sizes.p, block_sizes, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    EV_HIP(hipMemcpyAsync(starts_d.p, starts.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    if (planes_out) EV_TRY(devbuf_reserve(ctx, plane, (size_t)B * 16));
+    if (best_count_out) EV_TRY(devbuf_reserve(ctx, count, (size_t)B * 4));
+    if (best_index_out) EV_TRY(devbuf_reserve(ctx, index, (size_t)B * 4));
+    EV_HIP(hipStreamSynchronize(st));
+    EV_TRY(ransac_launch(ctx, xyz.as<double>(), M, starts_d.as<uint32_t>(), sizes.as<int32_t>(),
+                         nullptr, B, hyp.as<double>(), H, k, threshold, mask.as<uint8_t>(),
+                         planes_out ? plane.as<float>() : nullptr,
+                         best_count_out ? count.as<int32_t>() : nullptr,
+                         best_index_out ? index.as<int32_t>() : nullptr, nullptr, scratch));
+    if (planes_out) EV_HIP(hipMemcpyAsync(planes_out, plane.p, (size_t)B * 16, hipMemcpyDeviceToHost, st));
+    if (best_count_out) EV_HIP(hipMemcpyAsync(best_count_out, count.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    if (best_index_out) EV_HIP(hipMemcpyAsync(best_index_out, index.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  }
+  EV_HIP(hipMemcpyAsync(mask_out, mask.p, (size_t)M, hipMemcpyDeviceToHost, st));
+  EV_HIP(hipStreamSynchronize(st));
+  cleanup();
+#undef EV_TRY
+#undef EV_HIP
+  return OCTL_OK;
+}
+
+}  // extern "C"
+
+// ---- test hooks for the device-wide primitives (tests/test_gpu_primitives.py) ----------------
+extern "C" int octl_debug_exclusive_scan(octl_ctx* ctx, const uint32_t* in, int64_t n,
+                                         uint32_t* out, uint32_t* total) {
+  if (!ctx || n < 0 || (n > 0 && (!in || !out))) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  DevBuf buf;
+  OCTL_TRY(devbuf_reserve(ctx, buf, (size_t)(n + 8) * 4));
+  hipStream_t st = ctx->stream;
+  uint32_t* tot_d = ctx->small.as<uint32_t>() + 24;
+  int rc = OCTL_OK;
+  if (n > 0 && hipMemcpyAsync(buf.p, in, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = OCTL_E_HIP;
+  if (rc == OCTL_OK) rc = octl_exclusive_scan_u32(ctx, buf.as<uint32_t>(), buf.as<uint32_t>(), n, tot_d);
+  if (rc == OCTL_OK && n > 0 &&
+      hipMemcpyAsync(out, buf.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+    rc = OCTL_E_HIP;
+  if (rc == OCTL_OK && total &&
+      hipMemcpyAsync(total, tot_d, 4, hipMemcpyDeviceToHost, st) != hipSuccess)
+    rc = OCTL_E_HIP;
+  if (hipStreamSynchronize(st) != hipSuccess) rc = OCTL_E_HIP;
+  devbuf_free(buf);
+  return rc;
+}
+
+extern "C" int octl_debug_radix_sort(octl_ctx* ctx, uint64_t* keys, uint32_t* vals, int64_t n,
+                                     int key_bits) {
+  if (!ctx || n < 0 || (n > 0 && (!keys || !vals))) return OCTL_E_INVALID;
+  if (n == 0) return OCTL_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf k[2], v[2], hist;
+  int rc = OCTL_OK;
+  for (int b = 0; b < 2 && rc == OCTL_OK; ++b) {
+    rc = devbuf_reserve(ctx, k[b], (size_t)n * 8);
+    if (rc == OCTL_OK) rc = devbuf_reserve(ctx, v[b], (size_t)n * 4);
+  }
+  if (rc == OCTL_OK) {
+    if (hipMemcpyAsync(k[0].p, keys, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(v[0].p, vals, (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      rc = OCTL_E_HIP;
+  }
+  int res = 0;
+  if (rc == OCTL_OK) {
+    uint64_t* kk[2] = {k[0].as<uint64_t>(), k[1].as<uint64_t>()};
+    uint32_t* vv[2] = {v[0].as<uint32_t>(), v[1].as<uint32_t>()};
+    rc = octl_radix_sort_u64_u32(ctx, kk, vv, n, key_bits, hist, &res);
+  }
+  if (rc == OCTL_OK) {
+    if (hipMemcpyAsync(keys, k[res].p, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(vals, v[res].p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      rc = OCTL_E_HIP;
+  }
+  for (int b = 0; b < 2; ++b) {
+    devbuf_free(k[b]);
+    devbuf_free(v[b]);
+  }
+  devbuf_free(hist);
+  return rc;
+}

@@ -1,0 +1,1115 @@
+// insert + subdivide on the device.
+//
+// Replaces, for the count criterion len(points) > K (paths relative to /root/reference):
+//   Grid.insert_points          grid/grid.py:58-109      top-level voxel bucketing
+//   OctreeManager.subdivide     octree_manager.py:36-66  scheme from the union of poses
+//   OctreeNode.subdivide/_as    octree/octree.py:20-53   recursive 8-way split
+//   OctreeNode.insert_points    octree/octree.py:67-100  child index arithmetic
+//   OctreeNode._generate_children octree/octree.py:177-191 child corners / edges
+//
+// Pipeline (all kernels HBM-bound integer/compare work; nothing here is a contraction):
+//   k_keygen      xyz -> packed voxel key + 21-level child-digit path (reference arithmetic
+//                 restated as exact f64 comparisons), voxel bounding box
+//   k_linkey      voxel key -> compact linear key, point index (+ scheme-pose bit)
+//   radix sort    stable LSD sort by linear voxel key (radix_sort.hip)
+//   roots         one scheme node per top-level voxel
+//   level loop    level-synchronous recursive subdivide: every node whose scheme-pose count
+//                 exceeds K is split 8 ways by a stable tile partition (ballot ranks in LDS)
+//   k_finalize    leaf-ordered point permutation + coordinates, (leaf, pose) block table
+#include <algorithm>
+
+#include "forest.h"
+#include "ref_arith.h"
+#include "wave_utils.h"
+
+namespace {
+
+constexpr int LV_THREADS = 256;
+constexpr int LV_WAVES = LV_THREADS / 64;
+constexpr int LV_IPT = 4;
+constexpr int LV_TILE = LV_THREADS * LV_IPT;  // 1024 positions per tile
+constexpr int LV_WAVE_ITEMS = 64 * LV_IPT;
+constexpr uint32_t IDX_MASK = 0x7FFFFFFFu;
+constexpr int PATH_LEVELS = 21;
+
+// slots of the context's small device scalar block (uint32 units)
+enum {
+  SM_ERR = 0,       // domain error flag
+  SM_BBOX = 4,      // 6 x int32: min xyz, max xyz
+  SM_NVOX = 12,     // voxels with points
+  SM_NSPLIT = 13,   // nodes to split at the next level
+  SM_NTILES = 14,   // tiles of the next level
+  SM_ETOTAL = 15,   // total of the scanned tile histogram
+  SM_NBLOCKS = 16,
+};
+
+// ---------------------------------------------------------------------------------------------
+// reference arithmetic
+// ---------------------------------------------------------------------------------------------
+
+// Child digits of up to 21 consecutive levels below the cube (c, e).
+// Reference per level (octree/octree.py:73-75,94-97,181-191):
+//     idx = floor((p - corner) / (edge / 2))  per axis, must be 0 or 1
+//     child_id = 4*ix + 2*iy + iz ; child corner = corner + idx * (edge / 2) ; child edge = edge / 2
+// floor((p-c)/h) in {0,1} <=> 0 <= fl(p-c) < 2h, and it is 1 <=> fl(p-c) >= h: the division is
+// replaced by exact comparisons on the same rounded difference the reference forms.
+// Layout: digit of level j at bits [61-3j, 63-3j]; bit 0 = "bad" (some level had idx outside
+// {0,1}, or a non-finite coordinate) - such a point takes the slow path and raises a domain
+// error only if a node containing it is actually split, as in the reference.
+__device__ __forceinline__ uint64_t compute_path(double px, double py, double pz, double cx,
+                                                 double cy, double cz, double e) {
+  uint64_t path = 0;
+  double h = e / 2.0;
+#pragma unroll 1
+  for (int j = 0; j < PATH_LEVELS; ++j) {
+    const double ax = px - cx, ay = py - cy, az = pz - cz;
+    const bool ok = (ax >= 0.0) && (ax < e) && (ay >= 0.0) && (ay < e) && (az >= 0.0) && (az < e);
+    if (!ok) return path | 1ull;
+    const bool bx = ax >= h, by = ay >= h, bz = az >= h;
+    const uint64_t digit = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
+    path |= digit << (61 - 3 * j);
+    cx = cx + (bx ? h : 0.0);
+    cy = cy + (by ? h : 0.0);
+    cz = cz + (bz ? h : 0.0);
+    e = h;
+    h = e / 2.0;
+  }
+  return path;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// key generation
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
+                                                const uint8_t* __restrict__ alive, int64_t n,
+                                                int mode, double L, double c0x, double c0y,
+                                                double c0z, uint64_t* __restrict__ vkey,
+                                                uint64_t* __restrict__ path,
+                                                uint32_t* __restrict__ small) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = (i < n) && alive[i];
+  int qx = 0, qy = 0, qz = 0;
+  if (live) {
+    const double px = xyz[3 * i + 0], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+    double cx = c0x, cy = c0y, cz = c0z;
+    if (mode == 0) {
+      // voxel_indices = ((points - corner) // L * L).astype(int)   (grid.py:72-76, corner = 0)
+      const double fx = floor_div_exact(px, L), fy = floor_div_exact(py, L),
+                   fz = floor_div_exact(pz, L);
+      const double lim = (double)OCTL_VOX_BIAS;
+      const bool in_range =
+          (fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim);  // false for NaN
+      if (!in_range) {
+        atomicExch(&small[SM_ERR], (uint32_t)(-OCTL_E_DOMAIN));
+        live = false;
+      } else {
+        qx = (int)fx;
+        qy = (int)fy;
+        qz = (int)fz;
+        // the manager's corner is np.array(voxel_coords): int64(q*L) (grid.py:96-105)
+        cx = (double)(long long)(fx * L);
+        cy = (double)(long long)(fy * L);
+        cz = (double)(long long)(fz * L);
+      }
+    }
+    if (live) {
+      vkey[i] = ((uint64_t)(qx + OCTL_VOX_BIAS) << 42) | ((uint64_t)(qy + OCTL_VOX_BIAS) << 21) |
+                (uint64_t)(qz + OCTL_VOX_BIAS);
+      path[i] = compute_path(px, py, pz, cx, cy, cz, L);
+    }
+  }
+  if (i < n && !live) {
+    vkey[i] = OCTL_VOX_DEAD;
+    path[i] = 0;
+  }
+  // voxel bounding box: wave reduction, then six atomics per wave
+  const int big = 1 << 30;
+  const int mnx = wave_min_i32(live ? qx : big), mny = wave_min_i32(live ? qy : big),
+            mnz = wave_min_i32(live ? qz : big);
+  const int mxx = wave_max_i32(live ? qx : -big), mxy = wave_max_i32(live ? qy : -big),
+            mxz = wave_max_i32(live ? qz : -big);
+  if ((threadIdx.x & 63) == 0 && mnx != big) {
+    int* bb = reinterpret_cast<int*>(small + SM_BBOX);
+    atomicMin(&bb[0], mnx);
+    atomicMin(&bb[1], mny);
+    atomicMin(&bb[2], mnz);
+    atomicMax(&bb[3], mxx);
+    atomicMax(&bb[4], mxy);
+    atomicMax(&bb[5], mxz);
+  }
+}
+
+__device__ __forceinline__ int find_slot(const int64_t* __restrict__ pose_off, int n_poses,
+                                         int64_t idx) {
+  int lo = 0, hi = n_poses;  // pose_off[lo] <= idx < pose_off[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pose_off[mid] <= idx) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_linkey(const uint64_t* __restrict__ vkey, int64_t n,
+                                                int minx, int miny, int minz, uint64_t ny,
+                                                uint64_t nz, uint64_t dead_lin,
+                                                const int64_t* __restrict__ pose_off, int n_poses,
+                                                const uint8_t* __restrict__ scheme,
+                                                uint64_t* __restrict__ lin,
+                                                uint32_t* __restrict__ val) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t k = vkey[i];
+  uint64_t l = dead_lin;
+  if (k != OCTL_VOX_DEAD) {
+    const int64_t qx = (int64_t)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS;
+    const int64_t qy = (int64_t)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS;
+    const int64_t qz = (int64_t)(k & 0x1FFFFF) - OCTL_VOX_BIAS;
+    l = ((uint64_t)(qx - minx) * ny + (uint64_t)(qy - miny)) * nz + (uint64_t)(qz - minz);
+  }
+  lin[i] = l;
+  uint32_t v = (uint32_t)i;
+  if (scheme) {
+    if (scheme[find_slot(pose_off, n_poses, i)]) v |= 0x80000000u;
+  } else {
+    v |= 0x80000000u;
+  }
+  val[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// roots
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_heads(const uint64_t* __restrict__ lin, int64_t n_alive,
+                                               uint32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  flags[i] = (i == 0 || lin[i] != lin[i - 1]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_voxel_collect(const uint64_t* __restrict__ lin,
+                                                       const uint32_t* __restrict__ scanned,
+                                                       int64_t n_alive,
+                                                       uint64_t* __restrict__ vlin,
+                                                       uint32_t* __restrict__ vstart) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  if (i == 0 || lin[i] != lin[i - 1]) {
+    const uint32_t r = scanned[i];
+    vlin[r] = lin[i];
+    vstart[r] = (uint32_t)i;
+  }
+}
+
+// level-0 buffers: position -> root node, point index (+scheme bit), path word
+__global__ __launch_bounds__(256) void k_init_level0(
+    const uint64_t* __restrict__ lin, const uint32_t* __restrict__ scanned,
+    const uint32_t* __restrict__ val_sorted, const uint64_t* __restrict__ path, int64_t n_alive,
+    const int32_t* __restrict__ local2root, int32_t* __restrict__ pos_node,
+    uint32_t* __restrict__ idx0, uint64_t* __restrict__ path0) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  const uint32_t head = (i == 0 || lin[i] != lin[i - 1]) ? 1u : 0u;
+  const uint32_t local = scanned[i] + head - 1u;
+  pos_node[i] = local2root[local];
+  const uint32_t v = val_sorted[i];
+  idx0[i] = v;
+  path0[i] = path[v & IDX_MASK];
+}
+
+// scheme-pose point count of every root (only when a pose subset drives the scheme)
+__global__ __launch_bounds__(256) void k_count_scheme(const int32_t* __restrict__ pos_node,
+                                                      const uint32_t* __restrict__ idx0,
+                                                      int64_t n_alive,
+                                                      uint32_t* __restrict__ scount) {
+  __shared__ uint32_t part[4];
+  const int64_t base = (int64_t)blockIdx.x * 2048;
+  const int64_t last = min(base + 2048, n_alive) - 1;
+  const bool uniform = pos_node[base] == pos_node[last];  // positions are sorted by node
+  uint32_t c = 0;
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n_alive && (idx0[i] >> 31)) {
+      if (uniform) ++c; else atomicAdd(&scount[pos_node[i]], 1u);
+    }
+  }
+  if (uniform) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t t = part[0] + part[1] + part[2] + part[3];
+      if (t) atomicAdd(&scount[pos_node[base]], t);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// level loop
+// ---------------------------------------------------------------------------------------------
+struct NodePtrs {
+  uint32_t *start, *count, *scount;
+  int32_t *depth, *voxel, *parent, *first_child, *old_id, *epoch;
+  double *corner, *edge;
+};
+
+// split predicate for the freshly created nodes [first, first+n_new)
+//   K mode   : scheme-pose count > K                       (octree.py:26, octree_manager.py:53-61)
+//   keep mode: the node is internal in the previous scheme (octree.py:39-47, subdivide_as)
+__global__ __launch_bounds__(256) void k_split_flags(NodePtrs nd, int64_t first, int64_t n_new,
+                                                     int keep_mode, int64_t K,
+                                                     const int32_t* __restrict__ old_fc,
+                                                     uint32_t* __restrict__ flags) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_new) return;
+  const int64_t c = first + j;
+  bool split;
+  if (keep_mode) {
+    const int32_t o = nd.old_id[c];
+    split = (o >= 0) && (old_fc[o] >= 0);
+  } else {
+    split = (K >= 0) && ((int64_t)nd.scount[c] > K);
+  }
+  flags[j] = split ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_compact_split(NodePtrs nd, int64_t first, int64_t n_new,
+                                                       const uint32_t* __restrict__ flags_scanned,
+                                                       int keep_mode, int64_t K,
+                                                       const int32_t* __restrict__ old_fc,
+                                                       int32_t* __restrict__ split_nodes,
+                                                       uint32_t* __restrict__ split_tiles) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_new) return;
+  const int64_t c = first + j;
+  bool split;
+  if (keep_mode) {
+    const int32_t o = nd.old_id[c];
+    split = (o >= 0) && (old_fc[o] >= 0);
+  } else {
+    split = (K >= 0) && ((int64_t)nd.scount[c] > K);
+  }
+  if (split) {
+    const uint32_t pos = flags_scanned[j];
+    split_nodes[pos] = (int32_t)c;
+    split_tiles[pos] = (nd.count[c] + LV_TILE - 1) / LV_TILE;
+  }
+}
+
+// tile -> (split slot, tile inside the node, tiles of the node)
+struct TileRef {
+  int s;
+  uint32_t tl, nt, tile_base;
+};
+__device__ __forceinline__ TileRef locate_tile(const uint32_t* __restrict__ tile_base, int ns,
+                                               uint32_t n_tiles_total, uint32_t t) {
+  int lo = 0, hi = ns;  // tile_base[lo] <= t < tile_base[hi] (tile_base[ns] = total)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_base[mid] <= t) lo = mid; else hi = mid;
+  }
+  // nodes without points own zero tiles: several slots may share one tile_base; the owner of
+  // tile t is the LAST slot whose base is <= t, which the search above returns
+  TileRef r;
+  r.s = lo;
+  r.tile_base = tile_base[lo];
+  r.tl = t - r.tile_base;
+  r.nt = ((lo + 1 < ns) ? tile_base[lo + 1] : n_tiles_total) - r.tile_base;
+  return r;
+}
+
+// digit of a point whose precomputed path is unusable: redo the reference arithmetic against
+// the node's own cube; a point outside the cube of a node that is being split is the
+// reference's IndexError / wrong-child case (octree.py:94-98) -> domain error
+__device__ __forceinline__ uint32_t slow_digit(const double* __restrict__ xyz, uint32_t v,
+                                               const double* __restrict__ corner, double e,
+                                               uint32_t* __restrict__ small) {
+  const int64_t i = (int64_t)(v & IDX_MASK);
+  const double ax = xyz[3 * i] - corner[0], ay = xyz[3 * i + 1] - corner[1],
+               az = xyz[3 * i + 2] - corner[2];
+  const double h = e / 2.0;
+  const bool ok = (ax >= 0.0) && (ax < e) && (ay >= 0.0) && (ay < e) && (az >= 0.0) && (az < e);
+  if (!ok) {
+    atomicExch(&small[SM_ERR], (uint32_t)(-OCTL_E_DOMAIN));
+    return 0;
+  }
+  return ((ax >= h) ? 4u : 0u) | ((ay >= h) ? 2u : 0u) | ((az >= h) ? 1u : 0u);
+}
+
+// recompute the path words of the points of the nodes about to be split, relative to those
+// nodes (every 21 levels)
+__global__ __launch_bounds__(LV_THREADS) void k_lv_rekey(
+    const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
+    uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
+    uint64_t* __restrict__ path_io, const double* __restrict__ xyz) {
+  const TileRef tr = locate_tile(tile_base, ns, n_tiles, blockIdx.x);
+  const int32_t node = split_nodes[tr.s];
+  const uint32_t nstart = nd.start[node], nend = nstart + nd.count[node];
+  const double e = nd.edge[node];
+  const double cx = nd.corner[3 * (int64_t)node], cy = nd.corner[3 * (int64_t)node + 1],
+               cz = nd.corner[3 * (int64_t)node + 2];
+  for (int r = 0; r < LV_IPT; ++r) {
+    const uint32_t i = nstart + tr.tl * LV_TILE + r * LV_THREADS + threadIdx.x;
+    if (i < nend) {
+      const int64_t p = (int64_t)(idx_in[i] & IDX_MASK);
+      path_io[i] = compute_path(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2], cx, cy, cz, e);
+    }
+  }
+}
+
+template <bool SCHEME_SUBSET>
+__global__ __launch_bounds__(LV_THREADS) void k_lv_hist(
+    const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
+    uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
+    const uint64_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
+    uint32_t* __restrict__ entries, uint32_t* __restrict__ child_sc,
+    uint32_t* __restrict__ small) {
+  __shared__ uint32_t wc[LV_WAVES][8], wsc[LV_WAVES][8];
+  const TileRef tr = locate_tile(tile_base, ns, n_tiles, blockIdx.x);
+  const int32_t node = split_nodes[tr.s];
+  const uint32_t nstart = nd.start[node], nend = nstart + nd.count[node];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t wbase = nstart + tr.tl * LV_TILE + wave * LV_WAVE_ITEMS;
+  uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < LV_IPT; ++r) {
+    const uint32_t i = wbase + r * 64 + lane;
+    const bool valid = i < nend;
+    uint32_t d = 0, v = 0;
+    if (valid) {
+      const uint64_t pw = path_in[i];
+      v = idx_in[i];
+      d = (pw & 1ull) ? slow_digit(xyz, v, nd.corner + 3 * (int64_t)node, nd.edge[node], small)
+                      : (uint32_t)(pw >> shift) & 7u;
+    }
+    const uint64_t sm = SCHEME_SUBSET ? __ballot(valid && (v >> 31)) : 0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t m = __ballot(valid && d == (uint32_t)b);
+      c[b] += __popcll(m);
+      if (SCHEME_SUBSET) sc[b] += __popcll(m & sm);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      wc[wave][b] = c[b];
+      if (SCHEME_SUBSET) wsc[wave][b] = sc[b];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int b = threadIdx.x;
+    uint32_t t = 0, ts = 0;
+#pragma unroll
+    for (int w = 0; w < LV_WAVES; ++w) {
+      t += wc[w][b];
+      if (SCHEME_SUBSET) ts += wsc[w][b];
+    }
+    entries[(size_t)8 * tr.tile_base + (size_t)b * tr.nt + tr.tl] = t;
+    if (SCHEME_SUBSET && ts) atomicAdd(&child_sc[(size_t)8 * tr.s + b], ts);
+  }
+}
+
+__global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
+    const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
+    uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
+    const uint64_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
+    const uint32_t* __restrict__ entries_scanned, int32_t child_base,
+    uint32_t* __restrict__ idx_out, uint64_t* __restrict__ path_out,
+    int32_t* __restrict__ pos_node, uint32_t* __restrict__ small) {
+  __shared__ uint32_t cnt[LV_WAVES][8];
+  const TileRef tr = locate_tile(tile_base, ns, n_tiles, blockIdx.x);
+  const int32_t node = split_nodes[tr.s];
+  const uint32_t nstart = nd.start[node], nend = nstart + nd.count[node];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < LV_WAVES * 8) cnt[threadIdx.x >> 3][threadIdx.x & 7] = 0;
+  __syncthreads();
+  const uint32_t wbase = nstart + tr.tl * LV_TILE + wave * LV_WAVE_ITEMS;
+  uint32_t v[LV_IPT], d[LV_IPT], rank[LV_IPT];
+  uint64_t pw[LV_IPT];
+#pragma unroll
+  for (int r = 0; r < LV_IPT; ++r) {
+    const uint32_t i = wbase + r * 64 + lane;
+    const bool valid = i < nend;
+    v[r] = 0; d[r] = 0; pw[r] = 0;
+    if (valid) {
+      pw[r] = path_in[i];
+      v[r] = idx_in[i];
+      d[r] = (pw[r] & 1ull)
+                 ? slow_digit(xyz, v[r], nd.corner + 3 * (int64_t)node, nd.edge[node], small)
+                 : (uint32_t)(pw[r] >> shift) & 7u;
+    }
+    rank[r] = wave_stable_rank<3>(d[r], valid, cnt[wave]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int b = threadIdx.x;
+    const size_t ebase = (size_t)8 * tr.tile_base;
+    // destination of the first item with digit b of this tile, relative to the node start
+    uint32_t run = entries_scanned[ebase + (size_t)b * tr.nt + tr.tl] - entries_scanned[ebase];
+#pragma unroll
+    for (int w = 0; w < LV_WAVES; ++w) {
+      const uint32_t t = cnt[w][b];
+      cnt[w][b] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  const int32_t first_child = child_base + 8 * tr.s;
+#pragma unroll
+  for (int r = 0; r < LV_IPT; ++r) {
+    const uint32_t i = wbase + r * 64 + lane;
+    if (i < nend) {
+      const uint32_t dst = nstart + cnt[wave][d[r]] + rank[r];
+      idx_out[dst] = v[r];
+      path_out[dst] = pw[r];
+      pos_node[dst] = first_child + (int32_t)d[r];
+    }
+  }
+}
+
+// one thread per (split node, child): create the 8 children (octree.py:177-191)
+__global__ __launch_bounds__(256) void k_make_children(
+    const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
+    uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ entries_scanned,
+    const uint32_t* __restrict__ small, const uint32_t* __restrict__ child_sc, int all_scheme,
+    int32_t child_base, int keep_mode, int cur_epoch, const int32_t* __restrict__ old_fc,
+    const int32_t* __restrict__ old_epoch) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (int64_t)8 * ns) return;
+  const int s = (int)(g >> 3), j = (int)(g & 7);
+  const int32_t node = split_nodes[s];
+  const uint32_t tb = tile_base[s];
+  const uint32_t nt = ((s + 1 < ns) ? tile_base[s + 1] : n_tiles) - tb;
+  uint32_t off = 0, cnt = 0;
+  if (nt > 0) {
+    const size_t ebase = (size_t)8 * tb;
+    const uint32_t a = entries_scanned[ebase + (size_t)j * nt];
+    const uint32_t b = (j < 7 || (size_t)8 * (tb + nt) < (size_t)8 * n_tiles)
+                           ? entries_scanned[ebase + (size_t)(j + 1) * nt]
+                           : small[SM_ETOTAL];
+    off = a - entries_scanned[ebase];
+    cnt = b - a;
+  }
+  const int64_t c = (int64_t)child_base + 8 * (int64_t)s + j;
+  nd.start[c] = nd.start[node] + off;
+  nd.count[c] = cnt;
+  nd.scount[c] = all_scheme ? cnt : child_sc[(size_t)8 * s + j];
+  nd.depth[c] = nd.depth[node] + 1;
+  nd.voxel[c] = nd.voxel[node];
+  nd.parent[c] = node;
+  nd.first_child[c] = -1;
+  nd.epoch[c] = 0;
+  const int32_t po = nd.old_id[node];
+  const bool parent_was_internal = (po >= 0) && (old_fc[po] >= 0);
+  nd.old_id[c] = parent_was_internal ? old_fc[po] + j : -1;
+  // child_edge_length = edge / np.float_(2); corner = corner_min + offset, offsets from
+  // itertools.product([0, child_edge], repeat=3): x is the slowest axis
+  const double h = nd.edge[node] / 2.0;
+  nd.edge[c] = h;
+  nd.corner[3 * c + 0] = nd.corner[3 * (int64_t)node + 0] + ((j & 4) ? h : 0.0);
+  nd.corner[3 * c + 1] = nd.corner[3 * (int64_t)node + 1] + ((j & 2) ? h : 0.0);
+  nd.corner[3 * c + 2] = nd.corner[3 * (int64_t)node + 2] + ((j & 1) ? h : 0.0);
+  if (j == 0) {
+    nd.first_child[node] = child_base + 8 * s;
+    nd.epoch[node] = parent_was_internal ? old_epoch[po] : (keep_mode ? 0 : cur_epoch);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const int32_t* __restrict__ pos_node,
+                                                  const int32_t* __restrict__ depth,
+                                                  const uint32_t* __restrict__ idx_a,
+                                                  const uint32_t* __restrict__ idx_b,
+                                                  const double* __restrict__ xyz, int64_t n_alive,
+                                                  uint32_t* __restrict__ ord_idx,
+                                                  double* __restrict__ xyz_ord) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  const int d = depth[pos_node[i]];
+  const uint32_t v = ((d & 1) ? idx_b[i] : idx_a[i]) & IDX_MASK;
+  ord_idx[i] = v;
+  const double x = xyz[3 * (int64_t)v], y = xyz[3 * (int64_t)v + 1], z = xyz[3 * (int64_t)v + 2];
+  xyz_ord[3 * i] = x;
+  xyz_ord[3 * i + 1] = y;
+  xyz_ord[3 * i + 2] = z;
+}
+
+__device__ __forceinline__ bool block_head(const int32_t* __restrict__ pos_node,
+                                           const uint32_t* __restrict__ ord_idx,
+                                           const int64_t* __restrict__ pose_off, int n_poses,
+                                           int64_t i, int* slot_out) {
+  const int slot = find_slot(pose_off, n_poses, ord_idx[i]);
+  *slot_out = slot;
+  if (i == 0) return true;
+  if (pos_node[i] != pos_node[i - 1]) return true;
+  return find_slot(pose_off, n_poses, ord_idx[i - 1]) != slot;
+}
+
+__global__ __launch_bounds__(256) void k_block_heads(const int32_t* __restrict__ pos_node,
+                                                     const uint32_t* __restrict__ ord_idx,
+                                                     const int64_t* __restrict__ pose_off,
+                                                     int n_poses, int64_t n_alive,
+                                                     uint32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  int slot;
+  flags[i] = block_head(pos_node, ord_idx, pose_off, n_poses, i, &slot) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_block_fill(const int32_t* __restrict__ pos_node,
+                                                    const uint32_t* __restrict__ ord_idx,
+                                                    const int64_t* __restrict__ pose_off,
+                                                    int n_poses, int64_t n_alive,
+                                                    const uint32_t* __restrict__ scanned,
+                                                    int32_t* __restrict__ blk_node,
+                                                    int32_t* __restrict__ blk_slot,
+                                                    uint32_t* __restrict__ blk_start) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  int slot;
+  if (block_head(pos_node, ord_idx, pose_off, n_poses, i, &slot)) {
+    const uint32_t b = scanned[i];
+    blk_node[b] = pos_node[i];
+    blk_slot[b] = slot;
+    blk_start[b] = (uint32_t)i;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_block_sizes(const uint32_t* __restrict__ blk_start,
+                                                     int64_t nb, int64_t n_alive,
+                                                     int32_t* __restrict__ blk_size) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t e = (b + 1 < nb) ? blk_start[b + 1] : (uint32_t)n_alive;
+  blk_size[b] = (int32_t)(e - blk_start[b]);
+}
+
+NodePtrs node_ptrs(NodeTable& t) {
+  NodePtrs p;
+  p.start = t.start.as<uint32_t>();
+  p.count = t.count.as<uint32_t>();
+  p.scount = t.scount.as<uint32_t>();
+  p.depth = t.depth.as<int32_t>();
+  p.voxel = t.voxel.as<int32_t>();
+  p.parent = t.parent.as<int32_t>();
+  p.first_child = t.first_child.as<int32_t>();
+  p.old_id = t.old_id.as<int32_t>();
+  p.epoch = t.epoch.as<int32_t>();
+  p.corner = t.corner.as<double>();
+  p.edge = t.edge.as<double>();
+  return p;
+}
+
+inline unsigned grid_for(int64_t n, int threads = 256) { return (unsigned)ceil_div(n, threads); }
+
+int bits_for(uint64_t max_value) {
+  int b = 0;
+  while (b < 64 && (max_value >> b) != 0) ++b;
+  return b;
+}
+
+}  // namespace
+
+int nodes_reserve(octl_ctx* ctx, NodeTable& t, int64_t cap) {
+  if (cap <= t.cap) return OCTL_OK;
+  const int64_t want = std::max<int64_t>(cap + cap / 2, 1024);
+  for (DevBuf* b : {&t.start, &t.count, &t.scount, &t.depth, &t.voxel, &t.parent, &t.first_child,
+                    &t.old_id, &t.epoch})
+    OCTL_TRY(devbuf_reserve(ctx, *b, (size_t)want * 4, 1));
+  OCTL_TRY(devbuf_reserve(ctx, t.corner, (size_t)want * 24, 1));
+  OCTL_TRY(devbuf_reserve(ctx, t.edge, (size_t)want * 8, 1));
+  t.cap = want;
+  return OCTL_OK;
+}
+
+void nodes_free(NodeTable& t) {
+  for (DevBuf* b : {&t.start, &t.count, &t.scount, &t.depth, &t.voxel, &t.parent, &t.first_child,
+                    &t.old_id, &t.epoch, &t.corner, &t.edge})
+    devbuf_free(*b);
+  t.cap = t.n = 0;
+}
+
+// read `count` uint32 scalars of the small block (synchronises the stream)
+static int read_small(octl_ctx* ctx, int first, int count, uint32_t* out) {
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, ctx->small.as<uint32_t>() + first,
+                              (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(out, ctx->small_host, (size_t)count * 4);
+  return OCTL_OK;
+}
+
+int forest_make_blocks(octl_forest* f) {
+  octl_ctx* ctx = f->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t n = f->n_ord;
+  const int n_poses = (int)f->pose_off.size() - 1;
+  f->n_blocks = 0;
+  if (n <= 0) return OCTL_OK;
+  uint32_t* small = ctx->small.as<uint32_t>();
+  KTimer t(ctx, "blocks");
+  OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n + 8) * 4));
+  uint32_t* flags = f->flags.as<uint32_t>();
+  const int32_t* pos_node = f->pos_node.as<int32_t>();
+  hipLaunchKernelGGL(k_block_heads, dim3(grid_for(n)), dim3(256), 0, st, pos_node,
+                     (const uint32_t*)f->ord_idx.as<uint32_t>(),
+                     (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, n, flags);
+  HIP_TRY(ctx, hipGetLastError());
+  OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n, small + SM_NBLOCKS));
+  uint32_t nb;
+  OCTL_TRY(read_small(ctx, SM_NBLOCKS, 1, &nb));
+  const int64_t n_blocks = nb;
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_node, (size_t)n_blocks * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n_blocks * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n_blocks * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n_blocks * 4));
+  hipLaunchKernelGGL(k_block_fill, dim3(grid_for(n)), dim3(256), 0, st, pos_node,
+                     (const uint32_t*)f->ord_idx.as<uint32_t>(),
+                     (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, n,
+                     (const uint32_t*)flags, f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
+                     f->blk_start.as<uint32_t>());
+  HIP_TRY(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_block_sizes, dim3(grid_for(n_blocks)), dim3(256), 0, st,
+                     (const uint32_t*)f->blk_start.as<uint32_t>(), n_blocks, n,
+                     f->blk_size.as<int32_t>());
+  HIP_TRY(ctx, hipGetLastError());
+  f->n_blocks = n_blocks;
+  return OCTL_OK;
+}
+
+int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
+                 int32_t keep_scheme, int32_t max_depth, octl_build_info* info) {
+  octl_ctx* ctx = f->ctx;
+  hipStream_t st = ctx->stream;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int64_t N = f->n_store;
+  const int n_poses = (int)f->pose_off.size() - 1;
+  if (N >= ((int64_t)1 << 31))
+    return octl_set_error(ctx, OCTL_E_INVALID, "more than 2^31-1 points in one forest");
+  if (keep_scheme && !f->built)
+    return octl_set_error(ctx, OCTL_E_STATE, "keep_scheme build without a previous scheme");
+  if (scheme_mask && n_mask != n_poses)
+    return octl_set_error(ctx, OCTL_E_INVALID, "scheme mask has %d entries for %d poses", n_mask,
+                          n_poses);
+  if (max_depth <= 0) max_depth = 63;
+  uint32_t* small = ctx->small.as<uint32_t>();
+
+  bool all_scheme = true;
+  if (scheme_mask && !keep_scheme)
+    for (int p = 0; p < n_poses; ++p) all_scheme = all_scheme && scheme_mask[p];
+
+  // ---- reset the scalar block -------------------------------------------------------------
+  {
+    uint32_t init[32];
+    std::memset(init, 0, sizeof(init));
+    int* bb = reinterpret_cast<int*>(init + SM_BBOX);
+    bb[0] = bb[1] = bb[2] = 1 << 30;
+    bb[3] = bb[4] = bb[5] = -(1 << 30);
+    std::memcpy(ctx->small_host, init, sizeof(init));
+    HIP_TRY(ctx, hipMemcpyAsync(small, ctx->small_host, sizeof(init), hipMemcpyHostToDevice, st));
+  }
+
+  // ---- pose offsets / scheme mask on the device ----------------------------------------------
+  OCTL_TRY(devbuf_reserve(ctx, f->pose_off_dev, (size_t)(n_poses + 1) * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(f->pose_off_dev.p, f->pose_off.data(), (size_t)(n_poses + 1) * 8,
+                              hipMemcpyHostToDevice, st));
+  const uint8_t* scheme_dev = nullptr;
+  if (!all_scheme) {
+    OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)n_poses));
+    HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, scheme_mask, (size_t)n_poses,
+                                hipMemcpyHostToDevice, st));
+    scheme_dev = f->scheme_dev.as<uint8_t>();
+  }
+  // the H2D copies above read pageable host memory: complete them before it can change
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+
+  // ---- 1. keys -----------------------------------------------------------------------------------
+  const int64_t n_alive = f->n_alive;
+  if (N > 0) {
+    OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));
+    OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 8));
+    KTimer t(ctx, "keygen");
+    hipLaunchKernelGGL(k_keygen, dim3(grid_for(N)), dim3(256), 0, st, f->xyz.as<double>(),
+                       f->alive.as<uint8_t>(), N, f->mode, f->edge, f->corner[0], f->corner[1],
+                       f->corner[2], f->vkey.as<uint64_t>(), f->path.as<uint64_t>(), small);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  uint32_t sm[32];
+  OCTL_TRY(read_small(ctx, 0, 32, sm));
+  if (sm[SM_ERR])
+    return octl_set_error(ctx, OCTL_E_DOMAIN,
+                          "a point has a non-finite coordinate or a top-level voxel index "
+                          "outside +-%d", OCTL_VOX_BIAS);
+  int bb[6];
+  std::memcpy(bb, sm + SM_BBOX, sizeof(bb));
+  // the voxels of the previous scheme persist even when they have lost all their points
+  for (uint64_t k : f->vkeys) {
+    int64_t q[3];
+    vkey_decode(k, q);
+    for (int a = 0; a < 3; ++a) {
+      bb[a] = std::min<int>(bb[a], (int)q[a]);
+      bb[3 + a] = std::max<int>(bb[3 + a], (int)q[a]);
+    }
+  }
+  const bool any_voxel = bb[0] <= bb[3];
+  const uint64_t nx = any_voxel ? (uint64_t)(bb[3] - bb[0] + 1) : 1;
+  const uint64_t ny = any_voxel ? (uint64_t)(bb[4] - bb[1] + 1) : 1;
+  const uint64_t nz = any_voxel ? (uint64_t)(bb[5] - bb[2] + 1) : 1;
+  if (!any_voxel) bb[0] = bb[1] = bb[2] = 0;
+  const uint64_t dead_lin = nx * ny * nz;  // < 2^63
+  const int key_bits = bits_for(dead_lin);
+  auto lin_of = [&](uint64_t k) {
+    int64_t q[3];
+    vkey_decode(k, q);
+    return ((uint64_t)(q[0] - bb[0]) * ny + (uint64_t)(q[1] - bb[1])) * nz + (uint64_t)(q[2] - bb[2]);
+  };
+  auto vkey_of_lin = [&](uint64_t l) {
+    const uint64_t qz = l % nz, qy = (l / nz) % ny, qx = l / (nz * ny);
+    return ((uint64_t)((int64_t)qx + bb[0] + OCTL_VOX_BIAS) << 42) |
+           ((uint64_t)((int64_t)qy + bb[1] + OCTL_VOX_BIAS) << 21) |
+           (uint64_t)((int64_t)qz + bb[2] + OCTL_VOX_BIAS);
+  };
+
+  // ---- 2. sort by top-level voxel ---------------------------------------------------------------
+  int sorted = 0;
+  if (N > 0) {
+    for (int b = 0; b < 2; ++b) {
+      OCTL_TRY(devbuf_reserve(ctx, f->lin[b], (size_t)N * 8));
+      OCTL_TRY(devbuf_reserve(ctx, f->val[b], (size_t)N * 4));
+    }
+    {
+      KTimer t(ctx, "linkey");
+      hipLaunchKernelGGL(k_linkey, dim3(grid_for(N)), dim3(256), 0, st, f->vkey.as<uint64_t>(), N,
+                         bb[0], bb[1], bb[2], ny, nz, dead_lin, f->pose_off_dev.as<int64_t>(),
+                         n_poses, scheme_dev, f->lin[0].as<uint64_t>(), f->val[0].as<uint32_t>());
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    uint64_t* keys[2] = {f->lin[0].as<uint64_t>(), f->lin[1].as<uint64_t>()};
+    uint32_t* vals[2] = {f->val[0].as<uint32_t>(), f->val[1].as<uint32_t>()};
+    // a single voxel and no dead points: already "sorted"
+    if (!(dead_lin == 1 && n_alive == N))
+      OCTL_TRY(octl_radix_sort_u64_u32(ctx, keys, vals, N, key_bits, f->hist, &sorted));
+  }
+  const uint64_t* lin_sorted = f->lin[sorted].as<uint64_t>();
+  const uint32_t* val_sorted = f->val[sorted].as<uint32_t>();
+
+  // ---- 3. roots ------------------------------------------------------------------------------------
+  OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_alive, 8) + 8) * 4));
+  uint32_t* flags = f->flags.as<uint32_t>();
+  int64_t v_pts = 0;
+  std::vector<uint64_t> vlin_h;
+  std::vector<uint32_t> vstart_h;
+  if (n_alive > 0) {
+    KTimer t(ctx, "roots");
+    hipLaunchKernelGGL(k_heads, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted, n_alive,
+                       flags);
+    HIP_TRY(ctx, hipGetLastError());
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_alive, small + SM_NVOX));
+    uint32_t nv;
+    OCTL_TRY(read_small(ctx, SM_NVOX, 1, &nv));
+    v_pts = nv;
+    // lin[1-sorted] / val[1-sorted] are free now: reuse them as staging for the voxel table
+    uint64_t* vlin_d = f->lin[sorted ^ 1].as<uint64_t>();
+    uint32_t* vstart_d = f->val[sorted ^ 1].as<uint32_t>();
+    hipLaunchKernelGGL(k_voxel_collect, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted,
+                       (const uint32_t*)flags, n_alive, vlin_d, vstart_d);
+    HIP_TRY(ctx, hipGetLastError());
+    vlin_h.resize(v_pts);
+    vstart_h.resize(v_pts);
+    HIP_TRY(ctx, hipMemcpyAsync(vlin_h.data(), vlin_d, (size_t)v_pts * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(vstart_h.data(), vstart_d, (size_t)v_pts * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+  // union with the voxels of the previous scheme (both lists are sorted by lin: the packed key
+  // order and the lin order are both the lexicographic (x,y,z) order)
+  std::vector<uint64_t> new_vkeys;
+  std::vector<uint32_t> r_start, r_count;
+  std::vector<int32_t> r_old, local2root(std::max<int64_t>(v_pts, 1));
+  {
+    size_t a = 0, b = 0;
+    const size_t na = (size_t)v_pts, nb_old = f->vkeys.size();
+    while (a < na || b < nb_old) {
+      const uint64_t la = (a < na) ? vlin_h[a] : ~0ull;
+      const uint64_t lb = (b < nb_old) ? lin_of(f->vkeys[b]) : ~0ull;
+      const uint64_t l = std::min(la, lb);
+      const int32_t root = (int32_t)new_vkeys.size();
+      new_vkeys.push_back(vkey_of_lin(l));
+      if (la == l) {
+        const uint32_t s = vstart_h[a];
+        const uint32_t e = (a + 1 < na) ? vstart_h[a + 1] : (uint32_t)n_alive;
+        r_start.push_back(s);
+        r_count.push_back(e - s);
+        local2root[a] = root;
+        ++a;
+      } else {
+        r_start.push_back(0);
+        r_count.push_back(0);
+      }
+      if (lb == l) {
+        r_old.push_back((int32_t)b);  // old roots are nodes [0, V_old) in voxel order
+        ++b;
+      } else {
+        r_old.push_back(-1);
+      }
+    }
+    if (f->mode == 1 && new_vkeys.empty()) {  // a cube without points still has its root
+      new_vkeys.push_back(((uint64_t)OCTL_VOX_BIAS << 42) | ((uint64_t)OCTL_VOX_BIAS << 21) |
+                          (uint64_t)OCTL_VOX_BIAS);
+      r_start.push_back(0);
+      r_count.push_back(0);
+      r_old.push_back(f->built ? 0 : -1);
+    }
+  }
+  const int64_t V = (int64_t)new_vkeys.size();
+  NodeTable& nt = f->nodes[f->cur ^ 1];
+  NodeTable& old = f->nodes[f->cur];
+  const bool have_old = f->built;
+  OCTL_TRY(nodes_reserve(ctx, nt, std::max<int64_t>(V, 1)));
+  nt.n = V;
+  NodePtrs nd = node_ptrs(nt);
+  const int32_t* old_fc = have_old ? old.first_child.as<int32_t>() : nullptr;
+  const int32_t* old_epoch = have_old ? old.epoch.as<int32_t>() : nullptr;
+  if (V > 0) {
+    // one staging upload: [start | count | old | voxel | depth0 | parent-1 | fc-1 | epoch0 | corner | edge]
+    std::vector<int32_t> i32((size_t)V);
+    std::vector<double> cor((size_t)V * 3), edg((size_t)V, f->edge);
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    HIP_TRY(ctx, up(nd.start, r_start.data(), (size_t)V * 4));
+    HIP_TRY(ctx, up(nd.count, r_count.data(), (size_t)V * 4));
+    HIP_TRY(ctx, up(nd.old_id, r_old.data(), (size_t)V * 4));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int64_t v = 0; v < V; ++v) i32[v] = (int32_t)v;
+    HIP_TRY(ctx, up(nd.voxel, i32.data(), (size_t)V * 4));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipMemsetAsync(nd.depth, 0, (size_t)V * 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(nd.epoch, 0, (size_t)V * 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(nd.parent, 0xFF, (size_t)V * 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(nd.first_child, 0xFF, (size_t)V * 4, st));
+    for (int64_t v = 0; v < V; ++v) {
+      if (f->mode == 0) {
+        int64_t q[3];
+        vkey_decode(new_vkeys[v], q);
+        // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
+        for (int a = 0; a < 3; ++a) cor[3 * v + a] = (double)(int64_t)((double)q[a] * f->edge);
+      } else {
+        for (int a = 0; a < 3; ++a) cor[3 * v + a] = f->corner[a];
+      }
+    }
+    HIP_TRY(ctx, up(nd.corner, cor.data(), (size_t)V * 24));
+    HIP_TRY(ctx, up(nd.edge, edg.data(), (size_t)V * 8));
+    if (all_scheme || keep_scheme) {
+      HIP_TRY(ctx, up(nd.scount, r_count.data(), (size_t)V * 4));
+    } else {
+      HIP_TRY(ctx, hipMemsetAsync(nd.scount, 0, (size_t)V * 4, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+
+  // ---- 4. level-0 buffers ---------------------------------------------------------------------------
+  for (int b = 0; b < 2; ++b) {
+    OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 4));
+    OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 8));
+  }
+  OCTL_TRY(devbuf_reserve(ctx, f->pos_node, (size_t)std::max<int64_t>(n_alive, 1) * 4));
+  int32_t* pos_node = f->pos_node.as<int32_t>();
+  if (n_alive > 0) {
+    OCTL_TRY(devbuf_reserve(ctx, f->root_up, (size_t)v_pts * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(f->root_up.p, local2root.data(), (size_t)v_pts * 4,
+                                hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    KTimer t(ctx, "init_level0");
+    hipLaunchKernelGGL(k_init_level0, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted,
+                       (const uint32_t*)flags, val_sorted, (const uint64_t*)f->path.as<uint64_t>(),
+                       n_alive, (const int32_t*)f->root_up.as<int32_t>(), pos_node,
+                       f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint64_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    if (!all_scheme && !keep_scheme) {
+      hipLaunchKernelGGL(k_count_scheme, dim3((unsigned)ceil_div(n_alive, 2048)), dim3(256), 0, st,
+                         (const int32_t*)pos_node, (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
+                         n_alive, nd.scount);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
+
+  // ---- 5. level loop ----------------------------------------------------------------------------------
+  int64_t first_new = 0, n_new = V, n_internal = 0;
+  int level = 0;
+  std::vector<int64_t> level_first{0, V};
+  const int cur_epoch = f->epoch + (keep_scheme ? 0 : 1);
+  while (n_new > 0) {
+    // split list of the freshly created nodes
+    OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_new, n_alive) + 8) * 4));
+    flags = f->flags.as<uint32_t>();
+    for (int b = 0; b < 2; ++b) {
+      OCTL_TRY(devbuf_reserve(ctx, f->split[b], (size_t)(n_new + 8) * 4));
+      OCTL_TRY(devbuf_reserve(ctx, f->split_tiles[b], (size_t)(n_new + 8) * 4));
+    }
+    int32_t* split_nodes = f->split[0].as<int32_t>();
+    uint32_t* tile_base = f->split_tiles[0].as<uint32_t>();
+    {
+      KTimer t(ctx, "level_prepare");
+      hipLaunchKernelGGL(k_split_flags, dim3(grid_for(n_new)), dim3(256), 0, st, nd, first_new,
+                         n_new, (int)keep_scheme, K, old_fc, flags);
+      HIP_TRY(ctx, hipGetLastError());
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_new, small + SM_NSPLIT));
+      hipLaunchKernelGGL(k_compact_split, dim3(grid_for(n_new)), dim3(256), 0, st, nd, first_new,
+                         n_new, (const uint32_t*)flags, (int)keep_scheme, K, old_fc, split_nodes,
+                         tile_base);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    uint32_t ns_u;
+    OCTL_TRY(read_small(ctx, SM_NSPLIT, 1, &ns_u));
+    const int ns = (int)ns_u;
+    if (ns == 0) break;
+    if (level >= max_depth)
+      return octl_set_error(ctx, OCTL_E_DEPTH,
+                            "maximum depth %d exceeded (duplicate points with a count criterion "
+                            "never stop subdividing)", max_depth);
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_base, tile_base, ns, small + SM_NTILES));
+    uint32_t n_tiles;
+    OCTL_TRY(read_small(ctx, SM_NTILES, 1, &n_tiles));
+
+    const int64_t child_base = nt.n;
+    if (child_base + 8 * (int64_t)ns >= ((int64_t)1 << 31))
+      return octl_set_error(ctx, OCTL_E_NOMEM, "more than 2^31 scheme nodes");
+    OCTL_TRY(nodes_reserve(ctx, nt, child_base + 8 * (int64_t)ns));
+    nd = node_ptrs(nt);
+    if (!all_scheme && !keep_scheme) {
+      OCTL_TRY(devbuf_reserve(ctx, f->child_sc, (size_t)8 * ns * 4));
+      HIP_TRY(ctx, hipMemsetAsync(f->child_sc.p, 0, (size_t)8 * ns * 4, st));
+    }
+    const int src = level & 1;
+    const int shift = 61 - 3 * (level % PATH_LEVELS);
+    uint32_t* entries = nullptr;
+    if (n_tiles > 0) {
+      OCTL_TRY(devbuf_reserve(ctx, f->entries, ((size_t)8 * n_tiles + 8) * 4));
+      entries = f->entries.as<uint32_t>();
+      if (level > 0 && level % PATH_LEVELS == 0) {
+        KTimer t(ctx, "level_rekey");
+        hipLaunchKernelGGL(k_lv_rekey, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                           (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
+                           (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                           f->pathbuf[src].as<uint64_t>(), (const double*)f->xyz.as<double>());
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      {
+        KTimer t(ctx, "level_hist");
+        if (!all_scheme && !keep_scheme)
+          hipLaunchKernelGGL(k_lv_hist<true>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                             (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
+                             nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                             (const double*)f->xyz.as<double>(), shift, entries,
+                             f->child_sc.as<uint32_t>(), small);
+        else
+          hipLaunchKernelGGL(k_lv_hist<false>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                             (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
+                             nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                             (const double*)f->xyz.as<double>(), shift, entries,
+                             (uint32_t*)nullptr, small);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      {
+        KTimer t(ctx, "level_scan");
+        OCTL_TRY(octl_exclusive_scan_u32(ctx, entries, entries, (int64_t)8 * n_tiles,
+                                         small + SM_ETOTAL));
+      }
+      {
+        KTimer t(ctx, "level_scatter");
+        hipLaunchKernelGGL(k_lv_scatter, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                           (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
+                           (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                           (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                           (const double*)f->xyz.as<double>(), shift, (const uint32_t*)entries,
+                           (int32_t)child_base, f->idxbuf[src ^ 1].as<uint32_t>(),
+                           f->pathbuf[src ^ 1].as<uint64_t>(), pos_node, small);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+    }
+    {
+      KTimer t(ctx, "level_children");
+      hipLaunchKernelGGL(k_make_children, dim3(grid_for((int64_t)8 * ns)), dim3(256), 0, st,
+                         (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
+                         (const uint32_t*)entries, (const uint32_t*)small,
+                         (const uint32_t*)f->child_sc.as<uint32_t>(),
+                         (int)(all_scheme || keep_scheme), (int32_t)child_base, (int)keep_scheme,
+                         cur_epoch, old_fc, old_epoch);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    nt.n = child_base + 8 * (int64_t)ns;
+    level_first.push_back(nt.n);
+    first_new = child_base;
+    n_new = 8 * (int64_t)ns;
+    n_internal += ns;
+    ++level;
+  }
+  {
+    uint32_t e;
+    OCTL_TRY(read_small(ctx, SM_ERR, 1, &e));
+    if (e)
+      return octl_set_error(ctx, OCTL_E_DOMAIN,
+                            "a point lies outside the cube of a node that is being subdivided "
+                            "(the reference raises IndexError or picks a wrong child here)");
+  }
+
+  // ---- 6. leaf-ordered arrays and the block table ------------------------------------------------------
+  int64_t n_blocks = 0;
+  if (n_alive > 0) {
+    OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_alive * 4));
+    OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, (size_t)n_alive * 24));
+    {
+      KTimer t(ctx, "finalize");
+      hipLaunchKernelGGL(k_finalize, dim3(grid_for(n_alive)), dim3(256), 0, st,
+                         (const int32_t*)pos_node, (const int32_t*)nd.depth,
+                         (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
+                         (const uint32_t*)f->idxbuf[1].as<uint32_t>(),
+                         (const double*)f->xyz.as<double>(), n_alive, f->ord_idx.as<uint32_t>(),
+                         f->xyz_ord.as<double>());
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    f->n_ord = n_alive;
+    OCTL_TRY(forest_make_blocks(f));
+    n_blocks = f->n_blocks;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+
+  // ---- commit --------------------------------------------------------------------------------------------
+  f->cur ^= 1;
+  f->vkeys.swap(new_vkeys);
+  f->level_first.swap(level_first);
+  f->built = true;
+  f->epoch = cur_epoch;
+  f->n_ord = n_alive;
+  f->n_blocks = n_blocks;
+  f->n_internal = n_internal;
+  f->max_depth_reached = level;
+  f->mask_valid = false;
+  f->store_dirty = false;
+  if (info) {
+    info->n_points = n_alive;
+    info->n_voxels = V;
+    info->n_nodes = nt.n;
+    info->n_internal = n_internal;
+    info->n_blocks = n_blocks;
+    info->max_depth = level;
+    info->n_levels = level;
+  }
+  return OCTL_OK;
+}

@@ -1,0 +1,98 @@
+// Shared host-side infrastructure of liboctree_hip.so: context, device buffers, error
+// plumbing, per-kernel hipEvent timers.  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/octreelib_hip.h"
+
+#define OCTL_WAVE 64
+
+struct KernelTiming {
+  double ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct PendingEvent {
+  std::string name;
+  hipEvent_t start, stop;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct octl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  std::map<std::string, KernelTiming> timings;
+  std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+  // scratch for scans / sorts (grown on demand, reused across calls)
+  DevBuf scan_tmp[3];
+  DevBuf small;     // 4 KiB of device scalars (counters, flags)
+  void* small_host = nullptr;  // pinned mirror
+  // RCCL (route.hip)
+  void* comm = nullptr;
+  int n_ranks = 1, rank = 0;
+  // routed cloud of the last octl_route_points
+  DevBuf routed_xyz, routed_gidx;
+  int64_t routed_n = 0;
+};
+
+int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                 \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return octl_set_error((ctx), OCTL_E_HIP, "%s failed: %s (%s:%d)", #expr,             \
+                            hipGetErrorString(_e), __FILE__, __LINE__);                    \
+  } while (0)
+
+#define OCTL_TRY(expr)        \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != OCTL_OK) return _r; \
+  } while (0)
+
+// grow-only device buffer; contents are NOT preserved unless keep != 0
+int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep = 0);
+void devbuf_free(DevBuf& b);
+
+// RAII timer: records hipEvents around the launches in its scope when profiling is on
+struct KTimer {
+  octl_ctx* ctx;
+  int idx = -1;
+  KTimer(octl_ctx* c, const char* name);
+  ~KTimer();
+};
+// fold the pending event pairs into ctx->timings (synchronises the stream)
+int octl_collect_timings(octl_ctx* ctx);
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device-wide primitives (scan.hip, radix_sort.hip) ------------------------------------
+// exclusive prefix sum of n uint32 (in may equal out); if total_dev != nullptr the grand total
+// (uint32) is written there.  n up to 2^31.
+int octl_exclusive_scan_u32(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n,
+                            uint32_t* total_dev);
+// stable LSD radix sort of (key u64, value u32) pairs on bits [0, key_bits).  keys[0]/vals[0]
+// hold the input; keys[1]/vals[1] are ping-pong space of the same size.  *result (0 or 1)
+// tells which pair of buffers holds the sorted output.
+int octl_radix_sort_u64_u32(octl_ctx* ctx, uint64_t* keys[2], uint32_t* vals[2], int64_t n,
+                            int key_bits, DevBuf& hist_scratch, int* result);

@@ -1,0 +1,240 @@
+// Context, error plumbing, device buffers, kernel timers, small device utilities.
+#include <cstdarg>
+
+#include "common.h"
+
+int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
+  if (bytes <= b.cap) return OCTL_OK;
+  size_t want = bytes + bytes / 4 + 256;  // grow with slack so level loops rarely realloc
+  void* np = nullptr;
+  hipError_t e = hipMalloc(&np, want);
+  if (e != hipSuccess)
+    return octl_set_error(ctx, OCTL_E_NOMEM, "hipMalloc(%zu) failed: %s", want,
+                          hipGetErrorString(e));
+  if (keep && b.p && b.cap) {
+    e = hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(np);
+      return octl_set_error(ctx, OCTL_E_HIP, "devbuf copy failed: %s", hipGetErrorString(e));
+    }
+  } else if (b.p) {
+    // the old block may still be referenced by queued kernels
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (b.p) (void)hipFree(b.p);
+  b.p = np;
+  b.cap = want;
+  return OCTL_OK;
+}
+
+void devbuf_free(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+KTimer::KTimer(octl_ctx* c, const char* name) : ctx(c) {
+  if (!ctx->profiling) return;
+  PendingEvent pe;
+  pe.name = name;
+  for (hipEvent_t* ev : {&pe.start, &pe.stop}) {
+    if (!ctx->event_pool.empty()) {
+      *ev = ctx->event_pool.back();
+      ctx->event_pool.pop_back();
+    } else if (hipEventCreate(ev) != hipSuccess) {
+      return;
+    }
+  }
+  (void)hipEventRecord(pe.start, ctx->stream);
+  idx = (int)ctx->pending.size();
+  ctx->pending.push_back(pe);
+}
+
+KTimer::~KTimer() {
+  if (idx >= 0) (void)hipEventRecord(ctx->pending[idx].stop, ctx->stream);
+}
+
+int octl_collect_timings(octl_ctx* ctx) {
+  if (ctx->pending.empty()) return OCTL_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& pe : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+      auto& t = ctx->timings[pe.name];
+      t.ms += ms;
+      t.launches += 1;
+    }
+    ctx->event_pool.push_back(pe.start);
+    ctx->event_pool.push_back(pe.stop);
+  }
+  ctx->pending.clear();
+  return OCTL_OK;
+}
+
+extern "C" {
+
+int octl_abi_version(void) { return OCTL_ABI_VERSION; }
+
+int octl_device_count(int* count) {
+  if (!count) return OCTL_E_INVALID;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *count = (e == hipSuccess) ? n : 0;
+  return e == hipSuccess ? OCTL_OK : OCTL_E_HIP;
+}
+
+int octl_ctx_create(int device_id, octl_ctx** out) {
+  if (!out) return OCTL_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n)
+    return OCTL_E_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return OCTL_E_HIP;
+  octl_ctx* ctx = new octl_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return OCTL_E_HIP;
+  }
+  if (hipMalloc(&ctx->small.p, 4096) != hipSuccess ||
+      hipHostMalloc(&ctx->small_host, 4096, hipHostMallocDefault) != hipSuccess) {
+    if (ctx->small.p) (void)hipFree(ctx->small.p);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return OCTL_E_NOMEM;
+  }
+  ctx->small.cap = 4096;
+  (void)hipMemsetAsync(ctx->small.p, 0, 4096, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  *out = ctx;
+  return OCTL_OK;
+}
+
+int octl_comm_destroy(octl_ctx* ctx);
+
+void octl_ctx_destroy(octl_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm) (void)octl_comm_destroy(ctx);
+  for (auto& pe : ctx->pending) {
+    (void)hipEventDestroy(pe.start);
+    (void)hipEventDestroy(pe.stop);
+  }
+  for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+  for (auto& b : ctx->scan_tmp) devbuf_free(b);
+  devbuf_free(ctx->small);
+  devbuf_free(ctx->routed_xyz);
+  devbuf_free(ctx->routed_gidx);
+  if (ctx->small_host) (void)hipHostFree(ctx->small_host);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* octl_last_error(const octl_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int octl_ctx_sync(octl_ctx* ctx) {
+  if (!ctx) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+int octl_ctx_set_profiling(octl_ctx* ctx, int enabled) {
+  if (!ctx) return OCTL_E_INVALID;
+  OCTL_TRY(octl_collect_timings(ctx));
+  ctx->profiling = enabled != 0;
+  ctx->timings.clear();
+  return OCTL_OK;
+}
+
+int octl_ctx_get_timings(octl_ctx* ctx, char* names, int name_stride, float* ms,
+                         int64_t* launches, int cap, int* n) {
+  if (!ctx || !n) return OCTL_E_INVALID;
+  OCTL_TRY(octl_collect_timings(ctx));
+  *n = (int)ctx->timings.size();
+  int i = 0;
+  for (auto& kv : ctx->timings) {
+    if (i >= cap) break;
+    if (names && name_stride > 0) {
+      std::snprintf(names + (size_t)i * name_stride, name_stride, "%s", kv.first.c_str());
+    }
+    if (ms) ms[i] = (float)kv.second.ms;
+    if (launches) launches[i] = kv.second.launches;
+    ++i;
+  }
+  return OCTL_OK;
+}
+
+int octl_dev_alloc(octl_ctx* ctx, int64_t bytes, void** dptr) {
+  if (!ctx || !dptr || bytes < 0) return OCTL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 1));
+  if (e != hipSuccess)
+    return octl_set_error(ctx, OCTL_E_NOMEM, "hipMalloc(%lld) failed: %s", (long long)bytes,
+                          hipGetErrorString(e));
+  return OCTL_OK;
+}
+
+int octl_dev_free(octl_ctx* ctx, void* dptr) {
+  if (!ctx) return OCTL_E_INVALID;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (dptr) HIP_TRY(ctx, hipFree(dptr));
+  return OCTL_OK;
+}
+
+int octl_dev_upload(octl_ctx* ctx, void* dptr, const void* src, int64_t bytes) {
+  if (!ctx || (bytes > 0 && (!dptr || !src))) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipMemcpyAsync(dptr, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+int octl_dev_download(octl_ctx* ctx, void* dst, const void* dptr, int64_t bytes) {
+  if (!ctx || (bytes > 0 && (!dptr || !dst))) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipMemcpyAsync(dst, dptr, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+int octl_dev_copy_bandwidth(octl_ctx* ctx, int64_t bytes, int iters, double* bytes_per_s) {
+  if (!ctx || !bytes_per_s || bytes <= 0 || iters <= 0) return OCTL_E_INVALID;
+  void *a = nullptr, *b = nullptr;
+  HIP_TRY(ctx, hipMalloc(&a, (size_t)bytes));
+  if (hipMalloc(&b, (size_t)bytes) != hipSuccess) {
+    (void)hipFree(a);
+    return octl_set_error(ctx, OCTL_E_NOMEM, "hipMalloc failed");
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipMemsetAsync(a, 1, (size_t)bytes, ctx->stream);
+  (void)hipMemcpyAsync(b, a, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  (void)hipEventRecord(e0, ctx->stream);
+  for (int i = 0; i < iters; ++i)
+    (void)hipMemcpyAsync(b, a, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  (void)hipEventRecord(e1, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(a);
+  (void)hipFree(b);
+  if (e != hipSuccess) return octl_set_error(ctx, OCTL_E_HIP, "copy failed");
+  // a copy reads and writes every byte
+  *bytes_per_s = 2.0 * (double)bytes * iters / (ms * 1e-3);
+  return OCTL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+// Device-resident state of one Grid / OctreeManager / Octree ("forest" of top-level cubes).
+#pragma once
+#include "common.h"
+
+// Structure-of-arrays scheme node table on the device.
+struct NodeTable {
+  DevBuf start, count, scount;  // u32: range in the level buffers, scheme-pose point count
+  DevBuf depth, voxel, parent, first_child, old_id, epoch;  // i32
+  DevBuf corner, edge;          // f64 x3, f64
+  int64_t cap = 0, n = 0;
+};
+
+struct octl_forest {
+  octl_ctx* ctx = nullptr;
+  int mode = 0;  // 0 grid, 1 single cube
+  double corner[3] = {0, 0, 0};
+  double edge = 1.0;
+
+  // point store: all poses concatenated in slot order (pose-major), insertion order inside
+  DevBuf xyz;     // f64 [n_store][3]
+  DevBuf alive;   // u8  [n_store]
+  std::vector<int64_t> pose_off{0};  // [P+1] offsets into the store
+  int64_t n_store = 0, n_alive = 0;
+  bool store_dirty = true;  // points were added/removed since the last build
+
+  // scheme of the last build
+  NodeTable nodes[2];
+  int cur = 0;               // nodes[cur] is the current table
+  int epoch = 0;             // number of K-driven builds so far
+  bool built = false;
+  std::vector<uint64_t> vkeys;  // packed integer coordinates of the top-level voxels, sorted
+  int64_t n_internal = 0;
+  int32_t max_depth_reached = 0;
+
+  // leaf-ordered arrays of the last build
+  DevBuf ord_idx;    // u32 [n_ord] store index of the point at storage position i
+  DevBuf xyz_ord;    // f64 [n_ord][3]
+  DevBuf pos_node;   // i32 [n_ord] scheme leaf of position i
+  int64_t n_ord = 0;
+  // non-empty (leaf, pose) blocks in storage order
+  DevBuf blk_node, blk_slot, blk_start, blk_size;  // i32, i32, u32, i32
+  int64_t n_blocks = 0;
+  // RANSAC state
+  DevBuf mask;       // u8 [n_ord]
+  DevBuf blk_eval;   // u8 [n_blocks] block was evaluated since the last apply_mask
+  bool mask_valid = false;
+
+  DevBuf rs_scratch, rs_order, rs_hyp, rs_plane, rs_count, rs_index;  // ransac staging
+  DevBuf ord_idx2, xyz_ord2, pos_node2;  // compaction targets (swapped with the live arrays)
+  std::vector<int64_t> level_first;      // node id of the first node of every level (+ end)
+
+  // build scratch (kept between builds to avoid re-allocation)
+  DevBuf vkey, path, lin[2], val[2], hist, idxbuf[2], pathbuf[2], flags, entries, split[2],
+      split_tiles[2], child_sc, pose_off_dev, scheme_dev, root_up;
+};
+
+// packed voxel key: (qx+B)<<42 | (qy+B)<<21 | (qz+B), B = 2^20; lexicographic (x,y,z) order of
+// the integer voxel coordinates == numeric order of the key (np.unique(axis=0) order,
+// grid/grid.py:79-81)
+#define OCTL_VOX_BIAS (1 << 20)
+#define OCTL_VOX_DEAD (~0ull)
+static inline void vkey_decode(uint64_t k, int64_t q[3]) {
+  q[0] = (int64_t)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS;
+  q[1] = (int64_t)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS;
+  q[2] = (int64_t)(k & 0x1FFFFF) - OCTL_VOX_BIAS;
+}
+
+int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
+                 int32_t keep_scheme, int32_t max_depth, octl_build_info* info);
+int nodes_reserve(octl_ctx* ctx, NodeTable& t, int64_t cap);
+void nodes_free(NodeTable& t);
+
+// ransac.hip
+int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
+                  const uint32_t* blk_start, const int32_t* blk_size, const int32_t* order_dev,
+                  int64_t nb, const double* hyp_dev, int32_t H, int32_t k, double thr,
+                  uint8_t* mask_dev, float* plane_dev, int32_t* count_dev, int32_t* index_dev,
+                  uint8_t* evaluated_dev, DevBuf& scratch);
+// build.hip: (re)build the (leaf, pose) block table from pos_node / ord_idx
+int forest_make_blocks(octl_forest* f);

@@ -1,0 +1,249 @@
+// Device-side computation of the order in which the reference concatenates the leaves of a
+// batch of poses before the RANSAC kernel (Grid.map_leaf_points_cuda_ransac, grid/grid.py:
+// 173-191): for pose in batch; for top-level voxel in lexicographic order (grid.py:79-81,108);
+// for leaf in the octree's cached-leaf list, non-empty only (octree.py:256-263).
+//
+// The cached-leaf list (octree_base.py:152-158) is history dependent: a node that is split is
+// removed and its 8 children are appended (octree.py:183-191), and splits happen in DFS
+// preorder within one subdivide / subdivide_as call (octree.py:20-53).  Hence a leaf sorts by
+//     ( effective epoch of its parent, DFS-preorder rank of its parent, child index )
+// where the effective epoch of a parent for a pose tree created at epoch e0 is
+// max(epoch(parent), e0).  Everything is computed from the scheme node table:
+//   1. bottom-up: internal nodes per subtree; 2. top-down: global preorder rank of every
+//   internal node (voxel-major); 3. one key per (leaf, pose) block; 4. two stable radix sorts.
+#include "forest.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_sub_up(const int32_t* __restrict__ first_child,
+                                                int64_t a, int64_t b,
+                                                uint32_t* __restrict__ nint) {
+  const int64_t x = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= b) return;
+  const int32_t fc = first_child[x];
+  uint32_t s = 0;
+  if (fc >= 0) {
+    s = 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += nint[fc + j];
+  }
+  nint[x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_rank_down(const int32_t* __restrict__ first_child,
+                                                   int64_t a, int64_t b,
+                                                   const uint32_t* __restrict__ nint,
+                                                   uint32_t* __restrict__ rank) {
+  const int64_t x = a + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= b) return;
+  const int32_t fc = first_child[x];
+  if (fc < 0) return;
+  uint32_t r = rank[x] + 1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    rank[fc + j] = r;  // meaningful only for internal children
+    r += nint[fc + j];
+  }
+}
+
+// key1 = rank(parent) * 8 + child index (0 for a root leaf); key2 = (slot * V + voxel) << ebits
+// | effective epoch.  val = block id.
+__global__ __launch_bounds__(256) void k_block_keys(
+    const int32_t* __restrict__ blk_node, const int32_t* __restrict__ blk_slot, int64_t nb,
+    const int32_t* __restrict__ parent, const int32_t* __restrict__ first_child,
+    const int32_t* __restrict__ voxel, const int32_t* __restrict__ epoch,
+    const uint32_t* __restrict__ rank, const int32_t* __restrict__ e0, uint64_t V, int ebits,
+    uint64_t* __restrict__ key1, uint64_t* __restrict__ key2, uint32_t* __restrict__ val) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const int32_t l = blk_node[b], p = parent[l], s = blk_slot[b];
+  uint64_t k1 = 0, ee = 0;
+  if (p >= 0) {
+    k1 = (uint64_t)rank[p] * 8u + (uint64_t)(l - first_child[p]);
+    const int32_t ep = epoch[p], es = e0 ? e0[s] : 0;
+    ee = (uint64_t)(ep > es ? ep : es);
+  }
+  key1[b] = k1;
+  key2[b] = (((uint64_t)s * V + (uint64_t)voxel[l]) << ebits) | ee;
+  val[b] = (uint32_t)b;
+}
+
+__global__ __launch_bounds__(256) void k_gather_key2(const uint64_t* __restrict__ key2,
+                                                     const uint32_t* __restrict__ val, int64_t nb,
+                                                     uint64_t* __restrict__ out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) out[b] = key2[val[b]];
+}
+
+__global__ __launch_bounds__(256) void k_slot_hist(const int32_t* __restrict__ blk_slot, int64_t nb,
+                                                   uint32_t* __restrict__ hist) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) atomicAdd(&hist[blk_slot[b]], 1u);
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
+int bits_for(uint64_t max_value) {
+  int b = 0;
+  while (b < 64 && (max_value >> b) != 0) ++b;
+  return b;
+}
+
+}  // namespace
+
+// Fills f->rs_order (device, int32 per block) with all blocks in the reference's order
+// (slot-major).  e0_host: creation epoch of every pose tree (nullable = 0).  slot_counts_host
+// receives the number of blocks of every slot.
+int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<uint32_t>& slot_counts) {
+  octl_ctx* ctx = f->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t nb = f->n_blocks;
+  const int n_poses = (int)f->pose_off.size() - 1;
+  slot_counts.assign((size_t)std::max(n_poses, 1), 0);
+  if (nb <= 0) return OCTL_OK;
+  NodeTable& t = f->nodes[f->cur];
+  const int64_t V = (int64_t)f->vkeys.size();
+  KTimer timer(ctx, "ransac_order");
+  // scratch layout inside f->entries: [nint u32 n | rank u32 n]
+  const size_t nn = (size_t)t.n;
+  const size_t off_rank = ((nn + 8) * 4 + 15) & ~(size_t)15;
+  OCTL_TRY(devbuf_reserve(ctx, f->entries, off_rank + (nn + 8) * 4));
+  uint32_t* nint = f->entries.as<uint32_t>();
+  uint32_t* rank = reinterpret_cast<uint32_t*>(static_cast<char*>(f->entries.p) + off_rank);
+  const int32_t* fc = t.first_child.as<int32_t>();
+  const int n_levels = (int)f->level_first.size() - 1;  // level L = [level_first[L], level_first[L+1])
+  for (int L = n_levels - 1; L >= 0; --L) {
+    const int64_t a = f->level_first[L], b = f->level_first[L + 1];
+    if (b > a) {
+      hipLaunchKernelGGL(k_sub_up, dim3(grid_for(b - a)), dim3(256), 0, st, fc, a, b, nint);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
+  // roots: global rank base = exclusive scan of the per-voxel internal-node counts
+  OCTL_TRY(octl_exclusive_scan_u32(ctx, nint, rank, V, nullptr));
+  for (int L = 0; L < n_levels - 1; ++L) {
+    const int64_t a = f->level_first[L], b = f->level_first[L + 1];
+    if (b > a) {
+      hipLaunchKernelGGL(k_rank_down, dim3(grid_for(b - a)), dim3(256), 0, st, fc, a, b,
+                         (const uint32_t*)nint, rank);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+  }
+  // keys
+  int max_epoch = f->epoch;
+  const int32_t* e0_dev = nullptr;
+  if (e0_host) {
+    OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)n_poses * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, e0_host, (size_t)n_poses * 4,
+                                hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    e0_dev = f->scheme_dev.as<int32_t>();
+    for (int p = 0; p < n_poses; ++p) max_epoch = std::max(max_epoch, (int)e0_host[p]);
+  }
+  const int ebits = std::max(1, bits_for((uint64_t)max_epoch));
+  const int bits2 = bits_for((uint64_t)n_poses * (uint64_t)V) + ebits;
+  if (bits2 > 63) return octl_set_error(ctx, OCTL_E_INVALID, "order key too wide");
+  const int bits1 = bits_for((uint64_t)f->n_internal * 8u + 7u);
+  for (int b = 0; b < 2; ++b) {
+    OCTL_TRY(devbuf_reserve(ctx, f->lin[b], (size_t)nb * 8));
+    OCTL_TRY(devbuf_reserve(ctx, f->val[b], (size_t)nb * 4));
+  }
+  OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)nb * 8));  // key2 in block order
+  uint64_t* keys[2] = {f->lin[0].as<uint64_t>(), f->lin[1].as<uint64_t>()};
+  uint32_t* vals[2] = {f->val[0].as<uint32_t>(), f->val[1].as<uint32_t>()};
+  uint64_t* key2 = f->vkey.as<uint64_t>();
+  hipLaunchKernelGGL(k_block_keys, dim3(grid_for(nb)), dim3(256), 0, st,
+                     (const int32_t*)f->blk_node.as<int32_t>(),
+                     (const int32_t*)f->blk_slot.as<int32_t>(), nb,
+                     (const int32_t*)t.parent.as<int32_t>(), fc,
+                     (const int32_t*)t.voxel.as<int32_t>(), (const int32_t*)t.epoch.as<int32_t>(),
+                     (const uint32_t*)rank, e0_dev, (uint64_t)V, ebits, keys[0], key2, vals[0]);
+  HIP_TRY(ctx, hipGetLastError());
+  int res = 0;
+  OCTL_TRY(octl_radix_sort_u64_u32(ctx, keys, vals, nb, bits1, f->hist, &res));
+  // second (more significant) key, gathered in the order of the first sort
+  uint64_t* keys_b[2] = {keys[res ^ 1], keys[res]};
+  uint32_t* vals_b[2] = {vals[res], vals[res ^ 1]};
+  hipLaunchKernelGGL(k_gather_key2, dim3(grid_for(nb)), dim3(256), 0, st, (const uint64_t*)key2,
+                     (const uint32_t*)vals[res], nb, keys_b[0]);
+  HIP_TRY(ctx, hipGetLastError());
+  int res2 = 0;
+  OCTL_TRY(octl_radix_sort_u64_u32(ctx, keys_b, vals_b, nb, bits2, f->hist, &res2));
+  OCTL_TRY(devbuf_reserve(ctx, f->rs_order, (size_t)nb * 4));
+  HIP_TRY(ctx, hipMemcpyAsync(f->rs_order.p, vals_b[res2], (size_t)nb * 4,
+                              hipMemcpyDeviceToDevice, st));
+  // blocks per slot
+  uint32_t* hist = ctx->small.as<uint32_t>() + 64;
+  if (n_poses <= 256) {
+    HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)n_poses * 4, st));
+    hipLaunchKernelGGL(k_slot_hist, dim3(grid_for(nb)), dim3(256), 0, st,
+                       (const int32_t*)f->blk_slot.as<int32_t>(), nb, hist);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, hist, (size_t)n_poses * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::memcpy(slot_counts.data(), ctx->small_host, (size_t)n_poses * 4);
+  } else {
+    std::vector<int32_t> slots((size_t)nb);
+    HIP_TRY(ctx, hipMemcpyAsync(slots.data(), f->blk_slot.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (int32_t s : slots) slot_counts[(size_t)s] += 1;
+  }
+  return OCTL_OK;
+}
+
+extern "C" int octl_forest_reference_order(octl_forest* f, const int32_t* e0, int32_t n_e0,
+                                           int64_t cap, int32_t* order, int64_t* n_blocks) {
+  if (!f || !n_blocks) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  const int n_poses = (int)f->pose_off.size() - 1;
+  if (e0 && n_e0 != n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "e0 size mismatch");
+  std::vector<uint32_t> slot_counts;
+  OCTL_TRY(forest_reference_order(f, e0, slot_counts));
+  *n_blocks = f->n_blocks;
+  const int64_t n = std::min<int64_t>(cap, f->n_blocks);
+  if (n > 0 && order) {
+    HIP_TRY(ctx, hipMemcpyAsync(order, f->rs_order.p, (size_t)n * 4, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return OCTL_OK;
+}
+
+extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, const int32_t* e0,
+                                      int32_t n_e0, const double* hypotheses, int32_t H, int32_t k,
+                                      double threshold) {
+  if (!f || !hypotheses) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "ransac before build");
+  if (poses_per_batch < 1) return octl_set_error(ctx, OCTL_E_INVALID, "poses_per_batch < 1");
+  if (H < 1 || H > 1024 || k < 1) return octl_set_error(ctx, OCTL_E_INVALID, "bad H or k");
+  const int n_poses = (int)f->pose_off.size() - 1;
+  if (e0 && n_e0 != n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "e0 size mismatch");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // the mask of unevaluated positions is "keep"
+  if (!f->mask_valid) {
+    OCTL_TRY(devbuf_reserve(ctx, f->mask, (size_t)std::max<int64_t>(f->n_ord, 1)));
+    if (f->n_ord > 0) HIP_TRY(ctx, hipMemsetAsync(f->mask.p, 1, (size_t)f->n_ord, st));
+    f->mask_valid = true;
+  }
+  if (f->n_blocks == 0) return OCTL_OK;
+  OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
+  HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  std::vector<uint32_t> slot_counts;
+  OCTL_TRY(forest_reference_order(f, e0, slot_counts));
+  // one evaluate() per batch of poses_per_batch consecutive poses (grid.py:149-157,194)
+  int64_t off = 0;
+  for (int p0 = 0; p0 < n_poses; p0 += poses_per_batch) {
+    int64_t nbatch = 0;
+    for (int p = p0; p < std::min(n_poses, p0 + poses_per_batch); ++p) nbatch += slot_counts[p];
+    if (nbatch > 0)
+      OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
+                             f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>() + off, nbatch,
+                             f->rs_hyp.as<double>(), H, k, threshold, f->mask.as<uint8_t>(),
+                             nullptr, nullptr, nullptr, nullptr, f->rs_scratch));
+    off += nbatch;
+  }
+  return OCTL_OK;
+}

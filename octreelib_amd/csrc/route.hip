@@ -1,0 +1,351 @@
+// Multi-GPU: shard the Grid by top-level voxel and route every point to the rank that owns its
+// voxel with ONE all-to-all over xGMI (RCCL grouped ncclSend/ncclRecv; RCCL has no alltoallv).
+//
+// The reference has no distributed code at all; what makes the path shard is that
+// every top-level voxel is an independent OctreeManager (grid/grid.py:56,100-109) and
+// Grid.subdivide / RANSAC have no cross-voxel dependency (grid.py:255-258).  All poses of a
+// voxel go to the same rank, so synchronised subdivision stays local.
+//
+// RCCL is resolved with dlopen at communicator creation so the library loads (and the
+// single-GPU path runs) on machines without it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "forest.h"
+#include "ref_arith.h"
+
+namespace {
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+
+const char* rccl_load() {
+  if (g_rccl.handle) return nullptr;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return "librccl.so not found";
+#define RCCL_SYM(field, name)                                   \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+  if (!g_rccl.field) return "missing RCCL symbol " name;
+  RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+  RCCL_SYM(CommInitRank, "ncclCommInitRank")
+  RCCL_SYM(CommDestroy, "ncclCommDestroy")
+  RCCL_SYM(AllGather, "ncclAllGather")
+  RCCL_SYM(AllReduce, "ncclAllReduce")
+  RCCL_SYM(Send, "ncclSend")
+  RCCL_SYM(Recv, "ncclRecv")
+  RCCL_SYM(GroupStart, "ncclGroupStart")
+  RCCL_SYM(GroupEnd, "ncclGroupEnd")
+  RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+  g_rccl.handle = h;
+  return nullptr;
+}
+
+#define NCCL_TRY(ctx, expr)                                                               \
+  do {                                                                                    \
+    ncclResult_t _r = (expr);                                                             \
+    if (_r != ncclSuccess)                                                                \
+      return octl_set_error((ctx), OCTL_E_COMM, "%s failed: %s", #expr,                   \
+                            g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?");     \
+  } while (0)
+
+// destination rank of every point + per-destination counts (LDS histogram per block)
+__global__ __launch_bounds__(256) void k_route_dest(const double* __restrict__ xyz, int64_t n,
+                                                    double L, int n_ranks,
+                                                    uint64_t* __restrict__ dest_key,
+                                                    uint32_t* __restrict__ idx,
+                                                    unsigned long long* __restrict__ counts,
+                                                    uint32_t* __restrict__ err) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    // the same voxel index the local build will compute (build.hip k_keygen, grid.py:72-76)
+    const double fx = floor_div_exact(xyz[3 * i], L), fy = floor_div_exact(xyz[3 * i + 1], L),
+                 fz = floor_div_exact(xyz[3 * i + 2], L);
+    const double lim = (double)OCTL_VOX_BIAS;
+    int d = 0;
+    if ((fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim)) {
+      d = voxel_owner_hash((int64_t)fx, (int64_t)fy, (int64_t)fz, n_ranks);
+    } else {
+      atomicExch(err, 1u);
+    }
+    dest_key[i] = (uint64_t)d;
+    idx[i] = (uint32_t)i;
+    atomicAdd(&hist[d], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_ranks && hist[threadIdx.x])
+    atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_route_pack(const double* __restrict__ xyz,
+                                                    const int64_t* __restrict__ gidx,
+                                                    int64_t index_base,
+                                                    const uint32_t* __restrict__ order, int64_t n,
+                                                    double* __restrict__ out_xyz,
+                                                    int64_t* __restrict__ out_gidx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t s = order[i];
+  out_xyz[3 * i] = xyz[3 * s];
+  out_xyz[3 * i + 1] = xyz[3 * s + 1];
+  out_xyz[3 * i + 2] = xyz[3 * s + 2];
+  out_gidx[i] = gidx ? gidx[s] : index_base + s;
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
+
+}  // namespace
+
+extern "C" {
+
+int32_t octl_voxel_owner(int64_t qx, int64_t qy, int64_t qz, int32_t n_ranks) {
+  return voxel_owner_hash(qx, qy, qz, n_ranks);
+}
+
+int octl_comm_unique_id(uint8_t id[OCTL_UNIQUE_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == OCTL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  if (!id) return OCTL_E_INVALID;
+  if (rccl_load()) return OCTL_E_COMM;
+  ncclUniqueId uid;
+  if (g_rccl.GetUniqueId(&uid) != ncclSuccess) return OCTL_E_COMM;
+  std::memcpy(id, &uid, sizeof(uid));
+  return OCTL_OK;
+}
+
+int octl_comm_init(octl_ctx* ctx, int32_t n_ranks, int32_t rank,
+                   const uint8_t id[OCTL_UNIQUE_ID_BYTES]) {
+  if (!ctx || !id || n_ranks < 1 || n_ranks > 256 || rank < 0 || rank >= n_ranks)
+    return OCTL_E_INVALID;
+  if (const char* e = rccl_load()) return octl_set_error(ctx, OCTL_E_COMM, "%s", e);
+  if (ctx->comm) return octl_set_error(ctx, OCTL_E_STATE, "communicator already initialised");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm;
+  NCCL_TRY(ctx, g_rccl.CommInitRank(&comm, n_ranks, uid, rank));
+  ctx->comm = comm;
+  ctx->n_ranks = n_ranks;
+  ctx->rank = rank;
+  return OCTL_OK;
+}
+
+int octl_comm_destroy(octl_ctx* ctx) {
+  if (!ctx) return OCTL_E_INVALID;
+  if (ctx->comm && g_rccl.CommDestroy) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)g_rccl.CommDestroy(static_cast<ncclComm_t>(ctx->comm));
+  }
+  ctx->comm = nullptr;
+  ctx->n_ranks = 1;
+  ctx->rank = 0;
+  return OCTL_OK;
+}
+
+int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_dev, int64_t n,
+                      int64_t index_base, const double corner[3], double L, int64_t* n_recv,
+                      int64_t* send_counts) {
+  if (!ctx || !n_recv || n < 0 || (n > 0 && !xyz_dev) || !corner)
+    return OCTL_E_INVALID;
+  if (corner[0] != 0.0 || corner[1] != 0.0 || corner[2] != 0.0 || !(L > 0.0) ||
+      L != (double)(int64_t)L)
+    return octl_set_error(ctx, OCTL_E_INVALID, "routing needs corner = 0 and an integer valued L");
+  if (n >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "too many points");
+  const int R = ctx->n_ranks, me = ctx->rank;
+  if (R > 1 && !ctx->comm) return octl_set_error(ctx, OCTL_E_STATE, "communicator not initialised");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+
+  // --- 1. destination + counts ------------------------------------------------------------------
+  DevBuf keys[2], vals[2], hist, counts_d, matrix_d, send_xyz, send_gidx;
+  auto cleanup = [&]() {
+    for (DevBuf* b : {&keys[0], &keys[1], &vals[0], &vals[1], &hist, &counts_d, &matrix_d,
+                      &send_xyz, &send_gidx})
+      devbuf_free(*b);
+  };
+  int rc = OCTL_OK;
+#define RT_TRY(expr)       \
+  do {                     \
+    rc = (expr);           \
+    if (rc != OCTL_OK) {   \
+      cleanup();           \
+      return rc;           \
+    }                      \
+  } while (0)
+  const int64_t n1 = std::max<int64_t>(n, 1);
+  for (int b = 0; b < 2; ++b) {
+    RT_TRY(devbuf_reserve(ctx, keys[b], (size_t)n1 * 8));
+    RT_TRY(devbuf_reserve(ctx, vals[b], (size_t)n1 * 4));
+  }
+  RT_TRY(devbuf_reserve(ctx, counts_d, (size_t)R * 8 + 16));
+  RT_TRY(devbuf_reserve(ctx, matrix_d, (size_t)R * R * 8));
+  uint32_t* err = ctx->small.as<uint32_t>();
+  if (hipMemsetAsync(counts_d.p, 0, (size_t)R * 8 + 16, st) != hipSuccess ||
+      hipMemsetAsync(err, 0, 4, st) != hipSuccess) {
+    cleanup();
+    return octl_set_error(ctx, OCTL_E_HIP, "memset failed");
+  }
+  if (n > 0) {
+    KTimer t(ctx, "route_dest");
+    hipLaunchKernelGGL(k_route_dest, dim3(grid_for(n)), dim3(256), 0, st, xyz_dev, n, L, R,
+                       keys[0].as<uint64_t>(), vals[0].as<uint32_t>(),
+                       counts_d.as<unsigned long long>(), err);
+  }
+  // --- 2. stable partition by destination (one radix pass) ----------------------------------------
+  int sorted = 0;
+  if (n > 0 && R > 1) {
+    uint64_t* kk[2] = {keys[0].as<uint64_t>(), keys[1].as<uint64_t>()};
+    uint32_t* vv[2] = {vals[0].as<uint32_t>(), vals[1].as<uint32_t>()};
+    int bits = 0;
+    while ((1 << bits) < R) ++bits;
+    RT_TRY(octl_radix_sort_u64_u32(ctx, kk, vv, n, bits, hist, &sorted));
+  }
+  RT_TRY(devbuf_reserve(ctx, send_xyz, (size_t)n1 * 24));
+  RT_TRY(devbuf_reserve(ctx, send_gidx, (size_t)n1 * 8));
+  if (n > 0) {
+    KTimer t(ctx, "route_pack");
+    hipLaunchKernelGGL(k_route_pack, dim3(grid_for(n)), dim3(256), 0, st, xyz_dev, gidx_dev,
+                       index_base, (const uint32_t*)vals[sorted].as<uint32_t>(), n,
+                       send_xyz.as<double>(), send_gidx.as<int64_t>());
+  }
+  // --- 3. counts exchange -----------------------------------------------------------------------------
+  std::vector<int64_t> matrix((size_t)R * R, 0);
+  if (R > 1) {
+    ncclResult_t r = g_rccl.AllGather(counts_d.p, matrix_d.p, (size_t)R, ncclInt64, comm, st);
+    if (r != ncclSuccess) {
+      cleanup();
+      return octl_set_error(ctx, OCTL_E_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+    }
+    if (hipMemcpyAsync(matrix.data(), matrix_d.p, (size_t)R * R * 8, hipMemcpyDeviceToHost, st) !=
+        hipSuccess) {
+      cleanup();
+      return octl_set_error(ctx, OCTL_E_HIP, "count download failed");
+    }
+  } else {
+    matrix[0] = n;
+  }
+  uint32_t err_h = 0;
+  if (hipMemcpyAsync(ctx->small_host, err, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {
+    cleanup();
+    return octl_set_error(ctx, OCTL_E_HIP, "route: stream failed: %s",
+                          hipGetErrorString(hipGetLastError()));
+  }
+  std::memcpy(&err_h, ctx->small_host, 4);
+  if (err_h) {
+    cleanup();
+    return octl_set_error(ctx, OCTL_E_DOMAIN, "route: non-finite coordinate or voxel out of range");
+  }
+  std::vector<int64_t> soff(R + 1, 0), roff(R + 1, 0);
+  for (int p = 0; p < R; ++p) {
+    soff[p + 1] = soff[p] + matrix[(size_t)me * R + p];
+    roff[p + 1] = roff[p] + matrix[(size_t)p * R + me];
+    if (send_counts) send_counts[p] = matrix[(size_t)me * R + p];
+  }
+  const int64_t nr = roff[R];
+  if (nr >= ((int64_t)1 << 31)) {
+    cleanup();
+    return octl_set_error(ctx, OCTL_E_INVALID, "rank receives more than 2^31-1 points");
+  }
+  RT_TRY(devbuf_reserve(ctx, ctx->routed_xyz, (size_t)std::max<int64_t>(nr, 1) * 24));
+  RT_TRY(devbuf_reserve(ctx, ctx->routed_gidx, (size_t)std::max<int64_t>(nr, 1) * 8));
+  // --- 4. the all-to-all ----------------------------------------------------------------------------------
+  {
+    KTimer t(ctx, "route_alltoall");
+    const int64_t self = matrix[(size_t)me * R + me];
+    if (self > 0) {
+      (void)hipMemcpyAsync(ctx->routed_xyz.as<double>() + 3 * roff[me],
+                           send_xyz.as<double>() + 3 * soff[me], (size_t)self * 24,
+                           hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync(ctx->routed_gidx.as<int64_t>() + roff[me],
+                           send_gidx.as<int64_t>() + soff[me], (size_t)self * 8,
+                           hipMemcpyDeviceToDevice, st);
+    }
+    if (R > 1) {
+      ncclResult_t r = g_rccl.GroupStart();
+      for (int p = 0; p < R && r == ncclSuccess; ++p) {
+        if (p == me) continue;
+        const int64_t sc = matrix[(size_t)me * R + p], rcnt = matrix[(size_t)p * R + me];
+        if (sc > 0) {
+          r = g_rccl.Send(send_xyz.as<double>() + 3 * soff[p], (size_t)sc * 3, ncclDouble, p, comm, st);
+          if (r == ncclSuccess)
+            r = g_rccl.Send(send_gidx.as<int64_t>() + soff[p], (size_t)sc, ncclInt64, p, comm, st);
+        }
+        if (rcnt > 0 && r == ncclSuccess) {
+          r = g_rccl.Recv(ctx->routed_xyz.as<double>() + 3 * roff[p], (size_t)rcnt * 3, ncclDouble, p,
+                          comm, st);
+          if (r == ncclSuccess)
+            r = g_rccl.Recv(ctx->routed_gidx.as<int64_t>() + roff[p], (size_t)rcnt, ncclInt64, p,
+                            comm, st);
+        }
+      }
+      ncclResult_t r2 = g_rccl.GroupEnd();
+      if (r == ncclSuccess) r = r2;
+      if (r != ncclSuccess) {
+        cleanup();
+        return octl_set_error(ctx, OCTL_E_COMM, "all-to-all failed: %s", g_rccl.GetErrorString(r));
+      }
+    }
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) {
+    cleanup();
+    return octl_set_error(ctx, OCTL_E_HIP, "route: all-to-all stream failed");
+  }
+  ctx->routed_n = nr;
+  *n_recv = nr;
+  cleanup();
+#undef RT_TRY
+  return OCTL_OK;
+}
+
+int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot) {
+  if (!f) return OCTL_E_INVALID;
+  return octl_forest_add_pose_device(f, f->ctx->routed_xyz.as<double>(), f->ctx->routed_n, slot);
+}
+
+int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n) {
+  if (!ctx || !n) return OCTL_E_INVALID;
+  *n = ctx->routed_n;
+  const int64_t m = std::min<int64_t>(cap, ctx->routed_n);
+  if (m <= 0 || !gidx) return OCTL_OK;
+  HIP_TRY(ctx, hipMemcpyAsync(gidx, ctx->routed_gidx.p, (size_t)m * 8, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+int octl_comm_allreduce_i64(octl_ctx* ctx, int64_t* inout_host, int32_t n) {
+  if (!ctx || !inout_host || n < 0 || n > 256) return OCTL_E_INVALID;
+  if (ctx->n_ranks == 1 || n == 0) return OCTL_OK;
+  if (!ctx->comm) return octl_set_error(ctx, OCTL_E_STATE, "communicator not initialised");
+  hipStream_t st = ctx->stream;
+  int64_t* d = reinterpret_cast<int64_t*>(ctx->small.as<uint32_t>() + 512);  // 2 KiB into the block
+  HIP_TRY(ctx, hipMemcpyAsync(d, inout_host, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  NCCL_TRY(ctx, g_rccl.AllReduce(d, d, (size_t)n, ncclInt64, ncclSum,
+                                 static_cast<ncclComm_t>(ctx->comm), st));
+  HIP_TRY(ctx, hipMemcpyAsync(inout_host, d, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return OCTL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,515 @@
+"""
+Parity of the HIP path (through the C ABI and the drop-in Python classes) with
+  * the golden vectors produced by the reference itself (tests/golden/*.npz),
+  * the known answers of the reference's own tests,
+  * the oracle (oracle/octree_np.py, oracle/ransac_np.py) on seeded inputs.
+Bar: bit-exact leaf tables (corner bits, edge bits) -> original point index sets, leaf list
+order, counters; RANSAC inlier counts / winning hypothesis / f32 plane / mask exact.
+"""
+
+import numpy as np
+import pytest
+
+from tests._util import assert_same_leaves, canon_from_list, golden_canon, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def index_map(points):
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    d = {pts[i].tobytes(): i for i in range(len(pts))}
+    assert len(d) == len(pts)
+    return d
+
+
+def views_table(leaves, index):
+    out = []
+    for v in leaves:
+        p = np.ascontiguousarray(v.get_points(), dtype=np.float64)
+        out.append((np.asarray(v.corner_min, dtype=np.float64), np.float64(v.edge_length),
+                    [index[p[i].tobytes()] for i in range(len(p))]))
+    return out
+
+
+def crit(k):
+    return [lambda pts: len(pts) > k]
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors from the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2000, 20000])
+@pytest.mark.parametrize("k", [8, 32, 256])
+def test_octree_uniform_golden(n, k):
+    from octreelib_amd.octree import Octree, OctreeConfig
+
+    g = load_golden(f"octree_uniform_{n}.npz")
+    pts = g["points"]
+    index = index_map(pts)
+    oc = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+    oc.insert_points(pts)
+    assert (oc.get_points() == pts).all()  # insertion order before any subdivide
+    oc.subdivide(crit(k))
+    assert_same_leaves(canon_from_list(views_table(oc.get_leaf_points(), index)), golden_canon(g, f"k{k}"))
+    assert [oc.n_nodes, oc.n_leaves, oc.n_points] == list(g[f"k{k}_counts"])
+    all_leaves = oc.get_leaf_points(non_empty=False)
+    assert np.array_equal(np.array([v.corner_min for v in all_leaves]), g[f"k{k}_all_corners"])
+    assert np.array_equal(np.array([v.edge_length for v in all_leaves]), g[f"k{k}_all_edges"])
+    # within a leaf the points keep their insertion order (stable), DFS order overall
+    got = oc.get_points()
+    assert sorted(map(bytes, got)) == sorted(map(bytes, pts))
+
+
+def test_grid_L1_mixed_golden():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    g = load_golden("grid_L1_mixed.npz")
+    pts = g["points"]
+    index = index_map(pts)
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, pts)
+    assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(0), index)), golden_canon(g, "pre"))
+    assert [grid.n_nodes(0), grid.n_leaves(0), grid.n_points(0)] == list(g["pre_counts"])
+    grid.subdivide(crit(16))
+    assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(0), index)), golden_canon(g, "k16"))
+    assert [grid.n_nodes(0), grid.n_leaves(0), grid.n_points(0)] == list(g["k16_counts"])
+
+
+def test_grid_L5_two_poses_golden():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    g = load_golden("grid_L5_two_poses.npz")
+    grid = Grid(GridConfig(voxel_edge_length=5))
+    idx = []
+    for p in range(2):
+        grid.insert_points(p, g[f"points{p}"])
+        idx.append(index_map(g[f"points{p}"]))
+    grid.subdivide(crit(24))
+    for p in range(2):
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"p{p}"))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"p{p}_counts"])
+    grid.subdivide(crit(6), [1])  # refinement driven by pose 1 only
+    for p in range(2):
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"r_p{p}"))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"r_p{p}_counts"])
+
+
+def test_manager_four_poses_golden():
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+
+    g = load_golden("manager_four_poses.npz")
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 2.0)
+    idx = [index_map(g[f"points{p}"]) for p in range(4)]
+    for p in range(3):
+        m.insert_points(p, g[f"points{p}"])
+    m.subdivide(crit(40), [0, 2])
+    m.insert_points(3, g["points3"])  # inherits the scheme
+    for p in range(4):
+        got = canon_from_list(views_table(m.get_leaf_points(True, p), idx[p]))
+        assert_same_leaves(got, golden_canon(g, f"p{p}"))
+        assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == list(g[f"p{p}_counts"])
+    m.subdivide(crit(25))
+    for p in range(4):
+        got = canon_from_list(views_table(m.get_leaf_points(True, p), idx[p]))
+        assert_same_leaves(got, golden_canon(g, f"r_p{p}"))
+        assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == list(g[f"r_p{p}_counts"])
+
+
+@pytest.mark.parametrize("name", ["h64", "h1024", "h32k3"])
+def test_ransac_operator_golden_and_oracle(name):
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    g = load_golden(f"ransac_{name}.npz")
+    cloud, sizes, hyp, thr = g["cloud"], g["block_sizes"], g["hypotheses"], float(g["threshold"])
+    H, k = hyp.shape
+    np.random.seed(1000 + H)  # same draw as the generator: the table must come out identical
+    op = CudaRansac(threshold=thr, hypotheses_number=H, initial_points_number=k)
+    assert np.array_equal(op.random_hypotheses, hyp)
+    mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+    o_mask, o_count, o_plane, o_index, tied = rnp.evaluate(cloud, sizes, hyp, thr, details=True)
+    # exact against the oracle
+    assert np.array_equal(counts, o_count)
+    assert np.array_equal(index, o_index)
+    assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+    assert np.array_equal(mask, o_mask)
+    # against the reference kernel source: the winner among ties is a race upstream
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    for b in range(len(sizes)):
+        ref = g["mask"][starts[b] : starts[b + 1]]
+        assert int(ref.sum()) == int(counts[b])
+
+
+def test_grid_ransac_end_to_end_golden():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    g = load_golden("grid_ransac_e2e.npz")
+    grid = Grid(GridConfig(voxel_edge_length=5))
+    idx = []
+    for p in range(2):
+        grid.insert_points(p, g[f"points{p}"])
+        idx.append(index_map(g[f"points{p}"]))
+    np.random.seed(int(g["seed"]))
+    grid.map_leaf_points_cuda_ransac(poses_per_batch=10, threshold=0.01, hypotheses_number=256,
+                                     initial_points_number=6)
+    for p in range(2):
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"p{p}"))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"p{p}_counts"])
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own tests, run against the drop-in classes
+# ------------------------------------------------------------------------------------------------
+def test_reference_test_octree():
+    from octreelib_amd.octree import Octree, OctreeConfig, OctreeNode
+
+    pc = np.array([[0, 0, 1], [0, 0, 2], [0, 0, 3], [9, 9, 8], [9, 9, 9]], dtype=float)
+    cached = []
+    node = OctreeNode(np.array([0, 0, 0]), np.float64(10), cached)
+    node.insert_points(pc)
+    node.subdivide([lambda points: len(points) > 2])
+    assert node.n_leaves == 3 and node.n_points == 5
+    node.filter([lambda points: len(points) >= 2])
+    assert node.n_points == 4
+    assert len(cached) == 15
+    oc = Octree(OctreeConfig(), np.array([0, 0, 0]), np.float64(10))
+    oc.insert_points(pc)
+    assert (pc == oc.get_points()).all()
+    oc.subdivide([lambda points: len(points) > 2])
+    assert oc.n_leaves == 3 and oc.n_points == 5
+    oc.filter([lambda points: len(points) >= 2])
+    assert oc.n_points == 4
+
+
+def _multi_pose():
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0, 0, 0]), 5)
+    p0 = np.array([[0, 0, 1], [0, 0, 2], [0, 0, 3]], dtype=float)
+    p1 = np.array([[1, 0, 1], [4, 0, 2], [0, 2, 3]], dtype=float)
+    m.insert_points(0, p0)
+    m.insert_points(1, p1)
+    return m, {0: p0, 1: p1}
+
+
+def _same(a, b):
+    return set(map(str, np.asarray(a).tolist())) == set(map(str, np.asarray(b).tolist()))
+
+
+def test_reference_test_multi_pose():
+    from octreelib_amd.internal import Voxel
+
+    m, clouds = _multi_pose()
+    assert _same(m.get_points(0), clouds[0]) and _same(m.get_points(1), clouds[1])
+    assert [m.n_nodes(0), m.n_nodes(1), m.n_leaves(0), m.n_leaves(1)] == [1, 1, 1, 1]
+    assert [m.n_points(0), m.n_points(1)] == [3, 3]
+    m.subdivide([lambda points: len(points) > 2], [0])
+    assert [m.n_nodes(0), m.n_nodes(1)] == [9, 9]
+    assert [m.n_leaves(0), m.n_leaves(1)] == [2, 3]
+    exp0 = [Voxel(np.array([0, 0, 0]), 2.5), Voxel(np.array([0, 0, 2.5]), 2.5)]
+    exp1 = [Voxel(np.array([0, 0, 0]), 2.5), Voxel(np.array([0, 0, 2.5]), 2.5), Voxel(np.array([2.5, 0, 0]), 2.5)]
+    assert {v.id for v in m.get_leaf_points(pose_number=0)} == {v.id for v in exp0}
+    assert {v.id for v in m.get_leaf_points(pose_number=1)} == {v.id for v in exp1}
+
+    m, clouds = _multi_pose()
+    m.subdivide([lambda points: len(points) > 1], None)
+    assert [m.n_nodes(0), m.n_nodes(1)] == [33, 33]
+    assert [m.n_leaves(0), m.n_leaves(1)] == [3, 3]
+    exp0 = [Voxel(np.array([0, 0, 0.625]), 0.625), Voxel(np.array([0, 0, 1.25]), 1.25), Voxel(np.array([0, 0, 2.5]), 1.25)]
+    exp1 = [Voxel(np.array([0.625, 0, 0.625]), 0.625), Voxel(np.array([0, 1.25, 2.5]), 1.25), Voxel(np.array([2.5, 0, 0]), 2.5)]
+    assert {v.id for v in m.get_leaf_points(pose_number=0)} == {v.id for v in exp0}
+    assert {v.id for v in m.get_leaf_points(pose_number=1)} == {v.id for v in exp1}
+
+    m, clouds = _multi_pose()
+    m.map_leaf_points(lambda points: points[0].reshape((1, 3)), [0])
+    assert [m.n_points(0), m.n_points(1)] == [1, 3]
+    m, clouds = _multi_pose()
+    m.subdivide([lambda points: len(points) > 2], [0])
+    m.filter([lambda points: False], [0])
+    m.filter([lambda points: True], [1])
+    assert [m.n_points(0), m.n_points(1)] == [0, 3]
+
+
+def _grid():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    grid = Grid(GridConfig(voxel_edge_length=5))
+    p0 = np.array([[0, 0, 1], [0, 0, 2], [0, 0, 3], [9, 9, 8], [9, 9, 9]], dtype=float)
+    p1 = np.array([[1, 0, 1], [4, 0, 2], [0, 2, 3], [5, 9, 9], [9, 3, 8]], dtype=float)
+    grid.insert_points(0, p0)
+    grid.insert_points(1, p1)
+    return grid, [p0, p1]
+
+
+def test_reference_test_grid():
+    grid, pp = _grid()
+    assert [grid.n_leaves(0), grid.n_leaves(1)] == [2, 3]
+    assert [grid.n_points(0), grid.n_points(1)] == [5, 5]
+    assert [grid.n_nodes(0), grid.n_nodes(1)] == [2, 3]
+    assert _same(grid.get_points(0), pp[0]) and _same(grid.get_points(1), pp[1])
+    l0, l1 = grid.get_leaf_points(0), grid.get_leaf_points(1)
+    assert len({l0[0].id, l0[1].id, l1[0].id, l1[1].id, l1[2].id}) == 3
+    assert {v.id for v in l0}.issubset({v.id for v in l1})
+    assert _same(l0[0].get_points(), pp[0][:3]) and _same(l0[1].get_points(), pp[0][3:])
+    assert _same(l1[0].get_points(), pp[1][:3]) and _same(l1[1].get_points(), pp[1][4:])
+    assert _same(l1[2].get_points(), pp[1][3:4])
+    grid.subdivide([lambda points: len(points) > 2])
+    assert [grid.n_leaves(0), grid.n_leaves(1)] == [4, 5]
+    assert [grid.n_points(0), grid.n_points(1)] == [5, 5]
+    assert [grid.n_nodes(0), grid.n_nodes(1)] == [26, 27]
+    assert _same(grid.get_points(0), pp[0]) and _same(grid.get_points(1), pp[1])
+    grid, pp = _grid()
+    grid.subdivide([lambda points: len(points) > 3])
+    assert [grid.n_leaves(0), grid.n_leaves(1)] == [3, 5]
+    grid, pp = _grid()
+    assert grid.n_points(0) > grid.n_leaves(0)
+    grid.map_leaf_points(lambda cloud: [cloud[0]])
+    assert grid.n_points(0) == grid.n_leaves(0) and grid.n_points(1) == grid.n_leaves(1)
+    with pytest.raises(ValueError, match="Cannot insert points to existing pose 0"):
+        grid.insert_points(0, np.zeros((1, 3)))
+
+
+def test_reference_test_cuda_ransac_smoke_and_errors():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    def planar(n, coef, corner, edge, sigma):
+        vp = np.random.rand(n, 3) * np.array([edge - 6 * sigma] * 3) + corner + 3 * sigma
+        z = (-coef[0] * vp[:, 0] - coef[1] * vp[:, 1] - coef[3]) / coef[2] + np.random.normal(0, sigma, (n,))
+        return np.column_stack((vp[:, :2], z))
+
+    np.random.seed(3)
+    grid = Grid(GridConfig(voxel_edge_length=5))
+    grid.insert_points(0, planar(10, (1, 2, 3, 0.5), np.array([0, 0, 0]), 5, 0.1))
+    grid.insert_points(1, planar(10, (-1, 2, 3, 0.5), np.array([0, 0, 0]), 5, 0.1))
+    grid.map_leaf_points_cuda_ransac()
+    with pytest.raises(ValueError, match="Threshold must be positive"):
+        grid.map_leaf_points_cuda_ransac(threshold=0)
+    with pytest.raises(ValueError, match="Number of RANSAC hypotheses must be positive"):
+        grid.map_leaf_points_cuda_ransac(hypotheses_number=0)
+    with pytest.raises(ValueError, match="must be <= 1024 because of the CUDA thread limit"):
+        grid.map_leaf_points_cuda_ransac(hypotheses_number=1025)
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded inputs against the oracle
+# ------------------------------------------------------------------------------------------------
+def _oracle_pose_table(og, pose):
+    return canon_from_list(og.leaf_table(pose))
+
+
+@pytest.mark.parametrize("n,extent,k", [(60_000, 6.0, 64), (200_000, 8.0, 32)])
+def test_grid_uniform_vs_oracle(n, extent, k):
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    pts = np.random.default_rng(n).random((n, 3)) * extent - extent / 3
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, pts)
+    grid.subdivide(crit(k))
+    og = onp.OGrid(1)
+    og.insert_points(0, pts)
+    og.subdivide(k)
+    index = index_map(pts)
+    assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(0), index)), _oracle_pose_table(og, 0))
+    assert [grid.n_nodes(0), grid.n_leaves(0), grid.n_points(0)] == [og.n_nodes(0), og.n_leaves(0), og.n_points(0)]
+    # within-leaf order is the insertion order (stable), exactly like the oracle
+    f = grid._forest
+    blk, perm = f.blocks, f.perm
+    for s, z in zip(blk["start"][:200], blk["size"][:200]):
+        assert np.all(np.diff(perm[s : s + z]) > 0)
+
+
+def test_multi_pose_grid_vs_oracle_with_history():
+    """3 poses, scheme from a subset, a late pose, a refinement: leaf LIST ORDER depends on the
+    history of splits (cached-leaf list), reproduced on the device."""
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(5)
+    poses = [rng.random((n, 3)) * 4.0 for n in (9000, 7000, 8000, 5000)]
+    grid, og = Grid(GridConfig(voxel_edge_length=2)), onp.OGrid(2)
+    for p in range(3):
+        grid.insert_points(p, poses[p])
+        og.insert_points(p, poses[p])
+    grid.subdivide(crit(200), [0, 2])
+    og.subdivide(200, [0, 2])
+    grid.insert_points(3, poses[3])
+    og.insert_points(3, poses[3])
+    idx = [index_map(p) for p in poses]
+    for p in range(4):
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), _oracle_pose_table(og, p))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+    grid.subdivide(crit(60))
+    og.subdivide(60)
+    for p in range(4):
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), _oracle_pose_table(og, p))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+
+
+def test_deep_clusters_beyond_21_levels_vs_oracle():
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(9)
+    base = rng.random((300, 3))
+    clusters = np.vstack([c + rng.random((30, 3)) * 2e-9 for c in rng.random((4, 3)) * 0.8 + 0.1])
+    pts = np.unique(np.vstack([base, clusters]), axis=0)
+    rng.shuffle(pts)
+    oc = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+    oc.insert_points(pts)
+    oc.subdivide(crit(3))
+    t = onp.OTree(np.array([0.0, 0.0, 0.0]), np.float64(1))
+    t.insert_points(pts)
+    t.subdivide(3)
+    index = index_map(pts)
+    got = canon_from_list(views_table(oc.get_leaf_points(), index))
+    assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(t)))
+    assert oc._forest.info.max_depth > 21
+    assert [oc.n_nodes, oc.n_leaves, oc.n_points] == [t.n_nodes, t.n_leaves, t.n_points]
+
+
+def _planar_cloud(rng, n_vox, per_voxel):
+    parts = []
+    for c in np.argwhere(np.ones((n_vox, n_vox, n_vox))):
+        a, b = rng.uniform(-0.4, 0.4, 2)
+        n_in = int(per_voxel * 0.8)
+        xy = rng.random((n_in, 2))
+        z = 0.5 + a * (xy[:, 0] - 0.5) + b * (xy[:, 1] - 0.5) + rng.normal(0, 0.005, n_in)
+        inl = np.column_stack([xy, np.clip(z, 0.001, 0.999)])
+        out = rng.random((per_voxel - n_in, 3))
+        parts.append(np.vstack([inl, out]) + c)
+    pts = np.vstack(parts)
+    rng.shuffle(pts)
+    return pts
+
+
+def test_grid_ransac_pipeline_vs_oracle():
+    """insert + subdivide + RANSAC + apply_mask on two poses against the oracle end to end
+    (oracle leaf tables in the same stable order -> oracle kernel restatement -> masks)."""
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(17)
+    poses = [_planar_cloud(rng, 3, 300), _planar_cloud(rng, 3, 200)]
+    grid, og = Grid(GridConfig(voxel_edge_length=1)), onp.OGrid(1)
+    for p, pts in enumerate(poses):
+        grid.insert_points(p, pts)
+        og.insert_points(p, pts)
+    grid.subdivide(crit(64))
+    og.subdivide(64)
+    np.random.seed(0)
+    table = np.random.random((1024, 6))
+    np.random.seed(0)
+    grid.map_leaf_points_cuda_ransac(poses_per_batch=10, threshold=0.01, hypotheses_number=1024,
+                                     initial_points_number=6)
+    # oracle: one batch holding both poses (grid.py:149-191)
+    clouds, sizes = [], []
+    for p, pts in enumerate(poses):
+        for _, _, idx in og.leaf_table(p):
+            clouds.append(pts[idx])
+            sizes.append(len(idx))
+    mask = rnp.evaluate(np.vstack(clouds), np.array(sizes, dtype=np.int32), table, 0.01)
+    off = 0
+    for p, pts in enumerate(poses):
+        n = og.n_points(p)
+        og.apply_mask(p, mask[off : off + n])
+        off += n
+    for p, pts in enumerate(poses):
+        index = index_map(pts)
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)), _oracle_pose_table(og, p))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+    # a second subdivide works on the surviving points only
+    grid.subdivide(crit(20))
+    og.subdivide(20)
+    for p, pts in enumerate(poses):
+        index = index_map(pts)
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)), _oracle_pose_table(og, p))
+
+
+def test_ransac_operator_random_blocks_vs_oracle():
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(23)
+    sizes = rng.integers(0, 90, 400).astype(np.int32)
+    sizes[::37] = 700  # a few large leaves
+    cloud = rng.random((int(sizes.sum()), 3)) * 32.0
+    # make most blocks roughly planar so that the counts are informative
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    for b in range(len(sizes)):
+        s, e = starts[b], starts[b + 1]
+        if e - s >= 6 and b % 5:
+            cloud[s:e, 2] = 3.0 + 0.2 * cloud[s:e, 0] - 0.1 * cloud[s:e, 1] + rng.normal(0, 0.006, e - s)
+    for H, k in ((1024, 6), (100, 6), (64, 4)):
+        np.random.seed(H)
+        op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=k)
+        mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+        o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.01, details=True)
+        assert np.array_equal(counts, o_count)
+        assert np.array_equal(index, o_index)
+        assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+        assert np.array_equal(mask, o_mask)
+
+
+# ------------------------------------------------------------------------------------------------
+# edges of the parity domain
+# ------------------------------------------------------------------------------------------------
+def test_duplicates_raise_recursion_error():
+    from octreelib_amd.octree import Octree, OctreeConfig
+
+    oc = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+    oc.insert_points(np.tile(np.array([[0.3, 0.3, 0.3]]), (5, 1)))
+    with pytest.raises(RecursionError):
+        oc.subdivide(crit(2))
+
+
+def test_point_outside_cube_only_fails_when_its_node_splits():
+    from octreelib_amd.octree import Octree, OctreeConfig
+
+    pts = np.array([[0.1, 0.1, 0.1], [0.2, 0.2, 0.2], [1.5, 0.2, 0.2]])
+    oc = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+    oc.insert_points(pts)
+    oc.subdivide(crit(5))  # no split: the stray point lives in the root, as upstream
+    assert oc.n_points == 3 and oc.n_leaves == 1
+    oc2 = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+    oc2.insert_points(pts)
+    with pytest.raises((IndexError, ValueError)):
+        oc2.subdivide(crit(1))
+
+
+def test_tiny_negative_coordinate_is_the_reference_index_error():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    pts = np.array([[-5e-324, 0.5, 0.5], [-0.5, 0.5, 0.5], [-0.25, 0.25, 0.5]])
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, pts)
+    assert grid.n_leaves(0) == 1  # all three in voxel (-1, 0, 0)
+    with pytest.raises((IndexError, ValueError)):
+        grid.subdivide(crit(1))
+
+
+def test_non_finite_point_is_refused():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, np.array([[0.5, np.nan, 0.5]]))
+    with pytest.raises((ValueError, IndexError)):
+        grid.n_leaves(0)
+
+
+def test_empty_inputs():
+    from octreelib_amd.grid import Grid, GridConfig
+    from octreelib_amd.octree import Octree, OctreeConfig
+
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, np.empty((0, 3)))
+    assert [grid.n_leaves(0), grid.n_points(0), grid.n_nodes(0)] == [0, 0, 0]
+    grid.subdivide(crit(4))
+    assert grid.get_leaf_points(0) == []
+    oc = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+    assert [oc.n_nodes, oc.n_leaves, oc.n_points] == [1, 0, 0]
+    oc.subdivide(crit(4))
+    assert [oc.n_nodes, oc.n_leaves, oc.n_points] == [1, 0, 0]
