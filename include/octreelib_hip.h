@@ -90,6 +90,10 @@ int octl_forest_create(octl_ctx* ctx, int mode, const double corner[3], double e
                        octl_forest** out);
 void octl_forest_destroy(octl_forest* f);
 
+/* Forget all poses and the scheme but keep the device allocations (a fresh Grid without the
+ * hipMalloc cost).                                                                          */
+int octl_forest_clear(octl_forest* f);
+
 /* Append the cloud of a new pose slot (host pointer, copied to the device).  Returns the
  * slot through *slot.  Replaces Grid.insert_points' storage step.                        */
 int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* slot);

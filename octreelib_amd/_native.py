@@ -9,7 +9,10 @@ import threading
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liboctree_hip.so")
+_LIB_PATH = os.environ.get(
+    "OCTREELIB_AMD_LIB",  # kernel-variant experiments only
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "liboctree_hip.so"),
+)
 
 OCTL_OK = 0
 OCTL_E_INVALID = -1
@@ -59,6 +62,7 @@ SIGNATURES = {
     "octl_ctx_get_timings": (C.c_int, [_p, _p, C.c_int, _p, _p, C.c_int, C.POINTER(C.c_int)]),
     "octl_forest_create": (C.c_int, [_p, C.c_int, _p, _f64, C.POINTER(_p)]),
     "octl_forest_destroy": (None, [_p]),
+    "octl_forest_clear": (C.c_int, [_p]),
     "octl_forest_add_pose": (C.c_int, [_p, _p, _i64, _pi32]),
     "octl_forest_add_pose_device": (C.c_int, [_p, _p, _i64, _pi32]),
     "octl_forest_extend_pose": (C.c_int, [_p, _i32, _p, _i64]),

@@ -163,6 +163,26 @@ void octl_forest_destroy(octl_forest* f) {
   delete f;
 }
 
+int octl_forest_clear(octl_forest* f) {
+  if (!f) return OCTL_E_INVALID;
+  HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
+  f->pose_off.assign(1, 0);
+  f->n_store = f->n_alive = 0;
+  f->store_dirty = true;
+  f->nodes[0].n = f->nodes[1].n = 0;
+  f->cur = 0;
+  f->epoch = 0;
+  f->built = false;
+  f->vkeys.clear();
+  f->level_first.clear();
+  f->n_internal = 0;
+  f->max_depth_reached = 0;
+  f->n_ord = 0;
+  f->n_blocks = 0;
+  f->mask_valid = false;
+  return OCTL_OK;
+}
+
 int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* slot) {
   if (!f) return OCTL_E_INVALID;
   OCTL_TRY(store_append(f, xyz, n, false));

@@ -133,20 +133,31 @@ __global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
     vkey[i] = OCTL_VOX_DEAD;
     path[i] = 0;
   }
-  // voxel bounding box: wave reduction, then six atomics per wave
+  // voxel bounding box: wave + block reduction, then at most six atomics per BLOCK, and only
+  // when the block actually widens the box (same-address atomics serialise at ~10 ns each)
+  __shared__ int s_bb[4][6];
   const int big = 1 << 30;
   const int mnx = wave_min_i32(live ? qx : big), mny = wave_min_i32(live ? qy : big),
             mnz = wave_min_i32(live ? qz : big);
   const int mxx = wave_max_i32(live ? qx : -big), mxy = wave_max_i32(live ? qy : -big),
             mxz = wave_max_i32(live ? qz : -big);
-  if ((threadIdx.x & 63) == 0 && mnx != big) {
+  if ((threadIdx.x & 63) == 0) {
+    int* w = s_bb[threadIdx.x >> 6];
+    w[0] = mnx; w[1] = mny; w[2] = mnz; w[3] = mxx; w[4] = mxy; w[5] = mxz;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    int v = s_bb[0][a];
+    for (int w = 1; w < 4; ++w) v = (a < 3) ? min(v, s_bb[w][a]) : max(v, s_bb[w][a]);
     int* bb = reinterpret_cast<int*>(small + SM_BBOX);
-    atomicMin(&bb[0], mnx);
-    atomicMin(&bb[1], mny);
-    atomicMin(&bb[2], mnz);
-    atomicMax(&bb[3], mxx);
-    atomicMax(&bb[4], mxy);
-    atomicMax(&bb[5], mxz);
+    if (a < 3) {
+      if (v != big && v < __hip_atomic_load(&bb[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(&bb[a], v);
+    } else {
+      if (v != -big && v > __hip_atomic_load(&bb[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&bb[a], v);
+    }
   }
 }
 

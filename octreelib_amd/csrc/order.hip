@@ -75,10 +75,20 @@ __global__ __launch_bounds__(256) void k_gather_key2(const uint64_t* __restrict_
   if (b < nb) out[b] = key2[val[b]];
 }
 
+// blocks per pose slot (<= 256 slots): LDS histogram per workgroup, then one global atomic per
+// non-empty bin per workgroup (same-address global atomics serialise)
 __global__ __launch_bounds__(256) void k_slot_hist(const int32_t* __restrict__ blk_slot, int64_t nb,
                                                    uint32_t* __restrict__ hist) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) atomicAdd(&hist[blk_slot[b]], 1u);
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * 2048;
+  for (int r = 0; r < 8; ++r) {
+    const int64_t b = base + r * 256 + threadIdx.x;
+    if (b < nb) atomicAdd(&h[blk_slot[b]], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
@@ -175,7 +185,7 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   uint32_t* hist = ctx->small.as<uint32_t>() + 64;
   if (n_poses <= 256) {
     HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)n_poses * 4, st));
-    hipLaunchKernelGGL(k_slot_hist, dim3(grid_for(nb)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_slot_hist, dim3((unsigned)ceil_div(nb, 2048)), dim3(256), 0, st,
                        (const int32_t*)f->blk_slot.as<int32_t>(), nb, hist);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, hist, (size_t)n_poses * 4, hipMemcpyDeviceToHost, st));

@@ -19,18 +19,23 @@
 // scoring loop is FP64-VALU bound (3 mul + 3 add + compare + count per point x hypothesis);
 // MFMA is not used: the f64 evaluation order (and the f32-rounded plane) must be reproduced
 // exactly, and the product is 4 deep.
+#include <algorithm>
+#include <cstdlib>
+
 #include "forest.h"
 
 namespace {
 
-struct RansacBlocks {
-  const uint32_t* start;   // physical start of the block in the point array
-  const int32_t* size;     // points in the block
-  const int64_t* vstart;   // start of the block in the reference's concatenated batch cloud
-  const uint32_t* spill;   // physical index of the point that follows the block in the
-                           // reference's cloud (first point of the next block), or 0xFFFFFFFF
-  const int32_t* order;    // optional indirection: physical block id of batch entry b
-};
+// c / k, correctly rounded, for an integer 1 <= k <= 16 (see plane_from_samples).
+// zh = RN(1/k), zl = RN(1/k - zh); denormal / overflow ranges fall back to the true division.
+__device__ __forceinline__ double div_by_small_int(double c, int k) {
+  const double kd = (double)k;
+  const double zh = 1.0 / kd;                    // compile-time constant when k is
+  const double zl = fma(-kd, zh, 1.0) / kd;      // (1 - k*zh) is exact; zl to 2^-53 relative
+  const double a = fabs(c);
+  if (!(a > 1e-290 && a < 1e290)) return c / kd;  // also NaN / inf / 0
+  return fma(c, zh, c * zl);
+}
 
 // util.py:27-84 on k sampled points; returns the plane already rounded to f32
 // (cuda_ransac.py:110-113).  KT > 0: compile-time k (arrays stay in registers).
@@ -49,10 +54,13 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
       cz += sz[i];
     }
   }
-  const double kd = (double)k;
-  cx /= kd;  // util.py:42-44
-  cy /= kd;
-  cz /= kd;
+  // util.py:42-44: centroid / k with a true (correctly rounded) division.  For the integer
+  // divisor k <= 16 the quotient c/k is never closer than 1/(2k) ulp to a rounding midpoint, so
+  // RN(c*zh + RN(c*zl)) with zh + zl = 1/k to ~2^-106 IS the correctly rounded quotient:
+  // one multiply + one FMA instead of the 11-instruction IEEE division sequence.
+  cx = div_by_small_int(cx, k);
+  cy = div_by_small_int(cy, k);
+  cz = div_by_small_int(cz, k);
   double xx = 0.0, xy = 0.0, xz = 0.0, yy = 0.0, yz = 0.0, zz = 0.0;
 #pragma unroll
   for (int i = 0; i < (KT > 0 ? KT : KMAX); ++i) {  // util.py:48-57
@@ -106,89 +114,158 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
   return fabs(((a * x + b * y) + c * z) + d);
 }
 
-constexpr int RS_KMAX = 16;  // initial_points_number supported by the register path
+#ifndef RS_MINWAVES
+#define RS_MINWAVES 4
+#endif
+#ifndef RS_SCHED_BARRIER
+#define RS_SCHED_BARRIER 1
+#endif
+#ifndef RS_SCORE_UNROLL
+#define RS_SCORE_UNROLL 4
+#endif
+#define RS_PRAGMA_(x) _Pragma(#x)
+#define RS_PRAGMA(x) RS_PRAGMA_(x)
+constexpr int RS_KMAX = 16;   // initial_points_number supported by the register path
 
-// One workgroup per block; THREADS = 64*W lanes each owning HPL hypotheses: lane t handles
-// hypotheses t, t+THREADS, ...  (H <= THREADS*HPL)
-template <int THREADS, int HPL, int KT>
-__global__ __launch_bounds__(THREADS) void k_ransac(
-    const double* __restrict__ xyz, int64_t n_points, RansacBlocks blk,
-    const double* __restrict__ hyp, int H, int k, double thr, uint8_t* __restrict__ mask,
-    float* __restrict__ plane_out, int32_t* __restrict__ count_out,
-    int32_t* __restrict__ index_out, uint8_t* __restrict__ evaluated) {
-  __shared__ unsigned long long s_best[THREADS / 64];
-  __shared__ float s_plane[4];
-  const int be = blockIdx.x;
-  const int b = blk.order ? blk.order[be] : be;
-  const int n = blk.size[b];
-  if (evaluated) {
-    if (threadIdx.x == 0) evaluated[b] = 1;
-  }
-  if (n < k) {  // cuda_ransac.py:96-97: the whole block returns, mask stays False
-    for (int i = threadIdx.x; i < n; i += THREADS) mask[(int64_t)blk.start[b] + i] = 0;
-    if (threadIdx.x == 0) {
-      if (plane_out) {
-        plane_out[4 * (int64_t)be + 0] = 0.f; plane_out[4 * (int64_t)be + 1] = 0.f;
-        plane_out[4 * (int64_t)be + 2] = 0.f; plane_out[4 * (int64_t)be + 3] = 0.f;
-      }
-      if (count_out) count_out[be] = 0;
-      if (index_out) index_out[be] = -1;
+// everything the kernel needs to know about one batch entry, written by k_block_desc so that a
+// workgroup reads ONE 32-byte record instead of chasing order -> size -> start -> vstart
+struct __attribute__((aligned(32))) BlockDesc {
+  uint32_t pstart;   // physical start of the block in the point array
+  int32_t n;         // points in the block
+  int64_t vstart;    // start of the block in the reference's concatenated batch cloud
+  uint32_t pspill;   // physical index of the point one past the block in that cloud (the first
+                     // point of the next block; the last block of a batch clamps to its own last
+                     // point): reachable only through f64 rounding of R*n + s
+  uint32_t pad[3];
+};
+
+struct RansacOut {
+  uint8_t* mask;
+  float* plane;
+  int32_t* count;
+  int32_t* index;
+};
+
+// The k sampled points of hypothesis t of a block -> f32 plane (cuda_ransac.py:100-113)
+template <int KT, bool IN_LDS>
+__device__ __forceinline__ void fit_hypothesis(const double* __restrict__ hyp, uint32_t row_off,
+                                               int k_rt, int n,
+                                               int64_t vstart, const double* __restrict__ lx,
+                                               const double* __restrict__ ly,
+                                               const double* __restrict__ lz,
+                                               const double* __restrict__ xyz, int64_t pstart,
+                                               int64_t pspill, float (&pf)[4]) {
+  constexpr int KS = KT > 0 ? KT : RS_KMAX;
+  const int k = KT > 0 ? KT : k_rt;
+  double r[KS];
+  // uniform base + 32-bit per-lane byte offset: one VGPR of addressing instead of a 64-bit
+  // pointer per hypothesis (which the register allocator spilled)
+  const double* __restrict__ hyp_row =
+      reinterpret_cast<const double*>(reinterpret_cast<const char*>(hyp) + row_off);
+  if (KT > 0 && (KT % 2) == 0) {
+    // rows of an even number of doubles are 16-byte aligned: dwordx4 loads
+    const double2* __restrict__ h2 = reinterpret_cast<const double2*>(hyp_row);
+#pragma unroll
+    for (int i = 0; i < KS / 2; ++i) {
+      const double2 v = h2[i];
+      r[2 * i] = v.x;
+      r[2 * i + 1] = v.y;
     }
-    return;
+  } else {
+#pragma unroll
+    for (int i = 0; i < KS; ++i) r[i] = (i < k) ? hyp_row[i] : 0.0;
   }
-  const int64_t pstart = blk.start[b];
-  const int64_t vstart = blk.vstart ? blk.vstart[be] : pstart;
-  const uint32_t spill = blk.spill ? blk.spill[be] : 0xFFFFFFFFu;
-  const double* __restrict__ pts = xyz + 3 * pstart;
+  int g[KS];
+  const double dn = (double)n, dv = (double)vstart;
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    // initial_point_indices[i] = nb.int32(random_hypotheses[t][i] * block_size + block_start)
+    // (cuda_ransac.py:103-107): f64 multiply, f64 add, truncation
+    const double v = r[i] * dn + dv;
+    const int gi = (int)((int64_t)(int)v - vstart);  // position inside the block; may be == n
+    g[i] = gi < n ? gi : n;
+  }
+  double sx[KS], sy[KS], sz[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    sx[i] = sy[i] = sz[i] = 0.0;
+    if (i < k) {
+      if (IN_LDS) {
+        sx[i] = lx[g[i]];
+        sy[i] = ly[g[i]];
+        sz[i] = lz[g[i]];
+      } else {
+        const int64_t p = (g[i] < n) ? pstart + g[i] : pspill;
+        sx[i] = xyz[3 * p];
+        sy[i] = xyz[3 * p + 1];
+        sz[i] = xyz[3 * p + 2];
+      }
+    }
+  }
+  plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
+}
 
+// One block (leaf x pose) on one workgroup: THREADS lanes, HPL hypotheses per lane (lane t owns
+// hypotheses t, t+THREADS, ...).  IN_LDS: the block's points (and the spill point at index n)
+// are in the LDS arrays lx/ly/lz; otherwise they are read from global memory.
+template <int THREADS, int HPL, int KT, bool IN_LDS, int ABL>
+__device__ __forceinline__ void ransac_block(const BlockDesc& d, int be,
+                                             const double* __restrict__ xyz,
+                                             const double* __restrict__ lx,
+                                             const double* __restrict__ ly,
+                                             const double* __restrict__ lz,
+                                             const double* __restrict__ hyp, int H, int k,
+                                             double thr, const RansacOut& out,
+                                             unsigned long long* s_best, float* s_plane) {
+  const int n = d.n;
+  const int64_t pstart = d.pstart;
+  const double* __restrict__ pts = xyz + 3 * pstart;
   double pa[HPL], pb[HPL], pc[HPL], pd[HPL];
-  float pf[HPL][4];
   int cnt[HPL];
 #pragma unroll
   for (int q = 0; q < HPL; ++q) {
     const int t = threadIdx.x + q * THREADS;
     cnt[q] = -1;
     pa[q] = pb[q] = pc[q] = pd[q] = 0.0;
-    pf[q][0] = pf[q][1] = pf[q][2] = pf[q][3] = 0.f;
     if (t < H) {
-      constexpr int KS = KT > 0 ? KT : RS_KMAX;
-      double sx[KS], sy[KS], sz[KS];
-#pragma unroll
-      for (int i = 0; i < KS; ++i) {
-        sx[i] = sy[i] = sz[i] = 0.0;
-        if (i < k) {
-          // initial_point_indices[i] = nb.int32(random_hypotheses[t][i] * block_size +
-          // block_start) (cuda_ransac.py:103-107): f64 multiply, f64 add, truncation
-          const double v = hyp[(int64_t)t * k + i] * (double)n + (double)vstart;
-          const int64_t g = (int64_t)(int)v - vstart;  // position inside the block; may be == n
-          int64_t p;
-          if (g < n) {
-            p = pstart + g;
-          } else {
-            // rounding of R*n + s reached the first point of the next block of the batch
-            p = (spill != 0xFFFFFFFFu) ? (int64_t)spill : pstart + n - 1;
-          }
-          sx[i] = xyz[3 * p];
-          sy[i] = xyz[3 * p + 1];
-          sz[i] = xyz[3 * p + 2];
-        }
+      float pf[4];
+      if (ABL == 2) {  // ablation: no plane fit (timing only, results meaningless)
+        pf[0] = (float)hyp[(int64_t)t * k]; pf[1] = pf[0]; pf[2] = pf[0]; pf[3] = pf[0];
+      } else {
+        // d.pad[0] is always 0; adding it keeps the (loop invariant) row addresses from being
+        // hoisted out of the persistent block loop and spilled to scratch
+        fit_hypothesis<KT, IN_LDS>(hyp, (uint32_t)t * (uint32_t)(KT > 0 ? KT : k) * 8u + d.pad[0], k, n,
+                                   d.vstart, lx, ly, lz, xyz, pstart, (int64_t)d.pspill, pf);
       }
-      plane_from_samples<KT, KS>(sx, sy, sz, k, pf[q]);
-      pa[q] = (double)pf[q][0];
-      pb[q] = (double)pf[q][1];
-      pc[q] = (double)pf[q][2];
-      pd[q] = (double)pf[q][3];
+      // the f32-rounded plane, promoted back to f64 for scoring (cuda_ransac.py:110-121)
+      pa[q] = (double)pf[0];
+      pb[q] = (double)pf[1];
+      pc[q] = (double)pf[2];
+      pd[q] = (double)pf[3];
       cnt[q] = 0;
     }
+    // keep the plane fits of the lane's hypotheses apart: interleaving them (all sample loads
+    // hoisted to the top) needs > 200 VGPRs and halves the resident waves
+#if RS_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
-  // scoring: for each point of the block (wave-uniform address -> scalar loads), every
-  // hypothesis of the lane (cuda_ransac.py:116-121)
-  for (int i = 0; i < n; ++i) {
-    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+  // scoring: every point of the block against every hypothesis of the lane
+  // (cuda_ransac.py:116-121); the point is wave uniform (LDS broadcast / scalar load)
+  if (ABL != 1) {
+RS_PRAGMA(unroll RS_SCORE_UNROLL)
+    for (int i = 0; i < n; ++i) {
+      double x, y, z;
+      if (IN_LDS) {
+        x = lx[i]; y = ly[i]; z = lz[i];
+      } else {
+        x = pts[3 * (int64_t)i]; y = pts[3 * (int64_t)i + 1]; z = pts[3 * (int64_t)i + 2];
+      }
 #pragma unroll
-    for (int q = 0; q < HPL; ++q) {
-      const double dist = plane_distance(pa[q], pb[q], pc[q], pd[q], x, y, z);
-      cnt[q] += (dist < thr) ? 1 : 0;
+      for (int q = 0; q < HPL; ++q) {
+        const double dist = plane_distance(pa[q], pb[q], pc[q], pd[q], x, y, z);
+        cnt[q] += (dist < thr) ? 1 : 0;
+      }
     }
   }
   // block-wide maximum, lowest hypothesis index among the tied (cuda_ransac.py:125-146)
@@ -216,106 +293,247 @@ __global__ __launch_bounds__(THREADS) void k_ransac(
 #pragma unroll
   for (int q = 0; q < HPL; ++q) {
     if ((int)threadIdx.x + q * THREADS == win) {
-      s_plane[0] = pf[q][0]; s_plane[1] = pf[q][1]; s_plane[2] = pf[q][2]; s_plane[3] = pf[q][3];
-      if (plane_out) {
-        plane_out[4 * (int64_t)be + 0] = pf[q][0]; plane_out[4 * (int64_t)be + 1] = pf[q][1];
-        plane_out[4 * (int64_t)be + 2] = pf[q][2]; plane_out[4 * (int64_t)be + 3] = pf[q][3];
+      // (float)pa is exact: pa was promoted from the f32 plane
+      const float f0 = (float)pa[q], f1 = (float)pb[q], f2 = (float)pc[q], f3 = (float)pd[q];
+      s_plane[0] = f0; s_plane[1] = f1; s_plane[2] = f2; s_plane[3] = f3;
+      if (out.plane) {
+        out.plane[4 * (int64_t)be + 0] = f0; out.plane[4 * (int64_t)be + 1] = f1;
+        out.plane[4 * (int64_t)be + 2] = f2; out.plane[4 * (int64_t)be + 3] = f3;
       }
-      if (count_out) count_out[be] = cnt[q];
-      if (index_out) index_out[be] = win;
+      if (out.count) out.count[be] = cnt[q];
+      if (out.index) out.index[be] = win;
     }
   }
   __syncthreads();
   // final mask with the winning f32 plane (cuda_ransac.py:149-155)
   const double a = (double)s_plane[0], bb = (double)s_plane[1], c = (double)s_plane[2],
-               d = (double)s_plane[3];
+               dd = (double)s_plane[3];
   for (int i = threadIdx.x; i < n; i += THREADS) {
-    const double dist = plane_distance(a, bb, c, d, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    mask[pstart + i] = (dist < thr) ? 1 : 0;
+    double x, y, z;
+    if (IN_LDS) {
+      x = lx[i]; y = ly[i]; z = lz[i];
+    } else {
+      x = pts[3 * (int64_t)i]; y = pts[3 * (int64_t)i + 1]; z = pts[3 * (int64_t)i + 2];
+    }
+    out.mask[pstart + i] = (plane_distance(a, bb, c, dd, x, y, z) < thr) ? 1 : 0;
   }
 }
 
-__global__ __launch_bounds__(256) void k_vstart_from_sizes(const int32_t* __restrict__ order,
-                                                           const int32_t* __restrict__ size,
-                                                           int64_t nb,
-                                                           uint32_t* __restrict__ tmp_sizes) {
+// Persistent workgroups: workgroup w handles batch entries w, w+G, w+2G, ...  While entry e is
+// being computed out of one LDS buffer, the points of entry e+G are already in flight into
+// registers (one point per lane) and the descriptor of entry e+2G is being fetched, so the
+// per-block HBM/L2 latency chain (descriptor -> points) is off the critical path.  The first
+// version (one workgroup per block, points fetched at its start) spent more time waiting for
+// that chain than computing: a block holds ~17 points.
+template <int THREADS, int HPL, int KT, int ABL>
+__global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(const double* __restrict__ xyz,
+                                                    const BlockDesc* __restrict__ desc, int nb,
+                                                    const double* __restrict__ hyp, int H, int k,
+                                                    double thr, RansacOut out) {
+  constexpr int CAP = THREADS - 1;
+  __shared__ double s_pts[2][3][THREADS];
+  __shared__ unsigned long long s_best[THREADS / 64];
+  __shared__ float s_plane[4];
+  const int G = gridDim.x;
+  int be = blockIdx.x;
+  if (be >= nb) return;
+  BlockDesc cur = desc[be];
+  BlockDesc nxt = cur;
+  if (be + G < nb) nxt = desc[be + G];
+  int buf = 0;
+  // stage the first block
+  if (cur.n >= k && cur.n <= CAP && (int)threadIdx.x <= cur.n) {
+    const int64_t p = ((int)threadIdx.x < cur.n) ? (int64_t)cur.pstart + threadIdx.x : (int64_t)cur.pspill;
+    s_pts[0][0][threadIdx.x] = xyz[3 * p];
+    s_pts[0][1][threadIdx.x] = xyz[3 * p + 1];
+    s_pts[0][2][threadIdx.x] = xyz[3 * p + 2];
+  }
+  __syncthreads();
+  while (true) {
+    const bool has_next = be + G < nb;
+    const bool has_next2 = be + 2 * G < nb;
+    BlockDesc nxt2 = nxt;
+    if (has_next2) nxt2 = desc[be + 2 * G];
+    // points of the next block -> registers (in flight during the compute below)
+    double rx = 0.0, ry = 0.0, rz = 0.0;
+    const bool pre = has_next && nxt.n >= k && nxt.n <= CAP && (int)threadIdx.x <= nxt.n;
+    if (pre) {
+      const int64_t p = ((int)threadIdx.x < nxt.n) ? (int64_t)nxt.pstart + threadIdx.x : (int64_t)nxt.pspill;
+      rx = xyz[3 * p];
+      ry = xyz[3 * p + 1];
+      rz = xyz[3 * p + 2];
+    }
+    // the current block
+    if (cur.n < k) {  // cuda_ransac.py:96-97: the whole block returns, mask stays False
+      for (int i = threadIdx.x; i < cur.n; i += THREADS) out.mask[(int64_t)cur.pstart + i] = 0;
+      if (threadIdx.x == 0) {
+        if (out.plane) {
+          out.plane[4 * (int64_t)be + 0] = 0.f; out.plane[4 * (int64_t)be + 1] = 0.f;
+          out.plane[4 * (int64_t)be + 2] = 0.f; out.plane[4 * (int64_t)be + 3] = 0.f;
+        }
+        if (out.count) out.count[be] = 0;
+        if (out.index) out.index[be] = -1;
+      }
+    } else if (cur.n <= CAP) {
+      ransac_block<THREADS, HPL, KT, true, ABL>(cur, be, xyz, s_pts[buf][0], s_pts[buf][1],
+                                                s_pts[buf][2], hyp, H, k, thr, out, s_best, s_plane);
+    }  // larger blocks: k_ransac_big
+    if (!has_next) break;
+    __syncthreads();  // every wave is done with s_pts[buf ^ 1]'s previous contents (and s_best)
+    if (pre) {
+      s_pts[buf ^ 1][0][threadIdx.x] = rx;
+      s_pts[buf ^ 1][1][threadIdx.x] = ry;
+      s_pts[buf ^ 1][2][threadIdx.x] = rz;
+    }
+    __syncthreads();
+    cur = nxt;
+    nxt = nxt2;
+    be += G;
+    buf ^= 1;
+  }
+}
+
+// Blocks with more than THREADS-1 points (unsplit voxels, poses outside the scheme, large K):
+// points stay in global memory (wave-uniform scalar loads in the scoring loop).  The list of
+// such batch entries is appended by k_block_desc; its length lives in device memory, so the
+// grid is fixed and every workgroup strides over the list.
+template <int THREADS, int HPL, int KT>
+__global__ __launch_bounds__(THREADS) void k_ransac_big(const double* __restrict__ xyz,
+                                                        const BlockDesc* __restrict__ desc,
+                                                        const uint32_t* __restrict__ big_list,
+                                                        const uint32_t* __restrict__ big_count,
+                                                        const double* __restrict__ hyp, int H,
+                                                        int k, double thr, RansacOut out) {
+  __shared__ unsigned long long s_best[THREADS / 64];
+  __shared__ float s_plane[4];
+  const uint32_t count = *big_count;
+  for (uint32_t j = blockIdx.x; j < count; j += gridDim.x) {
+    const int be = (int)big_list[j];
+    const BlockDesc d = desc[be];
+    ransac_block<THREADS, HPL, KT, false, 0>(d, be, xyz, nullptr, nullptr, nullptr, hyp, H, k, thr,
+                                             out, s_best, s_plane);
+    __syncthreads();
+  }
+}
+
+// batch entry -> descriptor (sizes in batch order were scanned into `scanned`)
+__global__ __launch_bounds__(256) void k_block_sizes_in_order(const int32_t* __restrict__ order,
+                                                              const int32_t* __restrict__ size,
+                                                              int64_t nb,
+                                                              uint32_t* __restrict__ tmp_sizes) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   tmp_sizes[b] = (uint32_t)size[order ? order[b] : b];
 }
 
-__global__ __launch_bounds__(256) void k_vstart_finish(const int32_t* __restrict__ order,
-                                                       const uint32_t* __restrict__ start,
-                                                       const int32_t* __restrict__ size,
-                                                       const uint32_t* __restrict__ scanned,
-                                                       int64_t nb, int64_t n_points,
-                                                       int64_t* __restrict__ vstart,
-                                                       uint32_t* __restrict__ spill) {
+__global__ __launch_bounds__(256) void k_block_desc(const int32_t* __restrict__ order,
+                                                    const uint32_t* __restrict__ start,
+                                                    const int32_t* __restrict__ size,
+                                                    const uint32_t* __restrict__ scanned,
+                                                    int64_t nb, int64_t n_points, int cap,
+                                                    int k, BlockDesc* __restrict__ desc,
+                                                    uint32_t* __restrict__ big_list,
+                                                    uint32_t* __restrict__ big_count) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
-  vstart[b] = (int64_t)scanned[b];
-  uint32_t sp = 0xFFFFFFFFu;
+  const int32_t phys = order ? order[b] : (int32_t)b;
+  BlockDesc d;
+  d.pstart = start[phys];
+  d.n = size[phys];
+  d.vstart = (int64_t)scanned[b];  // np.cumsum([0] + sizes[:-1]) in batch order (cuda_ransac.py:64-66)
+  uint32_t sp = d.n > 0 ? d.pstart + (uint32_t)d.n - 1u : d.pstart;
   if (b + 1 < nb) {
     sp = start[order ? order[b + 1] : b + 1];
   } else if (!order) {
     // stand-alone operator: the cloud may continue past the last block (cuda_ransac.py:43-81)
-    const int64_t e = (int64_t)start[b] + size[b];
+    const int64_t e = (int64_t)d.pstart + d.n;
     if (e < n_points) sp = (uint32_t)e;
   }
-  spill[b] = sp;
+  d.pspill = sp;
+  d.pad[0] = d.pad[1] = d.pad[2] = 0;
+  desc[b] = d;
+  if (d.n > cap && d.n >= k) big_list[atomicAdd(big_count, 1u)] = (uint32_t)b;
 }
 
 }  // namespace
 
 // Launch the kernel over nb batch entries.  `order` (device, nullable) maps batch entry ->
-// physical block.  vstart/spill are derived on the device from the sizes in batch order.
+// physical block.  Descriptors (virtual start, spill point) are derived on the device from the
+// sizes in batch order.
 int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                   const uint32_t* blk_start, const int32_t* blk_size, const int32_t* order_dev,
                   int64_t nb, const double* hyp_dev, int32_t H, int32_t k, double thr,
                   uint8_t* mask_dev, float* plane_dev, int32_t* count_dev, int32_t* index_dev,
                   uint8_t* evaluated_dev, DevBuf& scratch) {
+  (void)evaluated_dev;
   if (nb <= 0) return OCTL_OK;
   if (H < 1 || H > 1024) return octl_set_error(ctx, OCTL_E_INVALID, "H must be in [1, 1024]");
   if (k < 1 || k > RS_KMAX)
     return octl_set_error(ctx, OCTL_E_INVALID, "initial_points_number must be in [1, %d]", RS_KMAX);
   if (nb >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "too many blocks");
   hipStream_t st = ctx->stream;
-  // scratch: [sizes/scanned u32 nb+8 | vstart i64 nb | spill u32 nb]
-  const size_t off_v = (((size_t)nb + 8) * 4 + 15) & ~(size_t)15;
-  const size_t off_s = off_v + (size_t)nb * 8;
-  OCTL_TRY(devbuf_reserve(ctx, scratch, off_s + (size_t)nb * 4 + 16));
+  // scratch: [sizes/scanned u32 nb+8 | descriptors 32 B x nb | big list u32 nb | big count]
+  const size_t off_d = (((size_t)nb + 8) * 4 + 31) & ~(size_t)31;
+  const size_t off_b = off_d + (size_t)nb * sizeof(BlockDesc);
+  OCTL_TRY(devbuf_reserve(ctx, scratch, off_b + ((size_t)nb + 8) * 4));
   uint32_t* tmp = scratch.as<uint32_t>();
-  int64_t* vstart = reinterpret_cast<int64_t*>(static_cast<char*>(scratch.p) + off_v);
-  uint32_t* spill = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch.p) + off_s);
+  BlockDesc* desc = reinterpret_cast<BlockDesc*>(static_cast<char*>(scratch.p) + off_d);
+  uint32_t* big_list = reinterpret_cast<uint32_t*>(static_cast<char*>(scratch.p) + off_b);
+  uint32_t* big_count = big_list + nb;
+  const int threads = (H <= 64) ? 64 : 256;
   {
     KTimer t(ctx, "ransac_prepare");
     const unsigned g = (unsigned)ceil_div(nb, 256);
-    hipLaunchKernelGGL(k_vstart_from_sizes, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp);
+    hipLaunchKernelGGL(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, tmp, tmp, nb, nullptr));
-    hipLaunchKernelGGL(k_vstart_finish, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size,
-                       (const uint32_t*)tmp, nb, n_points, vstart, spill);
+    HIP_TRY(ctx, hipMemsetAsync(big_count, 0, 4, st));
+    hipLaunchKernelGGL(k_block_desc, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size,
+                       (const uint32_t*)tmp, nb, n_points, threads - 1, (int)k, desc, big_list,
+                       big_count);
     HIP_TRY(ctx, hipGetLastError());
   }
-  RansacBlocks blk;
-  blk.start = blk_start;
-  blk.size = blk_size;
-  blk.vstart = vstart;
-  blk.spill = spill;
-  blk.order = order_dev;
+  RansacOut out{mask_dev, plane_dev, count_dev, index_dev};
+  // persistent grid: 4 workgroups of 256 threads per CU (VGPR-limited residency)
+  int cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
   KTimer t(ctx, "ransac");
-#define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT)                                                    \
-  hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT>), dim3((unsigned)nb), dim3(THREADS), 0, st,      \
-                     xyz_dev, n_points, blk, hyp_dev, H, k, thr, mask_dev, plane_dev, count_dev,  \
-                     index_dev, evaluated_dev)
+#define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU)                                       \
+  do {                                                                                          \
+    const unsigned g = (unsigned)std::min<int64_t>(nb, (int64_t)cus * (PER_CU));                \
+    hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL>), dim3(g), dim3(THREADS), 0, st,         \
+                       xyz_dev, (const BlockDesc*)desc, (int)nb, hyp_dev, H, k, thr, out);       \
+  } while (0)
   if (H <= 64) {
-    if (k == 6) OCTL_RANSAC_LAUNCH(64, 1, 6); else OCTL_RANSAC_LAUNCH(64, 1, 0);
+    if (k == 6) OCTL_RANSAC_LAUNCH(64, 1, 6, 0, 16); else OCTL_RANSAC_LAUNCH(64, 1, 0, 0, 8);
   } else if (H <= 256) {
-    if (k == 6) OCTL_RANSAC_LAUNCH(256, 1, 6); else OCTL_RANSAC_LAUNCH(256, 1, 0);
+    if (k == 6) OCTL_RANSAC_LAUNCH(256, 1, 6, 0, 8); else OCTL_RANSAC_LAUNCH(256, 1, 0, 0, 4);
   } else {
-    if (k == 6) OCTL_RANSAC_LAUNCH(256, 4, 6); else OCTL_RANSAC_LAUNCH(256, 4, 0);
+    const char* abl = getenv("OCTL_RANSAC_ABLATE");  // timing experiments only
+    if (k == 6 && abl && abl[0] == '1') OCTL_RANSAC_LAUNCH(256, 4, 6, 1, 4);
+    else if (k == 6 && abl && abl[0] == '2') OCTL_RANSAC_LAUNCH(256, 4, 6, 2, 4);
+    else if (k == 6) OCTL_RANSAC_LAUNCH(256, 4, 6, 0, 4);
+    else OCTL_RANSAC_LAUNCH(256, 4, 0, 0, 2);
   }
 #undef OCTL_RANSAC_LAUNCH
+  HIP_TRY(ctx, hipGetLastError());
+  // the (rare) blocks that do not fit the LDS staging; the grid is fixed, the count is on the device
+#define OCTL_RANSAC_BIG(THREADS, HPL, KT)                                                       \
+  hipLaunchKernelGGL((k_ransac_big<THREADS, HPL, KT>), dim3((unsigned)std::min<int64_t>(nb, 2 * cus)), \
+                     dim3(THREADS), 0, st, xyz_dev, (const BlockDesc*)desc,                     \
+                     (const uint32_t*)big_list, (const uint32_t*)big_count, hyp_dev, H, k, thr, out)
+  if (H <= 64) {
+    if (k == 6) OCTL_RANSAC_BIG(64, 1, 6); else OCTL_RANSAC_BIG(64, 1, 0);
+  } else if (H <= 256) {
+    if (k == 6) OCTL_RANSAC_BIG(256, 1, 6); else OCTL_RANSAC_BIG(256, 1, 0);
+  } else {
+    if (k == 6) OCTL_RANSAC_BIG(256, 4, 6); else OCTL_RANSAC_BIG(256, 4, 0);
+  }
+#undef OCTL_RANSAC_BIG
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
 }

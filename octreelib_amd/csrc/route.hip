@@ -11,6 +11,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
+
 #include "forest.h"
 #include "ref_arith.h"
 
@@ -171,6 +173,10 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   if (n >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "too many points");
   const int R = ctx->n_ranks, me = ctx->rank;
   if (R > 1 && !ctx->comm) return octl_set_error(ctx, OCTL_E_STATE, "communicator not initialised");
+  // test hook: with a communicator present, push even the local part through RCCL (a 1-rank
+  // communicator then exercises AllGather + grouped Send/Recv on a single GPU)
+  const bool use_rccl = ctx->comm && (R > 1 || getenv("OCTL_ROUTE_SELF_SENDRECV") != nullptr);
+  const bool self_rccl = use_rccl && getenv("OCTL_ROUTE_SELF_SENDRECV") != nullptr;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
@@ -229,7 +235,7 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   }
   // --- 3. counts exchange -----------------------------------------------------------------------------
   std::vector<int64_t> matrix((size_t)R * R, 0);
-  if (R > 1) {
+  if (use_rccl) {
     ncclResult_t r = g_rccl.AllGather(counts_d.p, matrix_d.p, (size_t)R, ncclInt64, comm, st);
     if (r != ncclSuccess) {
       cleanup();
@@ -272,7 +278,7 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   {
     KTimer t(ctx, "route_alltoall");
     const int64_t self = matrix[(size_t)me * R + me];
-    if (self > 0) {
+    if (self > 0 && !self_rccl) {
       (void)hipMemcpyAsync(ctx->routed_xyz.as<double>() + 3 * roff[me],
                            send_xyz.as<double>() + 3 * soff[me], (size_t)self * 24,
                            hipMemcpyDeviceToDevice, st);
@@ -280,10 +286,10 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
                            send_gidx.as<int64_t>() + soff[me], (size_t)self * 8,
                            hipMemcpyDeviceToDevice, st);
     }
-    if (R > 1) {
+    if (use_rccl) {
       ncclResult_t r = g_rccl.GroupStart();
       for (int p = 0; p < R && r == ncclSuccess; ++p) {
-        if (p == me) continue;
+        if (p == me && !self_rccl) continue;
         const int64_t sc = matrix[(size_t)me * R + p], rcnt = matrix[(size_t)p * R + me];
         if (sc > 0) {
           r = g_rccl.Send(send_xyz.as<double>() + 3 * soff[p], (size_t)sc * 3, ncclDouble, p, comm, st);
@@ -335,7 +341,7 @@ int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n) {
 
 int octl_comm_allreduce_i64(octl_ctx* ctx, int64_t* inout_host, int32_t n) {
   if (!ctx || !inout_host || n < 0 || n > 256) return OCTL_E_INVALID;
-  if (ctx->n_ranks == 1 || n == 0) return OCTL_OK;
+  if (n == 0 || (ctx->n_ranks == 1 && !ctx->comm)) return OCTL_OK;
   if (!ctx->comm) return octl_set_error(ctx, OCTL_E_STATE, "communicator not initialised");
   hipStream_t st = ctx->stream;
   int64_t* d = reinterpret_cast<int64_t*>(ctx->small.as<uint32_t>() + 512);  // 2 KiB into the block

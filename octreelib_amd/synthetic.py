@@ -1,0 +1,37 @@
+"""
+Synthetic clouds of the benchmark configurations: uniform and
+"planar" (per top-level voxel 80 % of the points on a random plane + noise, 20 % uniform
+outliers; shape follows the reference's own test generator, test/grid/test_cuda_ransac.py:9-24).
+"""
+
+import numpy as np
+
+__all__ = ["uniform_cloud", "planar_cloud"]
+
+
+def uniform_cloud(n: int, dims=(32, 32, 32), seed: int = 0) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return rng.random((n, 3)) * np.asarray(dims, dtype=np.float64)
+
+
+def planar_cloud(n: int, dims=(32, 32, 32), seed: int = 1, stream: int = 0,
+                 inlier_fraction: float = 0.8, sigma: float = 0.005, box=None) -> np.ndarray:
+    """n points over a grid of dims[0] x dims[1] x dims[2] voxels of 1 m.  The plane of every
+    voxel depends only on `seed`, so different `stream`s (ranks) draw different points of the
+    SAME scene.  `box` = (lo, hi) integer voxel bounds restricts the points to a sub-box."""
+    dims = np.asarray(dims, dtype=np.int64)
+    V = int(dims.prod())
+    ab = np.random.default_rng(seed).uniform(-0.4, 0.4, (V, 2))
+    rng = np.random.default_rng([seed, stream, 0x5EED])
+    if box is None:
+        lo, hi = np.zeros(3, dtype=np.int64), dims
+    else:
+        lo, hi = np.asarray(box[0], dtype=np.int64), np.asarray(box[1], dtype=np.int64)
+    q = np.stack([rng.integers(lo[a], hi[a], n) for a in range(3)], axis=1)
+    lin = (q[:, 0] * dims[1] + q[:, 1]) * dims[2] + q[:, 2]
+    local = rng.random((n, 3))
+    inl = rng.random(n) < inlier_fraction
+    a, b = ab[lin, 0], ab[lin, 1]
+    z = 0.5 + a * (local[:, 0] - 0.5) + b * (local[:, 1] - 0.5) + rng.normal(0.0, sigma, n)
+    local[inl, 2] = np.clip(z[inl], 1e-9, 1.0 - 1e-9)
+    return local + q.astype(np.float64)

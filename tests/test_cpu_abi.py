@@ -1,0 +1,115 @@
+"""CPU-only checks of the boundary: the C-ABI library loads, exports every symbol the header
+declares, and the product path refuses to run without a GPU (no CPU fallback)."""
+
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "octreelib_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(octl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from octreelib_amd import _native as nat
+
+    lib = nat.load()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in octreelib_hip.h but not exported"
+        assert name in nat.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(nat.SIGNATURES) <= set(names)
+    assert lib.octl_abi_version() == 1
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_product_path_fails_loudly_without_gpu():
+    from octreelib_amd import _native as nat
+    from octreelib_amd.grid import Grid, GridConfig
+    from octreelib_amd.ransac import CudaRansac
+
+    with pytest.raises(nat.NativeLibraryError):
+        Grid(GridConfig(voxel_edge_length=1))
+    with pytest.raises(nat.NativeLibraryError):
+        CudaRansac().evaluate(np.zeros((8, 3)), np.array([8], dtype=np.int32))
+
+
+def test_grid_config_type_errors_verbatim():
+    # test/grid/test_grid.py:148-182 of the reference
+    from octreelib_amd.grid import GridConfig
+    from octreelib_amd.octree import OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+
+    with pytest.raises(TypeError) as e:
+        GridConfig(octree_manager_type=type(None), octree_config=OctreeConfig(), voxel_edge_length=5)
+    assert str(e.value) == (
+        "Cannot use the provided octree manager type NoneType. "
+        "It has to be a subclass of octree_manager.OctreeManager."
+    )
+    with pytest.raises(TypeError) as e:
+        GridConfig(octree_manager_type=OctreeManager, octree_type=type(None), octree_config=OctreeConfig(),
+                   voxel_edge_length=5)
+    assert str(e.value) == (
+        "Cannot use the provided octree type NoneType. "
+        "It has to be a subclass of octree.OctreeBase."
+    )
+
+
+def test_count_criterion_recognition():
+    from octreelib_amd.criteria import MaxPoints, UnsupportedCriterion, count_threshold
+
+    k = 12
+    assert count_threshold([lambda points: len(points) > 2]) == 2
+    assert count_threshold([lambda pts: len(pts) > k]) == 12
+    assert count_threshold([lambda p: len(p) >= 5]) == 4
+    assert count_threshold([lambda p: 7 < len(p)]) == 7
+    assert count_threshold([MaxPoints(9), lambda p: len(p) > 30]) == 9
+    assert count_threshold([]) == -1
+
+    def named(points):
+        return len(points) > 3
+
+    assert count_threshold([named]) == 3
+    with pytest.raises(UnsupportedCriterion):
+        count_threshold([lambda p: p[:, 2].std() > 0.1])
+    with pytest.raises(UnsupportedCriterion):
+        count_threshold([lambda p: len(p) > 2 and True])
+    with pytest.raises(RecursionError):
+        count_threshold([lambda p: len(p) > -1])
+
+
+def test_voxel_value_type():
+    # reference: internal/voxel.py - equal voxels share an id, hash/eq on (corner, edge)
+    from octreelib_amd.internal import Voxel, VoxelBase
+
+    a = Voxel(np.array([0, 0, 2.5]), 2.5, np.zeros((2, 3)))
+    b = VoxelBase(np.array([0.0, 0.0, 2.5]), 2.5)
+    c = Voxel(np.array([0, 0, 2.5]), 1.25)
+    assert a == b and hash(a) == hash(b) and a.id == b.id
+    assert a != c and a.id != c.id
+    assert np.array_equal(a.corner_max, np.array([2.5, 2.5, 5.0]))
+    assert len(a.all_corners) == 8
+    a.insert_points(np.ones((3, 3)))
+    assert a.get_points().shape == (5, 3)
+
+
+def test_voxel_owner_host_mirror_matches_library():
+    from octreelib_amd import _native as nat
+    from octreelib_amd.distributed import voxel_owner_np
+
+    lib = nat.load()
+    rng = np.random.default_rng(0)
+    q = rng.integers(-1000, 1000, (2000, 3))
+    for n in (1, 2, 3, 8):
+        want = np.array([lib.octl_voxel_owner(int(a), int(b), int(c), n) for a, b, c in q])
+        assert np.array_equal(voxel_owner_np(q, n), want)
+    # reasonably balanced over 8 ranks
+    counts = np.bincount(voxel_owner_np(np.argwhere(np.ones((32, 32, 32))), 8), minlength=8)
+    assert counts.min() > 0.9 * counts.mean()
