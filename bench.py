@@ -187,6 +187,16 @@ def main():
         alg_bytes = {"ransac": 24.0 * n_step}
         dom_bytes = alg_bytes.get(dom, 24.0 * n_step)
         dom_launch_ms = kern[dom]["ms_avg"]
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there)
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["kernels"]
+            t = prof.get("k_" + dom)
+            if t and args.points == 10_000_000 and args.cloud == "planar" and world == 1:
+                traffic = t["fetch_bytes_corrected"] + t["write_bytes"]
+        except Exception:
+            traffic = None
         achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
         device_ms = sum(k["ms_per_step"] for k in kern.values())
         ransac_ms = kern.get("ransac", {}).get("ms_per_step", 0.0)
@@ -226,7 +236,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "launch_ms": dom_launch_ms,
                 "algorithmic_bytes_per_launch": dom_bytes,
                 "note": "the RANSAC scoring kernel is FP64-VALU bound, not HBM bound: see roofline_valu",
