@@ -1,0 +1,193 @@
+"""BASELINE.json's configurations at full size, checked through size-independent properties
+(the oracle cannot build 10 M points in seconds), and at reduced size against the oracle.
+
+  C2/C3  Grid of 1 m voxels, 10 M points, insert + subdivide (+ RANSAC)
+  C4     one OctreeManager, 64 poses, synchronised subdivision (64 x 1 M at full size)
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _forest_tables(f):
+    return f.nodes, f.blocks, f.perm
+
+
+def _check_structure(f, n_total, K, scheme_all=True):
+    """Properties every correct build has, whatever its size."""
+    nd, blk, perm = _forest_tables(f)
+    # 1. perm is a permutation of all points
+    assert len(perm) == n_total
+    seen = np.zeros(n_total, dtype=bool)
+    seen[perm] = True
+    assert seen.all()
+    # 2. blocks tile the storage exactly, in order
+    assert blk["start"][0] == 0
+    assert np.array_equal(blk["start"][1:], np.cumsum(blk["size"])[:-1])
+    assert int(blk["size"].sum()) == n_total
+    # 3. every block sits in a leaf; leaves of the scheme hold <= K scheme points; every internal
+    #    node holds > K (count rule, octree.py:26)
+    leaf = nd["first_child"] < 0
+    assert leaf[blk["node"]].all()
+    per_node = np.bincount(blk["node"], weights=blk["size"], minlength=len(leaf)).astype(np.int64)
+    if scheme_all:
+        assert per_node[leaf].max() <= K
+        # points under an internal node = sum over its subtree: accumulate bottom-up
+        tot = per_node.copy()
+        order = np.argsort(-nd["depth"], kind="stable")
+        par = nd["parent"]
+        for i in order:
+            if par[i] >= 0:
+                tot[par[i]] += tot[i]
+        assert (tot[~leaf] > K).all()
+    # 4. n_nodes = roots + 8 * internal
+    assert len(leaf) == len(f.voxels) + 8 * int((~leaf).sum())
+    # 5. inside a block the permutation is ascending (stable)
+    heads = np.zeros(n_total, dtype=bool)
+    heads[blk["start"]] = True
+    d = np.diff(perm)
+    assert (d[~heads[1:]] > 0).all()
+    return nd, blk, perm
+
+
+def _check_points_in_leaf_cubes(f, xyz_ord, sample=200_000, seed=0):
+    nd, blk = f.nodes, f.blocks
+    rng = np.random.default_rng(seed)
+    b = rng.integers(0, len(blk["node"]), min(sample, len(blk["node"])))
+    pos = blk["start"][b] + (rng.random(len(b)) * blk["size"][b]).astype(np.int64)
+    node = blk["node"][b]
+    c, e = nd["corner"][node], nd["edge"][node][:, None]
+    p = xyz_ord[pos]
+    assert ((p >= c) & (p < c + e)).all()
+
+
+def test_c3_grid_10M_properties():
+    from octreelib_amd import synthetic
+    from octreelib_amd._engine import Forest
+
+    n, K = 10_000_000, 64
+    pts = synthetic.planar_cloud(n, (32, 32, 32), seed=1)
+    f = Forest(0, np.zeros(3), 1.0)
+    f.add_pose(pts)
+    f.subdivide(K)
+    assert f.info.n_voxels == 32 * 32 * 32
+    nd, blk, perm = _check_structure(f, n, K)
+    xyz_ord = f.xyz
+    assert np.array_equal(xyz_ord, pts[perm])  # leaf-ordered coordinates are the permuted input
+    _check_points_in_leaf_cubes(f, xyz_ord)
+    # idempotence: building again gives the same tables
+    blocks_before = {k: v.copy() for k, v in blk.items()}
+    f.subdivide(K)
+    for k in blocks_before:
+        assert np.array_equal(f.blocks[k], blocks_before[k])
+    assert np.array_equal(f.perm, perm)
+    # the reference order is a permutation of the blocks, voxel-major
+    order = f.order
+    assert np.array_equal(np.sort(order), np.arange(len(order)))
+    v = nd["voxel"][blk["node"][order]]
+    assert (np.diff(v) >= 0).all()
+    # RANSAC: mask popcount per block equals the winner's count; n < 6 blocks are emptied
+    np.random.seed(0)
+    table = np.random.random((1024, 6))
+    sub = order[:50_000]
+    plane, count, index = f.ransac_blocks(sub, table, 0.01, details=True)
+    mask = f.device_mask()
+    starts, sizes = blk["start"][sub], blk["size"][sub]
+    cs = np.concatenate(([0], np.cumsum(mask, dtype=np.int64)))
+    pop = cs[starts + sizes] - cs[starts]
+    assert np.array_equal(pop, count)
+    assert (count[sizes < 6] == 0).all() and (index[sizes < 6] == -1).all()
+    assert (count <= sizes).all()
+    nrm = np.linalg.norm(plane[sizes >= 6, :3].astype(np.float64), axis=1)
+    # unit normals, or the all-zero plane of a degenerate sample (util.py:77-78), which scores n
+    zero = nrm == 0
+    assert np.allclose(nrm[~zero], 1.0, atol=1e-6)
+    assert (count[sizes >= 6][zero] == sizes[sizes >= 6][zero]).all()
+    f.close()
+
+
+def test_c3_reduced_size_checksum_against_oracle():
+    """Same scene generator, a 6^3-voxel sub-box: full pipeline against the oracle."""
+    from octreelib_amd import synthetic
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+    from oracle import ransac_np as rnp
+
+    pts = synthetic.planar_cloud(6 ** 3 * 305, (32, 32, 32), seed=1, stream=7, box=((0, 0, 0), (6, 6, 6)))
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, pts)
+    grid.subdivide([lambda p: len(p) > 64])
+    np.random.seed(0)
+    table = np.random.random((1024, 6))
+    np.random.seed(0)
+    grid.map_leaf_points_cuda_ransac()
+    og = onp.OGrid(1)
+    og.insert_points(0, pts)
+    og.subdivide(64)
+    rows = og.leaf_table(0)
+    mask = rnp.evaluate(np.vstack([pts[i] for _, _, i in rows]), np.array([len(i) for _, _, i in rows], dtype=np.int32), table, 0.01)
+    og.apply_mask(0, mask)
+    f = grid._forest
+    got = {(f.nodes["corner"][n].tobytes(), f.nodes["edge"][n].tobytes()): tuple(np.sort(f.perm[s : s + z]).tolist())
+           for n, s, z in zip(f.blocks["node"], f.blocks["start"], f.blocks["size"])}
+    want = {(np.asarray(c, dtype=np.float64).tobytes(), np.float64(e).tobytes()): tuple(sorted(i.tolist()))
+            for c, e, i in og.leaf_table(0)}
+    assert got == want
+    assert [grid.n_nodes(0), grid.n_leaves(0), grid.n_points(0)] == [og.n_nodes(0), og.n_leaves(0), og.n_points(0)]
+
+
+def test_c1_single_octree_100k_known_answer():
+    """BASELINE config 1: 100 k uniform points, len > 32; the reference's own result for exactly
+    this input is 6601 nodes / 5748 leaves (probed), 4681/4096 at len > 128."""
+    from octreelib_amd.octree import Octree, OctreeConfig
+
+    pts = np.random.default_rng(1234).random((100_000, 3))
+    for k, nodes, leaves in ((32, 6601, 5748), (128, 4681, 4096), (1024, 585, 512)):
+        oc = Octree(OctreeConfig(), np.array([0.0, 0.0, 0.0]), np.float64(1))
+        oc.insert_points(pts)
+        oc.subdivide([lambda p: len(p) > k])
+        assert [oc.n_nodes, oc.n_leaves, oc.n_points] == [nodes, leaves, 100_000]
+
+
+def test_c4_manager_multi_pose_reduced_vs_oracle_and_full_properties():
+    from octreelib_amd._engine import Forest
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+    from oracle import octree_np as onp
+
+    # reduced: 8 poses x 5000 points, K = 256, against the oracle (leaf sets, order, counters)
+    P, n, K = 8, 5000, 256
+    poses = [np.random.default_rng(100 + p).random((n, 3)) for p in range(P)]
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 1.0)
+    om = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(P):
+        m.insert_points(p, poses[p])
+        om.insert_points(p, poses[p])
+    m.subdivide([lambda pts: len(pts) > K])
+    om.subdivide(K)
+    for p in range(P):
+        index = {poses[p][i].tobytes(): i for i in range(n)}
+        got = [((np.asarray(v.corner_min, dtype=np.float64) + 0.0).tobytes(), np.float64(v.edge_length).tobytes(),
+                tuple(sorted(index[q.tobytes()] for q in v.get_points()))) for v in m.get_leaf_points(True, p)]
+        want = [((np.asarray(v.corner, dtype=np.float64) + 0.0).tobytes(), np.float64(v.edge).tobytes(),
+                 tuple(sorted(v.idx.tolist()))) for v in om.octrees[p].leaves()]
+        assert got == want
+        assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == [om.n_nodes(p), om.n_leaves(p), om.n_points(p)]
+
+    # full size: 64 poses x 1 M points in one cube, K = 4096 (union of 64 M points)
+    P, n, K = 64, 1_000_000, 4096
+    f = Forest(1, np.zeros(3), 1.0)
+    for p in range(P):
+        f.add_pose(np.random.default_rng(100 + p).random((n, 3)))
+    f.subdivide(K)
+    nd, blk, perm = _check_structure(f, P * n, K)
+    assert f.info.n_voxels == 1 and f.info.n_levels >= 4
+    # every leaf holds points of (almost) every pose, pose-major inside the leaf
+    assert np.array_equal(np.unique(blk["slot"]), np.arange(P))
+    same_leaf = blk["node"][1:] == blk["node"][:-1]
+    assert (np.diff(blk["slot"])[same_leaf] > 0).all()
+    f.close()
