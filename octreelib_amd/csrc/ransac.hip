@@ -120,6 +120,9 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #ifndef RS_SCHED_BARRIER
 #define RS_SCHED_BARRIER 1
 #endif
+#ifndef RS_SCREEN
+#define RS_SCREEN 0  // measured: exact but not faster yet (register pressure); see DESIGN.md
+#endif
 #ifndef RS_SCORE_UNROLL
 #define RS_SCORE_UNROLL 4
 #endif
@@ -208,7 +211,21 @@ __device__ __forceinline__ void fit_hypothesis(const double* __restrict__ hyp, u
 // One block (leaf x pose) on one workgroup: THREADS lanes, HPL hypotheses per lane (lane t owns
 // hypotheses t, t+THREADS, ...).  IN_LDS: the block's points (and the spill point at index n)
 // are in the LDS arrays lx/ly/lz; otherwise they are read from global memory.
-template <int THREADS, int HPL, int KT, bool IN_LDS, int ABL>
+//
+// SCREEN (LDS path only): the scoring loop - H x n distance tests, the FP64-VALU hot spot - is
+// first evaluated in f32 on coordinates local to the block and only the (rare) pairs whose f32
+// distance lands within a rigorous error bound of the threshold are re-evaluated with the
+// reference's exact f64 sequence.  The inlier COUNTS are therefore exactly the reference's:
+//   reference      t_ref = fl(fl(fl(A x + B y) + C z) + D)            (util.py:22-24, f64)
+//   identity       A x + B y + C z + D = T_o + A (x-ox) + B (y-oy) + C (z-oz),  o = first point
+//   screen         s = fma32(a, u, fma32(b, v, fma32(c, w, to)))      u = fl32(x-ox) ..., to = fl32(T_o)
+//   |s - t_ref| <= 2^-24 (4 |T_o| + 9 E) + 2^-50 (|o|_1 + |D| + E)     E = max |u|,|v|,|w| of the block
+//     (three f32 FMA roundings on partial sums <= |T_o| + 3E, the f32 roundings of u,v,w and to,
+//      and the f64 roundings of T_o and of t_ref itself; |a|,|b|,|c| <= 1)
+// delta is taken as TWICE that bound plus the f32 rounding of the thresholds themselves:
+//   |s| <  thr - delta  =>  |t_ref| < thr   (inlier)      |s| > thr + delta  =>  |t_ref| > thr
+// everything in between is decided by the exact sequence.
+template <int THREADS, int HPL, int KT, bool IN_LDS, int ABL, bool SCREEN = false>
 __device__ __forceinline__ void ransac_block(const BlockDesc& d, int be,
                                              const double* __restrict__ xyz,
                                              const double* __restrict__ lx,
@@ -216,17 +233,39 @@ __device__ __forceinline__ void ransac_block(const BlockDesc& d, int be,
                                              const double* __restrict__ lz,
                                              const double* __restrict__ hyp, int H, int k,
                                              double thr, const RansacOut& out,
-                                             unsigned long long* s_best, float* s_plane) {
+                                             unsigned long long* s_best, float* s_plane,
+                                             float4* s_loc = nullptr, int* s_extent = nullptr) {
   const int n = d.n;
   const int64_t pstart = d.pstart;
   const double* __restrict__ pts = xyz + 3 * pstart;
+  double ox = 0.0, oy = 0.0, oz = 0.0;
+  float extent = 0.f;
+  if (SCREEN) {
+    // block-local f32 coordinates and their extent (s_extent was zeroed two barriers ago)
+    ox = lx[0]; oy = ly[0]; oz = lz[0];
+    float m = 0.f;
+    if ((int)threadIdx.x < n) {
+      const float u = (float)(lx[threadIdx.x] - ox), v = (float)(ly[threadIdx.x] - oy),
+                  w = (float)(lz[threadIdx.x] - oz);
+      s_loc[threadIdx.x] = make_float4(u, v, w, 0.f);
+      m = fmaxf(fabsf(u), fmaxf(fabsf(v), fabsf(w)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    // non-negative floats order like their bit patterns; NaN/inf extents make everything ambiguous
+    if ((threadIdx.x & 63) == 0) atomicMax(s_extent, __float_as_int(m));
+    __syncthreads();
+    extent = __int_as_float(*s_extent);
+  }
+  // SCREEN keeps only the f32 plane (its f64 promotion is exact and is redone on demand)
   double pa[HPL], pb[HPL], pc[HPL], pd[HPL];
+  float fa[HPL], fb[HPL], fc[HPL], fd[HPL], sto[HPL], slo[HPL], shi[HPL];
   int cnt[HPL];
 #pragma unroll
   for (int q = 0; q < HPL; ++q) {
     const int t = threadIdx.x + q * THREADS;
     cnt[q] = -1;
-    pa[q] = pb[q] = pc[q] = pd[q] = 0.0;
+    if (!SCREEN) pa[q] = pb[q] = pc[q] = pd[q] = 0.0;
     if (t < H) {
       float pf[4];
       if (ABL == 2) {  // ablation: no plane fit (timing only, results meaningless)
@@ -238,11 +277,26 @@ __device__ __forceinline__ void ransac_block(const BlockDesc& d, int be,
                                    d.vstart, lx, ly, lz, xyz, pstart, (int64_t)d.pspill, pf);
       }
       // the f32-rounded plane, promoted back to f64 for scoring (cuda_ransac.py:110-121)
-      pa[q] = (double)pf[0];
-      pb[q] = (double)pf[1];
-      pc[q] = (double)pf[2];
-      pd[q] = (double)pf[3];
       cnt[q] = 0;
+      if (SCREEN) {
+        const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
+        const double to = ((A * ox + B * oy) + Cc * oz) + D;
+        const double delta = 0x1p-23 * (4.0 * fabs(to) + 9.0 * (double)extent) +
+                             0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + fabs(D) + (double)extent + 1.0) +
+                             0x1p-23 * fabs(thr);
+        fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
+        sto[q] = (float)to;
+        slo[q] = (float)(thr - delta);
+        shi[q] = (float)(thr + delta);
+      } else {
+        pa[q] = (double)pf[0];
+        pb[q] = (double)pf[1];
+        pc[q] = (double)pf[2];
+        pd[q] = (double)pf[3];
+      }
+    } else if (SCREEN) {
+      fa[q] = fb[q] = fc[q] = fd[q] = 0.f;
+      sto[q] = 0.f; slo[q] = 0.f; shi[q] = 0.f;
     }
     // keep the plane fits of the lane's hypotheses apart: interleaving them (all sample loads
     // hoisted to the top) needs > 200 VGPRs and halves the resident waves
@@ -252,7 +306,52 @@ __device__ __forceinline__ void ransac_block(const BlockDesc& d, int be,
   }
   // scoring: every point of the block against every hypothesis of the lane
   // (cuda_ransac.py:116-121); the point is wave uniform (LDS broadcast / scalar load)
-  if (ABL != 1) {
+  if (ABL != 1 && SCREEN) {
+    // two points per iteration, the next pair's LDS reads issued before the current pair is
+    // evaluated (the loop is otherwise bound by the LDS round trip, not by the VALU)
+    auto screen = [&](const float4& L, int q) -> int {
+      const float sv = fabsf(fmaf(fa[q], L.x, fmaf(fb[q], L.y, fmaf(fc[q], L.z, sto[q]))));
+      const bool in = sv < slo[q];
+      cnt[q] += in ? 1 : 0;
+      return (!in && (sv <= shi[q])) ? 1 : 0;
+    };
+    auto exact = [&](int i, int bits) {
+      const double x = lx[i], y = ly[i], z = lz[i];
+#pragma unroll
+      for (int q = 0; q < HPL; ++q) {
+        if (bits & (1 << q)) {
+          const double dist = plane_distance((double)fa[q], (double)fb[q], (double)fc[q],
+                                             (double)fd[q], x, y, z);
+          cnt[q] += (dist < thr) ? 1 : 0;
+        }
+      }
+    };
+    float4 L0 = s_loc[0], L1 = s_loc[1];  // s_loc has THREADS >= n + 1 entries
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+      const float4 N0 = s_loc[i + 2 < THREADS ? i + 2 : 0], N1 = s_loc[i + 3 < THREADS ? i + 3 : 0];
+      int b0 = 0, b1 = 0;
+#pragma unroll
+      for (int q = 0; q < HPL; ++q) {
+        b0 |= screen(L0, q) << q;
+        b1 |= screen(L1, q) << q;
+      }
+      if (__any((b0 | b1) != 0)) {  // rare: borderline pairs get the reference's f64 sequence
+        if (b0) exact(i, b0);
+        if (b1) exact(i + 1, b1);
+      }
+      L0 = N0;
+      L1 = N1;
+    }
+    if (i < n) {
+      int b0 = 0;
+#pragma unroll
+      for (int q = 0; q < HPL; ++q) b0 |= screen(L0, q) << q;
+      if (__any(b0 != 0)) {
+        if (b0) exact(i, b0);
+      }
+    }
+  } else if (ABL != 1) {
 RS_PRAGMA(unroll RS_SCORE_UNROLL)
     for (int i = 0; i < n; ++i) {
       double x, y, z;
@@ -294,7 +393,8 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
   for (int q = 0; q < HPL; ++q) {
     if ((int)threadIdx.x + q * THREADS == win) {
       // (float)pa is exact: pa was promoted from the f32 plane
-      const float f0 = (float)pa[q], f1 = (float)pb[q], f2 = (float)pc[q], f3 = (float)pd[q];
+      const float f0 = SCREEN ? fa[q] : (float)pa[q], f1 = SCREEN ? fb[q] : (float)pb[q],
+                  f2 = SCREEN ? fc[q] : (float)pc[q], f3 = SCREEN ? fd[q] : (float)pd[q];
       s_plane[0] = f0; s_plane[1] = f1; s_plane[2] = f2; s_plane[3] = f3;
       if (out.plane) {
         out.plane[4 * (int64_t)be + 0] = f0; out.plane[4 * (int64_t)be + 1] = f1;
@@ -332,11 +432,14 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(const double* _
                                                     double thr, RansacOut out) {
   constexpr int CAP = THREADS - 1;
   __shared__ double s_pts[2][3][THREADS];
+  __shared__ float4 s_loc[THREADS];
   __shared__ unsigned long long s_best[THREADS / 64];
   __shared__ float s_plane[4];
+  __shared__ int s_extent;
   const int G = gridDim.x;
   int be = blockIdx.x;
   if (be >= nb) return;
+  if (threadIdx.x == 0) s_extent = 0;
   BlockDesc cur = desc[be];
   BlockDesc nxt = cur;
   if (be + G < nb) nxt = desc[be + G];
@@ -375,10 +478,12 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(const double* _
         if (out.index) out.index[be] = -1;
       }
     } else if (cur.n <= CAP) {
-      ransac_block<THREADS, HPL, KT, true, ABL>(cur, be, xyz, s_pts[buf][0], s_pts[buf][1],
-                                                s_pts[buf][2], hyp, H, k, thr, out, s_best, s_plane);
+      ransac_block<THREADS, HPL, KT, true, ABL, RS_SCREEN != 0>(
+          cur, be, xyz, s_pts[buf][0], s_pts[buf][1], s_pts[buf][2], hyp, H, k, thr, out, s_best,
+          s_plane, s_loc, &s_extent);
     }  // larger blocks: k_ransac_big
     if (!has_next) break;
+    if (threadIdx.x == 0) s_extent = 0;  // read only before the plane fits; re-armed for the next block
     __syncthreads();  // every wave is done with s_pts[buf ^ 1]'s previous contents (and s_best)
     if (pre) {
       s_pts[buf ^ 1][0][threadIdx.x] = rx;
