@@ -100,7 +100,7 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
   }
   f->mask_valid = false;
   OCTL_TRY(forest_make_blocks(f));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  OCTL_TRY(forest_finish_blocks(f, nullptr));
   if (n_alive_out) *n_alive_out = f->n_ord;
   return OCTL_OK;
 }
@@ -158,7 +158,7 @@ void octl_forest_destroy(octl_forest* f) {
         &f->pos_node2, &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
         &f->hist, &f->idxbuf[0], &f->idxbuf[1], &f->pathbuf[0], &f->pathbuf[1], &f->flags,
         &f->entries, &f->split[0], &f->split[1], &f->split_tiles[0], &f->split_tiles[1],
-        &f->child_sc, &f->pose_off_dev, &f->scheme_dev, &f->root_up})
+        &f->child_sc, &f->pose_off_dev, &f->scheme_dev, &f->root_up, &f->vlin_dev})
     devbuf_free(*b);
   delete f;
 }
@@ -174,6 +174,8 @@ int octl_forest_clear(octl_forest* f) {
   f->epoch = 0;
   f->built = false;
   f->vkeys.clear();
+  f->vkeys_stale = false;
+  f->n_voxels = 0;
   f->level_first.clear();
   f->n_internal = 0;
   f->max_depth_reached = 0;
@@ -253,8 +255,9 @@ int octl_forest_get_nodes(octl_forest* f, int64_t cap, int32_t* voxel, int32_t* 
 int octl_forest_get_voxels(octl_forest* f, int64_t cap, int64_t* coords, int64_t* n_voxels) {
   if (!f || !n_voxels) return OCTL_E_INVALID;
   if (!f->built) return octl_set_error(f->ctx, OCTL_E_STATE, "no scheme has been built");
-  *n_voxels = (int64_t)f->vkeys.size();
+  *n_voxels = f->n_voxels;
   if (!coords) return OCTL_OK;
+  OCTL_TRY(forest_sync_vkeys(f));
   const int64_t n = std::min<int64_t>(cap, *n_voxels);
   for (int64_t v = 0; v < n; ++v) {
     int64_t q[3];

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_init_level0(
   if (i >= n_alive) return;
   const uint32_t head = (i == 0 || lin[i] != lin[i - 1]) ? 1u : 0u;
   const uint32_t local = scanned[i] + head - 1u;
-  pos_node[i] = local2root[local];
+  pos_node[i] = local2root ? local2root[local] : (int32_t)local;
   const uint32_t v = val_sorted[i];
   idx0[i] = v;
   path0[i] = path[v & IDX_MASK];
@@ -274,6 +274,42 @@ struct NodePtrs {
   int32_t *depth, *voxel, *parent, *first_child, *old_id, *epoch;
   double *corner, *edge;
 };
+
+// roots of a forest without a previous scheme, built on the device (no PCIe round trip)
+__global__ __launch_bounds__(256) void k_make_roots(const uint64_t* __restrict__ vlin,
+                                                    const uint32_t* __restrict__ vstart, int64_t V,
+                                                    int64_t n_alive, int mode, double L, double c0x,
+                                                    double c0y, double c0z, int minx, int miny,
+                                                    int minz, uint64_t ny, uint64_t nz,
+                                                    int scount_is_count, NodePtrs nd) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= V) return;
+  const uint32_t s = vstart[r];
+  const uint32_t e = (r + 1 < V) ? vstart[r + 1] : (uint32_t)n_alive;
+  nd.start[r] = s;
+  nd.count[r] = e - s;
+  nd.scount[r] = scount_is_count ? e - s : 0u;
+  nd.depth[r] = 0;
+  nd.voxel[r] = (int32_t)r;
+  nd.parent[r] = -1;
+  nd.first_child[r] = -1;
+  nd.old_id[r] = -1;
+  nd.epoch[r] = 0;
+  nd.edge[r] = L;
+  if (mode == 0) {
+    const uint64_t l = vlin[r];
+    const int64_t qz = (int64_t)(l % nz) + minz, qy = (int64_t)((l / nz) % ny) + miny,
+                  qx = (int64_t)(l / (nz * ny)) + minx;
+    // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
+    nd.corner[3 * r + 0] = (double)(long long)((double)qx * L);
+    nd.corner[3 * r + 1] = (double)(long long)((double)qy * L);
+    nd.corner[3 * r + 2] = (double)(long long)((double)qz * L);
+  } else {
+    nd.corner[3 * r + 0] = c0x;
+    nd.corner[3 * r + 1] = c0y;
+    nd.corner[3 * r + 2] = c0z;
+  }
+}
 
 // split predicate for the freshly created nodes [first, first+n_new)
 //   K mode   : scheme-pose count > K                       (octree.py:26, octree_manager.py:53-61)
@@ -602,8 +638,10 @@ __global__ __launch_bounds__(256) void k_block_fill(const int32_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_block_sizes(const uint32_t* __restrict__ blk_start,
-                                                     int64_t nb, int64_t n_alive,
+                                                     const uint32_t* __restrict__ nb_dev,
+                                                     int64_t n_alive,
                                                      int32_t* __restrict__ blk_size) {
+  const int64_t nb = (int64_t)*nb_dev;
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   const uint32_t e = (b + 1 < nb) ? blk_start[b + 1] : (uint32_t)n_alive;
@@ -664,41 +702,72 @@ static int read_small(octl_ctx* ctx, int first, int count, uint32_t* out) {
   return OCTL_OK;
 }
 
+// (Re)build the (leaf, pose) block table from pos_node / ord_idx.  Asynchronous: the block count
+// is left in small[SM_NBLOCKS]; forest_finish_blocks reads it (one synchronisation).
 int forest_make_blocks(octl_forest* f) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
   const int64_t n = f->n_ord;
   const int n_poses = (int)f->pose_off.size() - 1;
   f->n_blocks = 0;
-  if (n <= 0) return OCTL_OK;
   uint32_t* small = ctx->small.as<uint32_t>();
+  if (n <= 0) {
+    HIP_TRY(ctx, hipMemsetAsync(small + SM_NBLOCKS, 0, 4, st));
+    return OCTL_OK;
+  }
   KTimer t(ctx, "blocks");
   OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n + 8) * 4));
   uint32_t* flags = f->flags.as<uint32_t>();
   const int32_t* pos_node = f->pos_node.as<int32_t>();
+  // capacity = one block per point (grow-only buffers): the count is not known on the host yet
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_node, (size_t)n * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n * 4));
   hipLaunchKernelGGL(k_block_heads, dim3(grid_for(n)), dim3(256), 0, st, pos_node,
                      (const uint32_t*)f->ord_idx.as<uint32_t>(),
                      (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, n, flags);
   HIP_TRY(ctx, hipGetLastError());
   OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n, small + SM_NBLOCKS));
-  uint32_t nb;
-  OCTL_TRY(read_small(ctx, SM_NBLOCKS, 1, &nb));
-  const int64_t n_blocks = nb;
-  OCTL_TRY(devbuf_reserve(ctx, f->blk_node, (size_t)n_blocks * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n_blocks * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n_blocks * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n_blocks * 4));
   hipLaunchKernelGGL(k_block_fill, dim3(grid_for(n)), dim3(256), 0, st, pos_node,
                      (const uint32_t*)f->ord_idx.as<uint32_t>(),
                      (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, n,
                      (const uint32_t*)flags, f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
                      f->blk_start.as<uint32_t>());
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_block_sizes, dim3(grid_for(n_blocks)), dim3(256), 0, st,
-                     (const uint32_t*)f->blk_start.as<uint32_t>(), n_blocks, n,
-                     f->blk_size.as<int32_t>());
+  hipLaunchKernelGGL(k_block_sizes, dim3(grid_for(n)), dim3(256), 0, st,
+                     (const uint32_t*)f->blk_start.as<uint32_t>(),
+                     (const uint32_t*)(small + SM_NBLOCKS), n, f->blk_size.as<int32_t>());
   HIP_TRY(ctx, hipGetLastError());
-  f->n_blocks = n_blocks;
+  return OCTL_OK;
+}
+
+int forest_finish_blocks(octl_forest* f, uint32_t* err_out) {
+  uint32_t sm[32];
+  OCTL_TRY(read_small(f->ctx, 0, 32, sm));
+  f->n_blocks = sm[SM_NBLOCKS];
+  if (err_out) *err_out = sm[SM_ERR];
+  return OCTL_OK;
+}
+
+int forest_sync_vkeys(octl_forest* f) {
+  if (!f->vkeys_stale) return OCTL_OK;
+  octl_ctx* ctx = f->ctx;
+  std::vector<uint64_t> lin((size_t)f->n_voxels);
+  if (f->n_voxels > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(lin.data(), f->vlin_dev.p, (size_t)f->n_voxels * 8,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  f->vkeys.resize((size_t)f->n_voxels);
+  for (int64_t v = 0; v < f->n_voxels; ++v) {
+    const uint64_t l = lin[v];
+    const uint64_t qz = l % f->vl_nz, qy = (l / f->vl_nz) % f->vl_ny, qx = l / (f->vl_nz * f->vl_ny);
+    f->vkeys[v] = ((uint64_t)((int64_t)qx + f->vl_min[0] + OCTL_VOX_BIAS) << 42) |
+                  ((uint64_t)((int64_t)qy + f->vl_min[1] + OCTL_VOX_BIAS) << 21) |
+                  (uint64_t)((int64_t)qz + f->vl_min[2] + OCTL_VOX_BIAS);
+  }
+  f->vkeys_stale = false;
   return OCTL_OK;
 }
 
@@ -717,6 +786,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     return octl_set_error(ctx, OCTL_E_INVALID, "scheme mask has %d entries for %d poses", n_mask,
                           n_poses);
   if (max_depth <= 0) max_depth = 63;
+  OCTL_TRY(forest_sync_vkeys(f));  // the previous scheme's voxels persist (no-op when fresh)
   uint32_t* small = ctx->small.as<uint32_t>();
 
   bool all_scheme = true;
@@ -736,17 +806,31 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
 
   // ---- pose offsets / scheme mask on the device ----------------------------------------------
   OCTL_TRY(devbuf_reserve(ctx, f->pose_off_dev, (size_t)(n_poses + 1) * 8));
-  HIP_TRY(ctx, hipMemcpyAsync(f->pose_off_dev.p, f->pose_off.data(), (size_t)(n_poses + 1) * 8,
-                              hipMemcpyHostToDevice, st));
   const uint8_t* scheme_dev = nullptr;
-  if (!all_scheme) {
-    OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)n_poses));
-    HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, scheme_mask, (size_t)n_poses,
-                                hipMemcpyHostToDevice, st));
-    scheme_dev = f->scheme_dev.as<uint8_t>();
+  {
+    // small uploads go through pinned staging so that no synchronisation is needed; the region
+    // [0, 128 KiB) of ctx->pinned belongs to the build, [128 KiB, 256 KiB) to the RANSAC table
+    const size_t off_bytes = (size_t)(n_poses + 1) * 8;
+    const bool fits = off_bytes + (size_t)n_poses <= OCTL_PINNED_BYTES / 2;
+    char* pin = static_cast<char*>(ctx->pinned);
+    const void* src_off = f->pose_off.data();
+    if (fits) {
+      std::memcpy(pin, f->pose_off.data(), off_bytes);
+      src_off = pin;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(f->pose_off_dev.p, src_off, off_bytes, hipMemcpyHostToDevice, st));
+    if (!all_scheme) {
+      OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)n_poses));
+      const void* src_m = scheme_mask;
+      if (fits) {
+        std::memcpy(pin + off_bytes, scheme_mask, (size_t)n_poses);
+        src_m = pin + off_bytes;
+      }
+      HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, src_m, (size_t)n_poses, hipMemcpyHostToDevice, st));
+      scheme_dev = f->scheme_dev.as<uint8_t>();
+    }
+    if (!fits) HIP_TRY(ctx, hipStreamSynchronize(st));  // pageable sources must not change in flight
   }
-  // the H2D copies above read pageable host memory: complete them before it can change
-  HIP_TRY(ctx, hipStreamSynchronize(st));
 
   // ---- 1. keys -----------------------------------------------------------------------------------
   const int64_t n_alive = f->n_alive;
@@ -821,36 +905,57 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   // ---- 3. roots ------------------------------------------------------------------------------------
   OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_alive, 8) + 8) * 4));
   uint32_t* flags = f->flags.as<uint32_t>();
+  const bool have_old = f->built;
+  const bool fresh = !have_old && f->vkeys.empty() && n_alive > 0;  // roots made on the device
   int64_t v_pts = 0;
   std::vector<uint64_t> vlin_h;
   std::vector<uint32_t> vstart_h;
+  uint64_t* vlin_d = f->lin[sorted ^ 1].as<uint64_t>();   // free now: staging for the voxel table
+  uint32_t* vstart_d = f->val[sorted ^ 1].as<uint32_t>();
   if (n_alive > 0) {
     KTimer t(ctx, "roots");
     hipLaunchKernelGGL(k_heads, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted, n_alive,
                        flags);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_alive, small + SM_NVOX));
-    uint32_t nv;
-    OCTL_TRY(read_small(ctx, SM_NVOX, 1, &nv));
-    v_pts = nv;
-    // lin[1-sorted] / val[1-sorted] are free now: reuse them as staging for the voxel table
-    uint64_t* vlin_d = f->lin[sorted ^ 1].as<uint64_t>();
-    uint32_t* vstart_d = f->val[sorted ^ 1].as<uint32_t>();
     hipLaunchKernelGGL(k_voxel_collect, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted,
                        (const uint32_t*)flags, n_alive, vlin_d, vstart_d);
     HIP_TRY(ctx, hipGetLastError());
-    vlin_h.resize(v_pts);
-    vstart_h.resize(v_pts);
-    HIP_TRY(ctx, hipMemcpyAsync(vlin_h.data(), vlin_d, (size_t)v_pts * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(vstart_h.data(), vstart_d, (size_t)v_pts * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    uint32_t nv;
+    OCTL_TRY(read_small(ctx, SM_NVOX, 1, &nv));
+    v_pts = nv;
+    if (!fresh) {
+      vlin_h.resize(v_pts);
+      vstart_h.resize(v_pts);
+      HIP_TRY(ctx, hipMemcpyAsync(vlin_h.data(), vlin_d, (size_t)v_pts * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipMemcpyAsync(vstart_h.data(), vstart_d, (size_t)v_pts * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
   }
-  // union with the voxels of the previous scheme (both lists are sorted by lin: the packed key
-  // order and the lin order are both the lexicographic (x,y,z) order)
+  NodeTable& nt = f->nodes[f->cur ^ 1];
+  NodeTable& old = f->nodes[f->cur];
+  const int32_t* old_fc = have_old ? old.first_child.as<int32_t>() : nullptr;
+  const int32_t* old_epoch = have_old ? old.epoch.as<int32_t>() : nullptr;
   std::vector<uint64_t> new_vkeys;
-  std::vector<uint32_t> r_start, r_count;
-  std::vector<int32_t> r_old, local2root(std::max<int64_t>(v_pts, 1));
-  {
+  std::vector<int32_t> local2root;
+  int64_t V = 0;
+  NodePtrs nd;
+  if (fresh) {
+    V = v_pts;
+    OCTL_TRY(nodes_reserve(ctx, nt, std::max<int64_t>(V, 1)));
+    nt.n = V;
+    nd = node_ptrs(nt);
+    hipLaunchKernelGGL(k_make_roots, dim3(grid_for(V)), dim3(256), 0, st, (const uint64_t*)vlin_d,
+                       (const uint32_t*)vstart_d, V, n_alive, f->mode, f->edge, f->corner[0],
+                       f->corner[1], f->corner[2], bb[0], bb[1], bb[2], ny, nz,
+                       (int)(all_scheme || keep_scheme), nd);
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    // union with the voxels of the previous scheme (both lists are sorted by lin: the packed key
+    // order and the lin order are both the lexicographic (x,y,z) order)
+    std::vector<uint32_t> r_start, r_count;
+    std::vector<int32_t> r_old;
+    local2root.resize(std::max<int64_t>(v_pts, 1));
     size_t a = 0, b = 0;
     const size_t na = (size_t)v_pts, nb_old = f->vkeys.size();
     while (a < na || b < nb_old) {
@@ -860,10 +965,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       const int32_t root = (int32_t)new_vkeys.size();
       new_vkeys.push_back(vkey_of_lin(l));
       if (la == l) {
-        const uint32_t s = vstart_h[a];
-        const uint32_t e = (a + 1 < na) ? vstart_h[a + 1] : (uint32_t)n_alive;
-        r_start.push_back(s);
-        r_count.push_back(e - s);
+        const uint32_t s0 = vstart_h[a];
+        const uint32_t e0 = (a + 1 < na) ? vstart_h[a + 1] : (uint32_t)n_alive;
+        r_start.push_back(s0);
+        r_count.push_back(e0 - s0);
         local2root[a] = root;
         ++a;
       } else {
@@ -884,52 +989,45 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       r_count.push_back(0);
       r_old.push_back(f->built ? 0 : -1);
     }
-  }
-  const int64_t V = (int64_t)new_vkeys.size();
-  NodeTable& nt = f->nodes[f->cur ^ 1];
-  NodeTable& old = f->nodes[f->cur];
-  const bool have_old = f->built;
-  OCTL_TRY(nodes_reserve(ctx, nt, std::max<int64_t>(V, 1)));
-  nt.n = V;
-  NodePtrs nd = node_ptrs(nt);
-  const int32_t* old_fc = have_old ? old.first_child.as<int32_t>() : nullptr;
-  const int32_t* old_epoch = have_old ? old.epoch.as<int32_t>() : nullptr;
-  if (V > 0) {
-    // one staging upload: [start | count | old | voxel | depth0 | parent-1 | fc-1 | epoch0 | corner | edge]
-    std::vector<int32_t> i32((size_t)V);
-    std::vector<double> cor((size_t)V * 3), edg((size_t)V, f->edge);
-    auto up = [&](void* dst, const void* src, size_t bytes) {
-      return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-    };
-    HIP_TRY(ctx, up(nd.start, r_start.data(), (size_t)V * 4));
-    HIP_TRY(ctx, up(nd.count, r_count.data(), (size_t)V * 4));
-    HIP_TRY(ctx, up(nd.old_id, r_old.data(), (size_t)V * 4));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    for (int64_t v = 0; v < V; ++v) i32[v] = (int32_t)v;
-    HIP_TRY(ctx, up(nd.voxel, i32.data(), (size_t)V * 4));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    HIP_TRY(ctx, hipMemsetAsync(nd.depth, 0, (size_t)V * 4, st));
-    HIP_TRY(ctx, hipMemsetAsync(nd.epoch, 0, (size_t)V * 4, st));
-    HIP_TRY(ctx, hipMemsetAsync(nd.parent, 0xFF, (size_t)V * 4, st));
-    HIP_TRY(ctx, hipMemsetAsync(nd.first_child, 0xFF, (size_t)V * 4, st));
-    for (int64_t v = 0; v < V; ++v) {
-      if (f->mode == 0) {
-        int64_t q[3];
-        vkey_decode(new_vkeys[v], q);
-        // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
-        for (int a = 0; a < 3; ++a) cor[3 * v + a] = (double)(int64_t)((double)q[a] * f->edge);
-      } else {
-        for (int a = 0; a < 3; ++a) cor[3 * v + a] = f->corner[a];
+    V = (int64_t)new_vkeys.size();
+    OCTL_TRY(nodes_reserve(ctx, nt, std::max<int64_t>(V, 1)));
+    nt.n = V;
+    nd = node_ptrs(nt);
+    if (V > 0) {
+      std::vector<int32_t> i32((size_t)V);
+      std::vector<double> cor((size_t)V * 3), edg((size_t)V, f->edge);
+      auto up = [&](void* dst, const void* src, size_t bytes) {
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+      };
+      for (int64_t v = 0; v < V; ++v) {
+        i32[v] = (int32_t)v;
+        if (f->mode == 0) {
+          int64_t q[3];
+          vkey_decode(new_vkeys[v], q);
+          // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
+          for (int ax = 0; ax < 3; ++ax) cor[3 * v + ax] = (double)(int64_t)((double)q[ax] * f->edge);
+        } else {
+          for (int ax = 0; ax < 3; ++ax) cor[3 * v + ax] = f->corner[ax];
+        }
       }
+      HIP_TRY(ctx, up(nd.start, r_start.data(), (size_t)V * 4));
+      HIP_TRY(ctx, up(nd.count, r_count.data(), (size_t)V * 4));
+      HIP_TRY(ctx, up(nd.old_id, r_old.data(), (size_t)V * 4));
+      HIP_TRY(ctx, up(nd.voxel, i32.data(), (size_t)V * 4));
+      HIP_TRY(ctx, hipMemsetAsync(nd.depth, 0, (size_t)V * 4, st));
+      HIP_TRY(ctx, hipMemsetAsync(nd.epoch, 0, (size_t)V * 4, st));
+      HIP_TRY(ctx, hipMemsetAsync(nd.parent, 0xFF, (size_t)V * 4, st));
+      HIP_TRY(ctx, hipMemsetAsync(nd.first_child, 0xFF, (size_t)V * 4, st));
+      HIP_TRY(ctx, up(nd.corner, cor.data(), (size_t)V * 24));
+      HIP_TRY(ctx, up(nd.edge, edg.data(), (size_t)V * 8));
+      if (all_scheme || keep_scheme) {
+        HIP_TRY(ctx, up(nd.scount, r_count.data(), (size_t)V * 4));
+      } else {
+        HIP_TRY(ctx, hipMemsetAsync(nd.scount, 0, (size_t)V * 4, st));
+      }
+      // the sources above are pageable host vectors that die with this scope
+      HIP_TRY(ctx, hipStreamSynchronize(st));
     }
-    HIP_TRY(ctx, up(nd.corner, cor.data(), (size_t)V * 24));
-    HIP_TRY(ctx, up(nd.edge, edg.data(), (size_t)V * 8));
-    if (all_scheme || keep_scheme) {
-      HIP_TRY(ctx, up(nd.scount, r_count.data(), (size_t)V * 4));
-    } else {
-      HIP_TRY(ctx, hipMemsetAsync(nd.scount, 0, (size_t)V * 4, st));
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(st));
   }
 
   // ---- 4. level-0 buffers ---------------------------------------------------------------------------
@@ -940,14 +1038,18 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   OCTL_TRY(devbuf_reserve(ctx, f->pos_node, (size_t)std::max<int64_t>(n_alive, 1) * 4));
   int32_t* pos_node = f->pos_node.as<int32_t>();
   if (n_alive > 0) {
-    OCTL_TRY(devbuf_reserve(ctx, f->root_up, (size_t)v_pts * 4));
-    HIP_TRY(ctx, hipMemcpyAsync(f->root_up.p, local2root.data(), (size_t)v_pts * 4,
-                                hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int32_t* l2r = nullptr;
+    if (!fresh) {
+      OCTL_TRY(devbuf_reserve(ctx, f->root_up, (size_t)v_pts * 4));
+      HIP_TRY(ctx, hipMemcpyAsync(f->root_up.p, local2root.data(), (size_t)v_pts * 4,
+                                  hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      l2r = f->root_up.as<int32_t>();
+    }
     KTimer t(ctx, "init_level0");
     hipLaunchKernelGGL(k_init_level0, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted,
                        (const uint32_t*)flags, val_sorted, (const uint64_t*)f->path.as<uint64_t>(),
-                       n_alive, (const int32_t*)f->root_up.as<int32_t>(), pos_node,
+                       n_alive, l2r, pos_node,
                        f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint64_t>());
     HIP_TRY(ctx, hipGetLastError());
     if (!all_scheme && !keep_scheme) {
@@ -957,6 +1059,11 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       HIP_TRY(ctx, hipGetLastError());
     }
   }
+
+  // voxel keys of this build: kept on the device, decoded on the host only when someone asks
+  OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
+  if (fresh && V > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(f->vlin_dev.p, vlin_d, (size_t)V * 8, hipMemcpyDeviceToDevice, st));
 
   // ---- 5. level loop ----------------------------------------------------------------------------------
   int64_t first_new = 0, n_new = V, n_internal = 0;
@@ -979,22 +1086,24 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
                          n_new, (int)keep_scheme, K, old_fc, flags);
       HIP_TRY(ctx, hipGetLastError());
       OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_new, small + SM_NSPLIT));
+      // tiles of the nodes that split: scanned over n_new entries (zeros beyond the ns that are
+      // filled) so that ns and the tile count come back in ONE readback
+      HIP_TRY(ctx, hipMemsetAsync(tile_base, 0, (size_t)(n_new + 8) * 4, st));
       hipLaunchKernelGGL(k_compact_split, dim3(grid_for(n_new)), dim3(256), 0, st, nd, first_new,
                          n_new, (const uint32_t*)flags, (int)keep_scheme, K, old_fc, split_nodes,
                          tile_base);
       HIP_TRY(ctx, hipGetLastError());
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_base, tile_base, n_new, small + SM_NTILES));
     }
-    uint32_t ns_u;
-    OCTL_TRY(read_small(ctx, SM_NSPLIT, 1, &ns_u));
-    const int ns = (int)ns_u;
+    uint32_t lv[2];
+    OCTL_TRY(read_small(ctx, SM_NSPLIT, 2, lv));
+    const int ns = (int)lv[0];
+    const uint32_t n_tiles = lv[1];
     if (ns == 0) break;
     if (level >= max_depth)
       return octl_set_error(ctx, OCTL_E_DEPTH,
                             "maximum depth %d exceeded (duplicate points with a count criterion "
                             "never stop subdividing)", max_depth);
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_base, tile_base, ns, small + SM_NTILES));
-    uint32_t n_tiles;
-    OCTL_TRY(read_small(ctx, SM_NTILES, 1, &n_tiles));
 
     const int64_t child_base = nt.n;
     if (child_base + 8 * (int64_t)ns >= ((int64_t)1 << 31))
@@ -1071,15 +1180,6 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     n_internal += ns;
     ++level;
   }
-  {
-    uint32_t e;
-    OCTL_TRY(read_small(ctx, SM_ERR, 1, &e));
-    if (e)
-      return octl_set_error(ctx, OCTL_E_DOMAIN,
-                            "a point lies outside the cube of a node that is being subdivided "
-                            "(the reference raises IndexError or picks a wrong child here)");
-  }
-
   // ---- 6. leaf-ordered arrays and the block table ------------------------------------------------------
   int64_t n_blocks = 0;
   if (n_alive > 0) {
@@ -1095,15 +1195,37 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
                          f->xyz_ord.as<double>());
       HIP_TRY(ctx, hipGetLastError());
     }
-    f->n_ord = n_alive;
-    OCTL_TRY(forest_make_blocks(f));
-    n_blocks = f->n_blocks;
   }
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  const int64_t n_ord_before = f->n_ord;
+  f->n_ord = n_alive;
+  OCTL_TRY(forest_make_blocks(f));
+  {
+    uint32_t e = 0;
+    OCTL_TRY(forest_finish_blocks(f, &e));  // the build's final synchronisation
+    n_blocks = f->n_blocks;
+    if (e) {
+      f->n_ord = n_ord_before;
+      f->n_blocks = 0;
+      f->built = false;  // the leaf-ordered arrays were overwritten
+      return octl_set_error(ctx, OCTL_E_DOMAIN,
+                            "a point lies outside the cube of a node that is being subdivided "
+                            "(the reference raises IndexError or picks a wrong child here)");
+    }
+  }
 
   // ---- commit --------------------------------------------------------------------------------------------
   f->cur ^= 1;
-  f->vkeys.swap(new_vkeys);
+  f->n_voxels = V;
+  if (fresh) {
+    f->vkeys.clear();
+    f->vkeys_stale = true;
+    f->vl_min[0] = bb[0]; f->vl_min[1] = bb[1]; f->vl_min[2] = bb[2];
+    f->vl_ny = ny;
+    f->vl_nz = nz;
+  } else {
+    f->vkeys.swap(new_vkeys);
+    f->vkeys_stale = false;
+  }
   f->level_first.swap(level_first);
   f->built = true;
   f->epoch = cur_epoch;

@@ -14,6 +14,7 @@
 #include "../../include/octreelib_hip.h"
 
 #define OCTL_WAVE 64
+#define OCTL_PINNED_BYTES (256 * 1024)
 
 struct KernelTiming {
   double ms = 0.0;
@@ -46,6 +47,7 @@ struct octl_ctx {
   DevBuf scan_tmp[3];
   DevBuf small;     // 4 KiB of device scalars (counters, flags)
   void* small_host = nullptr;  // pinned mirror
+  void* pinned = nullptr;      // pinned staging for small uploads (OCTL_PINNED_BYTES)
   // RCCL (route.hip)
   void* comm = nullptr;
   int n_ranks = 1, rank = 0;

@@ -108,7 +108,8 @@ int octl_ctx_create(int device_id, octl_ctx** out) {
     return OCTL_E_HIP;
   }
   if (hipMalloc(&ctx->small.p, 4096) != hipSuccess ||
-      hipHostMalloc(&ctx->small_host, 4096, hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc(&ctx->small_host, 4096, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc(&ctx->pinned, OCTL_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
     if (ctx->small.p) (void)hipFree(ctx->small.p);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -138,6 +139,7 @@ void octl_ctx_destroy(octl_ctx* ctx) {
   devbuf_free(ctx->routed_xyz);
   devbuf_free(ctx->routed_gidx);
   if (ctx->small_host) (void)hipHostFree(ctx->small_host);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -29,6 +29,12 @@ struct octl_forest {
   int epoch = 0;             // number of K-driven builds so far
   bool built = false;
   std::vector<uint64_t> vkeys;  // packed integer coordinates of the top-level voxels, sorted
+                                // (filled lazily from vlin_dev: forest_sync_vkeys)
+  bool vkeys_stale = false;
+  int64_t n_voxels = 0;
+  DevBuf vlin_dev;              // u64 [n_voxels] compact linear voxel keys of the last build
+  int vl_min[3] = {0, 0, 0};    // decoding of vlin_dev: lin = ((qx-min0)*ny + (qy-min1))*nz + (qz-min2)
+  uint64_t vl_ny = 1, vl_nz = 1;
   int64_t n_internal = 0;
   int32_t max_depth_reached = 0;
 
@@ -78,3 +84,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                   uint8_t* evaluated_dev, DevBuf& scratch);
 // build.hip: (re)build the (leaf, pose) block table from pos_node / ord_idx
 int forest_make_blocks(octl_forest* f);
+// reads the block count (and the domain-error flag) left on the device: one synchronisation
+int forest_finish_blocks(octl_forest* f, uint32_t* err_out);
+// host copy of the voxel keys (synchronises when stale)
+int forest_sync_vkeys(octl_forest* f);

@@ -103,7 +103,8 @@ int bits_for(uint64_t max_value) {
 // Fills f->rs_order (device, int32 per block) with all blocks in the reference's order
 // (slot-major).  e0_host: creation epoch of every pose tree (nullable = 0).  slot_counts_host
 // receives the number of blocks of every slot.
-int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<uint32_t>& slot_counts) {
+int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<uint32_t>& slot_counts,
+                           bool need_slot_counts) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
   const int64_t nb = f->n_blocks;
@@ -111,7 +112,7 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   slot_counts.assign((size_t)std::max(n_poses, 1), 0);
   if (nb <= 0) return OCTL_OK;
   NodeTable& t = f->nodes[f->cur];
-  const int64_t V = (int64_t)f->vkeys.size();
+  const int64_t V = f->n_voxels;
   KTimer timer(ctx, "ransac_order");
   // scratch layout inside f->entries: [nint u32 n | rank u32 n]
   const size_t nn = (size_t)t.n;
@@ -143,9 +144,15 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   const int32_t* e0_dev = nullptr;
   if (e0_host) {
     OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)n_poses * 4));
-    HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, e0_host, (size_t)n_poses * 4,
-                                hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if ((size_t)n_poses * 4 <= 64 * 1024) {  // pinned staging: [192 KiB, 256 KiB) of ctx->pinned
+      char* pin = static_cast<char*>(ctx->pinned) + 192 * 1024;
+      std::memcpy(pin, e0_host, (size_t)n_poses * 4);
+      HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, pin, (size_t)n_poses * 4, hipMemcpyHostToDevice, st));
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, e0_host, (size_t)n_poses * 4,
+                                  hipMemcpyHostToDevice, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
     e0_dev = f->scheme_dev.as<int32_t>();
     for (int p = 0; p < n_poses; ++p) max_epoch = std::max(max_epoch, (int)e0_host[p]);
   }
@@ -181,9 +188,11 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   OCTL_TRY(devbuf_reserve(ctx, f->rs_order, (size_t)nb * 4));
   HIP_TRY(ctx, hipMemcpyAsync(f->rs_order.p, vals_b[res2], (size_t)nb * 4,
                               hipMemcpyDeviceToDevice, st));
-  // blocks per slot
+  // blocks per slot (only needed to cut the order into batches)
   uint32_t* hist = ctx->small.as<uint32_t>() + 64;
-  if (n_poses <= 256) {
+  if (!need_slot_counts) {
+    // nothing to do
+  } else if (n_poses <= 256) {
     HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)n_poses * 4, st));
     hipLaunchKernelGGL(k_slot_hist, dim3((unsigned)ceil_div(nb, 2048)), dim3(256), 0, st,
                        (const int32_t*)f->blk_slot.as<int32_t>(), nb, hist);
@@ -208,7 +217,7 @@ extern "C" int octl_forest_reference_order(octl_forest* f, const int32_t* e0, in
   const int n_poses = (int)f->pose_off.size() - 1;
   if (e0 && n_e0 != n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "e0 size mismatch");
   std::vector<uint32_t> slot_counts;
-  OCTL_TRY(forest_reference_order(f, e0, slot_counts));
+  OCTL_TRY(forest_reference_order(f, e0, slot_counts, false));
   *n_blocks = f->n_blocks;
   const int64_t n = std::min<int64_t>(cap, f->n_blocks);
   if (n > 0 && order) {
@@ -239,10 +248,24 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
   }
   if (f->n_blocks == 0) return OCTL_OK;
   OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
-  HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if ((size_t)H * k * 8 <= 64 * 1024) {  // pinned staging: [128 KiB, 192 KiB) of ctx->pinned
+    char* pin = static_cast<char*>(ctx->pinned) + 128 * 1024;
+    std::memcpy(pin, hypotheses, (size_t)H * k * 8);
+    HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, pin, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
+  const bool one_batch = n_poses <= poses_per_batch;
   std::vector<uint32_t> slot_counts;
-  OCTL_TRY(forest_reference_order(f, e0, slot_counts));
+  OCTL_TRY(forest_reference_order(f, e0, slot_counts, !one_batch));
+  if (one_batch) {
+    OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
+                           f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>(), f->n_blocks,
+                           f->rs_hyp.as<double>(), H, k, threshold, f->mask.as<uint8_t>(), nullptr,
+                           nullptr, nullptr, nullptr, f->rs_scratch));
+    return OCTL_OK;
+  }
   // one evaluate() per batch of poses_per_batch consecutive poses (grid.py:149-157,194)
   int64_t off = 0;
   for (int p0 = 0; p0 < n_poses; p0 += poses_per_batch) {
