@@ -80,6 +80,21 @@ def cpu_baseline(dims, table, budget_points=700_000):
     }
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on stdout when a communicator is created; the contract is ONE
+    JSON line on stdout, so file descriptor 1 points at stderr while the communicator comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +103,9 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="points per rank")
     ap.add_argument("--cloud", choices=["planar", "uniform"], default="planar")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--route", action="store_true",
+                    help="rehearse the multi-GPU step on one GPU: 1-rank RCCL communicator, the "
+                         "local part forced through AllGather + Send/Recv")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,15 +121,27 @@ def main():
 
     ctx = nat.Context(local_rank)
     lib = ctx.lib
+    route = world > 1 or args.route
+    if args.route and world == 1:
+        os.environ["OCTL_ROUTE_SELF_SENDRECV"] = "1"
+        buf = (C.c_uint8 * nat.UNIQUE_ID_BYTES)()
+        with stdout_to_stderr():
+            ctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
+            ctx.check(lib.octl_comm_init(ctx.handle, 1, 0, C.cast(buf, C.c_void_p)))
     if world > 1:
         uid = [None]
         if rank == 0:
             buf = (C.c_uint8 * nat.UNIQUE_ID_BYTES)()
-            ctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
+            with stdout_to_stderr():
+                ctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
             uid[0] = bytes(buf)
         dist.broadcast_object_list(uid, src=0)
         idbuf = (C.c_uint8 * nat.UNIQUE_ID_BYTES).from_buffer_copy(uid[0])
-        ctx.check(lib.octl_comm_init(ctx.handle, world, rank, C.cast(idbuf, C.c_void_p)))
+        with stdout_to_stderr():
+            ctx.check(lib.octl_comm_init(ctx.handle, world, rank, C.cast(idbuf, C.c_void_p)))
+            # the first collective finishes the lazy connection set-up (and its prints)
+            probe = np.zeros(1, dtype=np.int64)
+            ctx.check(lib.octl_comm_allreduce_i64(ctx.handle, nat.ptr(probe), 1))
 
     dims = scene_dims(world)
     n_local = args.points
@@ -138,7 +168,7 @@ def main():
 
     def step():
         ctx.check(lib.octl_forest_clear(fh))
-        if world > 1:
+        if route:
             ctx.check(lib.octl_route_points(ctx.handle, d_xyz, None, n_local, rank * n_local,
                                             nat.ptr(corner), 1.0, C.byref(n_recv), None))
             ctx.check(lib.octl_forest_add_pose_routed(fh, C.byref(slot)))
@@ -182,7 +212,7 @@ def main():
         kern = {k: {"ms_avg": v[0] / max(v[1], 1), "launches_per_step": v[1] / args.steps,
                     "ms_per_step": v[0] / args.steps} for k, v in timings.items()}
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        n_step = int(n_recv.value) if world > 1 else n_local
+        n_step = int(n_recv.value) if route else n_local
         # algorithmic HBM reads: 24 B/pt to place a point, 24 B/pt more (leaf ordered) for RANSAC
         alg_bytes = {"ransac": 24.0 * n_step}
         dom_bytes = alg_bytes.get(dom, 24.0 * n_step)
@@ -267,8 +297,9 @@ def main():
 
     lib.octl_forest_destroy(fh)
     ctx.check(lib.octl_dev_free(ctx.handle, d_xyz))
-    if world > 1:
+    if route:
         lib.octl_comm_destroy(ctx.handle)
+    if world > 1:
         dist.destroy_process_group()
     ctx.close()
 

@@ -123,6 +123,10 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #ifndef RS_SCREEN
 #define RS_SCREEN 0  // measured: exact but not faster yet (register pressure); see DESIGN.md
 #endif
+#ifndef RS_BIG_THREADS
+#define RS_BIG_THREADS 256  // lanes per workgroup for H > 256 (x RS_BIG_HPL hypotheses per lane)
+#endif
+#define RS_BIG_HPL (1024 / RS_BIG_THREADS)
 #ifndef RS_PER_CU
 #define RS_PER_CU 5
 #endif
@@ -264,6 +268,29 @@ __device__ __forceinline__ void ransac_block_global(const BlockDesc& d, int be,
                                            pts[3 * (int64_t)i + 2]) < thr) ? 1 : 0;
 }
 
+#if RS_SCREEN
+// block-local f32 coordinates of the point a lane is staging (relative to the block's first
+// point, read with a wave-uniform scalar load) and the per-wave maximum of their magnitudes
+template <int THREADS>
+__device__ __forceinline__ void stage_local(const double* __restrict__ xyz, const BlockDesc& d,
+                                            double px, double py, double pz, float4* loc,
+                                            float* wext) {
+  const double ox = xyz[3 * (int64_t)d.pstart], oy = xyz[3 * (int64_t)d.pstart + 1],
+               oz = xyz[3 * (int64_t)d.pstart + 2];
+  float m = 0.f;
+  if ((int)threadIdx.x < d.n) {
+    const float u = (float)(px - ox), v = (float)(py - oy), w = (float)(pz - oz);
+    loc[threadIdx.x] = make_float4(u, v, w, 0.f);
+    m = fmaxf(fabsf(u), fmaxf(fabsf(v), fabsf(w)));
+    // a NaN coordinate would be dropped by fmaxf: force "everything is ambiguous" instead
+    if (!(m == m) || u != u || v != v || w != w) m = __int_as_float(0x7f800000);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) wext[threadIdx.x >> 6] = m;
+}
+#endif
+
 // Persistent workgroups over the descriptors of all blocks with k <= n <= THREADS-1 points,
 // SORTED BY SIZE (largest first): workgroup w handles entries w, w+G, w+2G, ...
 //   * static striding over a size-sorted list balances the workgroups and ends on the
@@ -290,6 +317,12 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   __shared__ double s_pts[2][3][THREADS];
   __shared__ unsigned long long s_wbest[W];
   __shared__ float s_wplane[W][4];
+#if RS_SCREEN
+  // f32 screening of the scoring loop (see "screening" below): block-local f32 coordinates
+  // relative to the block's first point and, per wave, the largest |coordinate|
+  __shared__ float4 s_loc[2][THREADS];
+  __shared__ float s_wext[2][W];
+#endif
   const int nbs = (int)*n_sorted_ptr;
   const int G = gridDim.x;
   int j = blockIdx.x;
@@ -297,11 +330,20 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   BlockDesc cur = sdesc[j];
   BlockDesc nxt = cur;
   if (j + G < nbs) nxt = sdesc[j + G];
-  if ((int)threadIdx.x <= cur.n) {
-    const int64_t p = ((int)threadIdx.x < cur.n) ? (int64_t)cur.pstart + threadIdx.x : (int64_t)cur.pspill;
-    s_pts[0][0][threadIdx.x] = xyz[3 * p];
-    s_pts[0][1][threadIdx.x] = xyz[3 * p + 1];
-    s_pts[0][2][threadIdx.x] = xyz[3 * p + 2];
+  {
+    double px = 0.0, py = 0.0, pz = 0.0;
+    if ((int)threadIdx.x <= cur.n) {
+      const int64_t p = ((int)threadIdx.x < cur.n) ? (int64_t)cur.pstart + threadIdx.x : (int64_t)cur.pspill;
+      px = xyz[3 * p];
+      py = xyz[3 * p + 1];
+      pz = xyz[3 * p + 2];
+      s_pts[0][0][threadIdx.x] = px;
+      s_pts[0][1][threadIdx.x] = py;
+      s_pts[0][2][threadIdx.x] = pz;
+    }
+#if RS_SCREEN
+    stage_local<THREADS>(xyz, cur, px, py, pz, s_loc[0], s_wext[0]);
+#endif
   }
   __syncthreads();
   int buf = 0, cached_n = -1;
@@ -356,13 +398,27 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       }
     }
 
+#if RS_SCREEN
+    // screening keeps only the f32 plane (its promotion to f64 is exact and redone on demand)
+    float fa[HPL], fb[HPL], fc[HPL], fd[HPL], sto[HPL], slo[HPL], shi[HPL];
+    const double ox = lx[0], oy = ly[0], oz = lz[0];
+    float extent = s_wext[buf][0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) extent = fmaxf(extent, s_wext[buf][w]);
+#else
     double pa[HPL], pb[HPL], pc[HPL], pd[HPL];
+#endif
     int cnt[HPL];
 #pragma unroll
     for (int q = 0; q < HPL; ++q) {
       const int t = threadIdx.x + q * THREADS;
       cnt[q] = -1;
+#if RS_SCREEN
+      fa[q] = fb[q] = fc[q] = fd[q] = 0.f;
+      sto[q] = slo[q] = shi[q] = 0.f;
+#else
       pa[q] = pb[q] = pc[q] = pd[q] = 0.0;
+#endif
       if (t < H) {
         double sx[KS], sy[KS], sz[KS];
 #pragma unroll
@@ -382,18 +438,77 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         } else {
           plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
         }
+        cnt[q] = 0;
+#if RS_SCREEN
+        {
+          const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
+          const double to = ((A * ox + B * oy) + Cc * oz) + D;
+          const double delta = 0x1p-23 * (4.0 * fabs(to) + 9.0 * (double)extent) +
+                               0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + fabs(D) + (double)extent + 1.0) +
+                               0x1p-23 * fabs(thr);
+          fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
+          sto[q] = (float)to;
+          slo[q] = (float)(thr - delta);
+          shi[q] = (float)(thr + delta);
+        }
+#else
         // the f32-rounded plane, promoted back to f64 for scoring (cuda_ransac.py:110-121)
         pa[q] = (double)pf[0];
         pb[q] = (double)pf[1];
         pc[q] = (double)pf[2];
         pd[q] = (double)pf[3];
-        cnt[q] = 0;
+#endif
       }
       // keep the plane fits of the lane's hypotheses apart: interleaved they need > 200 VGPRs
       __builtin_amdgcn_sched_barrier(0);
     }
     // scoring: every point of the block against every hypothesis of the lane
     // (cuda_ransac.py:116-121); the point is a wave-uniform LDS broadcast
+#if RS_SCREEN
+    // Screening.  The H x n distance tests are evaluated in f32 on block-local coordinates; a
+    // pair is decided there only when its f32 distance is farther from the threshold than a
+    // rigorous bound of |s - t_ref|, everything else is re-evaluated with the reference's exact
+    // f64 sequence, so the inlier COUNTS are exactly the reference's:
+    //   reference   t_ref = fl(fl(fl(A x + B y) + C z) + D)           (util.py:22-24, f64)
+    //   identity    A x + B y + C z + D = T_o + A (x-ox) + B (y-oy) + C (z-oz),   o = first point
+    //   screen      s = fma32(a, u, fma32(b, v, fma32(c, w, to)))     u = fl32(x-ox).., to = fl32(T_o)
+    //   |s - t_ref| <= 2^-24 (4 |T_o| + 9 E) + 2^-50 (|o|_1 + |D| + E),   E = max |u|,|v|,|w|
+    //     (three f32 FMA roundings on partial sums <= |T_o| + 3E, the f32 roundings of u,v,w and
+    //      of to, the f64 roundings of T_o and of t_ref itself; |a|,|b|,|c| <= 1)
+    //   delta = twice that bound + the f32 rounding of the two thresholds
+    //   |s| < thr - delta => inlier,  |s| > thr + delta => not an inlier,  else: exact f64
+    // Two counters per hypothesis - pairs surely inside (|s| < thr - delta) and pairs possibly
+    // inside (|s| <= thr + delta) - keep the loop free of branches; a hypothesis whose two
+    // counters differ has borderline pairs and is recounted with the exact f64 sequence.
+    if (ABL != 1) {
+      int chi[HPL];
+#pragma unroll
+      for (int q = 0; q < HPL; ++q) chi[q] = cnt[q];
+      const float4* __restrict__ loc = s_loc[buf];
+RS_PRAGMA(unroll RS_SCORE_UNROLL)
+      for (int i = 0; i < n; ++i) {
+        const float4 L = loc[i];
+#pragma unroll
+        for (int q = 0; q < HPL; ++q) {
+          const float sv = fabsf(fmaf(fa[q], L.x, fmaf(fb[q], L.y, fmaf(fc[q], L.z, sto[q]))));
+          cnt[q] += (sv < slo[q]) ? 1 : 0;
+          chi[q] += (sv <= shi[q]) ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < HPL; ++q) {
+        const bool redo = cnt[q] >= 0 && cnt[q] != chi[q];
+        if (__any(redo)) {  // rare
+          int c = 0;
+          if (redo) {
+            const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
+            for (int i = 0; i < n; ++i) c += (plane_distance(A, B, Cc, D, lx[i], ly[i], lz[i]) < thr) ? 1 : 0;
+            cnt[q] = c;
+          }
+        }
+      }
+    }
+#else
     if (ABL != 1) {
 RS_PRAGMA(unroll RS_SCORE_UNROLL)
       for (int i = 0; i < n; ++i) {
@@ -403,6 +518,7 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
           cnt[q] += (plane_distance(pa[q], pb[q], pc[q], pd[q], x, y, z) < thr) ? 1 : 0;
       }
     }
+#endif
     // maximum over the lane, then over the wave; lowest hypothesis index among the tied
     // (cuda_ransac.py:125-146)
     unsigned long long best = 0;
@@ -415,7 +531,11 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
             ((unsigned long long)(unsigned)cnt[q] << 32) | (unsigned)(0x7FFFFFFF - t);
         if (key > best) {
           best = key;
+#if RS_SCREEN
+          wa = fa[q]; wb = fb[q]; wc = fc[q]; wd = fd[q];
+#else
           wa = pa[q]; wb = pb[q]; wc = pc[q]; wd = pd[q];
+#endif
         }
       }
     }
@@ -467,6 +587,9 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
       s_pts[buf ^ 1][1][threadIdx.x] = ry;
       s_pts[buf ^ 1][2][threadIdx.x] = rz;
     }
+#if RS_SCREEN
+    stage_local<THREADS>(xyz, nxt, rx, ry, rz, s_loc[buf ^ 1], s_wext[buf ^ 1]);
+#endif
     __syncthreads();  // B
     cur = nxt;
     nxt = nxt2;
@@ -648,7 +771,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   BlockDesc* sdesc = reinterpret_cast<BlockDesc*>(base + off_s);
   uint32_t* big_list = reinterpret_cast<uint32_t*>(base + off_b);
   uint32_t* counters = reinterpret_cast<uint32_t*>(base + off_c);
-  const int threads = (H <= 64) ? 64 : 256;
+  const int threads = (H <= 64) ? 64 : (H <= 256 ? 256 : RS_BIG_THREADS);
   RansacOut out{mask_dev, plane_dev, count_dev, index_dev};
   {
     KTimer t(ctx, "ransac_prepare");
@@ -687,10 +810,10 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     if (k == 6) OCTL_RANSAC_LAUNCH(256, 1, 6, 0, 8); else OCTL_RANSAC_LAUNCH(256, 1, 0, 0, 4);
   } else {
     const char* abl = getenv("OCTL_RANSAC_ABLATE");  // timing experiments only
-    if (k == 6 && abl && abl[0] == '1') OCTL_RANSAC_LAUNCH(256, 4, 6, 1, RS_PER_CU);
-    else if (k == 6 && abl && abl[0] == '2') OCTL_RANSAC_LAUNCH(256, 4, 6, 2, RS_PER_CU);
-    else if (k == 6) OCTL_RANSAC_LAUNCH(256, 4, 6, 0, RS_PER_CU);
-    else OCTL_RANSAC_LAUNCH(256, 4, 0, 0, 2);
+    if (k == 6 && abl && abl[0] == '1') OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 1, RS_PER_CU);
+    else if (k == 6 && abl && abl[0] == '2') OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 2, RS_PER_CU);
+    else if (k == 6) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 0, RS_PER_CU);
+    else OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 0, 0, 2);
   }
 #undef OCTL_RANSAC_LAUNCH
   HIP_TRY(ctx, hipGetLastError());
@@ -705,7 +828,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   } else if (H <= 256) {
     if (k == 6) OCTL_RANSAC_BIG(256, 1, 6); else OCTL_RANSAC_BIG(256, 1, 0);
   } else {
-    if (k == 6) OCTL_RANSAC_BIG(256, 4, 6); else OCTL_RANSAC_BIG(256, 4, 0);
+    if (k == 6) OCTL_RANSAC_BIG(RS_BIG_THREADS, RS_BIG_HPL, 6); else OCTL_RANSAC_BIG(RS_BIG_THREADS, RS_BIG_HPL, 0);
   }
 #undef OCTL_RANSAC_BIG
   HIP_TRY(ctx, hipGetLastError());

@@ -67,7 +67,8 @@ const char* rccl_load() {
                             g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?");     \
   } while (0)
 
-// destination rank of every point + per-destination counts (LDS histogram per block)
+// destination rank of every point + per-destination counts: LDS histogram over 2048 points,
+// then one global atomic per (workgroup, destination) - same-address atomics serialise
 __global__ __launch_bounds__(256) void k_route_dest(const double* __restrict__ xyz, int64_t n,
                                                     double L, int n_ranks,
                                                     uint64_t* __restrict__ dest_key,
@@ -77,21 +78,24 @@ __global__ __launch_bounds__(256) void k_route_dest(const double* __restrict__ x
   __shared__ uint32_t hist[256];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    // the same voxel index the local build will compute (build.hip k_keygen, grid.py:72-76)
-    const double fx = floor_div_exact(xyz[3 * i], L), fy = floor_div_exact(xyz[3 * i + 1], L),
-                 fz = floor_div_exact(xyz[3 * i + 2], L);
-    const double lim = (double)OCTL_VOX_BIAS;
-    int d = 0;
-    if ((fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim)) {
-      d = voxel_owner_hash((int64_t)fx, (int64_t)fy, (int64_t)fz, n_ranks);
-    } else {
-      atomicExch(err, 1u);
+  const int64_t base = (int64_t)blockIdx.x * 2048;
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      // the same voxel index the local build will compute (build.hip k_keygen, grid.py:72-76)
+      const double fx = floor_div_exact(xyz[3 * i], L), fy = floor_div_exact(xyz[3 * i + 1], L),
+                   fz = floor_div_exact(xyz[3 * i + 2], L);
+      const double lim = (double)OCTL_VOX_BIAS;
+      int d = 0;
+      if ((fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim)) {
+        d = voxel_owner_hash((int64_t)fx, (int64_t)fy, (int64_t)fz, n_ranks);
+      } else {
+        atomicExch(err, 1u);
+      }
+      dest_key[i] = (uint64_t)d;
+      idx[i] = (uint32_t)i;
+      atomicAdd(&hist[d], 1u);
     }
-    dest_key[i] = (uint64_t)d;
-    idx[i] = (uint32_t)i;
-    atomicAdd(&hist[d], 1u);
   }
   __syncthreads();
   if ((int)threadIdx.x < n_ranks && hist[threadIdx.x])
@@ -182,12 +186,14 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
 
   // --- 1. destination + counts ------------------------------------------------------------------
-  DevBuf keys[2], vals[2], hist, counts_d, matrix_d, send_xyz, send_gidx;
-  auto cleanup = [&]() {
-    for (DevBuf* b : {&keys[0], &keys[1], &vals[0], &vals[1], &hist, &counts_d, &matrix_d,
-                      &send_xyz, &send_gidx})
-      devbuf_free(*b);
-  };
+  DevBuf* keys = ctx->rt_keys;
+  DevBuf* vals = ctx->rt_vals;
+  DevBuf& hist = ctx->rt_hist;
+  DevBuf& counts_d = ctx->rt_counts;
+  DevBuf& matrix_d = ctx->rt_matrix;
+  DevBuf& send_xyz = ctx->rt_send_xyz;
+  DevBuf& send_gidx = ctx->rt_send_gidx;
+  auto cleanup = [&]() {};  // the scratch lives in the context (re-used by the next step)
   int rc = OCTL_OK;
 #define RT_TRY(expr)       \
   do {                     \
@@ -212,7 +218,7 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   }
   if (n > 0) {
     KTimer t(ctx, "route_dest");
-    hipLaunchKernelGGL(k_route_dest, dim3(grid_for(n)), dim3(256), 0, st, xyz_dev, n, L, R,
+    hipLaunchKernelGGL(k_route_dest, dim3((unsigned)ceil_div(n, 2048)), dim3(256), 0, st, xyz_dev, n, L, R,
                        keys[0].as<uint64_t>(), vals[0].as<uint32_t>(),
                        counts_d.as<unsigned long long>(), err);
   }
