@@ -304,7 +304,7 @@ __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, cons
 //   * the block's points are three f64 LDS arrays: the 6 sampled points of a hypothesis are
 //     per-lane LDS gathers (conflict free up to 32 points), the scoring loop reads each point as
 //     a wave-uniform broadcast;
-//   * two barriers per block.
+//   * ONE barrier per block (three rotating point buffers, reduction slots by parity).
 template <int THREADS, int HPL, int KT, int ABL>
 __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ xyz, const BlockDesc* __restrict__ sdesc,
@@ -314,14 +314,14 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   constexpr int GW = (KS + 3) / 4;  // packed sample positions: one byte each
   constexpr int W = THREADS / 64;
   const int k = KT > 0 ? KT : k_rt;
-  __shared__ double s_pts[2][3][THREADS];
-  __shared__ unsigned long long s_wbest[W];
-  __shared__ float s_wplane[W][4];
+  __shared__ double s_pts[3][3][THREADS];        // rotated: block t lives in buffer t % 3
+  __shared__ unsigned long long s_wbest[2][W];   // by block parity
+  __shared__ float s_wplane[2][W][4];
 #if RS_SCREEN
   // f32 screening of the scoring loop (see "screening" below): block-local f32 coordinates
   // relative to the block's first point and, per wave, the largest |coordinate|
-  __shared__ float4 s_loc[2][THREADS];
-  __shared__ float s_wext[2][W];
+  __shared__ float4 s_loc[3][THREADS];
+  __shared__ float s_wext[3][W];
 #endif
   const int nbs = (int)*n_sorted_ptr;
   const int G = gridDim.x;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #endif
   }
   __syncthreads();
-  int buf = 0, cached_n = -1;
+  int buf = 0, par = 0, cached_n = -1;
   uint32_t gpk[HPL][GW];
   uint32_t risk[HPL];
 #pragma unroll
@@ -547,25 +547,38 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
     }
     if (best == wbest && best != 0) {  // exactly one lane: keys are unique
       const int w = threadIdx.x >> 6;
-      s_wbest[w] = best;
-      s_wplane[w][0] = (float)wa;  // exact: promoted from the f32 plane
-      s_wplane[w][1] = (float)wb;
-      s_wplane[w][2] = (float)wc;
-      s_wplane[w][3] = (float)wd;
+      s_wbest[par][w] = best;
+      s_wplane[par][w][0] = (float)wa;  // exact: promoted from the f32 plane
+      s_wplane[par][w][1] = (float)wb;
+      s_wplane[par][w][2] = (float)wc;
+      s_wplane[par][w][3] = (float)wd;
     } else if (wbest == 0 && (threadIdx.x & 63) == 0) {
-      s_wbest[threadIdx.x >> 6] = 0;  // a wave without hypotheses (H < THREADS)
+      s_wbest[par][threadIdx.x >> 6] = 0;  // a wave without hypotheses (H < THREADS)
     }
-    __syncthreads();  // A
-    unsigned long long gbest = s_wbest[0];
+    // stage the next block.  Its buffer, (t+1) % 3, was last read for block t-2: every wave has
+    // passed the barrier of block t-1 since.  The reduction slots alternate by parity for the
+    // same reason, so ONE barrier per block publishes both the reduction and the staged points.
+    const int nbuf = buf == 2 ? 0 : buf + 1;
+    if (pre) {
+      s_pts[nbuf][0][threadIdx.x] = rx;
+      s_pts[nbuf][1][threadIdx.x] = ry;
+      s_pts[nbuf][2][threadIdx.x] = rz;
+    }
+#if RS_SCREEN
+    if (has_next) stage_local<THREADS>(xyz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf]);
+#endif
+    __syncthreads();
+    unsigned long long gbest = s_wbest[par][0];
     int gw = 0;
 #pragma unroll
     for (int w = 1; w < W; ++w) {
-      if (s_wbest[w] > gbest) {
-        gbest = s_wbest[w];
+      if (s_wbest[par][w] > gbest) {
+        gbest = s_wbest[par][w];
         gw = w;
       }
     }
-    const float f0 = s_wplane[gw][0], f1 = s_wplane[gw][1], f2 = s_wplane[gw][2], f3 = s_wplane[gw][3];
+    const float f0 = s_wplane[par][gw][0], f1 = s_wplane[par][gw][1], f2 = s_wplane[par][gw][2],
+                f3 = s_wplane[par][gw][3];
     if (threadIdx.x == 0) {
       if (out.plane) {
         out.plane[4 * (int64_t)be + 0] = f0; out.plane[4 * (int64_t)be + 1] = f1;
@@ -581,20 +594,11 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
       out.mask[(int64_t)cur.pstart + threadIdx.x] = (dist < thr) ? 1 : 0;
     }
     if (!has_next) break;
-    // the other buffer was last read one iteration ago (every wave has passed a barrier since)
-    if (pre) {
-      s_pts[buf ^ 1][0][threadIdx.x] = rx;
-      s_pts[buf ^ 1][1][threadIdx.x] = ry;
-      s_pts[buf ^ 1][2][threadIdx.x] = rz;
-    }
-#if RS_SCREEN
-    stage_local<THREADS>(xyz, nxt, rx, ry, rz, s_loc[buf ^ 1], s_wext[buf ^ 1]);
-#endif
-    __syncthreads();  // B
     cur = nxt;
     nxt = nxt2;
     j += G;
-    buf ^= 1;
+    buf = nbuf;
+    par ^= 1;
   }
 }
 
