@@ -1070,6 +1070,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   int level = 0;
   std::vector<int64_t> level_first{0, V};
   const int cur_epoch = f->epoch + (keep_scheme ? 0 : 1);
+  const int64_t old_internal = f->n_internal;
   while (n_new > 0) {
     // split list of the freshly created nodes
     OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_new, n_alive) + 8) * 4));
@@ -1232,6 +1233,8 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   f->n_ord = n_alive;
   f->n_blocks = n_blocks;
   f->n_internal = n_internal;
+  // nodes inherit an older epoch only from a previous scheme that had internal nodes
+  f->uniform_epoch = keep_scheme ? f->uniform_epoch : !(have_old && old_internal > 0);
   f->max_depth_reached = level;
   f->mask_valid = false;
   f->store_dirty = false;

@@ -36,6 +36,7 @@ struct octl_forest {
   int vl_min[3] = {0, 0, 0};    // decoding of vlin_dev: lin = ((qx-min0)*ny + (qy-min1))*nz + (qz-min2)
   uint64_t vl_ny = 1, vl_nz = 1;
   int64_t n_internal = 0;
+  bool uniform_epoch = true;  // every internal node of the current scheme has the same epoch
   int32_t max_depth_reached = 0;
 
   // leaf-ordered arrays of the last build

@@ -68,6 +68,63 @@ __global__ __launch_bounds__(256) void k_block_keys(
   val[b] = (uint32_t)b;
 }
 
+// ---- direct path (all internal nodes share one epoch: no history effects) ------------------------
+// slot of an internal node x in the "parents" sequence: per voxel one slot for "the root is a
+// leaf" followed by the voxel's internal nodes in preorder: idx(x) = rank[x] + voxel[x] + 1
+__global__ __launch_bounds__(256) void k_leaf_children(const int32_t* __restrict__ first_child,
+                                                       const int32_t* __restrict__ parent,
+                                                       const int32_t* __restrict__ voxel,
+                                                       const uint32_t* __restrict__ rank, int64_t n,
+                                                       uint32_t* __restrict__ seq) {
+  const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= n) return;
+  const int32_t fc = first_child[x];
+  if (fc >= 0) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c += first_child[fc + j] < 0 ? 1u : 0u;
+    seq[(size_t)rank[x] + (uint32_t)voxel[x] + 1u] = c;
+  } else if (parent[x] < 0) {
+    // a root that is a leaf: rank[x] holds the voxel's rank base (exclusive scan over the roots)
+    seq[(size_t)rank[x] + (uint32_t)voxel[x]] = 1u;
+  }
+}
+
+// position of every block in table[slot][cached leaf position]
+__global__ __launch_bounds__(256) void k_block_positions(
+    const int32_t* __restrict__ blk_node, const int32_t* __restrict__ blk_slot, int64_t nb,
+    const int32_t* __restrict__ parent, const int32_t* __restrict__ first_child,
+    const int32_t* __restrict__ voxel, const uint32_t* __restrict__ rank,
+    const uint32_t* __restrict__ seq_scanned, uint64_t n_leaves_total,
+    uint32_t* __restrict__ table) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const int32_t l = blk_node[b], p = parent[l];
+  uint32_t pos;
+  if (p < 0) {
+    pos = seq_scanned[(size_t)rank[l] + (uint32_t)voxel[l]];
+  } else {
+    const int32_t fc = first_child[p];
+    uint32_t before = 0;
+    for (int32_t c = fc; c < l; ++c) before += first_child[c] < 0 ? 1u : 0u;
+    pos = seq_scanned[(size_t)rank[p] + (uint32_t)voxel[p] + 1u] + before;
+  }
+  table[(uint64_t)blk_slot[b] * n_leaves_total + pos] = (uint32_t)b + 1u;
+}
+
+__global__ __launch_bounds__(256) void k_table_flags(const uint32_t* __restrict__ table, int64_t n,
+                                                     uint32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = table[i] ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_table_compact(const uint32_t* __restrict__ table,
+                                                       const uint32_t* __restrict__ scanned,
+                                                       int64_t n, int32_t* __restrict__ order) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && table[i]) order[scanned[i]] = (int32_t)(table[i] - 1u);
+}
+
 __global__ __launch_bounds__(256) void k_gather_key2(const uint64_t* __restrict__ key2,
                                                      const uint32_t* __restrict__ val, int64_t nb,
                                                      uint64_t* __restrict__ out) {
@@ -139,6 +196,55 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
       HIP_TRY(ctx, hipGetLastError());
     }
   }
+  // ---- direct path: no history effects and a table of P x #leaves that is small enough ----------
+  const int64_t n_leaves_total = (int64_t)t.n - f->n_internal;
+  const int64_t table_n = (int64_t)n_poses * n_leaves_total;
+  bool e0_ok = true;  // a pose created before the scheme's (single) epoch sees the same order
+  if (f->uniform_epoch && table_n > 0 && table_n <= ((int64_t)1 << 26)) {
+    const size_t seq_n = (size_t)f->n_internal + (size_t)V + 8;
+    const size_t off_tab = ((seq_n * 4) + 15) & ~(size_t)15;
+    const size_t off_flg = off_tab + (((size_t)table_n + 8) * 4 + 15) / 16 * 16;
+    OCTL_TRY(devbuf_reserve(ctx, f->hist, off_flg + ((size_t)table_n + 8) * 4));
+    char* base = static_cast<char*>(f->hist.p);
+    uint32_t* seq = reinterpret_cast<uint32_t*>(base);
+    uint32_t* table = reinterpret_cast<uint32_t*>(base + off_tab);
+    uint32_t* tflags = reinterpret_cast<uint32_t*>(base + off_flg);
+    HIP_TRY(ctx, hipMemsetAsync(seq, 0, off_flg, st));  // seq and table
+    hipLaunchKernelGGL(k_leaf_children, dim3(grid_for(t.n)), dim3(256), 0, st, fc,
+                       (const int32_t*)t.parent.as<int32_t>(), (const int32_t*)t.voxel.as<int32_t>(),
+                       (const uint32_t*)rank, t.n, seq);
+    HIP_TRY(ctx, hipGetLastError());
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, seq, seq, (int64_t)f->n_internal + V, nullptr));
+    hipLaunchKernelGGL(k_block_positions, dim3(grid_for(nb)), dim3(256), 0, st,
+                       (const int32_t*)f->blk_node.as<int32_t>(),
+                       (const int32_t*)f->blk_slot.as<int32_t>(), nb,
+                       (const int32_t*)t.parent.as<int32_t>(), fc,
+                       (const int32_t*)t.voxel.as<int32_t>(), (const uint32_t*)rank,
+                       (const uint32_t*)seq, (uint64_t)n_leaves_total, table);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_table_flags, dim3(grid_for(table_n)), dim3(256), 0, st,
+                       (const uint32_t*)table, table_n, tflags);
+    HIP_TRY(ctx, hipGetLastError());
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, tflags, tflags, table_n, nullptr));
+    OCTL_TRY(devbuf_reserve(ctx, f->rs_order, (size_t)nb * 4));
+    hipLaunchKernelGGL(k_table_compact, dim3(grid_for(table_n)), dim3(256), 0, st,
+                       (const uint32_t*)table, (const uint32_t*)tflags, table_n,
+                       f->rs_order.as<int32_t>());
+    HIP_TRY(ctx, hipGetLastError());
+  } else {
+    e0_ok = false;
+  }
+  if (e0_ok) {
+    // blocks per slot (only needed to cut the order into batches)
+    if (need_slot_counts) {
+      std::vector<int32_t> slots((size_t)nb);
+      HIP_TRY(ctx, hipMemcpyAsync(slots.data(), f->blk_slot.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      for (int32_t sl : slots) slot_counts[(size_t)sl] += 1;
+    }
+    return OCTL_OK;
+  }
+  // ---- general path: two stable radix sorts of per-block keys ------------------------------------------
   // keys
   int max_epoch = f->epoch;
   const int32_t* e0_dev = nullptr;
