@@ -123,6 +123,14 @@ typedef struct octl_build_info {
 int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
                       int32_t keep_scheme, int32_t max_depth, octl_build_info* info);
 
+/* Install a host-defined subdivision scheme (for criteria that are arbitrary host callables,
+ * octree.py:26: the host decides which nodes split, the device does the placement): nodes
+ * [0,V) are the roots in voxel order, the 8 children of node i are first_child[i]..+7 (-1 =
+ * leaf), epoch[i] = build at which node i became internal.  Follow with
+ * octl_forest_build(keep_scheme = 1) to place every point in this scheme.                     */
+int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int32_t* epoch,
+                           int64_t n_nodes, int32_t new_epoch);
+
 /* ---- results of the last build (host copies; size-query = pass NULL outputs) ---------- */
 
 /* Scheme nodes.  For node i: voxel (root) index, depth, parent (-1 for roots), first child

@@ -121,6 +121,80 @@ class Forest:
     def subdivide(self, K: int, scheme_slots=None, max_depth=0):
         self.build(K, scheme_slots, False, max_depth)
 
+    def subdivide_callable(self, criteria, scheme_slots=None, max_depth=63):
+        """Subdivision driven by arbitrary host callables (octree.py:26: a node splits when
+        any(criterion(points))).  A Python callable cannot run inside a kernel: the host evaluates
+        the predicates level by level on the points of the scheme octree's nodes (the union of the
+        selected poses, octree_manager.py:53-61) and installs the resulting scheme; every placement
+        (bucketing, partition into leaves, ordering) still happens on the device.  Cost: one
+        device re-placement per tree level - meant for API completeness, not for speed.
+        The order of the rows handed to a criterion is pose-major / insertion order (the
+        reference's order is an artefact of an unstable argsort)."""
+        self.ensure_built()
+        scheme = set(range(self.n_slots)) if scheme_slots is None else set(scheme_slots)
+        # epochs of nodes that stay internal are inherited (cached-leaf order is history dependent)
+        prev = {}
+        if self.has_scheme:
+            nd = self.nodes
+            path = _node_paths(nd)
+            vox = self.voxels
+            for i in np.nonzero(nd["first_child"] >= 0)[0]:
+                prev[(tuple(vox[nd["voxel"][i]]), path[i])] = int(nd["epoch"][i])
+        new_epoch = self.epoch + 1
+        V = len(self.voxels)
+        vox_keys = [tuple(v) for v in self.voxels.tolist()]
+        fc = [-1] * V
+        ep = [0] * V
+        node_vox = list(range(V))
+        node_path = [()] * V
+        frontier = list(range(V))
+        empty = np.empty((0, 3), dtype=float)
+        depth = 0
+        while True:
+            fca = np.ascontiguousarray(np.array(fc, dtype=np.int32))
+            epa = np.ascontiguousarray(np.array(ep, dtype=np.int32))
+            self.ctx.check(self.lib.octl_forest_set_scheme(self.handle, nat.ptr(fca), nat.ptr(epa), len(fca), new_epoch))
+            info = nat.BuildInfo()
+            self.ctx.check(self.lib.octl_forest_build(self.handle, 0, None, 0, 1, 0, C.byref(info)))
+            self.info = info
+            self.n_ord = int(info.n_points)
+            self._dirty = False
+            self._invalidate()
+            assert np.array_equal(self.nodes["first_child"], fca), "device and host node numbering differ"
+            if not frontier:
+                break
+            blk = self.blocks
+            xyz = self.xyz
+            by_node = {}
+            for n, s_, st, sz in zip(blk["node"].tolist(), blk["slot"].tolist(), blk["start"].tolist(), blk["size"].tolist()):
+                if s_ in scheme:
+                    by_node.setdefault(n, []).append((st, sz))
+            to_split = []
+            for n in frontier:
+                parts = by_node.get(n)
+                pts = np.vstack([xyz[a : a + b] for a, b in parts]) if parts else empty
+                if any([c(pts) for c in criteria]):
+                    to_split.append(n)
+            if not to_split:
+                break
+            depth += 1
+            if depth > max_depth:
+                raise RecursionError(f"maximum depth {max_depth} exceeded")
+            frontier = []
+            for n in sorted(to_split):
+                fc[n] = len(fc)
+                key = (vox_keys[node_vox[n]], node_path[n])
+                ep[n] = prev.get(key, new_epoch)
+                for j in range(8):
+                    frontier.append(len(fc))
+                    fc.append(-1)
+                    ep.append(0)
+                    node_vox.append(node_vox[n])
+                    node_path.append(node_path[n] + (j,))
+        self.epoch = new_epoch
+        self.has_scheme = True
+        self._update_membership()
+
     def ensure_built(self):
         """Bring the device structure up to date after insertions: a new pose inherits the
         current scheme (octree_manager.py:161-171); before any subdivide the scheme is just
@@ -354,6 +428,19 @@ class Forest:
             )
         )
         return plane, count, index
+
+
+def _node_paths(nd):
+    """Child-digit path (tuple) of every scheme node."""
+    n = len(nd["parent"])
+    paths = [()] * n
+    order = np.argsort(nd["depth"], kind="stable")
+    par, fc = nd["parent"], nd["first_child"]
+    for i in order.tolist():
+        p = par[i]
+        if p >= 0:
+            paths[i] = paths[p] + (int(i - fc[p]),)
+    return paths
 
 
 def _rank_rows(table: np.ndarray, rows: np.ndarray) -> np.ndarray:

@@ -5,7 +5,9 @@ The reference takes arbitrary Python callables ``points -> bool`` (octree/octree
 callable cannot run inside a HIP kernel.  The device path understands the one criterion the
 library is used with - the point count, ``len(points) > K`` - given either as ``MaxPoints(K)``
 or as a plain lambda/def of exactly that shape, which is recognised from its bytecode and
-double-checked by probing.  Anything else is refused loudly (no silent CPU fallback).
+double-checked by probing.  Any other callable is evaluated by the host, level by level, on the
+node point arrays the device produces (the predicate is the caller's Python code and can only
+run there); the bucketing / partition / ordering stays on the device.
 """
 
 import dis
@@ -13,7 +15,7 @@ from typing import Callable, Optional, Sequence
 
 import numpy as np
 
-__all__ = ["MaxPoints", "count_threshold", "UnsupportedCriterion"]
+__all__ = ["MaxPoints", "count_threshold", "try_count_threshold", "UnsupportedCriterion"]
 
 
 class UnsupportedCriterion(NotImplementedError):
@@ -95,6 +97,15 @@ def _probe(fn, k: int) -> bool:
     except Exception:
         return False
     return True
+
+
+def try_count_threshold(criteria: Sequence[Callable]):
+    """K for a pure point-count criterion (runs entirely on the device), or None when the
+    criteria are arbitrary callables (the host then evaluates them level by level)."""
+    try:
+        return count_threshold(criteria)
+    except UnsupportedCriterion:
+        return None
 
 
 def count_threshold(criteria: Sequence[Callable]) -> int:

@@ -227,6 +227,44 @@ int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int
   return forest_build(f, K, scheme_mask, n_mask, keep_scheme, max_depth, info);
 }
 
+int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int32_t* epoch,
+                           int64_t n_nodes, int32_t new_epoch) {
+  if (!f || !first_child || !epoch) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "set_scheme needs a built forest");
+  const int64_t V = f->n_voxels;
+  if (n_nodes < V || (n_nodes - V) % 8 != 0 || n_nodes >= ((int64_t)1 << 31))
+    return octl_set_error(ctx, OCTL_E_INVALID, "scheme must have V roots + 8 nodes per internal node");
+  int64_t n_internal = 0;
+  for (int64_t i = 0; i < n_nodes; ++i) {
+    const int32_t c = first_child[i];
+    if (c >= 0) {
+      if (c < V || (int64_t)c + 8 > n_nodes || (c - V) % 8 != 0)
+        return octl_set_error(ctx, OCTL_E_INVALID, "first_child[%lld] = %d is not a valid child group",
+                              (long long)i, c);
+      ++n_internal;
+    }
+  }
+  if (V + 8 * n_internal != n_nodes)
+    return octl_set_error(ctx, OCTL_E_INVALID, "node count does not match the number of internal nodes");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  NodeTable& t = f->nodes[f->cur];
+  OCTL_TRY(nodes_reserve(ctx, t, n_nodes));
+  HIP_TRY(ctx, hipMemcpyAsync(t.first_child.p, first_child, (size_t)n_nodes * 4, hipMemcpyHostToDevice,
+                              ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(t.epoch.p, epoch, (size_t)n_nodes * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  t.n = n_nodes;
+  f->n_internal = n_internal;
+  f->uniform_epoch = false;
+  if (new_epoch > f->epoch) f->epoch = new_epoch;
+  // only first_child / epoch of this table are meaningful until the next (keep_scheme) build
+  f->n_ord = 0;
+  f->n_blocks = 0;
+  f->mask_valid = false;
+  return OCTL_OK;
+}
+
 int octl_forest_get_nodes(octl_forest* f, int64_t cap, int32_t* voxel, int32_t* depth,
                           int32_t* parent, int32_t* first_child, double* corner, double* edge,
                           int32_t* epoch, int64_t* n_nodes) {

@@ -13,7 +13,7 @@ import numpy as np
 
 from octreelib_amd import _views
 from octreelib_amd._engine import Forest
-from octreelib_amd.criteria import count_threshold
+from octreelib_amd.criteria import try_count_threshold
 from octreelib_amd.grid.grid_base import GridBase, GridConfigBase, VisualizationConfig
 from octreelib_amd.internal.voxel import Voxel
 
@@ -54,9 +54,12 @@ class Grid(GridBase):
 
     # grid.py:244-258
     def subdivide(self, subdivision_criteria: List[Callable], pose_numbers: Optional[List[int]] = None):
-        k = count_threshold(subdivision_criteria)
+        k = try_count_threshold(subdivision_criteria)
         scheme = None if pose_numbers is None else [self._slots[p] for p in pose_numbers]
-        self._forest.subdivide(k, scheme)
+        if k is None:
+            self._forest.subdivide_callable(subdivision_criteria, scheme)
+        else:
+            self._forest.subdivide(k, scheme)
 
     # grid.py:217-232
     def get_leaf_points(self, pose_number: int, non_empty: bool = True) -> List[Voxel]:

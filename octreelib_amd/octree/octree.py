@@ -12,7 +12,7 @@ import numpy as np
 
 from octreelib_amd import _views
 from octreelib_amd._engine import Forest
-from octreelib_amd.criteria import count_threshold
+from octreelib_amd.criteria import try_count_threshold
 from octreelib_amd.internal import T, Voxel
 from octreelib_amd.octree.octree_base import OctreeBase, OctreeConfigBase, OctreeNodeBase
 
@@ -45,13 +45,18 @@ class Octree(OctreeBase, Generic[T]):
     def subdivide(self, subdivision_criteria: List[Callable]):
         """octree.py:214-220 / 20-32.  A root that is already split holds no points itself, so
         a count criterion is false on it and the call changes nothing (upstream behaviour)."""
-        k = count_threshold(subdivision_criteria)
+        k = try_count_threshold(subdivision_criteria)
         f = self._forest
         if self._slot is None:
             self._slot = f.add_pose(np.empty((0, 3)))
         if f.has_scheme and f.nodes["first_child"][0] >= 0:
-            return
-        f.subdivide(k)
+            # upstream evaluates the criteria on the (empty) point array of the split root
+            if not any([c(np.empty((0, 3), dtype=float)) for c in subdivision_criteria]):
+                return
+        if k is None:
+            f.subdivide_callable(subdivision_criteria)
+        else:
+            f.subdivide(k)
 
     def subdivide_as(self, other_octree: "Octree"):
         raise NotImplementedError(

@@ -10,7 +10,7 @@ import numpy as np
 
 from octreelib_amd import _views
 from octreelib_amd._engine import Forest
-from octreelib_amd.criteria import count_threshold
+from octreelib_amd.criteria import try_count_threshold
 from octreelib_amd.internal.voxel import Voxel, VoxelBase
 from octreelib_amd.octree.octree_base import OctreeBase, OctreeConfigBase
 
@@ -45,12 +45,15 @@ class OctreeManager(VoxelBase):
 
     # octree_manager.py:36-66
     def subdivide(self, subdivision_criteria: List[Callable], pose_numbers: Optional[List[int]] = None):
-        k = count_threshold(subdivision_criteria)
+        k = try_count_threshold(subdivision_criteria)
         if pose_numbers is None:
             scheme = None
         else:
             scheme = [self._slots[p] for p in pose_numbers]  # KeyError for an unknown pose, as upstream
-        self._forest.subdivide(k, scheme)
+        if k is None:
+            self._forest.subdivide_callable(subdivision_criteria, scheme)
+        else:
+            self._forest.subdivide(k, scheme)
 
     def _selected(self, pose_numbers):
         if pose_numbers is None:

@@ -443,7 +443,7 @@ def test_ransac_operator_random_blocks_vs_oracle():
         s, e = starts[b], starts[b + 1]
         if e - s >= 6 and b % 5:
             cloud[s:e, 2] = 3.0 + 0.2 * cloud[s:e, 0] - 0.1 * cloud[s:e, 1] + rng.normal(0, 0.006, e - s)
-    for H, k in ((1024, 6), (100, 6), (64, 4)):
+    for H, k in ((1024, 6), (100, 6), (64, 4), (1024, 5), (300, 9)):
         np.random.seed(H)
         op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=k)
         mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
@@ -513,3 +513,34 @@ def test_empty_inputs():
     assert [oc.n_nodes, oc.n_leaves, oc.n_points] == [1, 0, 0]
     oc.subdivide(crit(4))
     assert [oc.n_nodes, oc.n_leaves, oc.n_points] == [1, 0, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# arbitrary host callables as criteria (octree.py:26), evaluated level by level by the host
+# ------------------------------------------------------------------------------------------------
+def test_arbitrary_callable_criteria_vs_oracle():
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(77)
+    poses = [rng.random((4000, 3)) * 3.0, rng.random((3000, 3)) * 3.0]
+
+    def spread(points):  # not a count criterion: split while the cloud is both large and wide
+        return len(points) > 40 and float(points.max(axis=0).max() - points.min(axis=0).min()) > 0.3
+
+    grid, og = Grid(GridConfig(voxel_edge_length=1)), onp.OGrid(1)
+    for p, pts in enumerate(poses):
+        grid.insert_points(p, pts)
+        og.insert_points(p, pts)
+    grid.subdivide([spread], [0])
+    og.subdivide([spread], [0])
+    for p, pts in enumerate(poses):
+        index = index_map(pts)
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)), _oracle_pose_table(og, p))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+    # a count criterion afterwards refines on the device and inherits the epochs
+    grid.subdivide(crit(15))
+    og.subdivide(15)
+    for p, pts in enumerate(poses):
+        index = index_map(pts)
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)), _oracle_pose_table(og, p))
