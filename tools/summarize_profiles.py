@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs merged under gpurun_out/ into the small files kept in profiles/.
+
+usage: tools/summarize_profiles.py TAG STATS_DIR FETCH_DIR WRITE_DIR SQ_DIR BENCH_JSON
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import shutil
+import sys
+
+
+def short(k):
+    m = re.search(r"(k_[a-z0-9_]+|__amd_rocclr_[A-Za-z]+)", k)
+    return m.group(1) if m else k[:40]
+
+
+def counters(d):
+    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    per = collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        per[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for (k, _d, c), v in per.items():
+        agg[k][c].append(v)
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+
+
+def durations(d):
+    f = glob.glob(f"{d}/*/*kernel_trace.csv")[0]
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        dur[short(r["Kernel_Name"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return {k: sum(v) / len(v) for k, v in dur.items()}
+
+
+def main():
+    tag, stats_dir, fetch_dir, write_dir, sq_dir, bench_json = sys.argv[1:7]
+    shutil.copy(glob.glob(f"{stats_dir}/*/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
+    shutil.copy(bench_json, f"profiles/{tag}_bench_under_rocprof.json")
+    fetch, write = counters(fetch_dir), counters(write_dir)
+    out = {
+        "_note": "HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate "
+                 "passes (bench.py --steps 3 --warmup 1, 10 M planar points); counter unit KiB; gfx950 "
+                 "correction of MI355X_MICROARCH.md applied to the read side (FETCH_SIZE x 2 for wide "
+                 "coalesced reads; the raw value is kept), WRITE_SIZE as is.",
+        "kernels": {},
+    }
+    for k in fetch:
+        f = fetch[k].get("FETCH_SIZE", 0.0)
+        w = write.get(k, {}).get("WRITE_SIZE", 0.0)
+        out["kernels"][k] = {"fetch_KiB_raw": f, "fetch_bytes_corrected": 2048.0 * f, "write_bytes": 1024.0 * w}
+    json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+    sq, dur = counters(sq_dir), durations(sq_dir)
+    rows = {}
+    for k, c in sq.items():
+        if "SQ_INSTS_VALU" not in c or k not in dur:
+            continue
+        ns = dur[k]
+        cyc_per_xcd = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        clock_ghz = cyc_per_xcd / ns if ns else 0.0
+        busy = (c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0) / (1024.0 * cyc_per_xcd) if cyc_per_xcd else 0.0
+        rows[k] = {
+            "duration_us": ns / 1e3,
+            "wave_valu_instructions": c.get("SQ_INSTS_VALU"),
+            "valu_busy_fraction": busy,
+            "effective_clock_GHz": clock_ghz,
+            "waves_per_simd": (c.get("SQ_WAVE_CYCLES", 0.0) * 4.0) / (1024.0 * cyc_per_xcd) if cyc_per_xcd else 0.0,
+            "wait_any_fraction_of_wave_cycles": c.get("SQ_WAIT_ANY", 0.0) / c.get("SQ_WAVE_CYCLES", 1.0),
+        }
+    json.dump({"_note": "SQ counters per launch (sum over XCDs); SQ_* cycle counters are quad-cycles; "
+                        "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8)",
+               "kernels": rows}, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
+    for k in ("k_ransac", "k_keygen", "k_finalize", "k_lv_scatter"):
+        if k in rows:
+            print(k, json.dumps(rows[k]))
+        if k in out["kernels"]:
+            print(k, json.dumps(out["kernels"][k]))
+
+
+if __name__ == "__main__":
+    main()
