@@ -544,3 +544,113 @@ def test_arbitrary_callable_criteria_vs_oracle():
     for p, pts in enumerate(poses):
         index = index_map(pts)
         assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)), _oracle_pose_table(og, p))
+
+
+# ------------------------------------------------------------------------------------------------
+# batching, pose numbering and the per-pose mask plumbing of map_leaf_points_cuda_ransac
+# ------------------------------------------------------------------------------------------------
+def _oracle_grid_ransac(og, poses, pose_numbers, table, thr, poses_per_batch):
+    """grid.py:149-215 on the oracle: batches of consecutive pose numbers, one evaluate() each."""
+    from oracle import ransac_np as rnp
+
+    n = len(pose_numbers)
+    for i in range(0, n, poses_per_batch):
+        batch = list(range(i, min(i + poses_per_batch, n)))
+        clouds, sizes = [], []
+        for p in batch:
+            for _, _, idx in og.leaf_table(p):
+                clouds.append(poses[p][idx])
+                sizes.append(len(idx))
+        mask = rnp.evaluate(np.vstack(clouds), np.array(sizes, dtype=np.int32), table, thr)
+        off = 0
+        for p in batch:
+            m = og.n_points(p)
+            og.apply_mask(p, mask[off : off + m])
+            off += m
+
+
+@pytest.mark.parametrize("poses_per_batch", [1, 2, 10])
+def test_ransac_batches_vs_oracle(poses_per_batch):
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(31)
+    poses = {p: _planar_cloud(rng, 2, 150 + 40 * p) for p in range(3)}
+    grid, og = Grid(GridConfig(voxel_edge_length=1)), onp.OGrid(1)
+    for p in range(3):
+        grid.insert_points(p, poses[p])
+        og.insert_points(p, poses[p])
+    grid.subdivide(crit(48))
+    og.subdivide(48)
+    np.random.seed(5)
+    table = np.random.random((512, 6))
+    np.random.seed(5)
+    grid.map_leaf_points_cuda_ransac(poses_per_batch=poses_per_batch, threshold=0.01,
+                                     hypotheses_number=512, initial_points_number=6)
+    _oracle_grid_ransac(og, poses, [0, 1, 2], table, 0.01, poses_per_batch)
+    for p in range(3):
+        index = index_map(poses[p])
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)), _oracle_pose_table(og, p))
+        assert [grid.n_leaves(p), grid.n_points(p)] == [og.n_leaves(p), og.n_points(p)]
+
+
+def test_ransac_poses_inserted_out_of_numeric_order():
+    """Pose numbers 1, 0: the reference batches by pose NUMBER (grid.py:149-157); the device order
+    is by insertion slot, so this goes through the explicit block-order entry point."""
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(32)
+    poses = {0: _planar_cloud(rng, 2, 120), 1: _planar_cloud(rng, 2, 180)}
+    grid, og = Grid(GridConfig(voxel_edge_length=1)), onp.OGrid(1)
+    for p in (1, 0):
+        grid.insert_points(p, poses[p])
+        og.insert_points(p, poses[p])
+    grid.subdivide(crit(40))
+    og.subdivide(40)
+    np.random.seed(6)
+    table = np.random.random((256, 6))
+    np.random.seed(6)
+    grid.map_leaf_points_cuda_ransac(poses_per_batch=10, threshold=0.01, hypotheses_number=256)
+    _oracle_grid_ransac(og, poses, [0, 1], table, 0.01, 10)
+    for p in (0, 1):
+        index = index_map(poses[p])
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)), _oracle_pose_table(og, p))
+
+
+def test_manager_apply_mask_filter_and_map_per_pose():
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(33)
+    poses = [rng.random((600, 3)), rng.random((500, 3))]
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 1.0)
+    om = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(2):
+        m.insert_points(p, poses[p])
+        om.insert_points(p, poses[p])
+    m.subdivide(crit(30))
+    om.subdivide(30)
+    # apply_mask: the mask runs over the pose's non-empty leaves in cached-leaf order
+    mask = rng.random(600) < 0.7
+    m.apply_mask(mask, 0)
+    om.octrees[0].apply_mask(mask)
+    for p in range(2):
+        index = index_map(poses[p])
+        got = canon_from_list(views_table(m.get_leaf_points(True, p), index))
+        assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(om.octrees[p])))
+    # filter on one pose: leaves with fewer than 12 points are emptied (octree.py:102-112)
+    m.filter([lambda pts: len(pts) >= 12], [1])
+    for v in om.octrees[1].leaves():
+        if len(v.idx) < 12:
+            v.idx = np.empty(0, dtype=np.int64)
+    # map_leaf_points on the other pose: keep the first point of every leaf (octree.py:114-123)
+    m.map_leaf_points(lambda pts: pts[:1], [0])
+    for v in om.octrees[0].leaves():
+        v.idx = v.idx[:1]
+    for p in range(2):
+        index = index_map(poses[p])
+        got = canon_from_list(views_table(m.get_leaf_points(True, p), index))
+        assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(om.octrees[p])))
+        assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == [om.n_nodes(p), om.n_leaves(p), om.n_points(p)]
