@@ -30,7 +30,13 @@ constexpr int LV_IPT = 4;
 constexpr int LV_TILE = LV_THREADS * LV_IPT;  // 1024 positions per tile
 constexpr int LV_WAVE_ITEMS = 64 * LV_IPT;
 constexpr uint32_t IDX_MASK = 0x7FFFFFFFu;
-constexpr int PATH_LEVELS = 21;
+// child digits precomputed per path word.  The word has room for 21; trees are rarely deeper
+// than a few levels, so only the first PATH_LEVELS are computed up front (k_keygen is VALU bound on
+// exactly this loop) and k_lv_rekey extends the paths of the points that do go deeper.
+#ifndef OCTL_PATH_LEVELS
+#define OCTL_PATH_LEVELS 6
+#endif
+constexpr int PATH_LEVELS = OCTL_PATH_LEVELS;
 
 // slots of the context's small device scalar block (uint32 units)
 enum {
