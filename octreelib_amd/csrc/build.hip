@@ -17,7 +17,9 @@
 //                 exceeds K is split 8 ways by a stable tile partition (ballot ranks in LDS)
 //   k_finalize    leaf-ordered point permutation + coordinates, (leaf, pose) block table
 #include <algorithm>
+#include <cstdlib>
 
+#include "build_common.h"
 #include "forest.h"
 #include "ref_arith.h"
 #include "wave_utils.h"
@@ -29,7 +31,6 @@ constexpr int LV_WAVES = LV_THREADS / 64;
 constexpr int LV_IPT = 4;
 constexpr int LV_TILE = LV_THREADS * LV_IPT;  // 1024 positions per tile
 constexpr int LV_WAVE_ITEMS = 64 * LV_IPT;
-constexpr uint32_t IDX_MASK = 0x7FFFFFFFu;
 // child digits precomputed per path word.  The word has room for 21; trees are rarely deeper
 // than a few levels, so only the first PATH_LEVELS are computed up front (k_keygen is VALU bound on
 // exactly this loop) and k_lv_rekey extends the paths of the points that do go deeper.
@@ -37,17 +38,6 @@ constexpr uint32_t IDX_MASK = 0x7FFFFFFFu;
 #define OCTL_PATH_LEVELS 6
 #endif
 constexpr int PATH_LEVELS = OCTL_PATH_LEVELS;
-
-// slots of the context's small device scalar block (uint32 units)
-enum {
-  SM_ERR = 0,       // domain error flag
-  SM_BBOX = 4,      // 6 x int32: min xyz, max xyz
-  SM_NVOX = 12,     // voxels with points
-  SM_NSPLIT = 13,   // nodes to split at the next level
-  SM_NTILES = 14,   // tiles of the next level
-  SM_ETOTAL = 15,   // total of the scanned tile histogram
-  SM_NBLOCKS = 16,
-};
 
 // ---------------------------------------------------------------------------------------------
 // reference arithmetic
@@ -275,12 +265,6 @@ __global__ __launch_bounds__(256) void k_count_scheme(const int32_t* __restrict_
 // ---------------------------------------------------------------------------------------------
 // level loop
 // ---------------------------------------------------------------------------------------------
-struct NodePtrs {
-  uint32_t *start, *count, *scount;
-  int32_t *depth, *voxel, *parent, *first_child, *old_id, *epoch;
-  double *corner, *edge;
-};
-
 // roots of a forest without a previous scheme, built on the device (no PCIe round trip)
 __global__ __launch_bounds__(256) void k_make_roots(const uint64_t* __restrict__ vlin,
                                                     const uint32_t* __restrict__ vstart, int64_t V,
@@ -654,22 +638,6 @@ __global__ __launch_bounds__(256) void k_block_sizes(const uint32_t* __restrict_
   blk_size[b] = (int32_t)(e - blk_start[b]);
 }
 
-NodePtrs node_ptrs(NodeTable& t) {
-  NodePtrs p;
-  p.start = t.start.as<uint32_t>();
-  p.count = t.count.as<uint32_t>();
-  p.scount = t.scount.as<uint32_t>();
-  p.depth = t.depth.as<int32_t>();
-  p.voxel = t.voxel.as<int32_t>();
-  p.parent = t.parent.as<int32_t>();
-  p.first_child = t.first_child.as<int32_t>();
-  p.old_id = t.old_id.as<int32_t>();
-  p.epoch = t.epoch.as<int32_t>();
-  p.corner = t.corner.as<double>();
-  p.edge = t.edge.as<double>();
-  return p;
-}
-
 inline unsigned grid_for(int64_t n, int threads = 256) { return (unsigned)ceil_div(n, threads); }
 
 int bits_for(uint64_t max_value) {
@@ -1036,13 +1004,46 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
   }
 
+  // voxel keys of this build: kept on the device, decoded on the host only when someone asks
+  OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
+  if (fresh && V > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(f->vlin_dev.p, vlin_d, (size_t)V * 8, hipMemcpyDeviceToDevice, st));
+
+  const int cur_epoch = f->epoch + (keep_scheme ? 0 : 1);
+  const int64_t old_internal = have_old ? f->n_internal : 0;
+  int64_t first_new = 0, n_new = V, n_internal = 0;
+  int level = 0;
+  std::vector<int64_t> level_first{0, V};
+
+  // ---- 3b. voxel-local build: one wave per top-level voxel (voxel_build.hip) -------------------------
+  // a K-driven scheme without history; any voxel that does not fit sends the whole build down the
+  // level-synchronous path below
+  bool voxel_done = false;
+  if (!keep_scheme && K >= 0 && old_internal == 0 && n_alive > 0 && V > 0 &&
+      getenv("OCTL_NO_VOXEL_BUILD") == nullptr) {
+    VoxelBuildArgs va{val_sorted, n_alive, V, K, cur_epoch, max_depth};
+    int done = 0, lv = 0;
+    int64_t ni = 0;
+    std::vector<int64_t> lf;
+    OCTL_TRY(forest_voxel_build(f, va, nt, &done, &lf, &ni, &lv));
+    if (done) {
+      voxel_done = true;
+      level_first.swap(lf);
+      n_internal = ni;
+      level = lv;
+      nd = node_ptrs(nt);
+    }
+  }
+
+  int32_t* pos_node = nullptr;
+  if (!voxel_done) {
   // ---- 4. level-0 buffers ---------------------------------------------------------------------------
   for (int b = 0; b < 2; ++b) {
     OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 8));
   }
   OCTL_TRY(devbuf_reserve(ctx, f->pos_node, (size_t)std::max<int64_t>(n_alive, 1) * 4));
-  int32_t* pos_node = f->pos_node.as<int32_t>();
+  pos_node = f->pos_node.as<int32_t>();
   if (n_alive > 0) {
     const int32_t* l2r = nullptr;
     if (!fresh) {
@@ -1066,17 +1067,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
   }
 
-  // voxel keys of this build: kept on the device, decoded on the host only when someone asks
-  OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
-  if (fresh && V > 0)
-    HIP_TRY(ctx, hipMemcpyAsync(f->vlin_dev.p, vlin_d, (size_t)V * 8, hipMemcpyDeviceToDevice, st));
-
   // ---- 5. level loop ----------------------------------------------------------------------------------
-  int64_t first_new = 0, n_new = V, n_internal = 0;
-  int level = 0;
-  std::vector<int64_t> level_first{0, V};
-  const int cur_epoch = f->epoch + (keep_scheme ? 0 : 1);
-  const int64_t old_internal = f->n_internal;
   while (n_new > 0) {
     // split list of the freshly created nodes
     OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_new, n_alive) + 8) * 4));
@@ -1188,7 +1179,6 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     ++level;
   }
   // ---- 6. leaf-ordered arrays and the block table ------------------------------------------------------
-  int64_t n_blocks = 0;
   if (n_alive > 0) {
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_alive * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, (size_t)n_alive * 24));
@@ -1203,6 +1193,8 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       HIP_TRY(ctx, hipGetLastError());
     }
   }
+  }  // !voxel_done
+  int64_t n_blocks = 0;
   const int64_t n_ord_before = f->n_ord;
   f->n_ord = n_alive;
   OCTL_TRY(forest_make_blocks(f));

@@ -1,0 +1,58 @@
+// Declarations shared by the two build paths (build.hip: level-synchronous global path,
+// voxel_build.hip: one wave per top-level voxel).
+#pragma once
+#include "forest.h"
+
+constexpr uint32_t IDX_MASK = 0x7FFFFFFFu;
+
+// slots of the context's small device scalar block (uint32 units)
+enum {
+  SM_ERR = 0,       // domain error flag
+  SM_BBOX = 4,      // 6 x int32: min xyz, max xyz
+  SM_NVOX = 12,     // voxels with points
+  SM_NSPLIT = 13,   // nodes to split at the next level
+  SM_NTILES = 14,   // tiles of the next level
+  SM_ETOTAL = 15,   // total of the scanned tile histogram
+  SM_NBLOCKS = 16,
+  SM_VB_FALLBACK = 17,  // voxel build: some voxel does not fit (too many points / too deep / bad point)
+  SM_VB_DEPTH = 18,     // voxel build: deepest leaf
+  SM_VB_INTERNAL = 19,  // voxel build: internal nodes in total
+  // 20: kept count of apply_mask, 24: debug scan total, 64..: slot histogram, 512..: allreduce
+};
+
+struct NodePtrs {
+  uint32_t *start, *count, *scount;
+  int32_t *depth, *voxel, *parent, *first_child, *old_id, *epoch;
+  double *corner, *edge;
+};
+
+static inline NodePtrs node_ptrs(NodeTable& t) {
+  NodePtrs p;
+  p.start = t.start.as<uint32_t>();
+  p.count = t.count.as<uint32_t>();
+  p.scount = t.scount.as<uint32_t>();
+  p.depth = t.depth.as<int32_t>();
+  p.voxel = t.voxel.as<int32_t>();
+  p.parent = t.parent.as<int32_t>();
+  p.first_child = t.first_child.as<int32_t>();
+  p.old_id = t.old_id.as<int32_t>();
+  p.epoch = t.epoch.as<int32_t>();
+  p.corner = t.corner.as<double>();
+  p.edge = t.edge.as<double>();
+  return p;
+}
+
+// voxel_build.hip: complete build of every top-level voxel by one wave each (K-driven scheme, no
+// previous internal nodes).  Returns OCTL_OK with *done = 1 when the scheme, the leaf-ordered
+// arrays and pos_node are complete; *done = 0 when some voxel does not fit and the caller must
+// run the level-synchronous path instead (nothing the caller relies on has been modified).
+struct VoxelBuildArgs {
+  const uint32_t* val_sorted;  // store index | scheme bit, sorted by voxel
+  int64_t n_alive;
+  int64_t V;
+  int64_t K;
+  int cur_epoch;
+  int max_depth;
+};
+int forest_voxel_build(octl_forest* f, const VoxelBuildArgs& a, NodeTable& nt, int* done,
+                       std::vector<int64_t>* level_first, int64_t* n_internal, int* levels);

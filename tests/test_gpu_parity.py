@@ -654,3 +654,36 @@ def test_manager_apply_mask_filter_and_map_per_pose():
         got = canon_from_list(views_table(m.get_leaf_points(True, p), index))
         assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(om.octrees[p])))
         assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == [om.n_nodes(p), om.n_leaves(p), om.n_points(p)]
+
+
+# ------------------------------------------------------------------------------------------------
+# the two build paths (one wave per voxel / level-synchronous) must produce identical tables
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scheme", [None, [0]])
+def test_voxel_local_build_equals_level_synchronous_build(monkeypatch, scheme):
+    from octreelib_amd import synthetic
+    from octreelib_amd._engine import Forest
+
+    clouds = [synthetic.planar_cloud(120_000, (8, 8, 8), seed=3, stream=1),
+              synthetic.planar_cloud(60_000, (8, 8, 8), seed=3, stream=2)]
+
+    def build():
+        f = Forest(0, np.zeros(3), 1.0)
+        for c in clouds:
+            f.add_pose(c)
+        f.subdivide(48, scheme)
+        out = ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()},
+               f.perm.copy(), f.xyz.copy(), f.order.copy(), int(f.info.n_levels))
+        f.close()
+        return out
+
+    monkeypatch.delenv("OCTL_NO_VOXEL_BUILD", raising=False)
+    a = build()
+    monkeypatch.setenv("OCTL_NO_VOXEL_BUILD", "1")
+    b = build()
+    assert a[5] == b[5] and a[5] >= 2
+    for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
