@@ -119,7 +119,9 @@ typedef struct octl_build_info {
  * pose in its scheme leaf.  keep_scheme != 0 re-places the points in the EXISTING scheme
  * (a pose inserted after a subdivide inherits it, octree_manager.py:161-171) and ignores
  * K / scheme_mask.  K < 0 means "never split" (the state right after insert_points).
- * max_depth guards the recursion the reference does not bound (<= 0: default 63).         */
+ * max_depth guards the recursion the reference does not bound (<= 0: default 63).
+ * On OCTL_E_DOMAIN / OCTL_E_DEPTH / OCTL_E_NOMEM / OCTL_E_HIP the forest keeps its points and
+ * voxels but is left without a scheme (the next build starts from the top-level voxels).     */
 int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
                       int32_t keep_scheme, int32_t max_depth, octl_build_info* info);
 

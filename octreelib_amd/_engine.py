@@ -103,12 +103,21 @@ class Forest:
             mask = np.zeros(self.n_slots, dtype=np.uint8)
             mask[list(scheme_slots)] = 1
         info = nat.BuildInfo()
-        self.ctx.check(
-            self.lib.octl_forest_build(
-                self.handle, int(K), nat.ptr(mask), self.n_slots if mask is not None else 0,
-                1 if keep_scheme else 0, int(max_depth), C.byref(info),
+        try:
+            self.ctx.check(
+                self.lib.octl_forest_build(
+                    self.handle, int(K), nat.ptr(mask), self.n_slots if mask is not None else 0,
+                    1 if keep_scheme else 0, int(max_depth), C.byref(info),
+                )
             )
-        )
+        except (RecursionError, nat.DomainError, MemoryError, RuntimeError):
+            # the library dropped the scheme (include/octreelib_hip.h): the next query rebuilds the
+            # top-level voxels; the reference leaves a half-subdivided tree behind in these cases
+            self.has_scheme = False
+            self._dirty = True
+            self.info = None
+            self._invalidate()
+            raise
         self.info = info
         self.n_ord = int(info.n_points)
         self._dirty = False

@@ -224,7 +224,19 @@ int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int
 int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
                       int32_t keep_scheme, int32_t max_depth, octl_build_info* info) {
   if (!f) return OCTL_E_INVALID;
-  return forest_build(f, K, scheme_mask, n_mask, keep_scheme, max_depth, info);
+  const int rc = forest_build(f, K, scheme_mask, n_mask, keep_scheme, max_depth, info);
+  if (rc != OCTL_OK && rc != OCTL_E_INVALID && rc != OCTL_E_STATE) {
+    // a build that failed half way has overwritten scratch the previous tables referred to:
+    // the forest is left WITHOUT a scheme (its points and voxels are kept); the next build starts
+    // from the top-level voxels again
+    f->built = false;
+    f->n_ord = 0;
+    f->n_blocks = 0;
+    f->n_internal = 0;
+    f->mask_valid = false;
+    f->store_dirty = true;
+  }
+  return rc;
 }
 
 int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int32_t* epoch,

@@ -687,3 +687,20 @@ def test_voxel_local_build_equals_level_synchronous_build(monkeypatch, scheme):
     for k in a[1]:
         assert np.array_equal(a[1][k], b[1][k]), k
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+def test_forest_is_usable_after_a_failed_subdivide():
+    from octreelib_amd.grid import Grid, GridConfig
+
+    rng = np.random.default_rng(3)
+    pts = np.vstack([rng.random((500, 3)), np.tile(np.array([[0.25, 0.25, 0.25]]), (4, 1))])
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, pts)
+    grid.subdivide(crit(100))
+    assert grid.n_points(0) == 504
+    with pytest.raises(RecursionError):
+        grid.subdivide(crit(2))  # four identical points never separate
+    # the scheme is gone, the points are not
+    assert [grid.n_leaves(0), grid.n_points(0), grid.n_nodes(0)] == [1, 504, 1]
+    grid.subdivide(crit(100))
+    assert grid.n_points(0) == 504 and grid.n_leaves(0) > 1
