@@ -150,6 +150,11 @@ int octl_forest_get_voxels(octl_forest* f, int64_t cap, int64_t* coords, int64_t
  * the leaf, pose slot, start and size in the leaf-ordered arrays.                          */
 int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* slot,
                            int64_t* start, int32_t* size, int64_t* n_blocks);
+/* Ranks (indices into the voxel table, ascending) of the top-level voxels in which a pose slot
+ * currently has points - Grid.__pose_voxel_coordinates (grid.py:53,108) without fetching the
+ * node and block tables.                                                                     */
+int octl_forest_get_slot_voxels(octl_forest* f, int32_t slot, int64_t cap, int32_t* voxel_ranks,
+                                int64_t* n);
 /* Leaf-ordered point permutation: perm[i] = index of the point at storage position i in
  * the concatenation of all pose clouds in slot order (pose-local index = perm - offset of
  * its slot).  Within a block the order is ascending (stable).                              */

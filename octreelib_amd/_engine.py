@@ -229,13 +229,16 @@ class Forest:
         if all(k is not None for k in self.slot_voxel_keys):
             return
         vox = self.voxels
-        blk = self.blocks
-        node_vox = self.nodes["voxel"]
         for s in range(self.n_slots):
             if self.slot_voxel_keys[s] is not None:
                 continue
-            sel = blk["slot"] == s
-            vids = np.unique(node_vox[blk["node"][sel]])
+            n = C.c_int64(0)
+            self.ctx.check(self.lib.octl_forest_get_slot_voxels(self.handle, s, 0, None, C.byref(n)))
+            vids = np.empty(n.value, dtype=np.int32)
+            if n.value:
+                self.ctx.check(
+                    self.lib.octl_forest_get_slot_voxels(self.handle, s, n.value, nat.ptr(vids), C.byref(n))
+                )
             keys = vox[vids]
             self.slot_voxel_keys[s] = keys
             for k in map(tuple, keys.tolist()):

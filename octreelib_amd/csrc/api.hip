@@ -37,6 +37,23 @@ __global__ __launch_bounds__(256) void k_compact_ord(
   }
 }
 
+// voxels in which a pose slot has at least one block
+__global__ __launch_bounds__(256) void k_slot_voxel_flags(const int32_t* __restrict__ blk_node,
+                                                          const int32_t* __restrict__ blk_slot,
+                                                          int64_t nb, int32_t slot,
+                                                          const int32_t* __restrict__ node_voxel,
+                                                          uint32_t* __restrict__ flags) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb && blk_slot[b] == slot) flags[node_voxel[blk_node[b]]] = 1u;
+}
+
+__global__ __launch_bounds__(256) void k_flag_indices(const uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ scanned, int64_t n,
+                                                      int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) out[scanned[i]] = (int32_t)i;
+}
+
 __global__ __launch_bounds__(256) void k_widen_u32_i64(const uint32_t* __restrict__ in, int64_t n,
                                                        int64_t* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -340,6 +357,47 @@ int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* 
     HIP_TRY(ctx, hipMemcpyAsync(start, f->rs_scratch.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  return OCTL_OK;
+}
+
+int octl_forest_get_slot_voxels(octl_forest* f, int32_t slot, int64_t cap, int32_t* voxel_ranks,
+                                int64_t* n_out) {
+  if (!f || !n_out) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  const int n_poses = (int)f->pose_off.size() - 1;
+  if (slot < 0 || slot >= n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "bad pose slot");
+  *n_out = 0;
+  const int64_t V = f->n_voxels, nb = f->n_blocks;
+  if (V <= 0 || nb <= 0) return OCTL_OK;
+  hipStream_t st = ctx->stream;
+  // scratch inside rs_scratch: [flags u32 V+8 | scanned u32 V+8 | out i32 V]
+  const size_t seg = (((size_t)V + 8) * 4 + 15) & ~(size_t)15;
+  OCTL_TRY(devbuf_reserve(ctx, f->rs_scratch, 3 * seg));
+  char* base = static_cast<char*>(f->rs_scratch.p);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(base);
+  uint32_t* scanned = reinterpret_cast<uint32_t*>(base + seg);
+  int32_t* out = reinterpret_cast<int32_t*>(base + 2 * seg);
+  uint32_t* total = ctx->small.as<uint32_t>() + 21;
+  HIP_TRY(ctx, hipMemsetAsync(flags, 0, seg, st));
+  hipLaunchKernelGGL(k_slot_voxel_flags, dim3(grid_for(nb)), dim3(256), 0, st,
+                     (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
+                     nb, slot, (const int32_t*)f->nodes[f->cur].voxel.as<int32_t>(), flags);
+  HIP_TRY(ctx, hipGetLastError());
+  OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, scanned, V, total));
+  hipLaunchKernelGGL(k_flag_indices, dim3(grid_for(V)), dim3(256), 0, st, (const uint32_t*)flags,
+                     (const uint32_t*)scanned, V, out);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, total, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  uint32_t cnt;
+  std::memcpy(&cnt, ctx->small_host, 4);
+  *n_out = cnt;
+  const int64_t m = std::min<int64_t>(cap, cnt);
+  if (m > 0 && voxel_ranks) {
+    HIP_TRY(ctx, hipMemcpyAsync(voxel_ranks, out, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+  }
   return OCTL_OK;
 }
 
