@@ -128,7 +128,7 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #endif
 #define RS_BIG_HPL (1024 / RS_BIG_THREADS)
 #ifndef RS_PER_CU
-#define RS_PER_CU 5
+#define RS_PER_CU 16
 #endif
 #ifndef RS_SCORE_UNROLL
 #define RS_SCORE_UNROLL 4
