@@ -128,7 +128,7 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #endif
 #define RS_BIG_HPL (1024 / RS_BIG_THREADS)
 #ifndef RS_PER_CU
-#define RS_PER_CU 16
+#define RS_PER_CU 64
 #endif
 #ifndef RS_SCORE_UNROLL
 #define RS_SCORE_UNROLL 4
@@ -292,14 +292,14 @@ __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, cons
 #endif
 
 // Persistent workgroups over the descriptors of all blocks with k <= n <= THREADS-1 points,
-// SORTED BY SIZE (largest first): workgroup w handles entries w, w+G, w+2G, ...
-//   * static striding over a size-sorted list balances the workgroups and ends on the
-//     smallest blocks (no tail);
+// SORTED BY SIZE (largest first): workgroup w handles a contiguous chunk of the list
+//   * the grid is oversubscribed (64 workgroups per CU, 4 resident): the chunks with the largest
+//     blocks are dispatched first and the dispatcher evens out the rest (no tail);
 //   * consecutive blocks of a workgroup have the same size, so the positions of the sampled
 //     points - a function of (hypothesis, n) only, see sample_index_cached - are computed once
 //     per size and kept packed in registers, together with the hypothesis-table reads;
-//   * while entry e is computed out of one LDS buffer the points of entry e+G are already in
-//     flight into registers and the descriptor of entry e+2G is being fetched, so the per-block
+//   * while entry e is computed out of one LDS buffer the points of entry e+1 are already in
+//     flight into registers and the descriptor of entry e+2 is being fetched, so the per-block
 //     latency chain (descriptor -> points) is off the critical path;
 //   * the block's points are three f64 LDS arrays: the 6 sampled points of a hypothesis are
 //     per-lane LDS gathers (conflict free up to 32 points), the scoring loop reads each point as
@@ -324,12 +324,16 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   __shared__ float s_wext[3][W];
 #endif
   const int nbs = (int)*n_sorted_ptr;
-  const int G = gridDim.x;
-  int j = blockIdx.x;
-  if (j >= nbs) return;
+  // workgroup w owns the CONTIGUOUS chunk [w*C, (w+1)*C) of the size-sorted list: its blocks have
+  // (almost always) the same size, so the cached sample positions stay valid, and the chunks with
+  // the largest blocks are dispatched first
+  const int C = (nbs + (int)gridDim.x - 1) / (int)gridDim.x;
+  int j = (int)blockIdx.x * C;
+  const int j_end = min(nbs, j + C);
+  if (j >= j_end) return;
   BlockDesc cur = sdesc[j];
   BlockDesc nxt = cur;
-  if (j + G < nbs) nxt = sdesc[j + G];
+  if (j + 1 < j_end) nxt = sdesc[j + 1];
   {
     double px = 0.0, py = 0.0, pz = 0.0;
     if ((int)threadIdx.x <= cur.n) {
@@ -356,9 +360,9 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
   }
   for (;;) {
-    const bool has_next = j + G < nbs;
+    const bool has_next = j + 1 < j_end;
     BlockDesc nxt2 = nxt;
-    if (j + 2 * G < nbs) nxt2 = sdesc[j + 2 * G];
+    if (j + 2 < j_end) nxt2 = sdesc[j + 2];
     // points of the next block -> registers (in flight during the compute below)
     double rx = 0.0, ry = 0.0, rz = 0.0;
     const bool pre = has_next && (int)threadIdx.x <= nxt.n;
@@ -596,7 +600,7 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
     if (!has_next) break;
     cur = nxt;
     nxt = nxt2;
-    j += G;
+    j += 1;
     buf = nbuf;
     par ^= 1;
   }
