@@ -1,4 +1,4 @@
-# Builds liboctree_hip.so (gfx950 only) and the C oracle.  No cmake: plain hipcc / gcc.
+# Builds liboctree_hip.so (gfx950 only).  No cmake: plain hipcc.  (The oracle is NumPy: nothing to build.)
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 # -ffp-contract=off: the parity contract forbids fusing the reference's separate mul/add
@@ -8,7 +8,7 @@ HDRS = $(wildcard octreelib_amd/csrc/*.h) include/octreelib_hip.h
 OBJS = $(patsubst octreelib_amd/csrc/%.hip,build/%.o,$(SRCS))
 LIB  = octreelib_amd/lib/liboctree_hip.so
 
-all: $(LIB) oracle
+all: $(LIB)
 
 build/%.o: octreelib_amd/csrc/%.hip $(HDRS)
 	@mkdir -p build
@@ -18,11 +18,7 @@ $(LIB): $(OBJS)
 	@mkdir -p octreelib_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -ldl
 
-oracle:
-	$(MAKE) -C oracle
-
 clean:
 	rm -rf build $(LIB)
-	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all clean

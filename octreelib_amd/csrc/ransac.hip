@@ -121,7 +121,7 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #define RS_SCHED_BARRIER 1
 #endif
 #ifndef RS_SCREEN
-#define RS_SCREEN 0  // measured: exact but not faster yet (register pressure); see DESIGN.md
+#define RS_SCREEN 1  // f32 screening of the scoring loop (exact counts; see "Screening" in k_ransac)
 #endif
 #ifndef RS_BIG_THREADS
 #define RS_BIG_THREADS 256  // lanes per workgroup for H > 256 (x RS_BIG_HPL hypotheses per lane)
@@ -269,18 +269,36 @@ __device__ __forceinline__ void ransac_block_global(const BlockDesc& d, int be,
 }
 
 #if RS_SCREEN
+// Helpers of the screened scoring loop, as inline asm on purpose: the loop's instruction mix is
+// the whole point.  Plain v_fma_f32: left to itself hipcc SLP-packs neighbouring hypotheses into
+// v_pk_fma_f32, which measured SLOWER than two scalar FMAs on gfx950 (both as compiler output
+// and hand-packed with op_sel broadcasts: 5.56 vs 5.47 ms), and adds canonicalising v_max
+// around fminf.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float fma32(float a, float b, float c) {
+  float r;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// min(m, |a|, |b|)
+__device__ __forceinline__ float min3abs(float m, float a, float b) {
+  float r;
+  asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+}
+
 // block-local f32 coordinates of the point a lane is staging (relative to the block's first
 // point, read with a wave-uniform scalar load) and the per-wave maximum of their magnitudes
 template <int THREADS>
 __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, const BlockDesc& d,
-                                            double px, double py, double pz, float4* loc,
+                                            double px, double py, double pz, f4* loc,
                                             float* wext) {
   const double ox = xyz[3 * (int64_t)d.pstart], oy = xyz[3 * (int64_t)d.pstart + 1],
                oz = xyz[3 * (int64_t)d.pstart + 2];
   float m = 0.f;
   if ((int)threadIdx.x < d.n) {
     const float u = (float)(px - ox), v = (float)(py - oy), w = (float)(pz - oz);
-    loc[threadIdx.x] = make_float4(u, v, w, 0.f);
+    loc[threadIdx.x] = f4{u, v, w, 0.f};
     m = fmaxf(fabsf(u), fmaxf(fabsf(v), fabsf(w)));
     // a NaN coordinate would be dropped by fmaxf: force "everything is ambiguous" instead
     if (!(m == m) || u != u || v != v || w != w) m = __int_as_float(0x7f800000);
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #if RS_SCREEN
   // f32 screening of the scoring loop (see "screening" below): block-local f32 coordinates
   // relative to the block's first point and, per wave, the largest |coordinate|
-  __shared__ float4 s_loc[3][THREADS];
+  __shared__ f4 s_loc[3][THREADS];
   __shared__ float s_wext[3][W];
 #endif
   const int nbs = (int)*n_sorted_ptr;
@@ -404,7 +422,11 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 
 #if RS_SCREEN
     // screening keeps only the f32 plane (its promotion to f64 is exact and redone on demand)
-    float fa[HPL], fb[HPL], fc[HPL], fd[HPL], sto[HPL], slo[HPL], shi[HPL];
+    constexpr int NP = (HPL + 1) / 2;  // hypotheses are scored two at a time (v_pk_*_f32)
+    float fa[2 * NP], fb[2 * NP], fc[2 * NP], fd[2 * NP], sto[2 * NP], sdl[2 * NP];
+    if (HPL & 1) fa[HPL] = fb[HPL] = fc[HPL] = fd[HPL] = sto[HPL] = sdl[HPL] = 0.f;
+    // thresholds outside this range (nobody's plane tolerance) are always recounted exactly
+    const bool thr_sane = thr >= 0x1p-40 && thr <= 0x1p40;
     const double ox = lx[0], oy = ly[0], oz = lz[0];
     float extent = s_wext[buf][0];
 #pragma unroll
@@ -419,7 +441,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       cnt[q] = -1;
 #if RS_SCREEN
       fa[q] = fb[q] = fc[q] = fd[q] = 0.f;
-      sto[q] = slo[q] = shi[q] = 0.f;
+      sto[q] = sdl[q] = 0.f;
 #else
       pa[q] = pb[q] = pc[q] = pd[q] = 0.0;
 #endif
@@ -448,12 +470,13 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
           const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
           const double to = ((A * ox + B * oy) + Cc * oz) + D;
           const double delta = 0x1p-23 * (4.0 * fabs(to) + 9.0 * (double)extent) +
-                               0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + fabs(D) + (double)extent + 1.0) +
-                               0x1p-23 * fabs(thr);
+                               0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + fabs(D) + (double)extent + 1.0);
+          // the loop tests e = fl32(s*s - fl32(thr^2)): |e| >= dprime  =>  | |s| - thr | >= delta
+          const double dprime = ((2.0 * thr) * delta + delta * delta) + 0x1p-21 * (thr * thr);
+          const bool sane = thr_sane && (fabs(to) + (double)extent < 0x1p60);  // false for NaN
           fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
           sto[q] = (float)to;
-          slo[q] = (float)(thr - delta);
-          shi[q] = (float)(thr + delta);
+          sdl[q] = sane ? (float)(dprime * 1.000001) : __int_as_float(0x7f800000);
         }
 #else
         // the f32-rounded plane, promoted back to f64 for scoring (cuda_ransac.py:110-121)
@@ -479,35 +502,71 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     //   |s - t_ref| <= 2^-24 (4 |T_o| + 9 E) + 2^-50 (|o|_1 + |D| + E),   E = max |u|,|v|,|w|
     //     (three f32 FMA roundings on partial sums <= |T_o| + 3E, the f32 roundings of u,v,w and
     //      of to, the f64 roundings of T_o and of t_ref itself; |a|,|b|,|c| <= 1)
-    //   delta = twice that bound + the f32 rounding of the two thresholds
-    //   |s| < thr - delta => inlier,  |s| > thr + delta => not an inlier,  else: exact f64
-    // Two counters per hypothesis - pairs surely inside (|s| < thr - delta) and pairs possibly
-    // inside (|s| <= thr + delta) - keep the loop free of branches; a hypothesis whose two
-    // counters differ has borderline pairs and is recounted with the exact f64 sequence.
+    //   delta = twice that bound
+    // The test itself is done on squares:
+    //   e = fma32(s, s, -fl32(thr^2))     sign(e) = inlier bit, |e| = distance from the threshold
+    //   |e| >= dprime = 2 thr delta + delta^2 + 2^-21 thr^2   =>   | |s| - thr | >= delta and the
+    //   sign of e is the sign of s^2 - thr^2 (the last term absorbs the roundings of e and thr^2)
+    // so a hypothesis whose smallest |e| over the block stays above dprime has the reference's
+    // count; otherwise (rare) it is recounted with the exact f64 sequence.  Per point and
+    // hypothesis: 4 v_fma_f32, 1 v_alignbit (inlier bit into a 32-point history word, popcounted
+    // per 32 points) and half a v_min3_f32 - against 8 f64 instructions on the exact path.
     if (ABL != 1) {
-      int chi[HPL];
+      const float thr2 = (float)(thr * thr);
+      const float nthr2 = -thr2;
+      float margin[NP], dl2[NP];
 #pragma unroll
-      for (int q = 0; q < HPL; ++q) chi[q] = cnt[q];
-      const float4* __restrict__ loc = s_loc[buf];
-RS_PRAGMA(unroll RS_SCORE_UNROLL)
-      for (int i = 0; i < n; ++i) {
-        const float4 L = loc[i];
+      for (int p = 0; p < NP; ++p) {
+        dl2[p] = fmaxf(sdl[2 * p], sdl[2 * p + 1]);
+        margin[p] = __int_as_float(0x7f800000);
+      }
+      const f4* __restrict__ loc = s_loc[buf];
+      for (int base = 0; base < n; base += 32) {
+        const int m = __builtin_amdgcn_readfirstlane(min(32, n - base));
+        uint32_t hist[2 * NP];
 #pragma unroll
-        for (int q = 0; q < HPL; ++q) {
-          const float sv = fabsf(fmaf(fa[q], L.x, fmaf(fb[q], L.y, fmaf(fc[q], L.z, sto[q]))));
-          cnt[q] += (sv < slo[q]) ? 1 : 0;
-          chi[q] += (sv <= shi[q]) ? 1 : 0;
+        for (int q = 0; q < 2 * NP; ++q) hist[q] = 0;
+        auto score = [&](const f4 L) {
+#pragma unroll
+          for (int p = 0; p < NP; ++p) {
+            float e[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int q = 2 * p + h;
+              const float sv = fma32(fa[q], L.x, fma32(fb[q], L.y, fma32(fc[q], L.z, sto[q])));
+              e[h] = fma32(sv, sv, nthr2);
+              hist[q] = __builtin_amdgcn_alignbit(hist[q], __float_as_uint(e[h]), 31);
+            }
+            margin[p] = min3abs(margin[p], e[0], e[1]);
+          }
+        };
+        // unrolled by hand (the inline asm keeps the loop unroller away): 4 LDS reads in flight
+        int i = 0;
+        for (; i + 4 <= m; i += 4) {
+          const f4 L0 = loc[base + i], L1 = loc[base + i + 1], L2 = loc[base + i + 2],
+                   L3 = loc[base + i + 3];
+          score(L0);
+          score(L1);
+          score(L2);
+          score(L3);
         }
+        for (; i < m; ++i) score(loc[base + i]);
+#pragma unroll
+        for (int q = 0; q < HPL; ++q) cnt[q] += __popc(hist[q]);
       }
 #pragma unroll
-      for (int q = 0; q < HPL; ++q) {
-        const bool redo = cnt[q] >= 0 && cnt[q] != chi[q];
+      for (int p = 0; p < NP; ++p) {
+        const bool redo = !(margin[p] > dl2[p]);
         if (__any(redo)) {  // rare
-          int c = 0;
-          if (redo) {
-            const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
-            for (int i = 0; i < n; ++i) c += (plane_distance(A, B, Cc, D, lx[i], ly[i], lz[i]) < thr) ? 1 : 0;
-            cnt[q] = c;
+#pragma unroll
+          for (int q = 2 * p; q < 2 * p + 2 && q < HPL; ++q) {
+            if (redo && (int)threadIdx.x + q * THREADS < H) {
+              const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
+              int c = 0;
+              for (int ii = 0; ii < n; ++ii)
+                c += (plane_distance(A, B, Cc, D, lx[ii], ly[ii], lz[ii]) < thr) ? 1 : 0;
+              cnt[q] = c;
+            }
           }
         }
       }

@@ -454,6 +454,49 @@ def test_ransac_operator_random_blocks_vs_oracle():
         assert np.array_equal(mask, o_mask)
 
 
+@pytest.mark.parametrize(
+    "offset,scale,thr",
+    [
+        (0.0, 1.0, 1.0 / 64),        # lattice: many distances EXACTLY equal to the threshold (strict <)
+        (4096.0, 1.0, 1.0 / 64),     # the same far from the origin (block-local screening coordinates)
+        (1.0e6, 3.0, 3.0 / 64),      # large offsets, f64 rounding of the offset matters
+        (0.0, 1.0e-12, 1.0e-12 / 64),  # tiny scene
+        (0.0, 1.0e9, 1.0e9 / 64),    # huge scene
+        (0.0, 1.0, 1.0e-30),         # thresholds outside the screened range fall back to exact f64
+        (0.0, 1.0, 1.0e30),
+    ],
+)
+def test_ransac_distances_on_the_threshold_vs_oracle(offset, scale, thr):
+    """The scoring loop screens point-plane distances in f32 and recounts what it cannot decide:
+    the counts must be the exact f64 counts also when many distances sit ON the threshold."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(6, 120, 150).astype(np.int32)
+    n = int(sizes.sum())
+    # three lattice layers: planes through one layer see the others at exactly 1/64 and 2/64
+    cloud = np.empty((n, 3))
+    cloud[:, 0] = rng.integers(0, 64, n) / 64.0
+    cloud[:, 1] = rng.integers(0, 64, n) / 64.0
+    cloud[:, 2] = rng.integers(0, 3, n) / 64.0
+    # distinct points inside a block are not required by the operator; a few tilted blocks
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    for b in range(0, len(sizes), 4):
+        s, e = starts[b], starts[b + 1]
+        cloud[s:e, 2] += cloud[s:e, 0] / 2 + rng.integers(0, 2, e - s) / 64.0
+    cloud = cloud * scale + offset
+    for H in (1024, 200, 64):
+        np.random.seed(H + 1)
+        op = CudaRansac(threshold=thr, hypotheses_number=H, initial_points_number=6)
+        mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+        o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, thr, details=True)
+        assert np.array_equal(counts, o_count)
+        assert np.array_equal(index, o_index)
+        assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+        assert np.array_equal(mask, o_mask)
+
+
 # ------------------------------------------------------------------------------------------------
 # edges of the parity domain
 # ------------------------------------------------------------------------------------------------
