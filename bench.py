@@ -226,6 +226,14 @@ def main():
     extra = {}
     if world == 1 and not route:
         extra["insert_subdivide_only_ms"] = timed(step_build_only) * 1e3
+        # leaf sizes before RANSAC, for the algorithmic flop count of SURVEY.md 8(d)
+        nb = C.c_int64(0)
+        ctx.check(lib.octl_forest_get_blocks(fh, 0, None, None, None, None, C.byref(nb)))
+        sizes = np.empty(nb.value, dtype=np.int32)
+        ctx.check(lib.octl_forest_get_blocks(fh, nb.value, None, None, None, nat.ptr(sizes), C.byref(nb)))
+        fit = sizes[sizes >= KPTS].astype(np.int64)
+        extra["leaves_evaluated"] = int(len(fit))
+        extra["ransac_flops"] = float(H * (20.0 * KPTS * len(fit) + 6.0 * fit.sum()) + 6.0 * fit.sum())
         extra["pcie_inclusive_ms"] = timed(step_from_host) * 1e3
         step()  # leave the forest in the state the report describes
 
@@ -258,8 +266,10 @@ def main():
         achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
         device_ms = sum(k["ms_per_step"] for k in kern.values())
         ransac_ms = kern.get("ransac", {}).get("ms_per_step", 0.0)
-        # useful f64 flops of the scoring loop: 6 per (point, hypothesis) (3 mul + 3 add)
-        valu_tflops = (6.0 * H * n_step) / (ransac_ms * 1e-3) / 1e12 if ransac_ms else None
+        # algorithmic f64 flops of the RANSAC kernel: per leaf with n >= k points
+        # H * (20 k + 6 n) for plane fits + scoring, + 6 n for the final mask
+        flops = extra.get("ransac_flops", 6.0 * H * n_step)
+        valu_tflops = flops / (ransac_ms * 1e-3) / 1e12 if ransac_ms else None
         out = {
             "metric": "Mpoints/s insert+subdivide+RANSAC",
             "value": value,
@@ -308,8 +318,11 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": (valu_tflops / FP64_VALU_PEAK_TFLOPS) if valu_tflops else None,
                 "frac_no_fma": (valu_tflops / (FP64_VALU_PEAK_TFLOPS / 2)) if valu_tflops else None,
-                "note": "scoring flops only (6 per point x hypothesis); parity mode issues separate "
-                        "mul/add, so the attainable ceiling is peak/2",
+                "algorithmic_flops_per_launch": flops,
+                "leaves_evaluated": extra.get("leaves_evaluated"),
+                "note": "algorithmic f64 flops per leaf with n >= k points: H*(20k + 6n) + 6n (plane fits, "
+                        "scoring, final mask); parity mode issues separate mul/add (no FMA contraction), so "
+                        "the attainable ceiling is peak/2",
             },
             "pipeline_hbm": {
                 "algorithmic_bytes_per_point": 48,

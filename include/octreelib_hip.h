@@ -250,6 +250,11 @@ int octl_debug_exclusive_scan(octl_ctx* ctx, const uint32_t* in, int64_t n, uint
                               uint32_t* total);
 int octl_debug_radix_sort(octl_ctx* ctx, uint64_t* keys, uint32_t* vals, int64_t n,
                           int key_bits);
+/* The plane fit's two division shortcuts (csrc/ransac.hip: div3_by_norm, div_by_small_int) on
+ * caller data: q3[i,:] = num3[i,:] / den[i] (den > 0) and ck[i] = c[i] / kdiv (1 <= kdiv <= 16).
+ * Both must equal the IEEE f64 quotients the reference computes (util.py:42-44,80-82).       */
+int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den, const double* c,
+                           int32_t kdiv, int64_t n, double* q3, double* ck);
 
 #ifdef __cplusplus
 }

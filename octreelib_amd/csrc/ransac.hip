@@ -26,6 +26,10 @@
 
 namespace {
 
+#ifndef RS_FAST_DIV
+#define RS_FAST_DIV 1
+#endif
+
 // c / k, correctly rounded, for an integer 1 <= k <= 16 (see plane_from_samples).
 // zh = RN(1/k), zl = RN(1/k - zh); denormal / overflow ranges fall back to the true division.
 __device__ __forceinline__ double div_by_small_int(double c, int k) {
@@ -35,6 +39,35 @@ __device__ __forceinline__ double div_by_small_int(double c, int k) {
   const double a = fabs(c);
   if (!(a > 1e-290 && a < 1e290)) return c / kd;  // also NaN / inf / 0
   return fma(c, zh, c * zl);
+}
+
+// (ax, ay, az) / norm, correctly rounded (util.py:80-82), norm > 0.  In range this IS the
+// compiler's IEEE f64 division - v_rcp_f64, two Newton steps on the reciprocal, q0 = a*r,
+// q = fma(fma(-b, q0, a), r, q0) - with the reciprocal computed once for the three numerators and
+// without v_div_scale / v_div_fmas / v_div_fixup, which only act outside the guarded exponent range
+// (they rescale operands whose quotient or intermediates could leave the normal range, and patch
+// zeros / infinities / NaNs).  The sign is taken from the numerator: a (-0) numerator would
+// otherwise come out as +0 from the final fma.  Everything else takes the true division.
+__device__ __forceinline__ void div3_by_norm(double& ax, double& ay, double& az, double norm) {
+  const double lo = 0x1p-400, hi = 0x1p500;
+  // domain of the shortcut (false for NaN); in the plane fit |a_i| <= norm (1 + 2^-52) always
+  const bool ok = norm >= lo && norm < hi && (fabs(ax) >= lo || ax == 0.0) &&
+                  (fabs(ay) >= lo || ay == 0.0) && (fabs(az) >= lo || az == 0.0);
+  if (!ok) {
+    ax /= norm;
+    ay /= norm;
+    az /= norm;
+    return;
+  }
+  double r = __builtin_amdgcn_rcp(norm);
+  double e = fma(-norm, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-norm, r, 1.0);
+  r = fma(r, e, r);
+  const double qx = ax * r, qy = ay * r, qz = az * r;
+  ax = copysign(fma(fma(-norm, qx, ax), r, qx), ax);
+  ay = copysign(fma(fma(-norm, qy, ay), r, qy), ay);
+  az = copysign(fma(fma(-norm, qz, az), r, qz), az);
 }
 
 // util.py:27-84 on k sampled points; returns the plane already rounded to f32
@@ -98,9 +131,13 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
     plane[0] = plane[1] = plane[2] = plane[3] = 0.0f;
     return;
   }
+#if RS_FAST_DIV
+  div3_by_norm(ax, ay, az, norm);
+#else
   ax /= norm;
   ay /= norm;
   az /= norm;
+#endif
   const double d = -(ax * cx + ay * cy + az * cz);  // util.py:83
   plane[0] = (float)ax;
   plane[1] = (float)ay;
@@ -369,6 +406,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   }
   __syncthreads();
   int buf = 0, par = 0, cached_n = -1;
+  bool any_risk = false;
   uint32_t gpk[HPL][GW];
   uint32_t risk[HPL];
 #pragma unroll
@@ -399,6 +437,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     // sampled positions: recomputed only when the block size changes (wave-uniform branch)
     if (n != cached_n) {
       cached_n = n;
+      uint32_t risk_any = 0;
 #pragma unroll
       for (int q = 0; q < HPL; ++q) {
         const int t = threadIdx.x + q * THREADS;
@@ -417,7 +456,11 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
             }
           }
         }
+        risk_any |= risk[q];
       }
+      // does any lane of this wave hold a draw that needs the block's start (probability 2^-20
+      // per draw)?  Otherwise the gathers below skip the per-sample check.
+      any_risk = __any(risk_any != 0);
     }
 
 #if RS_SCREEN
@@ -425,12 +468,16 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     constexpr int NP = (HPL + 1) / 2;  // hypotheses are scored two at a time (v_pk_*_f32)
     float fa[2 * NP], fb[2 * NP], fc[2 * NP], fd[2 * NP], sto[2 * NP], sdl[2 * NP];
     if (HPL & 1) fa[HPL] = fb[HPL] = fc[HPL] = fd[HPL] = sto[HPL] = sdl[HPL] = 0.f;
-    // thresholds outside this range (nobody's plane tolerance) are always recounted exactly
-    const bool thr_sane = thr >= 0x1p-40 && thr <= 0x1p40;
     const double ox = lx[0], oy = ly[0], oz = lz[0];
     float extent = s_wext[buf][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) extent = fmaxf(extent, s_wext[buf][w]);
+    // block-uniform parts of the screening bound (see "Screening" below).  Thresholds or extents
+    // outside the sane range (nobody's plane tolerance) are always recounted exactly.
+    const double delta_blk = fma(0x1p-23 * 9.0, (double)extent,
+                                 0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + (double)extent + 1.0));
+    const double dprime_thr = 0x1p-21 * (thr * thr);
+    const bool blk_sane = thr >= 0x1p-40 && thr <= 0x1p40 && extent < 0x1p60f;
 #else
     double pa[HPL], pb[HPL], pc[HPL], pd[HPL];
 #endif
@@ -447,15 +494,28 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #endif
       if (t < H) {
         double sx[KS], sy[KS], sz[KS];
+        if (!any_risk) {  // wave-uniform: practically always
 #pragma unroll
-        for (int i = 0; i < KS; ++i) {
-          sx[i] = sy[i] = sz[i] = 0.0;
-          if (i < k) {
-            int g = (int)((gpk[q][i >> 2] >> (8 * (i & 3))) & 0xFFu);
-            if (risk[q] & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
-            sx[i] = lx[g];
-            sy[i] = ly[g];
-            sz[i] = lz[g];
+          for (int i = 0; i < KS; ++i) {
+            sx[i] = sy[i] = sz[i] = 0.0;
+            if (i < k) {
+              const int g = (int)((gpk[q][i >> 2] >> (8 * (i & 3))) & 0xFFu);
+              sx[i] = lx[g];
+              sy[i] = ly[g];
+              sz[i] = lz[g];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < KS; ++i) {
+            sx[i] = sy[i] = sz[i] = 0.0;
+            if (i < k) {
+              int g = (int)((gpk[q][i >> 2] >> (8 * (i & 3))) & 0xFFu);
+              if (risk[q] & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
+              sx[i] = lx[g];
+              sy[i] = ly[g];
+              sz[i] = lz[g];
+            }
           }
         }
         float pf[4];
@@ -467,16 +527,16 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         cnt[q] = 0;
 #if RS_SCREEN
         {
+          // (explicit fma: these are error BOUNDS and the screen's own inputs, not parity arithmetic)
           const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
-          const double to = ((A * ox + B * oy) + Cc * oz) + D;
-          const double delta = 0x1p-23 * (4.0 * fabs(to) + 9.0 * (double)extent) +
-                               0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + fabs(D) + (double)extent + 1.0);
+          const double to = fma(A, ox, fma(B, oy, fma(Cc, oz, D)));
+          const double delta = fma(0x1p-21, fabs(to), fma(0x1p-49, fabs(D), delta_blk));
           // the loop tests e = fl32(s*s - fl32(thr^2)): |e| >= dprime  =>  | |s| - thr | >= delta
-          const double dprime = ((2.0 * thr) * delta + delta * delta) + 0x1p-21 * (thr * thr);
-          const bool sane = thr_sane && (fabs(to) + (double)extent < 0x1p60);  // false for NaN
+          const double dprime = fma(delta, thr + thr + delta, dprime_thr) * 1.000001;
+          const bool sane = blk_sane && (fabs(to) < 0x1p60);  // false for NaN
           fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
           sto[q] = (float)to;
-          sdl[q] = sane ? (float)(dprime * 1.000001) : __int_as_float(0x7f800000);
+          sdl[q] = sane ? (float)dprime : __int_as_float(0x7f800000);
         }
 #else
         // the f32-rounded plane, promoted back to f64 for scoring (cuda_ransac.py:110-121)
@@ -900,4 +960,58 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 #undef OCTL_RANSAC_BIG
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
+}
+
+// ---- test hook: the two division shortcuts of the plane fit against the host's IEEE division --
+namespace {
+__global__ __launch_bounds__(256) void k_debug_plane_arith(const double* __restrict__ num3,
+                                                            const double* __restrict__ den,
+                                                            const double* __restrict__ c, int kdiv,
+                                                            int64_t n, double* __restrict__ q3,
+                                                            double* __restrict__ ck) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a = num3[3 * i], b = num3[3 * i + 1], cc = num3[3 * i + 2];
+  div3_by_norm(a, b, cc, den[i]);
+  q3[3 * i] = a;
+  q3[3 * i + 1] = b;
+  q3[3 * i + 2] = cc;
+  ck[i] = div_by_small_int(c[i], kdiv);
+}
+}  // namespace
+
+// q3[i] = num3[i] / den[i] (three numerators per divisor, den > 0) and ck[i] = c[i] / kdiv as the
+// plane fit computes them; host arrays in, host arrays out (tests/test_gpu_primitives.py)
+extern "C" int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den,
+                                      const double* c, int32_t kdiv, int64_t n, double* q3,
+                                      double* ck) {
+  if (!ctx || n < 0 || kdiv < 1 || kdiv > 16 || (n > 0 && (!num3 || !den || !c || !q3 || !ck)))
+    return OCTL_E_INVALID;
+  if (n == 0) return OCTL_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf buf;
+  OCTL_TRY(devbuf_reserve(ctx, buf, (size_t)n * 9 * 8));
+  double* d_num = buf.as<double>();
+  double* d_den = d_num + 3 * n;
+  double* d_c = d_den + n;
+  double* d_q = d_c + n;
+  double* d_ck = d_q + 3 * n;
+  int rc = OCTL_OK;
+  if (hipMemcpyAsync(d_num, num3, (size_t)n * 24, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_den, den, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_c, c, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = OCTL_E_HIP;
+  if (rc == OCTL_OK) {
+    hipLaunchKernelGGL(k_debug_plane_arith, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+                       (const double*)d_num, (const double*)d_den, (const double*)d_c, (int)kdiv, n,
+                       d_q, d_ck);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(q3, d_q, (size_t)n * 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(ck, d_ck, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
+      rc = OCTL_E_HIP;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) rc = OCTL_E_HIP;
+  devbuf_free(buf);
+  return rc == OCTL_OK ? OCTL_OK : octl_set_error(ctx, rc, "octl_debug_plane_arith failed");
 }

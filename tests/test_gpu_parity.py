@@ -454,6 +454,35 @@ def test_ransac_operator_random_blocks_vs_oracle():
         assert np.array_equal(mask, o_mask)
 
 
+@pytest.mark.parametrize("H", [1024, 256, 64])
+def test_ransac_draws_that_round_up_to_the_next_point_vs_oracle(H):
+    """int32(R*n + start) (cuda_ransac.py:103-107): draws with R*n just below an integer round UP once
+    the block's start is added, also past the block's end (first point of the next block).  The
+    kernel caches sample positions per block size and must take its exact path for those draws."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(77)
+    sizes = rng.choice(np.array([37, 37, 37, 64, 12, 6, 100], dtype=np.int32), 600)
+    n = int(sizes.sum())
+    cloud = rng.random((n, 3)) * 8.0
+    cloud[:, 2] = 1.0 + 0.3 * cloud[:, 0] + rng.normal(0, 0.01, n)
+    op = CudaRansac(threshold=0.02, hypotheses_number=H, initial_points_number=6)
+    table = rng.random((H, 6))
+    pick = rng.random((H, 6))
+    j = rng.integers(1, 38, (H, 6))
+    table = np.where(pick < 0.10, np.nextafter(j / 37.0, 0.0), table)      # just below j/37
+    table = np.where((pick >= 0.10) & (pick < 0.15), np.nextafter(1.0, 0.0), table)  # spills past the block
+    table = np.where((pick >= 0.15) & (pick < 0.18), j / 64.0 * (1 - 2.0 ** -40), table)
+    op._hypotheses = np.ascontiguousarray(table)  # the table is the operator's (cuda_ransac.py:39-41)
+    mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+    o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.02, details=True)
+    assert np.array_equal(counts, o_count)
+    assert np.array_equal(index, o_index)
+    assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+    assert np.array_equal(mask, o_mask)
+
+
 @pytest.mark.parametrize(
     "offset,scale,thr",
     [
