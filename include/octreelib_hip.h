@@ -250,11 +250,12 @@ int octl_debug_exclusive_scan(octl_ctx* ctx, const uint32_t* in, int64_t n, uint
                               uint32_t* total);
 int octl_debug_radix_sort(octl_ctx* ctx, uint64_t* keys, uint32_t* vals, int64_t n,
                           int key_bits);
-/* The plane fit's two division shortcuts (csrc/ransac.hip: div3_by_norm, div_by_small_int) on
- * caller data: q3[i,:] = num3[i,:] / den[i] (den > 0) and ck[i] = c[i] / kdiv (1 <= kdiv <= 16).
- * Both must equal the IEEE f64 quotients the reference computes (util.py:42-44,80-82).       */
+/* The plane fit's arithmetic shortcuts (csrc/ransac.hip: div3_by_norm, div_by_small_int,
+ * sqrt_rn_guarded) on caller data: q3[i,:] = num3[i,:] / den[i] (den > 0, |num| <= 2^60 den),
+ * ck[i] = c[i] / kdiv (1 <= kdiv <= 16), sq[i] = sqrt(c[i]).  All must equal the IEEE f64 results
+ * the reference computes (util.py:42-44,76,80-82).                                           */
 int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den, const double* c,
-                           int32_t kdiv, int64_t n, double* q3, double* ck);
+                           int32_t kdiv, int64_t n, double* q3, double* ck, double* sq);
 
 #ifdef __cplusplus
 }

@@ -37,8 +37,44 @@ __device__ __forceinline__ double div_by_small_int(double c, int k) {
   const double zh = 1.0 / kd;                    // compile-time constant when k is
   const double zl = fma(-kd, zh, 1.0) / kd;      // (1 - k*zh) is exact; zl to 2^-53 relative
   const double a = fabs(c);
-  if (!(a > 1e-290 && a < 1e290)) return c / kd;  // also NaN / inf / 0
-  return fma(c, zh, c * zl);
+  if (!(((a > 1e-290) | (c == 0.0)) & (a < 1e290))) return c / kd;  // also NaN / inf / tiny
+  return copysign(fma(c, zh, c * zl), c);         // (the sign: zl may be negative, c may be -0)
+}
+
+// the three centroid coordinates at once: one flat predicate, one (never taken) slow branch
+__device__ __forceinline__ void div3_by_small_int(double& cx, double& cy, double& cz, int k) {
+  const double kd = (double)k;
+  const double zh = 1.0 / kd;
+  const double zl = fma(-kd, zh, 1.0) / kd;
+  const double ax = fabs(cx), ay = fabs(cy), az = fabs(cz);
+  const bool ok = ((ax > 1e-290) | (cx == 0.0)) & (ax < 1e290) & ((ay > 1e-290) | (cy == 0.0)) &
+                  (ay < 1e290) & ((az > 1e-290) | (cz == 0.0)) & (az < 1e290);
+  if (!ok) {
+    cx /= kd;
+    cy /= kd;
+    cz /= kd;
+    return;
+  }
+  cx = copysign(fma(cx, zh, cx * zl), cx);  // (the sign: zl may be negative, c may be -0)
+  cy = copysign(fma(cy, zh, cy * zl), cy);
+  cz = copysign(fma(cz, zh, cz * zl), cz);
+}
+
+// sqrt(s), correctly rounded (util.py:76, `** 0.5`).  In range this IS the compiler's IEEE f64 square
+// root - v_rsq_f64, one coupled Goldschmidt step, two residual corrections - without the operand
+// rescaling it applies below 2^-767 and the patch for 0 / inf; everything else takes the full one.
+__device__ __forceinline__ double sqrt_rn_guarded(double s) {
+  if (!((s >= 0x1p-700) & (s < 0x1p1000))) return __dsqrt_rn(s);  // also NaN, 0, inf, negative
+  const double y = __builtin_amdgcn_rsq(s);
+  double g = s * y;
+  double h = y * 0.5;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, s);
+  g = fma(d, h, g);
+  d = fma(-g, g, s);
+  return fma(d, h, g);
 }
 
 // (ax, ay, az) / norm, correctly rounded (util.py:80-82), norm > 0.  In range this IS the
@@ -48,11 +84,13 @@ __device__ __forceinline__ double div_by_small_int(double c, int k) {
 // (they rescale operands whose quotient or intermediates could leave the normal range, and patch
 // zeros / infinities / NaNs).  The sign is taken from the numerator: a (-0) numerator would
 // otherwise come out as +0 from the final fma.  Everything else takes the true division.
+// Domain of the shortcut: |a_i| <= 2^60 norm (in the plane fit |a_i| <= norm (1 + 2^-52) always).
 __device__ __forceinline__ void div3_by_norm(double& ax, double& ay, double& az, double norm) {
   const double lo = 0x1p-400, hi = 0x1p500;
-  // domain of the shortcut (false for NaN); in the plane fit |a_i| <= norm (1 + 2^-52) always
-  const bool ok = norm >= lo && norm < hi && (fabs(ax) >= lo || ax == 0.0) &&
-                  (fabs(ay) >= lo || ay == 0.0) && (fabs(az) >= lo || az == 0.0);
+  // (bitwise on purpose: one flat predicate instead of a chain of short-circuit branches; all
+  //  comparisons are false for NaN)
+  const bool ok = (norm >= lo) & (norm < hi) & ((fabs(ax) >= lo) | (ax == 0.0)) &
+                  ((fabs(ay) >= lo) | (ay == 0.0)) & ((fabs(az) >= lo) | (az == 0.0));
   if (!ok) {
     ax /= norm;
     ay /= norm;
@@ -91,9 +129,7 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
   // divisor k <= 16 the quotient c/k is never closer than 1/(2k) ulp to a rounding midpoint, so
   // RN(c*zh + RN(c*zl)) with zh + zl = 1/k to ~2^-106 IS the correctly rounded quotient:
   // one multiply + one FMA instead of the 11-instruction IEEE division sequence.
-  cx = div_by_small_int(cx, k);
-  cy = div_by_small_int(cy, k);
-  cz = div_by_small_int(cz, k);
+  div3_by_small_int(cx, cy, cz, k);
   double xx = 0.0, xy = 0.0, xz = 0.0, yy = 0.0, yz = 0.0, zz = 0.0;
 #pragma unroll
   for (int i = 0; i < (KT > 0 ? KT : KMAX); ++i) {  // util.py:48-57
@@ -126,7 +162,11 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
     ay = xy * xz - yz * xx;
     az = det_z;
   }
+#if RS_FAST_DIV
+  const double norm = sqrt_rn_guarded(ax * ax + ay * ay + az * az);  // util.py:76
+#else
   const double norm = __dsqrt_rn(ax * ax + ay * ay + az * az);  // util.py:76
+#endif
   if (norm == 0.0) {                                            // util.py:77-78
     plane[0] = plane[1] = plane[2] = plane[3] = 0.0f;
     return;
@@ -968,7 +1008,8 @@ __global__ __launch_bounds__(256) void k_debug_plane_arith(const double* __restr
                                                             const double* __restrict__ den,
                                                             const double* __restrict__ c, int kdiv,
                                                             int64_t n, double* __restrict__ q3,
-                                                            double* __restrict__ ck) {
+                                                            double* __restrict__ ck,
+                                                            double* __restrict__ sq) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double a = num3[3 * i], b = num3[3 * i + 1], cc = num3[3 * i + 2];
@@ -976,27 +1017,34 @@ __global__ __launch_bounds__(256) void k_debug_plane_arith(const double* __restr
   q3[3 * i] = a;
   q3[3 * i + 1] = b;
   q3[3 * i + 2] = cc;
-  ck[i] = div_by_small_int(c[i], kdiv);
+  // the 3-wide form the plane fit uses, with neighbours as the other two lanes of the predicate
+  double c0 = c[i], c1 = c[i + 1 < n ? i + 1 : 0], c2 = c[i + 2 < n ? i + 2 : 0];
+  div3_by_small_int(c0, c1, c2, kdiv);
+  ck[i] = (i & 1) ? c0 : div_by_small_int(c[i], kdiv);
+  sq[i] = sqrt_rn_guarded(c[i]);
 }
 }  // namespace
 
-// q3[i] = num3[i] / den[i] (three numerators per divisor, den > 0) and ck[i] = c[i] / kdiv as the
-// plane fit computes them; host arrays in, host arrays out (tests/test_gpu_primitives.py)
+// q3[i] = num3[i] / den[i] (three numerators per divisor, den > 0), ck[i] = c[i] / kdiv and
+// sq[i] = sqrt(c[i]) as the plane fit computes them; host arrays in, host arrays out
+// (tests/test_gpu_primitives.py)
 extern "C" int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den,
                                       const double* c, int32_t kdiv, int64_t n, double* q3,
-                                      double* ck) {
-  if (!ctx || n < 0 || kdiv < 1 || kdiv > 16 || (n > 0 && (!num3 || !den || !c || !q3 || !ck)))
+                                      double* ck, double* sq) {
+  if (!ctx || n < 0 || kdiv < 1 || kdiv > 16 ||
+      (n > 0 && (!num3 || !den || !c || !q3 || !ck || !sq)))
     return OCTL_E_INVALID;
   if (n == 0) return OCTL_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   DevBuf buf;
-  OCTL_TRY(devbuf_reserve(ctx, buf, (size_t)n * 9 * 8));
+  OCTL_TRY(devbuf_reserve(ctx, buf, (size_t)n * 10 * 8));
   double* d_num = buf.as<double>();
   double* d_den = d_num + 3 * n;
   double* d_c = d_den + n;
   double* d_q = d_c + n;
   double* d_ck = d_q + 3 * n;
+  double* d_sq = d_ck + n;
   int rc = OCTL_OK;
   if (hipMemcpyAsync(d_num, num3, (size_t)n * 24, hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(d_den, den, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -1005,10 +1053,11 @@ extern "C" int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const d
   if (rc == OCTL_OK) {
     hipLaunchKernelGGL(k_debug_plane_arith, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                        (const double*)d_num, (const double*)d_den, (const double*)d_c, (int)kdiv, n,
-                       d_q, d_ck);
+                       d_q, d_ck, d_sq);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(q3, d_q, (size_t)n * 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipMemcpyAsync(ck, d_ck, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
+        hipMemcpyAsync(ck, d_ck, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(sq, d_sq, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess)
       rc = OCTL_E_HIP;
   }
   if (hipStreamSynchronize(st) != hipSuccess) rc = OCTL_E_HIP;

@@ -59,9 +59,10 @@ def _plane_arith(num3, den, c, k):
     n = len(den)
     q3 = np.empty((n, 3))
     ck = np.empty(n)
+    sq = np.empty(n)
     ctx.check(ctx.lib.octl_debug_plane_arith(ctx.handle, nat.ptr(np.ascontiguousarray(num3)), nat.ptr(np.ascontiguousarray(den)),
-                                             nat.ptr(np.ascontiguousarray(c)), k, n, nat.ptr(q3), nat.ptr(ck)))
-    return q3, ck
+                                             nat.ptr(np.ascontiguousarray(c)), k, n, nat.ptr(q3), nat.ptr(ck), nat.ptr(sq)))
+    return q3, ck, sq
 
 
 def _division_cases(seed, n=2_000_000):
@@ -97,14 +98,16 @@ def _division_cases(seed, n=2_000_000):
 
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_plane_fit_division_shortcuts_are_ieee_divisions(seed):
-    """csrc/ransac.hip divides the plane normal by its norm with one shared reciprocal and the
-    centroid by k with a two-term reciprocal: both must be the correctly rounded quotients the
-    reference computes (util.py:42-44,80-82), for every input incl. zeros, denormals, inf, NaN."""
+    """csrc/ransac.hip divides the plane normal by its norm with one shared reciprocal, the centroid
+    by k with a two-term reciprocal and takes the norm's square root without the library's range
+    handling: all must be the correctly rounded results the reference computes
+    (util.py:42-44,76,80-82), for every input incl. zeros, denormals, inf, NaN."""
     num3, den, c, k = _division_cases(seed)
-    q3, ck = _plane_arith(num3, den, c, k)
+    q3, ck, sq = _plane_arith(num3, den, c, k)
     with np.errstate(all="ignore"):
         assert _same_bits(q3, num3 / den[:, None]).all()
         assert _same_bits(ck, c / np.float64(k)).all()
+        assert _same_bits(sq, np.sqrt(c)).all()
 
 
 def test_plane_fit_divisions_near_rounding_midpoints():
@@ -133,6 +136,7 @@ def test_plane_fit_divisions_near_rounding_midpoints():
             num[i, j] = float(a) * 2.0 ** e * random.choice((1.0, -1.0, 0.5, 0.25))
     c = np.array([float(random.getrandbits(53)) for _ in range(n)])
     for k in (3, 5, 6, 7, 9, 11, 13):
-        q3, ck = _plane_arith(num, den, c, k)
+        q3, ck, sq = _plane_arith(num, den, c, k)
         assert _same_bits(q3, num / den[:, None]).all()
         assert _same_bits(ck, c / np.float64(k)).all()
+        assert _same_bits(sq, np.sqrt(c)).all()

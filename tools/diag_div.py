@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from tests.test_gpu_primitives import _plane_arith, _same_bits, _division_cases
 num3, den, c, k = _division_cases(0)
 n = len(den)
-q3, ck = _plane_arith(num3, den, c, k)
+q3, ck, _sq = _plane_arith(num3, den, c, k)
 with np.errstate(all='ignore'):
     want = num3 / den[:, None]
 bad = ~_same_bits(q3, want).reshape(n, 3)
