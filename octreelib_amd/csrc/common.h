@@ -45,6 +45,8 @@ struct octl_ctx {
   std::vector<hipEvent_t> event_pool;
   // scratch for scans / sorts (grown on demand, reused across calls)
   DevBuf scan_tmp[3];
+  DevBuf scan_status;            // single-pass scan: per-tile status words
+  uint32_t scan_epoch = 0;
   DevBuf small;     // 4 KiB of device scalars (counters, flags)
   void* small_host = nullptr;  // pinned mirror
   void* pinned = nullptr;      // pinned staging for small uploads (OCTL_PINNED_BYTES)

@@ -135,6 +135,7 @@ void octl_ctx_destroy(octl_ctx* ctx) {
   }
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
   for (auto& b : ctx->scan_tmp) devbuf_free(b);
+  devbuf_free(ctx->scan_status);
   devbuf_free(ctx->small);
   devbuf_free(ctx->routed_xyz);
   devbuf_free(ctx->routed_gidx);

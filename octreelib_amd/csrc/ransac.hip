@@ -37,7 +37,7 @@ __device__ __forceinline__ double div_by_small_int(double c, int k) {
   const double zh = 1.0 / kd;                    // compile-time constant when k is
   const double zl = fma(-kd, zh, 1.0) / kd;      // (1 - k*zh) is exact; zl to 2^-53 relative
   const double a = fabs(c);
-  if (!(((a > 1e-290) | (c == 0.0)) & (a < 1e290))) return c / kd;  // also NaN / inf / tiny
+  if (!((int(a > 1e-290) | int(c == 0.0)) & int(a < 1e290))) return c / kd;  // also NaN / inf / tiny
   return copysign(fma(c, zh, c * zl), c);         // (the sign: zl may be negative, c may be -0)
 }
 
@@ -47,8 +47,10 @@ __device__ __forceinline__ void div3_by_small_int(double& cx, double& cy, double
   const double zh = 1.0 / kd;
   const double zl = fma(-kd, zh, 1.0) / kd;
   const double ax = fabs(cx), ay = fabs(cy), az = fabs(cz);
-  const bool ok = ((ax > 1e-290) | (cx == 0.0)) & (ax < 1e290) & ((ay > 1e-290) | (cy == 0.0)) &
-                  (ay < 1e290) & ((az > 1e-290) | (cz == 0.0)) & (az < 1e290);
+  // (ints on purpose: one flat predicate, no short-circuit branches)
+  const int ok = (int(ax > 1e-290) | int(cx == 0.0)) & int(ax < 1e290) &
+                 (int(ay > 1e-290) | int(cy == 0.0)) & int(ay < 1e290) &
+                 (int(az > 1e-290) | int(cz == 0.0)) & int(az < 1e290);
   if (!ok) {
     cx /= kd;
     cy /= kd;
@@ -64,7 +66,7 @@ __device__ __forceinline__ void div3_by_small_int(double& cx, double& cy, double
 // root - v_rsq_f64, one coupled Goldschmidt step, two residual corrections - without the operand
 // rescaling it applies below 2^-767 and the patch for 0 / inf; everything else takes the full one.
 __device__ __forceinline__ double sqrt_rn_guarded(double s) {
-  if (!((s >= 0x1p-700) & (s < 0x1p1000))) return __dsqrt_rn(s);  // also NaN, 0, inf, negative
+  if (!(int(s >= 0x1p-700) & int(s < 0x1p1000))) return __dsqrt_rn(s);  // also NaN, 0, inf, negative
   const double y = __builtin_amdgcn_rsq(s);
   double g = s * y;
   double h = y * 0.5;
@@ -87,10 +89,10 @@ __device__ __forceinline__ double sqrt_rn_guarded(double s) {
 // Domain of the shortcut: |a_i| <= 2^60 norm (in the plane fit |a_i| <= norm (1 + 2^-52) always).
 __device__ __forceinline__ void div3_by_norm(double& ax, double& ay, double& az, double norm) {
   const double lo = 0x1p-400, hi = 0x1p500;
-  // (bitwise on purpose: one flat predicate instead of a chain of short-circuit branches; all
-  //  comparisons are false for NaN)
-  const bool ok = (norm >= lo) & (norm < hi) & ((fabs(ax) >= lo) | (ax == 0.0)) &
-                  ((fabs(ay) >= lo) | (ay == 0.0)) & ((fabs(az) >= lo) | (az == 0.0));
+  // (ints and bitwise on purpose: one flat predicate instead of a chain of short-circuit
+  //  branches; all comparisons are false for NaN)
+  const int ok = int(norm >= lo) & int(norm < hi) & (int(fabs(ax) >= lo) | int(ax == 0.0)) &
+                 (int(fabs(ay) >= lo) | int(ay == 0.0)) & (int(fabs(az) >= lo) | int(az == 0.0));
   if (!ok) {
     ax /= norm;
     ay /= norm;

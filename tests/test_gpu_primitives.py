@@ -15,7 +15,7 @@ def ctx():
     return nat.get_context()
 
 
-@pytest.mark.parametrize("n", [0, 1, 7, 2048, 2049, 100_000, 3_000_001])
+@pytest.mark.parametrize("n", [0, 1, 7, 2048, 2049, 100_000, 2_097_152, 2_097_153, 3_000_001])
 def test_exclusive_scan(ctx, n):
     from octreelib_amd import _native as nat
 
@@ -27,6 +27,23 @@ def test_exclusive_scan(ctx, n):
     want = np.concatenate(([0], np.cumsum(a, dtype=np.uint64)[:-1])).astype(np.uint32) if n else a
     assert np.array_equal(out, want)
     assert total.value == int(a.sum(dtype=np.uint64) & 0xFFFFFFFF)
+
+
+def test_exclusive_scan_back_to_back(ctx):
+    """The single-pass scan reuses its per-tile status words across calls (an epoch tag makes the
+    words of earlier scans read as unpublished): many scans of changing sizes in a row."""
+    from octreelib_amd import _native as nat
+
+    rng = np.random.default_rng(99)
+    for n in [500_000, 4096, 1_999_999, 2048, 70_000, 1_200_000, 3, 650_000] * 3:
+        a = rng.integers(0, 5000, n, dtype=np.uint32)
+        out = np.empty(n, dtype=np.uint32)
+        total = C.c_uint32(0)
+        ctx.check(ctx.lib.octl_debug_exclusive_scan(ctx.handle, nat.ptr(a), n, nat.ptr(out), C.byref(total)))
+        cs = np.cumsum(a, dtype=np.uint64)
+        want = (np.concatenate((np.zeros(1, dtype=np.uint64), cs[:-1])) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        assert np.array_equal(out, want)  # sums wrap modulo 2^32
+        assert total.value == int(cs[-1] & np.uint64(0xFFFFFFFF))
 
 
 @pytest.mark.parametrize("n,bits", [(1, 8), (63, 3), (2048, 8), (5000, 17), (250_000, 24), (1_000_003, 40)])
