@@ -38,7 +38,8 @@ class Forest:
         # grid bookkeeping that must survive rebuilds: voxels each pose was inserted into and
         # the order in which voxels were first created (Grid.__octrees dict order, grid.py:56)
         self.slot_voxel_keys: List[Optional[np.ndarray]] = []
-        self.voxel_creation: Dict[tuple, int] = {}
+        self._edge_int = int(edge) if mode == 0 else 1
+        self._creation_codes = np.empty(0, dtype=np.int64)   # packed voxel keys, creation order
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -241,9 +242,24 @@ class Forest:
                 )
             keys = vox[vids]
             self.slot_voxel_keys[s] = keys
-            for k in map(tuple, keys.tolist()):
-                if k not in self.voxel_creation:
-                    self.voxel_creation[k] = len(self.voxel_creation)
+            # voxels seen for the first time, in this pose's (lexicographic = np.unique) order
+            codes = self._voxel_codes(keys)
+            fresh = codes[~np.isin(codes, self._creation_codes)]
+            if len(fresh):
+                self._creation_codes = np.concatenate((self._creation_codes, fresh))
+
+    def _voxel_codes(self, keys: np.ndarray) -> np.ndarray:
+        """(m,3) int64 voxel corners -> one int64 per voxel (bijective: |index| < 2^20 per axis,
+        include/octreelib_hip.h)."""
+        q = np.asarray(keys, dtype=np.int64).reshape(-1, 3) // self._edge_int + (1 << 20)
+        return (q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2]
+
+    def creation_ranks(self, keys: np.ndarray) -> np.ndarray:
+        """Position of every voxel of `keys` in the order voxels were first created
+        (the dict order of Grid.__octrees, grid.py:56,100-109)."""
+        order = np.argsort(self._creation_codes, kind="stable")
+        pos = np.searchsorted(self._creation_codes[order], self._voxel_codes(keys))
+        return order[pos].astype(np.int64)
 
     # -- tables -----------------------------------------------------------------------------
     @property

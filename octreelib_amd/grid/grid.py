@@ -74,7 +74,7 @@ class Grid(GridBase):
         if len(sel) == 0:
             return np.empty((0, 3), dtype=float)
         vox_rank = f.nodes["voxel"][blk["node"][sel]]
-        creation = np.array([f.voxel_creation[tuple(v)] for v in f.voxels.tolist()], dtype=np.int64)
+        creation = f.creation_ranks(f.voxels)
         order = np.lexsort((blk["start"][sel], creation[vox_rank]))
         xyz = f.xyz
         starts, sizes = blk["start"][sel][order], blk["size"][sel][order]
