@@ -49,7 +49,7 @@ def scene_dims(n_ranks: int):
     return tuple(d)
 
 
-def cpu_baseline(dims, table, budget_points=700_000):
+def cpu_baseline(dims, table, budget_points=1_000_000):
     """NumPy port of the reference's algorithm (oracle/), single thread, on a sub-box of the
     same scene holding about `budget_points` points."""
     from oracle import octree_np as onp
@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="points per rank")
     ap.add_argument("--cloud", choices=["planar", "uniform"], default="planar")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k-split", type=int, default=K_SPLIT,
+                    help="count criterion len > K (experiments; the benchmarked workload is K = 64)")
     ap.add_argument("--route", action="store_true",
                     help="rehearse the multi-GPU step on one GPU: 1-rank RCCL communicator, the "
                          "local part forced through AllGather + Send/Recv")
@@ -174,7 +176,7 @@ def main():
             ctx.check(lib.octl_forest_add_pose_routed(fh, C.byref(slot)))
         else:
             ctx.check(lib.octl_forest_add_pose_device(fh, d_xyz, n_local, C.byref(slot)))
-        ctx.check(lib.octl_forest_build(fh, K_SPLIT, None, 0, 0, 0, C.byref(info)))
+        ctx.check(lib.octl_forest_build(fh, args.k_split, None, 0, 0, 0, C.byref(info)))
         ctx.check(lib.octl_forest_ransac_all(fh, 10, nat.ptr(e0), 1, nat.ptr(table), H, KPTS, THRESHOLD))
         ctx.check(lib.octl_forest_apply_mask(fh, C.byref(n_alive)))
 
@@ -214,12 +216,12 @@ def main():
     def step_build_only():
         ctx.check(lib.octl_forest_clear(fh))
         ctx.check(lib.octl_forest_add_pose_device(fh, d_xyz, n_local, C.byref(slot)))
-        ctx.check(lib.octl_forest_build(fh, K_SPLIT, None, 0, 0, 0, C.byref(info)))
+        ctx.check(lib.octl_forest_build(fh, args.k_split, None, 0, 0, 0, C.byref(info)))
 
     def step_from_host():
         ctx.check(lib.octl_forest_clear(fh))
         ctx.check(lib.octl_forest_add_pose(fh, nat.ptr(pts), n_local, C.byref(slot)))
-        ctx.check(lib.octl_forest_build(fh, K_SPLIT, None, 0, 0, 0, C.byref(info)))
+        ctx.check(lib.octl_forest_build(fh, args.k_split, None, 0, 0, 0, C.byref(info)))
         ctx.check(lib.octl_forest_ransac_all(fh, 10, nat.ptr(e0), 1, nat.ptr(table), H, KPTS, THRESHOLD))
         ctx.check(lib.octl_forest_apply_mask(fh, C.byref(n_alive)))
 
@@ -285,12 +287,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"Grid 1 m voxels, {n_local} {args.cloud} points per GPU "
-                            f"(scene {dims[0]}x{dims[1]}x{dims[2]} voxels), insert + subdivide(len>64) + "
+                            f"(scene {dims[0]}x{dims[1]}x{dims[2]} voxels), insert + subdivide(len>{args.k_split}) + "
                             f"map_leaf_points_cuda_ransac(H=1024, k=6, thr=0.01, poses_per_batch=10) "
                             f"incl. apply_mask"
                             + (", sharded by top-level voxel with one RCCL all-to-all" if world > 1 else ""),
                 "points_per_gpu": n_local,
-                "K": K_SPLIT,
+                "K": args.k_split,
                 "hypotheses": H,
                 "leaves": int(info.n_blocks),
                 "nodes": int(info.n_nodes),
