@@ -458,14 +458,20 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
   }
   for (;;) {
+    // lane-constant addresses (LDS slots, output offsets) are cheap to recompute; derived from
+    // threadIdx.x directly the compiler hoists them out of this loop and then SPILLS them (48 B of
+    // scratch per lane, written by every workgroup: 200 MB of HBM writes per launch - measured).
+    // An opaque copy of the lane index per iteration keeps them in-loop.
+    unsigned tx = threadIdx.x;
+    asm volatile("" : "+v"(tx));
     const bool has_next = j + 1 < j_end;
     BlockDesc nxt2 = nxt;
     if (j + 2 < j_end) nxt2 = sdesc[j + 2];
     // points of the next block -> registers (in flight during the compute below)
     double rx = 0.0, ry = 0.0, rz = 0.0;
-    const bool pre = has_next && (int)threadIdx.x <= nxt.n;
+    const bool pre = has_next && (int)tx <= nxt.n;
     if (pre) {
-      const int64_t p = ((int)threadIdx.x < nxt.n) ? (int64_t)nxt.pstart + threadIdx.x : (int64_t)nxt.pspill;
+      const int64_t p = ((int)tx < nxt.n) ? (int64_t)nxt.pstart + tx : (int64_t)nxt.pspill;
       rx = xyz[3 * p];
       ry = xyz[3 * p + 1];
       rz = xyz[3 * p + 2];
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       uint32_t risk_any = 0;
 #pragma unroll
       for (int q = 0; q < HPL; ++q) {
-        const int t = threadIdx.x + q * THREADS;
+        const int t = tx + q * THREADS;
         risk[q] = 0;
 #pragma unroll
         for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     int cnt[HPL];
 #pragma unroll
     for (int q = 0; q < HPL; ++q) {
-      const int t = threadIdx.x + q * THREADS;
+      const int t = tx + q * THREADS;
       cnt[q] = -1;
 #if RS_SCREEN
       fa[q] = fb[q] = fc[q] = fd[q] = 0.f;
@@ -662,7 +668,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         if (__any(redo)) {  // rare
 #pragma unroll
           for (int q = 2 * p; q < 2 * p + 2 && q < HPL; ++q) {
-            if (redo && (int)threadIdx.x + q * THREADS < H) {
+            if (redo && (int)tx + q * THREADS < H) {
               const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
               int c = 0;
               for (int ii = 0; ii < n; ++ii)
@@ -690,7 +696,7 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
     double wa = 0.0, wb = 0.0, wc = 0.0, wd = 0.0;
 #pragma unroll
     for (int q = 0; q < HPL; ++q) {
-      const int t = threadIdx.x + q * THREADS;
+      const int t = tx + q * THREADS;
       if (t < H) {
         const unsigned long long key =
             ((unsigned long long)(unsigned)cnt[q] << 32) | (unsigned)(0x7FFFFFFF - t);
@@ -711,23 +717,23 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
       wbest = o > wbest ? o : wbest;
     }
     if (best == wbest && best != 0) {  // exactly one lane: keys are unique
-      const int w = threadIdx.x >> 6;
+      const int w = tx >> 6;
       s_wbest[par][w] = best;
       s_wplane[par][w][0] = (float)wa;  // exact: promoted from the f32 plane
       s_wplane[par][w][1] = (float)wb;
       s_wplane[par][w][2] = (float)wc;
       s_wplane[par][w][3] = (float)wd;
-    } else if (wbest == 0 && (threadIdx.x & 63) == 0) {
-      s_wbest[par][threadIdx.x >> 6] = 0;  // a wave without hypotheses (H < THREADS)
+    } else if (wbest == 0 && (tx & 63) == 0) {
+      s_wbest[par][tx >> 6] = 0;  // a wave without hypotheses (H < THREADS)
     }
     // stage the next block.  Its buffer, (t+1) % 3, was last read for block t-2: every wave has
     // passed the barrier of block t-1 since.  The reduction slots alternate by parity for the
     // same reason, so ONE barrier per block publishes both the reduction and the staged points.
     const int nbuf = buf == 2 ? 0 : buf + 1;
     if (pre) {
-      s_pts[nbuf][0][threadIdx.x] = rx;
-      s_pts[nbuf][1][threadIdx.x] = ry;
-      s_pts[nbuf][2][threadIdx.x] = rz;
+      s_pts[nbuf][0][tx] = rx;
+      s_pts[nbuf][1][tx] = ry;
+      s_pts[nbuf][2][tx] = rz;
     }
 #if RS_SCREEN
     if (has_next) stage_local<THREADS>(xyz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf]);
@@ -744,7 +750,7 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
     }
     const float f0 = s_wplane[par][gw][0], f1 = s_wplane[par][gw][1], f2 = s_wplane[par][gw][2],
                 f3 = s_wplane[par][gw][3];
-    if (threadIdx.x == 0) {
+    if (tx == 0) {
       if (out.plane) {
         out.plane[4 * (int64_t)be + 0] = f0; out.plane[4 * (int64_t)be + 1] = f1;
         out.plane[4 * (int64_t)be + 2] = f2; out.plane[4 * (int64_t)be + 3] = f3;
@@ -753,10 +759,10 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
       if (out.index) out.index[be] = 0x7FFFFFFF - (int)(unsigned)(gbest & 0xFFFFFFFFu);
     }
     // final mask with the winning f32 plane (cuda_ransac.py:149-155); n <= THREADS - 1
-    if ((int)threadIdx.x < n) {
+    if ((int)tx < n) {
       const double dist = plane_distance((double)f0, (double)f1, (double)f2, (double)f3,
-                                         lx[threadIdx.x], ly[threadIdx.x], lz[threadIdx.x]);
-      out.mask[(int64_t)cur.pstart + threadIdx.x] = (dist < thr) ? 1 : 0;
+                                         lx[tx], ly[tx], lz[tx]);
+      out.mask[(int64_t)cur.pstart + tx] = (dist < thr) ? 1 : 0;
     }
     if (!has_next) break;
     cur = nxt;
