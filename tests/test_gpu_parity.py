@@ -454,6 +454,31 @@ def test_ransac_operator_random_blocks_vs_oracle():
         assert np.array_equal(mask, o_mask)
 
 
+@pytest.mark.parametrize("H,k", [(1, 6), (2, 3), (65, 6), (255, 2), (257, 1), (1000, 16), (1024, 7), (64, 16)])
+def test_ransac_operator_boundary_shapes_vs_oracle(H, k):
+    """Block sizes around the LDS-staged / global-memory split (255 | 256 points), around k, empty
+    blocks; hypothesis counts around the 64 / 256 / 1024 lane mappings; every supported k."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(100 * H + k)
+    sizes = np.array([255, 256, 257, 254, 0, k, max(k - 1, 0), k + 1, 1, 300, 64, 63, 65, 2, 0, 1023, 17],
+                     dtype=np.int32)
+    sizes = np.concatenate([sizes, rng.integers(0, 40, 60).astype(np.int32)])
+    rng.shuffle(sizes)
+    n = int(sizes.sum())
+    cloud = rng.random((n, 3)) * 4.0
+    cloud[:, 2] = 0.5 * cloud[:, 0] - 0.25 * cloud[:, 1] + rng.normal(0, 0.008, n)
+    np.random.seed(H + k)
+    op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=k)
+    mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+    o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.01, details=True)
+    assert np.array_equal(counts, o_count)
+    assert np.array_equal(index, o_index)
+    assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+    assert np.array_equal(mask, o_mask)
+
+
 @pytest.mark.parametrize("H", [1024, 256, 64])
 def test_ransac_draws_that_round_up_to_the_next_point_vs_oracle(H):
     """int32(R*n + start) (cuda_ransac.py:103-107): draws with R*n just below an integer round UP once
