@@ -196,6 +196,9 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #ifndef RS_MINWAVES
 #define RS_MINWAVES 4
 #endif
+#ifndef RS_BIG_PER_CU
+#define RS_BIG_PER_CU 16  // workgroups per CU striding over the list of large blocks
+#endif
 #ifndef RS_SCHED_BARRIER
 #define RS_SCHED_BARRIER 1
 #endif
@@ -994,7 +997,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   HIP_TRY(ctx, hipGetLastError());
   // the (rare) blocks that do not fit the LDS staging; the grid is fixed, the count is on the device
 #define OCTL_RANSAC_BIG(THREADS, HPL, KT)                                                       \
-  hipLaunchKernelGGL((k_ransac_big<THREADS, HPL, KT>), dim3((unsigned)std::min<int64_t>(nb, 2 * cus)), \
+  hipLaunchKernelGGL((k_ransac_big<THREADS, HPL, KT>), dim3((unsigned)std::min<int64_t>(nb, (int64_t)RS_BIG_PER_CU * cus)), \
                      dim3(THREADS), 0, st, xyz_dev, (const BlockDesc*)desc,                     \
                      (const uint32_t*)big_list, (const uint32_t*)(counters + RC_BIG), hyp_dev,  \
                      H, k, thr, out)
