@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="points per rank")
     ap.add_argument("--cloud", choices=["planar", "uniform"], default="planar")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", type=int, nargs=3, default=None, metavar=("X", "Y", "Z"),
+                    help="scene extent in 1 m voxels (experiments; default 32768 voxels per rank)")
     ap.add_argument("--k-split", type=int, default=K_SPLIT,
                     help="count criterion len > K (experiments; the benchmarked workload is K = 64)")
     ap.add_argument("--route", action="store_true",
@@ -145,7 +147,7 @@ def main():
             probe = np.zeros(1, dtype=np.int64)
             ctx.check(lib.octl_comm_allreduce_i64(ctx.handle, nat.ptr(probe), 1))
 
-    dims = scene_dims(world)
+    dims = tuple(args.scene) if args.scene else scene_dims(world)
     n_local = args.points
     if args.cloud == "planar":
         pts = synthetic.planar_cloud(n_local, dims, seed=1, stream=rank)

@@ -17,12 +17,25 @@
 //                 exceeds K is split 8 ways by a stable tile partition (ballot ranks in LDS)
 //   k_finalize    leaf-ordered point permutation + coordinates, (leaf, pose) block table
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 
 #include "build_common.h"
 #include "forest.h"
 #include "ref_arith.h"
 #include "wave_utils.h"
+
+// OCTL_TRACE_BUILD=1: host wall time between the phases of forest_build on stderr (diagnostics)
+struct BuildTrace {
+  bool on = getenv("OCTL_TRACE_BUILD") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[build] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+    t = now;
+  }
+};
 
 namespace {
 
@@ -760,7 +773,9 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     return octl_set_error(ctx, OCTL_E_INVALID, "scheme mask has %d entries for %d poses", n_mask,
                           n_poses);
   if (max_depth <= 0) max_depth = 63;
+  BuildTrace trace;
   OCTL_TRY(forest_sync_vkeys(f));  // the previous scheme's voxels persist (no-op when fresh)
+  trace.mark("sync_vkeys");
   uint32_t* small = ctx->small.as<uint32_t>();
 
   bool all_scheme = true;
@@ -853,6 +868,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
            (uint64_t)((int64_t)qz + bb[2] + OCTL_VOX_BIAS);
   };
 
+  trace.mark("keys + bbox readback");
   // ---- 2. sort by top-level voxel ---------------------------------------------------------------
   int sorted = 0;
   if (N > 0) {
@@ -876,6 +892,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   const uint64_t* lin_sorted = f->lin[sorted].as<uint64_t>();
   const uint32_t* val_sorted = f->val[sorted].as<uint32_t>();
 
+  trace.mark("sort (enqueue)");
   // ---- 3. roots ------------------------------------------------------------------------------------
   OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_alive, 8) + 8) * 4));
   uint32_t* flags = f->flags.as<uint32_t>();
@@ -1004,6 +1021,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
   }
 
+  trace.mark("roots (+ union with old voxels)");
   // voxel keys of this build: kept on the device, decoded on the host only when someone asks
   OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
   if (fresh && V > 0)
@@ -1037,6 +1055,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
 
   int32_t* pos_node = nullptr;
   if (!voxel_done) {
+  trace.mark("voxel-local build");
   // ---- 4. level-0 buffers ---------------------------------------------------------------------------
   for (int b = 0; b < 2; ++b) {
     OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 4));
@@ -1067,6 +1086,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
   }
 
+  trace.mark("level-0 buffers");
   // ---- 5. level loop ----------------------------------------------------------------------------------
   while (n_new > 0) {
     // split list of the freshly created nodes
@@ -1178,6 +1198,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     n_internal += ns;
     ++level;
   }
+  trace.mark("level loop");
   // ---- 6. leaf-ordered arrays and the block table ------------------------------------------------------
   if (n_alive > 0) {
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_alive * 4));
@@ -1194,6 +1215,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
   }
   }  // !voxel_done
+  trace.mark("finalize (enqueue)");
   int64_t n_blocks = 0;
   const int64_t n_ord_before = f->n_ord;
   f->n_ord = n_alive;
@@ -1212,6 +1234,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
   }
 
+  trace.mark("blocks + final sync");
   // ---- commit --------------------------------------------------------------------------------------------
   f->cur ^= 1;
   f->n_voxels = V;
