@@ -23,7 +23,7 @@ class LeafView(Voxel):
     def __init__(self, corner_min, edge_length, xyz, start, size, node):
         self._corner_min = corner_min
         self._edge_length = edge_length
-        self._lazy_id = None
+        self._id = None  # resolved on first access (internal/voxel.py)
         self._points = None
         self._xyz = xyz
         self._start = int(start)

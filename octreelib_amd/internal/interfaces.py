@@ -1,20 +1,19 @@
 """Mix-in for objects that carry an id (reference: internal/interfaces.py:12-32)."""
 
+import itertools
 from abc import ABC
-from typing import Optional
 
 __all__ = ["WithID"]
 
+_fresh_ids = itertools.count()
+
 
 class WithID(ABC):
-    _id_static_counter = 0
+    """`WithID()` draws the next number of a process-wide sequence; `WithID(n)` adopts `n`."""
 
-    def __init__(self, _id: Optional[int] = None):
-        if _id is None:
-            _id = WithID._id_static_counter
-            WithID._id_static_counter += 1
-        self._id = _id
+    __slots__ = ("_id",)
 
-    @property
-    def id(self):
-        return self._id
+    def __init__(self, _id=None):
+        self._id = next(_fresh_ids) if _id is None else _id
+
+    id = property(lambda self: self._id)
