@@ -787,6 +787,64 @@ def test_voxel_local_build_equals_level_synchronous_build(monkeypatch, scheme):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_voxel_local_build_random_voxels_vs_level_synchronous_build(monkeypatch, seed):
+    """Random voxel populations around the limits of the voxel-local path (1 ... 512 points per
+    voxel, K from 1, clusters that need more than its 7 levels and send the build down the general
+    path): node tables, blocks, permutation, coordinates and leaf order must be bit-identical
+    whichever path ran."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    rng = np.random.default_rng(500 + seed)
+    dims = rng.integers(2, 7, 3)
+    K = int(rng.choice([1, 2, 3, 8, 64, 511]))
+    deep = seed % 3 == 2   # clusters tighter than 2^-7 of the voxel: the voxel-local path must fall back
+    poses = []
+    for _ in range(int(rng.integers(1, 4))):
+        parts = []
+        for c in np.argwhere(np.ones(dims)):
+            r = rng.random()
+            m = 0 if r < 0.1 else (170 if r < 0.2 else int(rng.integers(1, 171)))   # <= 512 over three poses
+            pts = rng.random((m, 3))
+            if m and rng.random() < 0.3:
+                w = 2.0 ** -(12 if deep else 4)
+                pts[: m // 2] = rng.random(3) * (1 - w) + rng.random((m // 2, 3)) * w
+            parts.append(pts + c)
+        cloud = np.unique(np.vstack(parts), axis=0)
+        rng.shuffle(cloud)
+        poses.append(cloud)
+    scheme = None if rng.random() < 0.5 else sorted(rng.choice(len(poses), int(rng.integers(1, len(poses) + 1)), replace=False).tolist())
+    ctx = nat.get_context()
+
+    def build():
+        f = Forest(0, np.zeros(3), 1.0)
+        for c in poses:
+            f.add_pose(c)
+        ctx.set_profiling(True)
+        f.subdivide(K, scheme)
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        out = ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()},
+               f.perm.copy(), f.xyz.copy(), f.order.copy(), int(f.info.n_levels))
+        f.close()
+        return out, names
+
+    monkeypatch.delenv("OCTL_NO_VOXEL_BUILD", raising=False)
+    a, names_a = build()
+    monkeypatch.setenv("OCTL_NO_VOXEL_BUILD", "1")
+    b, names_b = build()
+    assert "voxel_build_a" in names_a and "voxel_build_a" not in names_b
+    if not deep and K >= 8:
+        assert "level_hist" not in names_a    # the voxel-local path did the whole build
+    assert a[5] == b[5]
+    for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
 def test_forest_is_usable_after_a_failed_subdivide():
     from octreelib_amd.grid import Grid, GridConfig
 
