@@ -21,6 +21,7 @@
 // exactly, and the product is 4 deep.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "forest.h"
 
@@ -198,6 +199,12 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #endif
 #ifndef RS_BIG_PER_CU
 #define RS_BIG_PER_CU 16  // workgroups per CU striding over the list of large blocks
+#endif
+#ifndef RS_EARLY_EXIT
+#define RS_EARLY_EXIT 1  // skip the later hypothesis groups once one hypothesis holds all points
+#endif
+#ifndef RS_FIRST_GROUPS
+#define RS_FIRST_GROUPS 1  // hypothesis groups (of THREADS) evaluated before the early-exit check
 #endif
 #ifndef RS_SCHED_BARRIER
 #define RS_SCHED_BARRIER 1
@@ -389,6 +396,55 @@ __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, cons
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
   if ((threadIdx.x & 63) == 0) wext[threadIdx.x >> 6] = m;
 }
+
+// The screened scoring of the block's n staged points (block-local f32 coordinates in LDS, read
+// as wave-uniform broadcasts) against NH hypotheses of the lane; see "Screening" in k_ransac.
+// Per point and hypothesis: 4 v_fma_f32, 1 v_alignbit (inlier bit into a 32-point history word,
+// popcounted per 32 points) and half a v_min3_f32 (one margin for the group: the smallest |e|).
+template <int NH>
+__device__ __forceinline__ void screen_group(const f4* __restrict__ loc, int n, const float* fa,
+                                             const float* fb, const float* fc, const float* sto,
+                                             float nthr2, int* cnt, float& margin) {
+  for (int base = 0; base < n; base += 32) {
+    const int m = __builtin_amdgcn_readfirstlane(min(32, n - base));
+    uint32_t hist[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) hist[h] = 0;
+    auto score = [&](const f4 L, float (&e)[NH]) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const float sv = fma32(fa[h], L.x, fma32(fb[h], L.y, fma32(fc[h], L.z, sto[h])));
+        e[h] = fma32(sv, sv, nthr2);
+        hist[h] = __builtin_amdgcn_alignbit(hist[h], __float_as_uint(e[h]), 31);
+      }
+    };
+    // unrolled by hand (the inline asm keeps the loop unroller away): 4 LDS reads in flight
+    // (issuing the next iteration's reads ahead of the scoring gained nothing and cost 16 VGPRs)
+    int i = 0;
+    for (; i + 4 <= m; i += 4) {
+      const f4 L0 = loc[base + i], L1 = loc[base + i + 1], L2 = loc[base + i + 2],
+               L3 = loc[base + i + 3];
+      float e0[NH], e1[NH], e2[NH], e3[NH];
+      score(L0, e0);
+      score(L1, e1);
+      score(L2, e2);
+      score(L3, e3);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        margin = min3abs(margin, e0[h], e1[h]);
+        margin = min3abs(margin, e2[h], e3[h]);
+      }
+    }
+    for (; i < m; ++i) {
+      float e[NH];
+      score(loc[base + i], e);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) margin = min3abs(margin, e[h], e[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) cnt[h] += __popc(hist[h]);
+  }
+}
 #endif
 
 // Persistent workgroups over the descriptors of all blocks with k <= n <= THREADS-1 points,
@@ -514,35 +570,50 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       any_risk = __any(risk_any != 0);
     }
 
-#if RS_SCREEN
-    // screening keeps only the f32 plane (its promotion to f64 is exact and redone on demand)
-    constexpr int NP = (HPL + 1) / 2;  // hypotheses are scored two at a time (v_pk_*_f32)
-    float fa[2 * NP], fb[2 * NP], fc[2 * NP], fd[2 * NP], sto[2 * NP], sdl[2 * NP];
-    if (HPL & 1) fa[HPL] = fb[HPL] = fc[HPL] = fd[HPL] = sto[HPL] = sdl[HPL] = 0.f;
+    // ---- the block's hypotheses -------------------------------------------------------------
+    // Screening.  The H x n distance tests are evaluated in f32 on block-local coordinates; a
+    // pair is decided there only when its f32 distance is farther from the threshold than a
+    // rigorous bound of |s - t_ref|, everything else is re-evaluated with the reference's exact
+    // f64 sequence, so the inlier COUNTS are exactly the reference's:
+    //   reference   t_ref = fl(fl(fl(A x + B y) + C z) + D)           (util.py:22-24, f64)
+    //   identity    A x + B y + C z + D = T_o + A (x-ox) + B (y-oy) + C (z-oz),   o = first point
+    //   screen      s = fma32(a, u, fma32(b, v, fma32(c, w, to)))     u = fl32(x-ox).., to = fl32(T_o)
+    //   |s - t_ref| <= 2^-24 (4 |T_o| + 9 E) + 2^-50 (|o|_1 + |D| + E),   E = max |u|,|v|,|w|
+    //     (three f32 FMA roundings on partial sums <= |T_o| + 3E, the f32 roundings of u,v,w and
+    //      of to, the f64 roundings of T_o and of t_ref itself; |a|,|b|,|c| <= 1)
+    //   delta = twice that bound
+    // The test itself is done on squares:
+    //   e = fma32(s, s, -fl32(thr^2))     sign(e) = inlier bit, |e| = distance from the threshold
+    //   |e| >= dprime = 2 thr delta + delta^2 + 2^-21 thr^2   =>   | |s| - thr | >= delta and the
+    //   sign of e is the sign of s^2 - thr^2 (the last term absorbs the roundings of e and thr^2)
+    // so a group of hypotheses whose smallest |e| over the block stays above its largest dprime
+    // has the reference's counts; otherwise (rare) it is recounted with the exact f64 sequence
+    // (screen_group: 5.5 instructions per point and hypothesis against 8 f64 ones).
+    //
+    // Early exit (exact).  The winner is the LOWEST index among the hypotheses with the maximal
+    // count, and no count exceeds n.  Hypotheses 0 .. THREADS-1 (group 0 of every lane) go first;
+    // when one of them holds all n points, no hypothesis of a later group can win - their plane
+    // fits and scores are skipped.  On the benchmark scene this is one leaf in five.
     const double ox = lx[0], oy = ly[0], oz = lz[0];
     float extent = s_wext[buf][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) extent = fmaxf(extent, s_wext[buf][w]);
-    // block-uniform parts of the screening bound (see "Screening" below).  Thresholds or extents
-    // outside the sane range (nobody's plane tolerance) are always recounted exactly.
+    // block-uniform parts of the bound.  Thresholds or extents outside the sane range (nobody's
+    // plane tolerance) are always recounted exactly.
     const double delta_blk = fma(0x1p-23 * 9.0, (double)extent,
                                  0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + (double)extent + 1.0));
     const double dprime_thr = 0x1p-21 * (thr * thr);
     const bool blk_sane = thr >= 0x1p-40 && thr <= 0x1p40 && extent < 0x1p60f;
-#else
-    double pa[HPL], pb[HPL], pc[HPL], pd[HPL];
-#endif
+    const float nthr2 = -(float)(thr * thr);
+    const f4* __restrict__ loc = s_loc[buf];
+
+    float fa[HPL], fb[HPL], fc[HPL], fd[HPL], sto[HPL], sdl[HPL];
     int cnt[HPL];
-#pragma unroll
-    for (int q = 0; q < HPL; ++q) {
+    // plane of hypothesis group q (f32, as the reference stores it) + its screening constants
+    auto fit = [&](const int q) {
       const int t = tx + q * THREADS;
-      cnt[q] = -1;
-#if RS_SCREEN
-      fa[q] = fb[q] = fc[q] = fd[q] = 0.f;
-      sto[q] = sdl[q] = 0.f;
-#else
-      pa[q] = pb[q] = pc[q] = pd[q] = 0.0;
-#endif
+      cnt[q] = 0;
+      fa[q] = fb[q] = fc[q] = fd[q] = sto[q] = sdl[q] = 0.f;
       if (t < H) {
         double sx[KS], sy[KS], sz[KS];
         if (!any_risk) {  // wave-uniform: practically always
@@ -575,141 +646,80 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         } else {
           plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
         }
-        cnt[q] = 0;
-#if RS_SCREEN
-        {
-          // (explicit fma: these are error BOUNDS and the screen's own inputs, not parity arithmetic)
-          const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
-          const double to = fma(A, ox, fma(B, oy, fma(Cc, oz, D)));
-          const double delta = fma(0x1p-21, fabs(to), fma(0x1p-49, fabs(D), delta_blk));
-          // the loop tests e = fl32(s*s - fl32(thr^2)): |e| >= dprime  =>  | |s| - thr | >= delta
-          const double dprime = fma(delta, thr + thr + delta, dprime_thr) * 1.000001;
-          const bool sane = blk_sane && (fabs(to) < 0x1p60);  // false for NaN
-          fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
-          sto[q] = (float)to;
-          sdl[q] = sane ? (float)dprime : __int_as_float(0x7f800000);
-        }
-#else
-        // the f32-rounded plane, promoted back to f64 for scoring (cuda_ransac.py:110-121)
-        pa[q] = (double)pf[0];
-        pb[q] = (double)pf[1];
-        pc[q] = (double)pf[2];
-        pd[q] = (double)pf[3];
-#endif
+        // (explicit fma: error BOUNDS and the screen's own inputs, not parity arithmetic)
+        const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
+        const double to = fma(A, ox, fma(B, oy, fma(Cc, oz, D)));
+        const double delta = fma(0x1p-21, fabs(to), fma(0x1p-49, fabs(D), delta_blk));
+        const double dprime = fma(delta, thr + thr + delta, dprime_thr) * 1.000001;
+        const bool sane = blk_sane && (fabs(to) < 0x1p60);  // false for NaN
+        fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
+        sto[q] = (float)to;
+        sdl[q] = sane ? (float)dprime : __int_as_float(0x7f800000);
       }
       // keep the plane fits of the lane's hypotheses apart: interleaved they need > 200 VGPRs
       __builtin_amdgcn_sched_barrier(0);
-    }
-    // scoring: every point of the block against every hypothesis of the lane
-    // (cuda_ransac.py:116-121); the point is a wave-uniform LDS broadcast
-#if RS_SCREEN
-    // Screening.  The H x n distance tests are evaluated in f32 on block-local coordinates; a
-    // pair is decided there only when its f32 distance is farther from the threshold than a
-    // rigorous bound of |s - t_ref|, everything else is re-evaluated with the reference's exact
-    // f64 sequence, so the inlier COUNTS are exactly the reference's:
-    //   reference   t_ref = fl(fl(fl(A x + B y) + C z) + D)           (util.py:22-24, f64)
-    //   identity    A x + B y + C z + D = T_o + A (x-ox) + B (y-oy) + C (z-oz),   o = first point
-    //   screen      s = fma32(a, u, fma32(b, v, fma32(c, w, to)))     u = fl32(x-ox).., to = fl32(T_o)
-    //   |s - t_ref| <= 2^-24 (4 |T_o| + 9 E) + 2^-50 (|o|_1 + |D| + E),   E = max |u|,|v|,|w|
-    //     (three f32 FMA roundings on partial sums <= |T_o| + 3E, the f32 roundings of u,v,w and
-    //      of to, the f64 roundings of T_o and of t_ref itself; |a|,|b|,|c| <= 1)
-    //   delta = twice that bound
-    // The test itself is done on squares:
-    //   e = fma32(s, s, -fl32(thr^2))     sign(e) = inlier bit, |e| = distance from the threshold
-    //   |e| >= dprime = 2 thr delta + delta^2 + 2^-21 thr^2   =>   | |s| - thr | >= delta and the
-    //   sign of e is the sign of s^2 - thr^2 (the last term absorbs the roundings of e and thr^2)
-    // so a hypothesis whose smallest |e| over the block stays above dprime has the reference's
-    // count; otherwise (rare) it is recounted with the exact f64 sequence.  Per point and
-    // hypothesis: 4 v_fma_f32, 1 v_alignbit (inlier bit into a 32-point history word, popcounted
-    // per 32 points) and half a v_min3_f32 - against 8 f64 instructions on the exact path.
-    if (ABL != 1) {
-      const float thr2 = (float)(thr * thr);
-      const float nthr2 = -thr2;
-      float margin[NP], dl2[NP];
+    };
+    // counts of the groups [q0, q0 + NH): the screen, then the exact recount where it cannot decide
+    auto score = [&](auto nh_tag, const int q0) {
+      constexpr int NH = decltype(nh_tag)::value;
+      if (ABL == 1) return;  // ablation: no scoring
+      float margin = __int_as_float(0x7f800000), dl = 0.f;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        dl2[p] = fmaxf(sdl[2 * p], sdl[2 * p + 1]);
-        margin[p] = __int_as_float(0x7f800000);
-      }
-      const f4* __restrict__ loc = s_loc[buf];
-      for (int base = 0; base < n; base += 32) {
-        const int m = __builtin_amdgcn_readfirstlane(min(32, n - base));
-        uint32_t hist[2 * NP];
+      for (int h = 0; h < NH; ++h) dl = fmaxf(dl, sdl[q0 + h]);  // (never NaN: +inf instead)
+      screen_group<NH>(loc, n, fa + q0, fb + q0, fc + q0, sto + q0, nthr2, cnt + q0, margin);
+      const bool redo = !(margin > dl);
+      if (__any(redo)) {  // rare
 #pragma unroll
-        for (int q = 0; q < 2 * NP; ++q) hist[q] = 0;
-        auto score = [&](const f4 L) {
-#pragma unroll
-          for (int p = 0; p < NP; ++p) {
-            float e[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int q = 2 * p + h;
-              const float sv = fma32(fa[q], L.x, fma32(fb[q], L.y, fma32(fc[q], L.z, sto[q])));
-              e[h] = fma32(sv, sv, nthr2);
-              hist[q] = __builtin_amdgcn_alignbit(hist[q], __float_as_uint(e[h]), 31);
-            }
-            margin[p] = min3abs(margin[p], e[0], e[1]);
-          }
-        };
-        // unrolled by hand (the inline asm keeps the loop unroller away): 4 LDS reads in flight
-        int i = 0;
-        for (; i + 4 <= m; i += 4) {
-          const f4 L0 = loc[base + i], L1 = loc[base + i + 1], L2 = loc[base + i + 2],
-                   L3 = loc[base + i + 3];
-          score(L0);
-          score(L1);
-          score(L2);
-          score(L3);
-        }
-        for (; i < m; ++i) score(loc[base + i]);
-#pragma unroll
-        for (int q = 0; q < HPL; ++q) cnt[q] += __popc(hist[q]);
-      }
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const bool redo = !(margin[p] > dl2[p]);
-        if (__any(redo)) {  // rare
-#pragma unroll
-          for (int q = 2 * p; q < 2 * p + 2 && q < HPL; ++q) {
-            if (redo && (int)tx + q * THREADS < H) {
-              const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
-              int c = 0;
-              for (int ii = 0; ii < n; ++ii)
-                c += (plane_distance(A, B, Cc, D, lx[ii], ly[ii], lz[ii]) < thr) ? 1 : 0;
-              cnt[q] = c;
-            }
+        for (int h = 0; h < NH; ++h) {
+          const int q = q0 + h;
+          if (redo && (int)tx + q * THREADS < H) {
+            const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
+            int c = 0;
+            for (int ii = 0; ii < n; ++ii)
+              c += (plane_distance(A, B, Cc, D, lx[ii], ly[ii], lz[ii]) < thr) ? 1 : 0;
+            cnt[q] = c;
           }
         }
       }
-    }
-#else
-    if (ABL != 1) {
-RS_PRAGMA(unroll RS_SCORE_UNROLL)
-      for (int i = 0; i < n; ++i) {
-        const double x = lx[i], y = ly[i], z = lz[i];
+    };
+    // pass 1: the first F groups (hypotheses 0 .. F * THREADS - 1), pass 2: the rest.
+    // (Measured: the two-pass structure itself costs ~6 % with the exit disabled - not VALU work,
+    // not LDS bandwidth, not the instruction cache; the exit removes 10 % of the VALU instructions
+    // on the benchmark scene; net -2 %.  Gating the two passes by block size generated worse
+    // code - spills - and was slower than either.)
+    constexpr int F = HPL > RS_FIRST_GROUPS ? RS_FIRST_GROUPS : HPL;
+    bool skipped = false;  // pass 2 not evaluated (wave-uniform)
 #pragma unroll
-        for (int q = 0; q < HPL; ++q)
-          cnt[q] += (plane_distance(pa[q], pb[q], pc[q], pd[q], x, y, z) < thr) ? 1 : 0;
+    for (int q = 0; q < F; ++q) fit(q);
+    score(std::integral_constant<int, F>{}, 0);
+    if (HPL > F) {
+      // does a hypothesis of pass 1 hold every point?  (every index of pass 2 is higher: nothing
+      // there can beat it, and a tie goes to the lower index).  Decided per wavefront, no
+      // barrier: the pass-2 hypotheses of THIS wave all have higher indices than its full
+      // hypothesis; a wave without one carries on (a barrier + shared flag measured no better).
+      bool full = false;
+#pragma unroll
+      for (int q = 0; q < F; ++q) full = full || ((int)tx + q * THREADS < H && cnt[q] == n);
+      skipped = RS_EARLY_EXIT && __any(full);
+      if (!skipped) {
+#pragma unroll
+        for (int q = F; q < HPL; ++q) fit(q);
+        score(std::integral_constant<int, (HPL > F ? HPL - F : 1)>{}, F);
       }
     }
-#endif
     // maximum over the lane, then over the wave; lowest hypothesis index among the tied
     // (cuda_ransac.py:125-146)
     unsigned long long best = 0;
-    double wa = 0.0, wb = 0.0, wc = 0.0, wd = 0.0;
+    float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
 #pragma unroll
     for (int q = 0; q < HPL; ++q) {
       const int t = tx + q * THREADS;
-      if (t < H) {
+      if (t < H && (q < F || !skipped)) {
         const unsigned long long key =
             ((unsigned long long)(unsigned)cnt[q] << 32) | (unsigned)(0x7FFFFFFF - t);
         if (key > best) {
           best = key;
-#if RS_SCREEN
           wa = fa[q]; wb = fb[q]; wc = fc[q]; wd = fd[q];
-#else
-          wa = pa[q]; wb = pb[q]; wc = pc[q]; wd = pd[q];
-#endif
         }
       }
     }
@@ -722,10 +732,10 @@ RS_PRAGMA(unroll RS_SCORE_UNROLL)
     if (best == wbest && best != 0) {  // exactly one lane: keys are unique
       const int w = tx >> 6;
       s_wbest[par][w] = best;
-      s_wplane[par][w][0] = (float)wa;  // exact: promoted from the f32 plane
-      s_wplane[par][w][1] = (float)wb;
-      s_wplane[par][w][2] = (float)wc;
-      s_wplane[par][w][3] = (float)wd;
+      s_wplane[par][w][0] = wa;
+      s_wplane[par][w][1] = wb;
+      s_wplane[par][w][2] = wc;
+      s_wplane[par][w][3] = wd;
     } else if (wbest == 0 && (tx & 63) == 0) {
       s_wbest[par][tx >> 6] = 0;  // a wave without hypotheses (H < THREADS)
     }

@@ -479,6 +479,38 @@ def test_ransac_operator_boundary_shapes_vs_oracle(H, k):
     assert np.array_equal(mask, o_mask)
 
 
+@pytest.mark.parametrize("H", [1024, 700, 257, 513])
+def test_ransac_early_exit_keeps_the_lowest_index_winner(H):
+    """The kernel skips the hypotheses H >= 256 of a wavefront once one of its first hypotheses
+    holds ALL points of the block (nothing later can beat it; ties go to the lower index).  Many
+    small blocks that are fully explained by some hypotheses but not by all: winner index, count,
+    plane and mask must still be the reference's, wherever the first full hypothesis sits."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(H)
+    sizes = rng.integers(6, 30, 3000).astype(np.int32)
+    n = int(sizes.sum())
+    cloud = rng.random((n, 3)) * 0.3
+    cloud[:, 2] = 0.2 * cloud[:, 0] - 0.1 * cloud[:, 1] + rng.normal(0, 0.0045, n)
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    for b in range(0, len(sizes), 7):       # exactly planar blocks: every proper hypothesis is full
+        s_, e_ = starts[b], starts[b + 1]
+        cloud[s_:e_, 2] = 0.25 * cloud[s_:e_, 0] + 0.125 * cloud[s_:e_, 1]
+    for b in range(3, len(sizes), 11):      # one far outlier: no hypothesis is full
+        cloud[starts[b], 2] += 0.5
+    np.random.seed(H)
+    op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=6)
+    mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+    o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.01, details=True)
+    full = o_count == sizes
+    assert 0.1 < full.mean() < 0.95          # the exit is exercised and so is the full evaluation
+    assert np.array_equal(counts, o_count)
+    assert np.array_equal(index, o_index)
+    assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+    assert np.array_equal(mask, o_mask)
+
+
 @pytest.mark.parametrize("H", [1024, 256, 64])
 def test_ransac_draws_that_round_up_to_the_next_point_vs_oracle(H):
     """int32(R*n + start) (cuda_ransac.py:103-107): draws with R*n just below an integer round UP once
