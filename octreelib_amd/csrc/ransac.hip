@@ -1001,6 +1001,11 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     if (k == 6 && abl && abl[0] == '1') OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 1, RS_PER_CU);
     else if (k == 6 && abl && abl[0] == '2') OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 2, RS_PER_CU);
     else if (k == 6) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 0, RS_PER_CU);
+    // the other small sample sizes also get compile-time k (sample arrays in registers; the generic
+    // instantiation indexes them at run time and spills)
+    else if (k == 5) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 5, 0, RS_PER_CU);
+    else if (k == 4) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 4, 0, RS_PER_CU);
+    else if (k == 3) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 3, 0, RS_PER_CU);
     else OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 0, 0, 2);
   }
 #undef OCTL_RANSAC_LAUNCH
