@@ -404,7 +404,11 @@ __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, cons
 template <int NH>
 __device__ __forceinline__ void screen_group(const f4* __restrict__ loc, int n, const float* fa,
                                              const float* fb, const float* fc, const float* sto,
-                                             float nthr2, int* cnt, float& margin) {
+                                             float nthr2, int* cnt, float* margin) {
+  // the smallest |e| of every hypothesis (two running minima each: even / odd point pairs)
+  float mg[2][NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) mg[0][h] = mg[1][h] = __int_as_float(0x7f800000);
   for (int base = 0; base < n; base += 32) {
     const int m = __builtin_amdgcn_readfirstlane(min(32, n - base));
     uint32_t hist[NH];
@@ -431,19 +435,21 @@ __device__ __forceinline__ void screen_group(const f4* __restrict__ loc, int n, 
       score(L3, e3);
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        margin = min3abs(margin, e0[h], e1[h]);
-        margin = min3abs(margin, e2[h], e3[h]);
+        mg[0][h] = min3abs(mg[0][h], e0[h], e1[h]);
+        mg[1][h] = min3abs(mg[1][h], e2[h], e3[h]);
       }
     }
     for (; i < m; ++i) {
       float e[NH];
       score(loc[base + i], e);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) margin = min3abs(margin, e[h], e[h]);
+      for (int h = 0; h < NH; ++h) mg[0][h] = min3abs(mg[0][h], e[h], e[h]);
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) cnt[h] += __popc(hist[h]);
   }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) margin[h] = fminf(mg[0][h], mg[1][h]);
 }
 #endif
 
@@ -586,8 +592,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     //   e = fma32(s, s, -fl32(thr^2))     sign(e) = inlier bit, |e| = distance from the threshold
     //   |e| >= dprime = 2 thr delta + delta^2 + 2^-21 thr^2   =>   | |s| - thr | >= delta and the
     //   sign of e is the sign of s^2 - thr^2 (the last term absorbs the roundings of e and thr^2)
-    // so a group of hypotheses whose smallest |e| over the block stays above its largest dprime
-    // has the reference's counts; otherwise (rare) it is recounted with the exact f64 sequence
+    // so a hypothesis whose smallest |e| over the block stays above its dprime has the
+    // reference's count; otherwise (rare) it is recounted with the exact f64 sequence
     // (screen_group: 5.5 instructions per point and hypothesis against 8 f64 ones).
     //
     // Early exit (exact).  The winner is the LOWEST index among the hypotheses with the maximal
@@ -663,16 +669,17 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     auto score = [&](auto nh_tag, const int q0) {
       constexpr int NH = decltype(nh_tag)::value;
       if (ABL == 1) return;  // ablation: no scoring
-      float margin = __int_as_float(0x7f800000), dl = 0.f;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) dl = fmaxf(dl, sdl[q0 + h]);  // (never NaN: +inf instead)
+      float margin[NH];
       screen_group<NH>(loc, n, fa + q0, fb + q0, fc + q0, sto + q0, nthr2, cnt + q0, margin);
-      const bool redo = !(margin > dl);
-      if (__any(redo)) {  // rare
+      // a hypothesis whose smallest |e| does not clear its bound is recounted exactly (per
+      // hypothesis: a recount costs the whole wave 8 n instructions, and by the bound some lane
+      // needs one in a few percent of the (wave, hypothesis group) pairs of the benchmark scene)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          const int q = q0 + h;
-          if (redo && (int)tx + q * THREADS < H) {
+      for (int h = 0; h < NH; ++h) {
+        const int q = q0 + h;
+        const bool redo = (int)tx + q * THREADS < H && !(margin[h] > sdl[q]);  // (NaN: recount)
+        if (__any(redo)) {
+          if (redo) {
             const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
             int c = 0;
             for (int ii = 0; ii < n; ++ii)
@@ -683,10 +690,10 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       }
     };
     // pass 1: the first F groups (hypotheses 0 .. F * THREADS - 1), pass 2: the rest.
-    // (Measured: the two-pass structure itself costs ~6 % with the exit disabled - not VALU work,
-    // not LDS bandwidth, not the instruction cache; the exit removes 10 % of the VALU instructions
-    // on the benchmark scene; net -2 %.  Gating the two passes by block size generated worse
-    // code - spills - and was slower than either.)
+    // (Measured with the exit disabled: the two-pass structure costs ~1.5 % against fitting all
+    // groups and scoring them in one loop; the exit removes 10 % of the VALU instructions on the
+    // benchmark scene.  Gating the two passes by block size - inside the kernel or as two
+    // launches - was slower than the plain two-pass kernel.)
     constexpr int F = HPL > RS_FIRST_GROUPS ? RS_FIRST_GROUPS : HPL;
     bool skipped = false;  // pass 2 not evaluated (wave-uniform)
 #pragma unroll
