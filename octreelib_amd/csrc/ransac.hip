@@ -677,15 +677,32 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int q = q0 + h;
+#ifdef RS_NO_REDO  // timing experiment only: results are wrong where the screen cannot decide
+        const bool redo = false;
+#else
         const bool redo = (int)tx + q * THREADS < H && !(margin[h] > sdl[q]);  // (NaN: recount)
-        if (__any(redo)) {
-          if (redo) {
-            const double A = (double)fa[q], B = (double)fb[q], Cc = (double)fc[q], D = (double)fd[q];
-            int c = 0;
-            for (int ii = 0; ii < n; ++ii)
-              c += (plane_distance(A, B, Cc, D, lx[ii], ly[ii], lz[ii]) < thr) ? 1 : 0;
-            cnt[q] = c;
+#endif
+        // The recount is done by the whole wavefront for one flagged lane at a time (almost
+        // always exactly one): its plane is broadcast, every lane tests one point per round and
+        // a ballot counts.  Left to the flagged lane alone it is a serial loop over the block
+        // that holds up the lane's wave - and behind it the workgroup's barrier - for ~n LDS
+        // round trips: measured 7 % of the kernel although only 2 % of the checks recount.
+        unsigned long long todo = __ballot(redo);
+        while (todo) {
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const double A = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fa[q]), src));
+          const double B = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fb[q]), src));
+          const double Cc = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fc[q]), src));
+          const double D = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fd[q]), src));
+          int c = 0;
+          for (int base = 0; base < n; base += 64) {
+            const int ii = base + (int)(tx & 63u);
+            const bool in = ii < n && plane_distance(A, B, Cc, D, lx[ii < n ? ii : 0], ly[ii < n ? ii : 0],
+                                                     lz[ii < n ? ii : 0]) < thr;
+            c += __popcll(__ballot(in));
           }
+          if ((int)(tx & 63u) == src) cnt[q] = c;
         }
       }
     };
