@@ -348,7 +348,7 @@ def main():
                     "note": "same step, cloud uploaded from pageable host memory inside the step",
                 },
             }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the other ranks would wait)
             out["cpu_baseline"] = cpu_baseline(dims, table)
         print(json.dumps(out))
 
