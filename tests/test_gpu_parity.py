@@ -877,6 +877,34 @@ def test_voxel_local_build_random_voxels_vs_level_synchronous_build(monkeypatch,
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
 
 
+def test_grid_get_points_follows_voxel_creation_order():
+    """Grid.get_points walks ALL managers in the order they were first created (the dict order of
+    Grid.__octrees, grid.py:56,100-109,240-242), not in lexicographic voxel order: a voxel first
+    touched by a later pose comes after every voxel of the earlier poses."""
+    from octreelib_amd.grid import Grid, GridConfig
+
+    rng = np.random.default_rng(8)
+    in_voxel = lambda q, m: rng.random((m, 3)) * 0.9 + np.asarray(q, dtype=float)  # noqa: E731
+    a, b, c, d = (0, 0, 0), (0, 1, 0), (2, 0, 0), (1, 5, 1)      # a < b < d < c lexicographically
+    p0 = np.vstack([in_voxel(c, 5), in_voxel(b, 4)])              # creates b, c (np.unique order)
+    p1 = np.vstack([in_voxel(c, 3), in_voxel(a, 6), in_voxel(d, 2)])   # creates a, d afterwards
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, p0)
+    grid.insert_points(1, p1)
+    # creation order: b, c, a, d
+    assert np.array_equal(grid.get_points(0), np.vstack([p0[5:], p0[:5]]))
+    assert np.array_equal(grid.get_points(1), np.vstack([p1[:3], p1[3:9], p1[9:]]))
+    grid.subdivide(crit(2))
+    got = grid.get_points(1)
+    vox = np.floor(got).astype(int)
+    firsts = [tuple(v) for i, v in enumerate(vox.tolist()) if i == 0 or vox[i].tolist() != vox[i - 1].tolist()]
+    assert firsts == [c, a, d]                                    # still creation order after subdivide
+    assert sorted(map(bytes, got)) == sorted(map(bytes, p1))
+    # leaves, in contrast, are listed in lexicographic voxel order (grid.py:217-232)
+    lv = [tuple(np.floor(np.asarray(v.corner_min, dtype=float)).astype(int).tolist()) for v in grid.get_leaf_points(1)]
+    assert [k for i, k in enumerate(lv) if i == 0 or lv[i - 1] != k] == [a, d, c]
+
+
 def test_forest_is_usable_after_a_failed_subdivide():
     from octreelib_amd.grid import Grid, GridConfig
 
