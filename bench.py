@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="points per rank")
     ap.add_argument("--cloud", choices=["planar", "uniform"], default="planar")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="route inside the step on the compute stream instead of one step ahead on a "
+                         "second context (A/B)")
     ap.add_argument("--scene", type=int, nargs=3, default=None, metavar=("X", "Y", "Z"),
                     help="scene extent in 1 m voxels (experiments; default 32768 voxels per rank)")
     ap.add_argument("--k-split", type=int, default=K_SPLIT,
@@ -126,26 +129,32 @@ def main():
     ctx = nat.Context(local_rank)
     lib = ctx.lib
     route = world > 1 or args.route
+    # Routing runs one step ahead on a second context (own stream, own RCCL communicator) driven by
+    # a second host thread, so that the all-to-all of step i+1 overlaps insert/subdivide/RANSAC of
+    # step i.  The timed region still contains exactly K routings and K computes (the pipeline is
+    # drained before the clock starts).
+    overlap = route and not args.no_overlap
+    rctx = nat.Context(local_rank) if overlap else ctx
     if args.route and world == 1:
         os.environ["OCTL_ROUTE_SELF_SENDRECV"] = "1"
         buf = (C.c_uint8 * nat.UNIQUE_ID_BYTES)()
         with stdout_to_stderr():
-            ctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
-            ctx.check(lib.octl_comm_init(ctx.handle, 1, 0, C.cast(buf, C.c_void_p)))
+            rctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
+            rctx.check(lib.octl_comm_init(rctx.handle, 1, 0, C.cast(buf, C.c_void_p)))
     if world > 1:
         uid = [None]
         if rank == 0:
             buf = (C.c_uint8 * nat.UNIQUE_ID_BYTES)()
             with stdout_to_stderr():
-                ctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
+                rctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
             uid[0] = bytes(buf)
         dist.broadcast_object_list(uid, src=0)
         idbuf = (C.c_uint8 * nat.UNIQUE_ID_BYTES).from_buffer_copy(uid[0])
         with stdout_to_stderr():
-            ctx.check(lib.octl_comm_init(ctx.handle, world, rank, C.cast(idbuf, C.c_void_p)))
+            rctx.check(lib.octl_comm_init(rctx.handle, world, rank, C.cast(idbuf, C.c_void_p)))
             # the first collective finishes the lazy connection set-up (and its prints)
             probe = np.zeros(1, dtype=np.int64)
-            ctx.check(lib.octl_comm_allreduce_i64(ctx.handle, nat.ptr(probe), 1))
+            rctx.check(lib.octl_comm_allreduce_i64(rctx.handle, nat.ptr(probe), 1))
 
     dims = tuple(args.scene) if args.scene else scene_dims(world)
     n_local = args.points
@@ -170,34 +179,92 @@ def main():
     n_recv = C.c_int64(n_local)
     slot = C.c_int32(0)
 
-    def step():
-        ctx.check(lib.octl_forest_clear(fh))
-        if route:
-            ctx.check(lib.octl_route_points(ctx.handle, d_xyz, None, n_local, rank * n_local,
-                                            nat.ptr(corner), 1.0, C.byref(n_recv), None))
-            ctx.check(lib.octl_forest_add_pose_routed(fh, C.byref(slot)))
-        else:
-            ctx.check(lib.octl_forest_add_pose_device(fh, d_xyz, n_local, C.byref(slot)))
+    def route_once():
+        rctx.check(lib.octl_route_points(rctx.handle, d_xyz, None, n_local, rank * n_local,
+                                         nat.ptr(corner), 1.0, C.byref(n_recv), None))
+
+    def compute():
         ctx.check(lib.octl_forest_build(fh, args.k_split, None, 0, 0, 0, C.byref(info)))
         ctx.check(lib.octl_forest_ransac_all(fh, 10, nat.ptr(e0), 1, nat.ptr(table), H, KPTS, THRESHOLD))
         ctx.check(lib.octl_forest_apply_mask(fh, C.byref(n_alive)))
 
+    def step():
+        ctx.check(lib.octl_forest_clear(fh))
+        if route:
+            route_once()
+            ctx.check(lib.octl_forest_add_pose_routed(fh, C.byref(slot)))
+        else:
+            ctx.check(lib.octl_forest_add_pose_device(fh, d_xyz, n_local, C.byref(slot)))
+        compute()
+
+    def run_overlapped(count):
+        """`count` steps; the cloud of step i+1 is routed (second context, second host thread; the
+        library calls release the GIL) while step i is computed.  Starts and ends drained."""
+        import threading
+
+        routed, free, failed = threading.Event(), threading.Event(), []
+        free.set()
+
+        def router():
+            try:
+                for _ in range(count):
+                    free.wait()
+                    free.clear()
+                    route_once()
+                    routed.set()
+            except BaseException as exc:  # surfaces in the main thread
+                failed.append(exc)
+                routed.set()
+
+        th = threading.Thread(target=router, name="route-ahead")
+        th.start()
+        try:
+            for _ in range(count):
+                routed.wait()
+                routed.clear()
+                if failed:
+                    raise failed[0]
+                ctx.check(lib.octl_forest_clear(fh))
+                ctx.check(lib.octl_forest_add_pose_routed_from(fh, rctx.handle, C.byref(slot)))
+                ctx.sync()   # the routed buffer has been copied into the forest: free for the next cloud
+                free.set()
+                compute()
+        finally:
+            free.set()
+            th.join()
+        if failed:
+            raise failed[0]
+
+    def run(count):
+        if count <= 0:
+            return
+        if overlap:
+            run_overlapped(count)
+        else:
+            for _ in range(count):
+                step()
+
     def barrier():
         ctx.sync()
+        if rctx is not ctx:
+            rctx.sync()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     ctx.set_profiling(True)
+    if rctx is not ctx:
+        rctx.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     timings = ctx.timings()
     ctx.set_profiling(False)
+    if rctx is not ctx:
+        timings.update(rctx.timings())
+        rctx.set_profiling(False)
     if dist is not None:
         import torch
 
@@ -292,7 +359,8 @@ def main():
                             f"(scene {dims[0]}x{dims[1]}x{dims[2]} voxels), insert + subdivide(len>{args.k_split}) + "
                             f"map_leaf_points_cuda_ransac(H=1024, k=6, thr=0.01, poses_per_batch=10) "
                             f"incl. apply_mask"
-                            + (", sharded by top-level voxel with one RCCL all-to-all" if world > 1 else ""),
+                            + (", sharded by top-level voxel with one RCCL all-to-all" if world > 1 else "")
+                            + (" routed one step ahead on a second stream" if overlap else ""),
                 "points_per_gpu": n_local,
                 "K": args.k_split,
                 "hypotheses": H,
@@ -355,9 +423,11 @@ def main():
     lib.octl_forest_destroy(fh)
     ctx.check(lib.octl_dev_free(ctx.handle, d_xyz))
     if route:
-        lib.octl_comm_destroy(ctx.handle)
+        lib.octl_comm_destroy(rctx.handle)
     if world > 1:
         dist.destroy_process_group()
+    if rctx is not ctx:
+        rctx.close()
     ctx.close()
 
 

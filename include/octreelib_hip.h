@@ -232,6 +232,11 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
                       int64_t n, int64_t index_base, const double corner[3], double L,
                       int64_t* n_recv, int64_t* send_counts /* [n_ranks], nullable */);
 int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot);
+/* The same with the routed cloud of ANOTHER context on the same device: routing (its kernels, the
+ * RCCL communicator and its stream) can then run in a second context - from a second host thread -
+ * while this forest's context builds and fits the previous cloud.  The cloud is copied into the
+ * forest on the forest's stream; route_ctx may be re-used once that stream has been synchronised. */
+int octl_forest_add_pose_routed_from(octl_forest* f, octl_ctx* route_ctx, int32_t* slot);
 /* global indices of the routed cloud of the last octl_route_points call (n_recv) i64        */
 int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n);
 /* sum-all-reduce of small int64 vectors (counters) over the communicator                   */

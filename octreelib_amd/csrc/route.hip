@@ -334,6 +334,15 @@ int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot) {
   return octl_forest_add_pose_device(f, f->ctx->routed_xyz.as<double>(), f->ctx->routed_n, slot);
 }
 
+int octl_forest_add_pose_routed_from(octl_forest* f, octl_ctx* route_ctx, int32_t* slot) {
+  if (!f || !route_ctx) return OCTL_E_INVALID;
+  if (route_ctx->device != f->ctx->device)
+    return octl_set_error(f->ctx, OCTL_E_INVALID, "the routing context lives on another device");
+  // octl_route_points returns after its stream has drained: the routed cloud is complete, and the
+  // copy below runs on the forest's stream
+  return octl_forest_add_pose_device(f, route_ctx->routed_xyz.as<double>(), route_ctx->routed_n, slot);
+}
+
 int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n) {
   if (!ctx || !n) return OCTL_E_INVALID;
   *n = ctx->routed_n;

@@ -33,3 +33,79 @@ def test_sharded_grid_single_rank_through_rccl(monkeypatch):
     np.random.seed(0)
     grid.map_leaf_points_cuda_ransac()
     assert got == (grid.n_nodes(0), grid.n_leaves(0), grid.n_points(0))
+
+
+def test_route_ahead_on_a_second_context(monkeypatch):
+    """bench.py routes step i+1 on a second context (own stream + communicator, second host
+    thread) while step i is computed: the cloud routed there, handed over with
+    octl_forest_add_pose_routed_from, must build the same forest as a direct insert."""
+    import ctypes as C
+    import threading
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+
+    monkeypatch.setenv("OCTL_ROUTE_SELF_SENDRECV", "1")
+    ctx, rctx = nat.get_context(), nat.Context(0)
+    lib = ctx.lib
+    uid = (C.c_uint8 * nat.UNIQUE_ID_BYTES)()
+    rctx.check(lib.octl_comm_unique_id(C.cast(uid, C.c_void_p)))
+    rctx.check(lib.octl_comm_init(rctx.handle, 1, 0, C.cast(uid, C.c_void_p)))
+    corner = np.zeros(3)
+    clouds = [np.ascontiguousarray(synthetic.planar_cloud(60_000, (4, 4, 4), seed=2, stream=s)) for s in range(3)]
+    d_xyz = []
+    for c in clouds:
+        p = C.c_void_p()
+        ctx.check(lib.octl_dev_alloc(ctx.handle, c.nbytes, C.byref(p)))
+        ctx.check(lib.octl_dev_upload(ctx.handle, p, nat.ptr(c), c.nbytes))
+        d_xyz.append(p)
+    fh, fref = C.c_void_p(), C.c_void_p()
+    ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(corner), 1.0, C.byref(fh)))
+    ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(corner), 1.0, C.byref(fref)))
+    info, iref, slot, n_recv = nat.BuildInfo(), nat.BuildInfo(), C.c_int32(0), C.c_int64(0)
+    routed, free, errors = threading.Event(), threading.Event(), []
+    free.set()
+
+    def router():
+        try:
+            for p, c in zip(d_xyz, clouds):
+                free.wait()
+                free.clear()
+                rctx.check(lib.octl_route_points(rctx.handle, p, None, len(c), 0, nat.ptr(corner), 1.0,
+                                                 C.byref(n_recv), None))
+                routed.set()
+        except BaseException as exc:  # pragma: no cover
+            errors.append(exc)
+            routed.set()
+
+    th = threading.Thread(target=router)
+    th.start()
+    try:
+        for p, c in zip(d_xyz, clouds):
+            routed.wait()
+            routed.clear()
+            assert not errors, errors
+            assert n_recv.value == len(c)
+            ctx.check(lib.octl_forest_clear(fh))
+            ctx.check(lib.octl_forest_add_pose_routed_from(fh, rctx.handle, C.byref(slot)))
+            ctx.sync()
+            free.set()
+            ctx.check(lib.octl_forest_build(fh, 32, None, 0, 0, 0, C.byref(info)))
+            ctx.check(lib.octl_forest_clear(fref))
+            ctx.check(lib.octl_forest_add_pose_device(fref, p, len(c), C.byref(slot)))
+            ctx.check(lib.octl_forest_build(fref, 32, None, 0, 0, 0, C.byref(iref)))
+            assert (info.n_points, info.n_voxels, info.n_nodes, info.n_blocks) == (
+                iref.n_points, iref.n_voxels, iref.n_nodes, iref.n_blocks)
+            a, b = np.empty((len(c), 3)), np.empty((len(c), 3))
+            ctx.check(lib.octl_forest_get_points(fh, 0, len(c), nat.ptr(a)))
+            ctx.check(lib.octl_forest_get_points(fref, 0, len(c), nat.ptr(b)))
+            assert np.array_equal(a, b)
+    finally:
+        free.set()
+        th.join()
+        lib.octl_forest_destroy(fh)
+        lib.octl_forest_destroy(fref)
+        for p in d_xyz:
+            lib.octl_dev_free(ctx.handle, p)
+        lib.octl_comm_destroy(rctx.handle)
+        rctx.close()
