@@ -239,6 +239,12 @@ int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot);
 int octl_forest_add_pose_routed_from(octl_forest* f, octl_ctx* route_ctx, int32_t* slot);
 /* global indices of the routed cloud of the last octl_route_points call (n_recv) i64        */
 int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n);
+/* Test hook: the communicator-independent half of octl_route_points for ANY number of ranks -
+ * destination of every point (host cloud in), per-destination counts [n_ranks], and the packed
+ * send buffers (points and global indices stably partitioned by destination).                */
+int octl_debug_route_partition(octl_ctx* ctx, const double* xyz, int64_t n, int64_t index_base,
+                               double L, int32_t n_ranks, int64_t* counts, double* xyz_out,
+                               int64_t* gidx_out);
 /* sum-all-reduce of small int64 vectors (counters) over the communicator                   */
 int octl_comm_allreduce_i64(octl_ctx* ctx, int64_t* inout_host, int32_t n);
 

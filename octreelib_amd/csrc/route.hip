@@ -119,6 +119,56 @@ __global__ __launch_bounds__(256) void k_route_pack(const double* __restrict__ x
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
+// Steps 1-2 of the routing for R destination ranks: destination of every point + counts, stable
+// partition by destination (one radix pass), packed send buffers (xyz, global index) in the
+// context's scratch.  Independent of the communicator (the test hook below runs it for any R).
+static int route_partition(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_dev, int64_t n,
+                           int64_t index_base, double L, int R) {
+  hipStream_t st = ctx->stream;
+  DevBuf* keys = ctx->rt_keys;
+  DevBuf* vals = ctx->rt_vals;
+  DevBuf& hist = ctx->rt_hist;
+  DevBuf& counts_d = ctx->rt_counts;
+  DevBuf& matrix_d = ctx->rt_matrix;
+  DevBuf& send_xyz = ctx->rt_send_xyz;
+  DevBuf& send_gidx = ctx->rt_send_gidx;
+  const int64_t n1 = std::max<int64_t>(n, 1);
+  for (int b = 0; b < 2; ++b) {
+    OCTL_TRY(devbuf_reserve(ctx, keys[b], (size_t)n1 * 8));
+    OCTL_TRY(devbuf_reserve(ctx, vals[b], (size_t)n1 * 4));
+  }
+  OCTL_TRY(devbuf_reserve(ctx, counts_d, (size_t)R * 8 + 16));
+  OCTL_TRY(devbuf_reserve(ctx, matrix_d, (size_t)R * R * 8));
+  uint32_t* err = ctx->small.as<uint32_t>();
+  HIP_TRY(ctx, hipMemsetAsync(counts_d.p, 0, (size_t)R * 8 + 16, st));
+  HIP_TRY(ctx, hipMemsetAsync(err, 0, 4, st));
+  if (n > 0) {
+    KTimer t(ctx, "route_dest");
+    hipLaunchKernelGGL(k_route_dest, dim3((unsigned)ceil_div(n, 2048)), dim3(256), 0, st, xyz_dev, n, L, R,
+                       keys[0].as<uint64_t>(), vals[0].as<uint32_t>(),
+                       counts_d.as<unsigned long long>(), err);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  int sorted = 0;
+  if (n > 0 && R > 1) {
+    uint64_t* kk[2] = {keys[0].as<uint64_t>(), keys[1].as<uint64_t>()};
+    uint32_t* vv[2] = {vals[0].as<uint32_t>(), vals[1].as<uint32_t>()};
+    int bits = 0;
+    while ((1 << bits) < R) ++bits;
+    OCTL_TRY(octl_radix_sort_u64_u32(ctx, kk, vv, n, bits, hist, &sorted));
+  }
+  OCTL_TRY(devbuf_reserve(ctx, send_xyz, (size_t)n1 * 24));
+  OCTL_TRY(devbuf_reserve(ctx, send_gidx, (size_t)n1 * 8));
+  if (n > 0) {
+    KTimer t(ctx, "route_pack");
+    hipLaunchKernelGGL(k_route_pack, dim3(grid_for(n)), dim3(256), 0, st, xyz_dev, gidx_dev,
+                       index_base, (const uint32_t*)vals[sorted].as<uint32_t>(), n,
+                       send_xyz.as<double>(), send_gidx.as<int64_t>());
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return OCTL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -185,10 +235,7 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   hipStream_t st = ctx->stream;
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
 
-  // --- 1. destination + counts ------------------------------------------------------------------
-  DevBuf* keys = ctx->rt_keys;
-  DevBuf* vals = ctx->rt_vals;
-  DevBuf& hist = ctx->rt_hist;
+  // --- 1-2. destinations, counts, stable partition, packed send buffers ---------------------------------
   DevBuf& counts_d = ctx->rt_counts;
   DevBuf& matrix_d = ctx->rt_matrix;
   DevBuf& send_xyz = ctx->rt_send_xyz;
@@ -203,42 +250,8 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
       return rc;           \
     }                      \
   } while (0)
-  const int64_t n1 = std::max<int64_t>(n, 1);
-  for (int b = 0; b < 2; ++b) {
-    RT_TRY(devbuf_reserve(ctx, keys[b], (size_t)n1 * 8));
-    RT_TRY(devbuf_reserve(ctx, vals[b], (size_t)n1 * 4));
-  }
-  RT_TRY(devbuf_reserve(ctx, counts_d, (size_t)R * 8 + 16));
-  RT_TRY(devbuf_reserve(ctx, matrix_d, (size_t)R * R * 8));
+  RT_TRY(route_partition(ctx, xyz_dev, gidx_dev, n, index_base, L, R));
   uint32_t* err = ctx->small.as<uint32_t>();
-  if (hipMemsetAsync(counts_d.p, 0, (size_t)R * 8 + 16, st) != hipSuccess ||
-      hipMemsetAsync(err, 0, 4, st) != hipSuccess) {
-    cleanup();
-    return octl_set_error(ctx, OCTL_E_HIP, "memset failed");
-  }
-  if (n > 0) {
-    KTimer t(ctx, "route_dest");
-    hipLaunchKernelGGL(k_route_dest, dim3((unsigned)ceil_div(n, 2048)), dim3(256), 0, st, xyz_dev, n, L, R,
-                       keys[0].as<uint64_t>(), vals[0].as<uint32_t>(),
-                       counts_d.as<unsigned long long>(), err);
-  }
-  // --- 2. stable partition by destination (one radix pass) ----------------------------------------
-  int sorted = 0;
-  if (n > 0 && R > 1) {
-    uint64_t* kk[2] = {keys[0].as<uint64_t>(), keys[1].as<uint64_t>()};
-    uint32_t* vv[2] = {vals[0].as<uint32_t>(), vals[1].as<uint32_t>()};
-    int bits = 0;
-    while ((1 << bits) < R) ++bits;
-    RT_TRY(octl_radix_sort_u64_u32(ctx, kk, vv, n, bits, hist, &sorted));
-  }
-  RT_TRY(devbuf_reserve(ctx, send_xyz, (size_t)n1 * 24));
-  RT_TRY(devbuf_reserve(ctx, send_gidx, (size_t)n1 * 8));
-  if (n > 0) {
-    KTimer t(ctx, "route_pack");
-    hipLaunchKernelGGL(k_route_pack, dim3(grid_for(n)), dim3(256), 0, st, xyz_dev, gidx_dev,
-                       index_base, (const uint32_t*)vals[sorted].as<uint32_t>(), n,
-                       send_xyz.as<double>(), send_gidx.as<int64_t>());
-  }
   // --- 3. counts exchange -----------------------------------------------------------------------------
   std::vector<int64_t> matrix((size_t)R * R, 0);
   if (use_rccl) {
@@ -367,6 +380,31 @@ int octl_comm_allreduce_i64(octl_ctx* ctx, int64_t* inout_host, int32_t n) {
   HIP_TRY(ctx, hipMemcpyAsync(inout_host, d, (size_t)n * 8, hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return OCTL_OK;
+}
+
+int octl_debug_route_partition(octl_ctx* ctx, const double* xyz, int64_t n, int64_t index_base,
+                               double L, int32_t n_ranks, int64_t* counts, double* xyz_out,
+                               int64_t* gidx_out) {
+  if (!ctx || n < 0 || n_ranks < 1 || n_ranks > 256 || (n > 0 && (!xyz || !xyz_out || !gidx_out)) ||
+      !counts)
+    return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf in;
+  OCTL_TRY(devbuf_reserve(ctx, in, (size_t)std::max<int64_t>(n, 1) * 24));
+  int rc = OCTL_OK;
+  if (n > 0 && hipMemcpyAsync(in.p, xyz, (size_t)n * 24, hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = OCTL_E_HIP;
+  if (rc == OCTL_OK) rc = route_partition(ctx, in.as<double>(), nullptr, n, index_base, L, n_ranks);
+  if (rc == OCTL_OK) {
+    if (hipMemcpyAsync(counts, ctx->rt_counts.p, (size_t)n_ranks * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (n > 0 && (hipMemcpyAsync(xyz_out, ctx->rt_send_xyz.p, (size_t)n * 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                   hipMemcpyAsync(gidx_out, ctx->rt_send_gidx.p, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess)))
+      rc = OCTL_E_HIP;
+  }
+  if (hipStreamSynchronize(st) != hipSuccess) rc = rc == OCTL_OK ? OCTL_E_HIP : rc;
+  devbuf_free(in);
+  return rc == OCTL_E_HIP ? octl_set_error(ctx, rc, "octl_debug_route_partition failed") : rc;
 }
 
 }  // extern "C"

@@ -109,3 +109,49 @@ def test_route_ahead_on_a_second_context(monkeypatch):
             lib.octl_dev_free(ctx.handle, p)
         lib.octl_comm_destroy(rctx.handle)
         rctx.close()
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
+def test_device_partition_for_many_ranks_and_emulated_exchange(n_ranks):
+    """The communicator-independent half of the routing (destination keys, counts, stable partition,
+    packing) for R > 1 ranks on one GPU, against NumPy; then the all-to-all emulated on the host:
+    every virtual rank builds its shard, and the shards add up to the unsharded grid."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+    from octreelib_amd.distributed import voxel_owner_np
+    from octreelib_amd.grid import Grid, GridConfig
+
+    ctx = nat.get_context()
+    lib = ctx.lib
+    L = 1.0
+    clouds = [np.ascontiguousarray(synthetic.planar_cloud(30_000, (6, 5, 4), seed=4, stream=r)) for r in range(n_ranks)]
+    clouds[0][:50] -= 3.0   # negative voxel indices too
+    send = []
+    for r, c in enumerate(clouds):
+        counts = np.zeros(n_ranks, dtype=np.int64)
+        xyz_out, gidx_out = np.empty_like(c), np.empty(len(c), dtype=np.int64)
+        base = 1_000_000 * r
+        ctx.check(lib.octl_debug_route_partition(ctx.handle, nat.ptr(c), len(c), base, L, n_ranks,
+                                                 nat.ptr(counts), nat.ptr(xyz_out), nat.ptr(gidx_out)))
+        owner = voxel_owner_np(np.floor(c / L).astype(np.int64), n_ranks)
+        order = np.argsort(owner, kind="stable")
+        assert np.array_equal(counts, np.bincount(owner, minlength=n_ranks))
+        assert np.array_equal(gidx_out, base + order)           # stable partition by destination
+        assert np.array_equal(xyz_out, c[order])
+        off = np.concatenate(([0], np.cumsum(counts)))
+        send.append([(xyz_out[off[q]:off[q + 1]], gidx_out[off[q]:off[q + 1]]) for q in range(n_ranks)])
+    # emulated all-to-all: rank q receives, in source-rank order, what every rank p packed for it
+    total = np.zeros(3, dtype=np.int64)
+    for q in range(n_ranks):
+        recv = np.vstack([send[p][q][0] for p in range(n_ranks)])
+        assert (voxel_owner_np(np.floor(recv / L).astype(np.int64), n_ranks) == q).all()
+        g = Grid(GridConfig(voxel_edge_length=1))
+        g.insert_points(0, recv)
+        g.subdivide([lambda p: len(p) > 32])
+        total += np.array([g.n_nodes(0), g.n_leaves(0), g.n_points(0)])
+    ref = Grid(GridConfig(voxel_edge_length=1))
+    ref.insert_points(0, np.vstack(clouds))
+    ref.subdivide([lambda p: len(p) > 32])
+    assert total.tolist() == [ref.n_nodes(0), ref.n_leaves(0), ref.n_points(0)]
