@@ -59,10 +59,13 @@ class Octree(OctreeBase, Generic[T]):
             f.subdivide(k)
 
     def subdivide_as(self, other_octree: "Octree"):
-        raise NotImplementedError(
-            "Octree.subdivide_as between two stand-alone octrees is not supported; use "
-            "OctreeManager, which keeps all poses of a cube on one shared scheme"
-        )
+        """octree.py:222-227: split this octree wherever `other_octree` is split (the operation an
+        OctreeManager applies to every pose).  The scheme is copied on the host, every point is
+        placed on the device."""
+        f = self._forest
+        if self._slot is None:
+            self._slot = f.add_pose(np.empty((0, 3)))
+        f.adopt_scheme(other_octree._forest)
 
     # -- queries ------------------------------------------------------------------------
     def get_points(self):

@@ -905,6 +905,53 @@ def test_grid_get_points_follows_voxel_creation_order():
     assert [k for i, k in enumerate(lv) if i == 0 or lv[i - 1] != k] == [a, d, c]
 
 
+def test_octree_subdivide_as_between_stand_alone_octrees_vs_oracle():
+    """Octree.subdivide_as(other) (octree.py:222-227): structure, leaf order (history dependent) and
+    counters against the oracle, incl. a second call with a finer scheme."""
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(12)
+    corner, edge = np.array([0.0, 0.0, 0.0]), np.float64(2)
+    pa = rng.random((3000, 3)) * 2.0
+    pb = np.vstack([rng.random((1500, 3)) * 2.0, 0.3 + rng.random((2500, 3)) * 0.2])
+    a, b = Octree(OctreeConfig(), corner, edge), Octree(OctreeConfig(), corner, edge)
+    oa, ob = onp.OTree(corner, edge), onp.OTree(corner, edge)
+    for t, o, p in ((a, oa, pa), (b, ob, pb)):
+        t.insert_points(p)
+        o.insert_points(p)
+    b.subdivide(crit(100))
+    ob.subdivide(100)
+    a.subdivide(crit(900))          # a has its own coarser history first
+    oa.subdivide(900)
+    a.subdivide_as(b)
+    oa.subdivide_as(ob)
+    ia = index_map(pa)
+    assert_same_leaves(canon_from_list(views_table(a.get_leaf_points(), ia)), canon_from_list(onp.tree_leaf_table(oa)))
+    assert [a.n_nodes, a.n_leaves, a.n_points] == [oa.n_nodes, oa.n_leaves, oa.n_points]
+    assert a.n_nodes == b.n_nodes
+    # a finer scheme from another octree (subdividing b again would change nothing: its root holds
+    # no points any more, octree.py:20-32)
+    b2, ob2 = Octree(OctreeConfig(), corner, edge), onp.OTree(corner, edge)
+    b2.insert_points(pb)
+    ob2.insert_points(pb)
+    b2.subdivide(crit(30))
+    ob2.subdivide(30)
+    assert b2.n_nodes > b.n_nodes
+    a.subdivide_as(b2)
+    oa.subdivide_as(ob2)
+    b, ob = b2, ob2
+    assert_same_leaves(canon_from_list(views_table(a.get_leaf_points(), ia)), canon_from_list(onp.tree_leaf_table(oa)))
+    assert [a.n_nodes, a.n_leaves, a.n_points] == [oa.n_nodes, oa.n_leaves, oa.n_points]
+    # an empty octree takes the structure too
+    c, oc = Octree(OctreeConfig(), corner, edge), onp.OTree(corner, edge)
+    c.subdivide_as(b)
+    oc.subdivide_as(ob)
+    assert [c.n_nodes, c.n_leaves, c.n_points] == [oc.n_nodes, oc.n_leaves, oc.n_points]
+    with pytest.raises(ValueError):
+        Octree(OctreeConfig(), corner + 1.0, edge).subdivide_as(b)
+
+
 def test_forest_is_usable_after_a_failed_subdivide():
     from octreelib_amd.grid import Grid, GridConfig
 
