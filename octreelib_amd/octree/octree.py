@@ -131,7 +131,9 @@ class OctreeNode(OctreeNodeBase):
         self._refresh_cache()
 
     def subdivide_as(self, other):
-        self._tree.subdivide_as(other)
+        """octree.py:34-53: `other` is a node (or an Octree) over the same cube."""
+        self._tree.subdivide_as(other._tree if isinstance(other, OctreeNode) else other)
+        self._refresh_cache()
 
     def get_points(self):
         return self._tree.get_points()

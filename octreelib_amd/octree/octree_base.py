@@ -50,11 +50,22 @@ class _TreeOps(ABC):
 
 
 class OctreeNodeBase(Voxel, _TreeOps):
+    def __init__(self, corner_min, edge_length, octree_cached_leaves):
+        """octree_base.py:36-49: a node registers itself in its octree's list of leaves."""
+        Voxel.__init__(self, corner_min, edge_length)
+        self._cached_leaves = octree_cached_leaves
+        self._cached_leaves.append(self)
+
     @abstractmethod
     def get_leaf_points(self): ...
 
 
 class OctreeBase(Voxel, _TreeOps):
+    def __init__(self, octree_config, corner_min, edge_length):
+        """octree_base.py:136-150."""
+        Voxel.__init__(self, corner_min, edge_length)
+        self._config = octree_config
+
     @abstractmethod
     def get_leaf_points(self, non_empty: bool): ...
 
