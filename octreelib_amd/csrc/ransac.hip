@@ -16,9 +16,11 @@
 //
 // Mapping on CDNA4: one workgroup of W waves per (leaf, pose) block, hypotheses on the lanes
 // (HPL per lane), the block's points broadcast to all lanes through wave-uniform loads.  The
-// scoring loop is FP64-VALU bound (3 mul + 3 add + compare + count per point x hypothesis);
+// kernel is VALU bound: 1024 plane fits per block (~265 f64-dominated instructions each) and
+// H x n distance tests, which are decided on an f32 screen wherever a rigorous error bound
+// allows and recounted in the reference's f64 sequence otherwise (exact counts either way).
 // MFMA is not used: the f64 evaluation order (and the f32-rounded plane) must be reproduced
-// exactly, and the product is 4 deep.
+// exactly, and the product is 4 deep; an f32 MFMA screen was measured slower.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -218,9 +220,6 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #define RS_BIG_HPL (1024 / RS_BIG_THREADS)
 #ifndef RS_PER_CU
 #define RS_PER_CU 64
-#endif
-#ifndef RS_SCORE_UNROLL
-#define RS_SCORE_UNROLL 4
 #endif
 #define RS_PRAGMA_(x) _Pragma(#x)
 #define RS_PRAGMA(x) RS_PRAGMA_(x)
