@@ -967,3 +967,29 @@ def test_forest_is_usable_after_a_failed_subdivide():
     assert [grid.n_leaves(0), grid.n_points(0), grid.n_nodes(0)] == [1, 504, 1]
     grid.subdivide(crit(100))
     assert grid.n_points(0) == 504 and grid.n_leaves(0) > 1
+
+
+def test_integration_md_binding_stub_runs():
+    """The reference-side ctypes binding shown in INTEGRATION.md (Option B) is executed verbatim
+    (only the library path is made absolute) and must return the oracle's mask."""
+    import os
+    import re
+
+    from octreelib_amd import _native as nat
+    from oracle import ransac_np as rnp
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# octreelib/ransac/hip_ransac.py.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("liboctree_hip.so")', f'C.CDLL({nat.lib_path()!r})')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:hip_ransac.py", "exec"), ns)
+    rng = np.random.default_rng(2)
+    sizes = rng.integers(0, 50, 80).astype(np.int32)
+    cloud = rng.random((int(sizes.sum()), 3))
+    cloud[:, 2] = 0.3 * cloud[:, 0] + rng.normal(0, 0.004, len(cloud))
+    np.random.seed(42)
+    op = ns["HipRansac"](threshold=0.01, hypotheses_number=512, initial_points_number=6)
+    mask = op.evaluate(cloud, sizes)
+    assert mask.dtype == np.bool_ and mask.shape == (len(cloud),)
+    assert np.array_equal(mask, rnp.evaluate(cloud, sizes, op._table, 0.01))
