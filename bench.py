@@ -6,20 +6,29 @@ One "step" = one pass of the path over one synthetic cloud that is already resid
     insert (top-level voxel bucketing)  -> Grid.insert_points
     subdivide, count criterion len > 64 -> Grid.subdivide
     per-leaf RANSAC (1024 hyp., k = 6)  -> Grid.map_leaf_points_cuda_ransac (incl. apply_mask)
-through the C ABI of liboctree_hip.so.  With N > 1 ranks (one process per GPU, launched by
-torch.distributed.run) every rank holds its own 10 M points of one larger scene, the grid is
-sharded by top-level voxel and one RCCL all-to-all over xGMI routes the points to their owners
-inside the step (weak scaling).
+through the C ABI of liboctree_hip.so.
+
+N = 1 (default): BASELINE config 3 - 10 M planar points over 32^3 voxels of 1 m.
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (through
+torch.distributed.run, BEFORE anything in this process touches a GPU); launched under torchrun
+(WORLD_SIZE in the environment) it is one of the ranks.  Every rank holds its own part of one
+larger scene, the grid is sharded by top-level voxel and one RCCL all-to-all over xGMI routes the
+points to their owners inside the step (weak scaling).  Points per rank: 125 M at N = 8 - BASELINE
+config 5, 10^9 points over [0,128)^3 - otherwise 10 M (`--points-per-rank` overrides; at N = 8 the
+10 M/rank point of the weak-scaling series is measured as well and reported under `secondary`).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
-kernel, live hipEvent timings) and `cpu_baseline` (the NumPy port of the reference's algorithm,
-timed on this box's host on a bounded sample of the same workload).
+kernel, live hipEvent timings), `roofline_build` (dominant streaming kernel of insert+subdivide)
+and `cpu_baseline` (the NumPy port of the reference's algorithm, timed on this box's host on a
+bounded sample of the same workload).
 """
 
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,18 +37,23 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from octreelib_amd import _native as nat  # noqa: E402
+from octreelib_amd import _native as nat  # noqa: E402  (loading the library does not touch the GPU)
 from octreelib_amd import synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector FP64, FMA counted as 2 flops
 K_SPLIT = 64
 H, KPTS, THRESHOLD = 1024, 6, 0.01
+C5_POINTS_PER_RANK = 125_000_000   # BASELINE config 5: 10^9 points over 8 ranks
+GEN_CHUNK = 10_000_000             # host-side generation granularity (bounds host memory)
 
 
-def scene_dims(n_ranks: int):
-    """32768 voxels of 1 m per rank: the extent doubles along z, y, x in turn."""
-    d = [32, 32, 32]
+def scene_dims(n_ranks: int, dense: bool):
+    """Voxels of 1 m per rank: 32^3 at ~305 points per voxel (10 M points per rank, BASELINE
+    config 2/3) or 64^3 at ~477 (125 M per rank: at 8 ranks the [0,128)^3 scene of config 5).
+    The extent doubles along z, y, x in turn with the number of ranks."""
+    s = 64 if dense else 32
+    d = [s, s, s]
     a = 2
     r = n_ranks
     while r > 1:
@@ -95,25 +109,229 @@ class stdout_to_stderr:
         os.close(self._saved)
 
 
-def main():
+def visible_gpus() -> int:
+    """Number of HIP devices, counted in a CHILD process: this one must stay clear of the GPU
+    until it has started its ranks."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from octreelib_amd import _native as n; "
+            "c = C.c_int(0); n.load().octl_device_count(C.byref(c)); print(c.value)" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (children of this process,
+    one per GPU, rendezvous on 127.0.0.1) and pass their exit code on."""
+    have = visible_gpus()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs, this machine shows {have}; nothing was run",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=10_000_000, help="points per rank")
+    ap.add_argument("--points-per-rank", "--points", dest="points", type=int, default=None,
+                    help="default: 125 M at --gpus 8 (BASELINE config 5), else 10 M")
     ap.add_argument("--cloud", choices=["planar", "uniform"], default="planar")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-overlap", action="store_true",
                     help="route inside the step on the compute stream instead of one step ahead on a "
                          "second context (A/B)")
     ap.add_argument("--scene", type=int, nargs=3, default=None, metavar=("X", "Y", "Z"),
-                    help="scene extent in 1 m voxels (experiments; default 32768 voxels per rank)")
+                    help="scene extent in 1 m voxels (experiments)")
     ap.add_argument("--k-split", type=int, default=K_SPLIT,
                     help="count criterion len > K (experiments; the benchmarked workload is K = 64)")
     ap.add_argument("--route", action="store_true",
                     help="rehearse the multi-GPU step on one GPU: 1-rank RCCL communicator, the "
                          "local part forced through AllGather + Send/Recv")
-    args = ap.parse_args()
+    ap.add_argument("--shard-of", type=int, default=0, metavar="R",
+                    help="one GPU: generate only the points rank 0 of R would own after routing (a "
+                         "rank's shard of the R-rank scene, e.g. --shard-of 8 --points-per-rank 125000000 "
+                         "= one rank of BASELINE config 5)")
+    return ap.parse_args()
+
+
+class Workload:
+    """One rank's cloud in HBM + the forest it is built into + the step functions."""
+
+    def __init__(self, ctx, rctx, rank, world, n_local, dims, cloud, k_split, route, overlap, shard_of=0):
+        self.ctx, self.rctx, self.lib = ctx, rctx, ctx.lib
+        self.rank, self.world, self.n_local, self.dims = rank, world, n_local, dims
+        self.k_split, self.route, self.overlap = k_split, route, overlap
+        lib = self.lib
+        self.d_xyz = C.c_void_p()
+        ctx.check(lib.octl_dev_alloc(ctx.handle, n_local * 24, C.byref(self.d_xyz)))
+        self.host_pts = None
+        done = 0
+        chunk_id = 0
+        while done < n_local:
+            m = min(GEN_CHUNK, n_local - done)
+            stream = rank if n_local <= GEN_CHUNK else rank * 4096 + chunk_id
+            if shard_of > 1:
+                pts = shard_cloud(m, dims, cloud, stream, shard_of)
+            elif cloud == "planar":
+                pts = synthetic.planar_cloud(m, dims, seed=1, stream=stream)
+            elif cloud == "uniform32":   # BASELINE C2-U / C3-U: default_rng(0).random((n,3)) * 32
+                pts = np.random.default_rng(0).random((m, 3)) * 32.0
+            else:
+                pts = synthetic.uniform_cloud(m, dims, seed=1000 + stream)
+            pts = np.ascontiguousarray(pts)
+            ctx.check(lib.octl_dev_upload(ctx.handle, C.c_void_p(self.d_xyz.value + done * 24), nat.ptr(pts),
+                                          pts.nbytes))
+            if n_local <= GEN_CHUNK:
+                self.host_pts = pts
+            done += m
+            chunk_id += 1
+        self.corner = np.zeros(3)
+        self.fh = C.c_void_p()
+        ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(self.corner), 1.0, C.byref(self.fh)))
+        self.info = nat.BuildInfo()
+        self.e0 = np.zeros(1, dtype=np.int32)
+        self.n_alive = C.c_int64(0)
+        self.n_recv = C.c_int64(n_local)
+        self.slot = C.c_int32(0)
+        np.random.seed(0)
+        self.table = np.ascontiguousarray(np.random.random((H, KPTS)))
+
+    def route_once(self):
+        self.rctx.check(self.lib.octl_route_points(self.rctx.handle, self.d_xyz, None, self.n_local,
+                                                   self.rank * self.n_local, nat.ptr(self.corner), 1.0,
+                                                   C.byref(self.n_recv), None))
+
+    def build(self):
+        self.ctx.check(self.lib.octl_forest_build(self.fh, self.k_split, None, 0, 0, 0, C.byref(self.info)))
+
+    def compute(self):
+        lib, ctx = self.lib, self.ctx
+        self.build()
+        ctx.check(lib.octl_forest_ransac_all(self.fh, 10, nat.ptr(self.e0), 1, nat.ptr(self.table), H, KPTS,
+                                             THRESHOLD))
+        ctx.check(lib.octl_forest_apply_mask(self.fh, C.byref(self.n_alive)))
+
+    def insert(self):
+        lib, ctx = self.lib, self.ctx
+        ctx.check(lib.octl_forest_clear(self.fh))
+        if self.route:
+            self.route_once()
+            ctx.check(lib.octl_forest_add_pose_routed(self.fh, C.byref(self.slot)))
+        else:
+            ctx.check(lib.octl_forest_add_pose_device(self.fh, self.d_xyz, self.n_local, C.byref(self.slot)))
+
+    def step(self):
+        self.insert()
+        self.compute()
+
+    def step_build_only(self):
+        self.insert()
+        self.build()
+
+    def step_from_host(self):
+        lib, ctx = self.lib, self.ctx
+        ctx.check(lib.octl_forest_clear(self.fh))
+        ctx.check(lib.octl_forest_add_pose(self.fh, nat.ptr(self.host_pts), self.n_local, C.byref(self.slot)))
+        self.compute()
+
+    def run_overlapped(self, count):
+        """`count` steps; the cloud of step i+1 is routed (second context, second host thread; the
+        library calls release the GIL) while step i is computed.  Starts and ends drained."""
+        import threading
+
+        lib, ctx, rctx = self.lib, self.ctx, self.rctx
+        routed, free, failed = threading.Event(), threading.Event(), []
+        free.set()
+
+        def router():
+            try:
+                for _ in range(count):
+                    free.wait()
+                    free.clear()
+                    self.route_once()
+                    routed.set()
+            except BaseException as exc:  # surfaces in the main thread
+                failed.append(exc)
+                routed.set()
+
+        th = threading.Thread(target=router, name="route-ahead")
+        th.start()
+        try:
+            for _ in range(count):
+                routed.wait()
+                routed.clear()
+                if failed:
+                    raise failed[0]
+                ctx.check(lib.octl_forest_clear(self.fh))
+                ctx.check(lib.octl_forest_add_pose_routed_from(self.fh, rctx.handle, C.byref(self.slot)))
+                ctx.sync()   # the routed buffer has been copied into the forest: free for the next cloud
+                free.set()
+                self.compute()
+        finally:
+            free.set()
+            th.join()
+        if failed:
+            raise failed[0]
+
+    def run(self, count):
+        if count <= 0:
+            return
+        if self.overlap:
+            self.run_overlapped(count)
+        else:
+            for _ in range(count):
+                self.step()
+
+    def leaf_sizes(self):
+        """Block sizes of the current build (before RANSAC), for the algorithmic flop count."""
+        nb = C.c_int64(0)
+        self.ctx.check(self.lib.octl_forest_get_blocks(self.fh, 0, None, None, None, None, C.byref(nb)))
+        sizes = np.empty(nb.value, dtype=np.int32)
+        self.ctx.check(self.lib.octl_forest_get_blocks(self.fh, nb.value, None, None, None, nat.ptr(sizes),
+                                                       C.byref(nb)))
+        return sizes
+
+    def close(self):
+        self.lib.octl_forest_destroy(self.fh)
+        self.ctx.check(self.lib.octl_dev_free(self.ctx.handle, self.d_xyz))
+
+
+def shard_cloud(m, dims, cloud, stream, n_ranks):
+    """m points of the scene that all lie in voxels owned by rank 0 of n_ranks: what one rank holds
+    after the all-to-all.  Points are drawn over the whole scene and those of other owners are
+    rejected, so the density per owned voxel is the scene's."""
+    from octreelib_amd.distributed import voxel_indices_np, voxel_owner_np
+
+    out, have, sub = [], 0, 0
+    while have < m:
+        want = int((m - have) * n_ranks * 1.02) + 1024
+        want = min(want, 4 * GEN_CHUNK)
+        s = stream * 64 + sub
+        pts = (synthetic.planar_cloud(want, dims, seed=1, stream=s) if cloud == "planar"
+               else synthetic.uniform_cloud(want, dims, seed=1000 + s))
+        keep = pts[voxel_owner_np(voxel_indices_np(pts, 1.0), n_ranks) == 0]
+        out.append(keep[: m - have])
+        have += len(out[-1])
+        sub += 1
+    return np.vstack(out)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,6 +343,11 @@ def main():
         dist.init_process_group(backend="gloo")
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    n_local = args.points if args.points else (C5_POINTS_PER_RANK if world == 8 else 10_000_000)
+    dense = n_local > 50_000_000
+    scene_ranks = args.shard_of if (world == 1 and args.shard_of > 1) else world
+    dims = tuple(args.scene) if args.scene else scene_dims(scene_ranks, dense)
 
     ctx = nat.Context(local_rank)
     lib = ctx.lib
@@ -156,94 +379,6 @@ def main():
             probe = np.zeros(1, dtype=np.int64)
             rctx.check(lib.octl_comm_allreduce_i64(rctx.handle, nat.ptr(probe), 1))
 
-    dims = tuple(args.scene) if args.scene else scene_dims(world)
-    n_local = args.points
-    if args.cloud == "planar":
-        pts = synthetic.planar_cloud(n_local, dims, seed=1, stream=rank)
-    else:
-        pts = synthetic.uniform_cloud(n_local, dims, seed=rank)
-    pts = np.ascontiguousarray(pts)
-    np.random.seed(0)
-    table = np.ascontiguousarray(np.random.random((H, KPTS)))
-
-    # inputs resident in HBM before the timed region
-    d_xyz = C.c_void_p()
-    ctx.check(lib.octl_dev_alloc(ctx.handle, pts.nbytes, C.byref(d_xyz)))
-    ctx.check(lib.octl_dev_upload(ctx.handle, d_xyz, nat.ptr(pts), pts.nbytes))
-    corner = np.zeros(3)
-    fh = C.c_void_p()
-    ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(corner), 1.0, C.byref(fh)))
-    info = nat.BuildInfo()
-    e0 = np.zeros(1, dtype=np.int32)
-    n_alive = C.c_int64(0)
-    n_recv = C.c_int64(n_local)
-    slot = C.c_int32(0)
-
-    def route_once():
-        rctx.check(lib.octl_route_points(rctx.handle, d_xyz, None, n_local, rank * n_local,
-                                         nat.ptr(corner), 1.0, C.byref(n_recv), None))
-
-    def compute():
-        ctx.check(lib.octl_forest_build(fh, args.k_split, None, 0, 0, 0, C.byref(info)))
-        ctx.check(lib.octl_forest_ransac_all(fh, 10, nat.ptr(e0), 1, nat.ptr(table), H, KPTS, THRESHOLD))
-        ctx.check(lib.octl_forest_apply_mask(fh, C.byref(n_alive)))
-
-    def step():
-        ctx.check(lib.octl_forest_clear(fh))
-        if route:
-            route_once()
-            ctx.check(lib.octl_forest_add_pose_routed(fh, C.byref(slot)))
-        else:
-            ctx.check(lib.octl_forest_add_pose_device(fh, d_xyz, n_local, C.byref(slot)))
-        compute()
-
-    def run_overlapped(count):
-        """`count` steps; the cloud of step i+1 is routed (second context, second host thread; the
-        library calls release the GIL) while step i is computed.  Starts and ends drained."""
-        import threading
-
-        routed, free, failed = threading.Event(), threading.Event(), []
-        free.set()
-
-        def router():
-            try:
-                for _ in range(count):
-                    free.wait()
-                    free.clear()
-                    route_once()
-                    routed.set()
-            except BaseException as exc:  # surfaces in the main thread
-                failed.append(exc)
-                routed.set()
-
-        th = threading.Thread(target=router, name="route-ahead")
-        th.start()
-        try:
-            for _ in range(count):
-                routed.wait()
-                routed.clear()
-                if failed:
-                    raise failed[0]
-                ctx.check(lib.octl_forest_clear(fh))
-                ctx.check(lib.octl_forest_add_pose_routed_from(fh, rctx.handle, C.byref(slot)))
-                ctx.sync()   # the routed buffer has been copied into the forest: free for the next cloud
-                free.set()
-                compute()
-        finally:
-            free.set()
-            th.join()
-        if failed:
-            raise failed[0]
-
-    def run(count):
-        if count <= 0:
-            return
-        if overlap:
-            run_overlapped(count)
-        else:
-            for _ in range(count):
-                step()
-
     def barrier():
         ctx.sync()
         if rctx is not ctx:
@@ -251,13 +386,34 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    run(args.warmup)
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
+        import torch
+
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(fn, reps=3):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        return max_over_ranks((time.perf_counter() - t1) / reps)
+
+    wl = Workload(ctx, rctx, rank, world, n_local, dims, args.cloud, args.k_split, route, overlap,
+                  shard_of=args.shard_of if world == 1 else 0)
+
+    # ---- the timed region: W warm-up steps, then exactly K steps between barriers ----------------
+    wl.run(args.warmup)
     ctx.set_profiling(True)
     if rctx is not ctx:
         rctx.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    run(args.steps)
+    wl.run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     timings = ctx.timings()
@@ -265,48 +421,85 @@ def main():
     if rctx is not ctx:
         timings.update(rctx.timings())
         rctx.set_profiling(False)
-    if dist is not None:
-        import torch
+    dt = max_over_ranks(dt)
+    info, n_alive_after = wl.info, int(wl.n_alive.value)
+    leaves, nodes, levels = int(info.n_blocks), int(info.n_nodes), int(info.n_levels)
 
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- secondary figures (outside the timed region) --------------------------------------------
+    secondary = {}
+    flops = None
+    leaves_evaluated = None
+    if not args.no_secondary:
+        if world == 1 and not route:
+            ms = timed(wl.step_build_only) * 1e3
+            secondary["insert_subdivide_only"] = {
+                "ms": ms, "Mpoints_per_s": n_local / ms / 1e3,
+                "hbm_read_roofline_frac": 24.0 * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "BASELINE config 2: insert + subdivide alone, algorithmic 24 B/point",
+            }
+            sizes = wl.leaf_sizes()
+            fit = sizes[sizes >= KPTS].astype(np.int64)
+            leaves_evaluated = int(len(fit))
+            flops = float(H * (20.0 * KPTS * len(fit) + 6.0 * fit.sum()) + 6.0 * fit.sum())
+            if wl.host_pts is not None:
+                ms = timed(wl.step_from_host) * 1e3
+                secondary["pcie_inclusive"] = {
+                    "ms": ms, "Mpoints_per_s": n_local / ms / 1e3,
+                    "note": "same step, cloud uploaded from pageable host memory inside the step",
+                }
+            wl.step()  # leave the forest in the state the report describes
+        if world == 1 and not route and n_local == 10_000_000 and args.cloud == "planar" and not args.shard_of:
+            # the same step through the drop-in Python classes, cloud handed over from the host
+            from octreelib_amd import MaxPoints
+            from octreelib_amd.grid import Grid, GridConfig
 
-    # secondary figures (untimed region of the contract): insert+subdivide alone (BASELINE config 2)
-    # and the same step fed from pageable host memory (PCIe inclusive)
-    def timed(fn, reps=3):
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        barrier()
-        return (time.perf_counter() - t1) / reps
+            def api_step():
+                grid = Grid(GridConfig(voxel_edge_length=1))
+                grid.insert_points(0, wl.host_pts)
+                grid.subdivide([MaxPoints(args.k_split)])
+                np.random.seed(0)
+                grid.map_leaf_points_cuda_ransac()
+                kept = grid.n_points(0)
+                grid._forest.close()
+                return kept
 
-    def step_build_only():
-        ctx.check(lib.octl_forest_clear(fh))
-        ctx.check(lib.octl_forest_add_pose_device(fh, d_xyz, n_local, C.byref(slot)))
-        ctx.check(lib.octl_forest_build(fh, args.k_split, None, 0, 0, 0, C.byref(info)))
-
-    def step_from_host():
-        ctx.check(lib.octl_forest_clear(fh))
-        ctx.check(lib.octl_forest_add_pose(fh, nat.ptr(pts), n_local, C.byref(slot)))
-        ctx.check(lib.octl_forest_build(fh, args.k_split, None, 0, 0, 0, C.byref(info)))
-        ctx.check(lib.octl_forest_ransac_all(fh, 10, nat.ptr(e0), 1, nat.ptr(table), H, KPTS, THRESHOLD))
-        ctx.check(lib.octl_forest_apply_mask(fh, C.byref(n_alive)))
-
-    extra = {}
-    if world == 1 and not route:
-        extra["insert_subdivide_only_ms"] = timed(step_build_only) * 1e3
-        # leaf sizes before RANSAC, for the algorithmic flop count of SURVEY.md 8(d)
-        nb = C.c_int64(0)
-        ctx.check(lib.octl_forest_get_blocks(fh, 0, None, None, None, None, C.byref(nb)))
-        sizes = np.empty(nb.value, dtype=np.int32)
-        ctx.check(lib.octl_forest_get_blocks(fh, nb.value, None, None, None, nat.ptr(sizes), C.byref(nb)))
-        fit = sizes[sizes >= KPTS].astype(np.int64)
-        extra["leaves_evaluated"] = int(len(fit))
-        extra["ransac_flops"] = float(H * (20.0 * KPTS * len(fit) + 6.0 * fit.sum()) + 6.0 * fit.sum())
-        extra["pcie_inclusive_ms"] = timed(step_from_host) * 1e3
-        step()  # leave the forest in the state the report describes
+            api_step()
+            t1 = time.perf_counter()
+            kept = api_step()
+            ms = (time.perf_counter() - t1) * 1e3
+            secondary["api_inclusive"] = {
+                "ms": ms, "Mpoints_per_s": n_local / ms / 1e3, "points_after_ransac": int(kept),
+                "note": "Grid(GridConfig(1)).insert_points(host cloud) + subdivide([MaxPoints(64)]) + "
+                        "map_leaf_points_cuda_ransac() + n_points(), a fresh Grid per step",
+            }
+            # BASELINE C2-U / C3-U: uniform cloud default_rng(0).random((10 M, 3)) * 32
+            uw = Workload(ctx, ctx, 0, 1, n_local, (32, 32, 32), "uniform32", args.k_split, False, False)
+            uw.step()
+            ms_full = timed(uw.step) * 1e3
+            ms_build = timed(uw.step_build_only) * 1e3
+            secondary["uniform_scene"] = {
+                "ms": ms_full, "Mpoints_per_s": n_local / ms_full / 1e3,
+                "insert_subdivide_only_ms": ms_build,
+                "insert_subdivide_only_Mpoints_per_s": n_local / ms_build / 1e3,
+                "leaves": int(uw.info.n_blocks),
+                "note": "BASELINE C2-U / C3-U: np.random.default_rng(0).random((10 M, 3)) * 32, same step",
+            }
+            uw.close()
+        if world == 8 and n_local != 10_000_000 and not args.scene:
+            # the 10 M points per rank point of the weak-scaling series (the N = 1 line's per-rank load)
+            w10 = Workload(ctx, rctx, rank, world, 10_000_000, scene_dims(world, False), args.cloud,
+                           args.k_split, route, overlap)
+            w10.run(2)
+            barrier()
+            t1 = time.perf_counter()
+            w10.run(10)
+            barrier()
+            d10 = max_over_ranks(time.perf_counter() - t1)
+            secondary["weak_scaling_10M_per_rank"] = {
+                "ms_per_step": d10 / 10 * 1e3, "Mpoints_per_s": 10_000_000 * world * 10 / d10 / 1e6,
+                "note": "same step with 10 M points per rank (the per-rank load of the N = 1 line)",
+            }
+            w10.close()
 
     # copy bandwidth of this box (reported beside the datasheet peak)
     bw = C.c_double(0.0)
@@ -319,28 +512,43 @@ def main():
         kern = {k: {"ms_avg": v[0] / max(v[1], 1), "launches_per_step": v[1] / args.steps,
                     "ms_per_step": v[0] / args.steps} for k, v in timings.items()}
         dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        n_step = int(n_recv.value) if route else n_local
+        n_step = int(wl.n_recv.value) if route else n_local
         # algorithmic HBM reads: 24 B/pt to place a point, 24 B/pt more (leaf ordered) for RANSAC
-        alg_bytes = {"ransac": 24.0 * n_step}
-        dom_bytes = alg_bytes.get(dom, 24.0 * n_step)
+        dom_bytes = 24.0 * n_step
         dom_launch_ms = kern[dom]["ms_avg"]
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied there)
-        traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["kernels"]
-            t = prof.get("k_" + dom)
-            if t and args.points == 10_000_000 and args.cloud == "planar" and world == 1:
-                traffic = t["fetch_bytes_corrected"] + t["write_bytes"]
-        except Exception:
-            traffic = None
         achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
         device_ms = sum(k["ms_per_step"] for k in kern.values())
         ransac_ms = kern.get("ransac", {}).get("ms_per_step", 0.0)
         # algorithmic f64 flops of the RANSAC kernel: per leaf with n >= k points
         # H * (20 k + 6 n) for plane fits + scoring, + 6 n for the final mask
-        flops = extra.get("ransac_flops", 6.0 * H * n_step)
+        if flops is None:
+            flops = 6.0 * H * n_step
         valu_tflops = flops / (ransac_ms * 1e-3) / 1e12 if ransac_ms else None
+        # dominant STREAMING kernel of insert + subdivide: algorithmic bytes per point it must move
+        # (DESIGN.md section 4), live hipEvent time
+        build_alg = BUILD_ALG_BYTES
+        build_k = [k for k in kern if k in build_alg]
+        roofline_build = None
+        if build_k:
+            bdom = max(build_k, key=lambda k: kern[k]["ms_per_step"])
+            b_bytes = build_alg[bdom] * n_step
+            b_ms = kern[bdom]["ms_per_step"]
+            roofline_build = {
+                "kernel": bdom, "bound": "hbm", "achieved": b_bytes / (b_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ms_per_step": b_ms, "algorithmic_bytes_per_step": b_bytes,
+                "algorithmic_bytes_per_point": build_alg[bdom], "traffic": None,
+                "traffic_profile": "profiles/r02_hbm_traffic.json",
+                "all": {k: {"ms_per_step": kern[k]["ms_per_step"],
+                            "GBs": build_alg[k] * n_step / (kern[k]["ms_per_step"] * 1e-3) / 1e9}
+                        for k in build_k if kern[k]["ms_per_step"] > 0},
+            }
+        if dense and world == 8:
+            what = "BASELINE config 5: 10^9 points, "
+        elif world == 1 and n_local == 10_000_000 and not args.shard_of:
+            what = "BASELINE config 3: "
+        else:
+            what = ""
         out = {
             "metric": "Mpoints/s insert+subdivide+RANSAC",
             "value": value,
@@ -355,19 +563,20 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"Grid 1 m voxels, {n_local} {args.cloud} points per GPU "
+                "workload": what + f"Grid 1 m voxels, {n_local} {args.cloud} points per GPU "
                             f"(scene {dims[0]}x{dims[1]}x{dims[2]} voxels), insert + subdivide(len>{args.k_split}) + "
                             f"map_leaf_points_cuda_ransac(H=1024, k=6, thr=0.01, poses_per_batch=10) "
                             f"incl. apply_mask"
                             + (", sharded by top-level voxel with one RCCL all-to-all" if world > 1 else "")
+                            + (f", one rank's shard of a {args.shard_of}-rank scene" if args.shard_of > 1 else "")
                             + (" routed one step ahead on a second stream" if overlap else ""),
                 "points_per_gpu": n_local,
                 "K": args.k_split,
                 "hypotheses": H,
-                "leaves": int(info.n_blocks),
-                "nodes": int(info.n_nodes),
-                "levels": int(info.n_levels),
-                "points_after_ransac": int(n_alive.value),
+                "leaves": leaves,
+                "nodes": nodes,
+                "levels": levels,
+                "points_after_ransac": n_alive_after,
             },
             "roofline": {
                 "kernel": dom,
@@ -376,10 +585,13 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": None,
+                "traffic_profile": "profiles/r02_hbm_traffic.json (rocprofv3 --pmc passes of this command; "
+                                   "not measured by the run that prints this line)",
                 "launch_ms": dom_launch_ms,
                 "algorithmic_bytes_per_launch": dom_bytes,
-                "note": "the RANSAC scoring kernel is FP64-VALU bound, not HBM bound: see roofline_valu",
+                "note": "the RANSAC scoring kernel is FP64-VALU bound, not HBM bound: see roofline_valu; "
+                        "the streaming kernels of insert+subdivide are in roofline_build",
             },
             "roofline_valu": {
                 "kernel": "ransac",
@@ -391,11 +603,12 @@ def main():
                 "frac": (valu_tflops / FP64_VALU_PEAK_TFLOPS) if valu_tflops else None,
                 "frac_no_fma": (valu_tflops / (FP64_VALU_PEAK_TFLOPS / 2)) if valu_tflops else None,
                 "algorithmic_flops_per_launch": flops,
-                "leaves_evaluated": extra.get("leaves_evaluated"),
+                "leaves_evaluated": leaves_evaluated,
                 "note": "algorithmic f64 flops per leaf with n >= k points: H*(20k + 6n) + 6n (plane fits, "
                         "scoring, final mask); parity mode issues separate mul/add (no FMA contraction), so "
                         "the attainable ceiling is peak/2",
             },
+            "roofline_build": roofline_build,
             "pipeline_hbm": {
                 "algorithmic_bytes_per_point": 48,
                 "device_ms_per_step": device_ms,
@@ -404,24 +617,13 @@ def main():
             },
             "kernels": kern,
         }
-        if extra:
-            out["secondary"] = {
-                "insert_subdivide_only": {
-                    "ms": extra["insert_subdivide_only_ms"],
-                    "Mpoints_per_s": n_local / extra["insert_subdivide_only_ms"] / 1e3,
-                },
-                "pcie_inclusive": {
-                    "ms": extra["pcie_inclusive_ms"],
-                    "Mpoints_per_s": n_local / extra["pcie_inclusive_ms"] / 1e3,
-                    "note": "same step, cloud uploaded from pageable host memory inside the step",
-                },
-            }
+        if secondary:
+            out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the other ranks would wait)
-            out["cpu_baseline"] = cpu_baseline(dims, table)
+            out["cpu_baseline"] = cpu_baseline(scene_dims(1, False), wl.table)
         print(json.dumps(out))
 
-    lib.octl_forest_destroy(fh)
-    ctx.check(lib.octl_dev_free(ctx.handle, d_xyz))
+    wl.close()
     if route:
         lib.octl_comm_destroy(rctx.handle)
     if world > 1:
@@ -429,6 +631,20 @@ def main():
     if rctx is not ctx:
         rctx.close()
     ctx.close()
+
+
+# algorithmic HBM bytes per point of the streaming kernels of insert + subdivide (reads + unavoidable
+# writes of what each one produces), keyed by the library's timer names
+BUILD_ALG_BYTES = {
+    "keygen": 24 + 16,
+    "linkey": 8 + 12,
+    "sort_hist": 8,
+    "sort_scatter": 12 + 12,
+    "voxel_build_a": 4 + 24 + 4 + 24 + 4,
+    "voxel_build_b": 4 + 4,
+    "finalize": 4 + 24 + 4 + 24,
+    "apply_mask": 1 + 4 + 24 + 4 + 4 + 24 + 4,
+}
 
 
 if __name__ == "__main__":

@@ -2,8 +2,97 @@
 // RANSAC operator.  See include/octreelib_hip.h for the reference interfaces each entry point
 // replaces.
 #include "forest.h"
+#include "ref_arith.h"
 
 namespace {
+
+// ---- ingest: Grid.insert_points' storage step -------------------------------------------------------
+// One pass over the new points of a pose: copies them into the forest's store (device sources),
+// marks them alive and folds their top-level voxel indices - floor((p - corner) / L), grid.py:72-76 -
+// into the forest's voxel bounding box, so that the build can form compact linear voxel keys without
+// a pass of its own.  Two points per thread, 16-byte accesses.
+template <bool COPY>
+__global__ __launch_bounds__(256) void k_ingest(const double* __restrict__ src, double* __restrict__ dst,
+                                                uint8_t* __restrict__ alive, int64_t n, int mode,
+                                                double L, int32_t* __restrict__ bbox) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p0 = 2 * t;
+  const int big = 1 << 30;
+  int mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+  bool bad = false;
+  if (p0 < n) {
+    double v[6];
+    const int m = (p0 + 1 < n) ? 6 : 3;
+    if (m == 6) {
+      const double2* s2 = reinterpret_cast<const double2*>(src + 3 * p0);
+      const double2 a = s2[0], b = s2[1], c = s2[2];
+      v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+      if (COPY) {
+        double2* d2 = reinterpret_cast<double2*>(dst + 3 * p0);
+        d2[0] = a; d2[1] = b; d2[2] = c;
+      }
+      *reinterpret_cast<uint16_t*>(alive + p0) = 0x0101;
+    } else {
+      for (int j = 0; j < 3; ++j) {
+        v[j] = src[3 * p0 + j];
+        if (COPY) dst[3 * p0 + j] = v[j];
+      }
+      alive[p0] = 1;
+    }
+    if (mode == 0) {
+      const double lim = (double)OCTL_VOX_BIAS;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j < m) {
+          const double f = floor_div_exact(v[j], L);
+          if (fabs(f) < lim) {  // false for NaN / inf
+            const int q = (int)f;
+            mn[j % 3] = min(mn[j % 3], q);
+            mx[j % 3] = max(mx[j % 3], q);
+          } else {
+            bad = true;
+          }
+        }
+      }
+    } else {
+      mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0;
+    }
+  }
+  // wave + block reduction, then at most six atomics per block and only when the block widens the
+  // box (same-address atomics serialise)
+  __shared__ int s_bb[4][6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], off));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], off));
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicExch(reinterpret_cast<uint32_t*>(bbox + 6), 1u);
+  if ((threadIdx.x & 63) == 0) {
+    int* w = s_bb[threadIdx.x >> 6];
+    w[0] = mn[0]; w[1] = mn[1]; w[2] = mn[2]; w[3] = mx[0]; w[4] = mx[1]; w[5] = mx[2];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    int v = s_bb[0][a];
+    for (int w = 1; w < 4; ++w) v = (a < 3) ? min(v, s_bb[w][a]) : max(v, s_bb[w][a]);
+    if (a < 3) {
+      if (v != big && v < __hip_atomic_load(&bbox[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(&bbox[a], v);
+    } else {
+      if (v != -big && v > __hip_atomic_load(&bbox[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&bbox[a], v);
+    }
+  }
+}
+
+__global__ void k_bbox_reset(int32_t* __restrict__ bbox) {
+  const int a = threadIdx.x;
+  if (a < 8) bbox[a] = a < 3 ? (1 << 30) : (a < 6 ? -(1 << 30) : 0);
+}
 
 __global__ __launch_bounds__(256) void k_fill_u8(uint8_t* p, int64_t n, uint8_t v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,6 +151,21 @@ __global__ __launch_bounds__(256) void k_widen_u32_i64(const uint32_t* __restric
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
+int bbox_reset(octl_forest* f) {
+  octl_ctx* ctx = f->ctx;
+  if (!f->bbox_dev.p) {
+    OCTL_TRY(devbuf_reserve(ctx, f->bbox_dev, 32));
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->bbox_host), 32, hipHostMallocDefault));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&f->bbox_event, hipEventDisableTiming));
+  }
+  hipLaunchKernelGGL(k_bbox_reset, dim3(1), dim3(64), 0, ctx->stream, f->bbox_dev.as<int32_t>());
+  HIP_TRY(ctx, hipGetLastError());
+  return OCTL_OK;
+}
+
+// Device sources are consumed in stream order (no synchronisation: the caller keeps the buffer
+// unchanged until the next synchronising call on the context); host sources are copied before the
+// call returns.
 int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device) {
   octl_ctx* ctx = f->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -69,14 +173,41 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
   const int64_t total = f->n_store + n;
   if (total >= ((int64_t)1 << 31))
     return octl_set_error(ctx, OCTL_E_INVALID, "more than 2^31-1 points in one forest");
-  OCTL_TRY(devbuf_reserve(ctx, f->xyz, (size_t)std::max<int64_t>(total, 1) * 24, 1));
-  OCTL_TRY(devbuf_reserve(ctx, f->alive, (size_t)std::max<int64_t>(total, 1), 1));
+  OCTL_TRY(devbuf_reserve(ctx, f->xyz, (size_t)std::max<int64_t>(total, 1) * 24 + 16, 1));
+  OCTL_TRY(devbuf_reserve(ctx, f->alive, (size_t)std::max<int64_t>(total, 1) + 2, 1));
+  if (!f->bbox_dev.p) OCTL_TRY(bbox_reset(f));
   if (n > 0) {
-    HIP_TRY(ctx, hipMemcpyAsync(f->xyz.as<double>() + 3 * f->n_store, xyz, (size_t)n * 24,
-                                from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(f->alive.as<uint8_t>() + f->n_store, 1, (size_t)n, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipStream_t st = ctx->stream;
+    double* dst = f->xyz.as<double>() + 3 * f->n_store;
+    uint8_t* alive = f->alive.as<uint8_t>() + f->n_store;
+    const unsigned grid = (unsigned)ceil_div(ceil_div(n, 2), 256);
+    KTimer t(ctx, "ingest");
+    // (an odd store offset would misalign the 16-byte accesses of the pair-wise kernel: such a pose
+    //  goes through the plain copy + the in-place form on its own, 8-byte aligned, pointer)
+    const bool aligned = (f->n_store % 2) == 0 && (reinterpret_cast<uintptr_t>(xyz) % 16) == 0;
+    if (from_device && aligned) {
+      hipLaunchKernelGGL(k_ingest<true>, dim3(grid), dim3(256), 0, st, xyz, dst, alive, n, f->mode,
+                         f->edge, f->bbox_dev.as<int32_t>());
+    } else {
+      HIP_TRY(ctx, hipMemcpyAsync(dst, xyz, (size_t)n * 24,
+                                  from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+      if ((f->n_store % 2) == 0) {
+        hipLaunchKernelGGL(k_ingest<false>, dim3(grid), dim3(256), 0, st, (const double*)dst, dst, alive,
+                           n, f->mode, f->edge, f->bbox_dev.as<int32_t>());
+      } else {
+        // first point alone, then the aligned rest
+        hipLaunchKernelGGL(k_ingest<false>, dim3(1), dim3(256), 0, st, (const double*)dst, dst, alive,
+                           (int64_t)1, f->mode, f->edge, f->bbox_dev.as<int32_t>());
+        if (n > 1)
+          hipLaunchKernelGGL(k_ingest<false>, dim3((unsigned)ceil_div(ceil_div(n - 1, 2), 256)), dim3(256),
+                             0, st, (const double*)(dst + 3), dst + 3, alive + 1, n - 1, f->mode, f->edge,
+                             f->bbox_dev.as<int32_t>());
+      }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(f->bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipEventRecord(f->bbox_event, st));
+    if (!from_device) HIP_TRY(ctx, hipStreamSynchronize(st));  // the host buffer is the caller's again
   }
   return OCTL_OK;
 }
@@ -168,8 +299,11 @@ void octl_forest_destroy(octl_forest* f) {
   (void)hipStreamSynchronize(f->ctx->stream);
   nodes_free(f->nodes[0]);
   nodes_free(f->nodes[1]);
+  if (f->bbox_host) (void)hipHostFree(f->bbox_host);
+  if (f->bbox_event) (void)hipEventDestroy(f->bbox_event);
   for (DevBuf* b :
-       {&f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
+       {&f->bbox_dev, &f->part_lin[0], &f->part_lin[1], &f->part_idx[0], &f->part_idx[1], &f->part_xyz[0],
+        &f->part_xyz[1], &f->bk_table, &f->bk_tot, &f->bk_vox, &f->leafinfo, &f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
         &f->blk_start, &f->blk_size, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order,
         &f->rs_hyp, &f->rs_plane, &f->rs_count, &f->rs_index, &f->ord_idx2, &f->xyz_ord2,
         &f->pos_node2, &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
@@ -182,7 +316,7 @@ void octl_forest_destroy(octl_forest* f) {
 
 int octl_forest_clear(octl_forest* f) {
   if (!f) return OCTL_E_INVALID;
-  HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
+  if (f->bbox_dev.p) OCTL_TRY(bbox_reset(f));  // (stream ordered: no synchronisation needed)
   f->pose_off.assign(1, 0);
   f->n_store = f->n_alive = 0;
   f->store_dirty = true;
@@ -441,6 +575,7 @@ int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
   if (nb < 0 || (nb > 0 && !block_order) || !hypotheses)
     return octl_set_error(ctx, OCTL_E_INVALID, "bad ransac arguments");
   if (H < 1 || H > 1024 || k < 1) return octl_set_error(ctx, OCTL_E_INVALID, "bad H or k");
+  OCTL_TRY(ransac_check_table(ctx, hypotheses, H, k));
   for (int64_t b = 0; b < nb; ++b)
     if (block_order[b] < 0 || block_order[b] >= f->n_blocks)
       return octl_set_error(ctx, OCTL_E_INVALID, "block index out of range");
@@ -523,6 +658,7 @@ int octl_ransac_evaluate(octl_ctx* ctx, const double* point_cloud, int64_t M,
       (M > 0 && !mask_out))
     return octl_set_error(ctx, OCTL_E_INVALID, "bad ransac_evaluate arguments");
   if (H < 1 || H > 1024 || k < 1) return octl_set_error(ctx, OCTL_E_INVALID, "bad H or k");
+  OCTL_TRY(ransac_check_table(ctx, hypotheses, H, k));
   if (M >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "cloud too large");
   int64_t total = 0;
   std::vector<uint32_t> starts((size_t)std::max<int64_t>(B, 1));

@@ -821,8 +821,48 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     if (!fits) HIP_TRY(ctx, hipStreamSynchronize(st));  // pageable sources must not change in flight
   }
 
-  // ---- 1. keys -----------------------------------------------------------------------------------
   const int64_t n_alive = f->n_alive;
+  // ---- 0. fresh forest: the bucket build does insert + subdivide in one go (bucket_build.hip) -----------
+  if (!keep_scheme && !f->built && f->vkeys.empty() && n_alive > 0) {
+    NodeTable& bt = f->nodes[f->cur ^ 1];
+    BucketBuildArgs ba{K, scheme_dev, f->epoch + 1, max_depth};
+    BucketBuildGeom geom;
+    int done = 0, lv = 0;
+    int64_t ni = 0, nv = 0, nblk = 0;
+    std::vector<int64_t> lf;
+    OCTL_TRY(forest_bucket_build(f, ba, bt, &done, &lf, &ni, &lv, &nv, &nblk, &geom));
+    trace.mark("bucket build");
+    if (done) {
+      f->cur ^= 1;
+      f->n_voxels = nv;
+      f->vkeys.clear();
+      f->vkeys_stale = true;
+      f->vl_min[0] = geom.min[0]; f->vl_min[1] = geom.min[1]; f->vl_min[2] = geom.min[2];
+      f->vl_ny = geom.ny;
+      f->vl_nz = geom.nz;
+      f->level_first.swap(lf);
+      f->built = true;
+      f->epoch = f->epoch + 1;
+      f->n_ord = n_alive;
+      f->n_blocks = nblk;
+      f->n_internal = ni;
+      f->uniform_epoch = true;
+      f->max_depth_reached = lv;
+      f->mask_valid = false;
+      f->store_dirty = false;
+      if (info) {
+        info->n_points = n_alive;
+        info->n_voxels = nv;
+        info->n_nodes = bt.n;
+        info->n_internal = ni;
+        info->n_blocks = nblk;
+        info->max_depth = lv;
+        info->n_levels = lv;
+      }
+      return OCTL_OK;
+    }
+  }
+  // ---- 1. keys -----------------------------------------------------------------------------------
   if (N > 0) {
     OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));
     OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 8));

@@ -17,7 +17,10 @@ enum {
   SM_VB_FALLBACK = 17,  // voxel build: some voxel does not fit (too many points / too deep / bad point)
   SM_VB_DEPTH = 18,     // voxel build: deepest leaf
   SM_VB_INTERNAL = 19,  // voxel build: internal nodes in total
-  // 20: kept count of apply_mask, 24: debug scan total, 64..: slot histogram, 512..: allreduce
+  // 20: kept count of apply_mask, 21: slot-voxel count, 24: debug scan total
+  SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
+  SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
+  // 64..: slot histogram, 512..: allreduce
 };
 
 struct NodePtrs {
@@ -56,3 +59,20 @@ struct VoxelBuildArgs {
 };
 int forest_voxel_build(octl_forest* f, const VoxelBuildArgs& a, NodeTable& nt, int* done,
                        std::vector<int64_t>* level_first, int64_t* n_internal, int* levels);
+
+// bucket_build.hip: complete build of a fresh forest (K-driven scheme or K < 0, no previous scheme) by
+// one MSD partition into buckets of consecutive voxels + one workgroup per bucket.  *done = 0 when
+// the path does not apply and the caller must run the general path.
+struct BucketBuildArgs {
+  int64_t K;
+  const uint8_t* scheme_dev;  // per pose slot: 1 = the pose drives the scheme; nullptr = all poses
+  int cur_epoch;
+  int max_depth;
+};
+struct BucketBuildGeom {  // decoding of the linear voxel keys: lin = ((qx-min0)*ny + (qy-min1))*nz + (qz-min2)
+  int min[3];
+  uint64_t ny, nz;
+};
+int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,
+                        std::vector<int64_t>* level_first, int64_t* n_internal, int* levels,
+                        int64_t* n_voxels, int64_t* n_blocks, BucketBuildGeom* geom);

@@ -50,6 +50,9 @@ struct octl_ctx {
   DevBuf small;     // 4 KiB of device scalars (counters, flags)
   void* small_host = nullptr;  // pinned mirror
   void* pinned = nullptr;      // pinned staging for small uploads (OCTL_PINNED_BYTES)
+  // one event per staging region ([0,128K) build, [128K,192K) hypothesis table, [192K,256K) pose
+  // epochs): recorded after the region's H2D copy, waited for before the region is written again
+  hipEvent_t pin_event[3] = {nullptr, nullptr, nullptr};
   // RCCL (route.hip)
   void* comm = nullptr;
   int n_ranks = 1, rank = 0;
@@ -74,6 +77,11 @@ int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...);
     int _r = (expr);          \
     if (_r != OCTL_OK) return _r; \
   } while (0)
+
+// staging regions of ctx->pinned: wait until the previous asynchronous copy out of region r has
+// finished / mark a new one as in flight
+int pin_region_wait(octl_ctx* ctx, int r);
+int pin_region_mark(octl_ctx* ctx, int r);
 
 // grow-only device buffer; contents are NOT preserved unless keep != 0
 int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep = 0);

@@ -38,6 +38,18 @@ int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
   return OCTL_OK;
 }
 
+int pin_region_wait(octl_ctx* ctx, int r) {
+  if (ctx->pin_event[r]) HIP_TRY(ctx, hipEventSynchronize(ctx->pin_event[r]));
+  return OCTL_OK;
+}
+
+int pin_region_mark(octl_ctx* ctx, int r) {
+  if (!ctx->pin_event[r])
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pin_event[r], hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventRecord(ctx->pin_event[r], ctx->stream));
+  return OCTL_OK;
+}
+
 void devbuf_free(DevBuf& b) {
   if (b.p) (void)hipFree(b.p);
   b.p = nullptr;
@@ -134,6 +146,8 @@ void octl_ctx_destroy(octl_ctx* ctx) {
     (void)hipEventDestroy(pe.stop);
   }
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+  for (auto ev : ctx->pin_event)
+    if (ev) (void)hipEventDestroy(ev);
   for (auto& b : ctx->scan_tmp) devbuf_free(b);
   devbuf_free(ctx->scan_status);
   devbuf_free(ctx->small);

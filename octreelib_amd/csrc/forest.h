@@ -22,6 +22,12 @@ struct octl_forest {
   std::vector<int64_t> pose_off{0};  // [P+1] offsets into the store
   int64_t n_store = 0, n_alive = 0;
   bool store_dirty = true;  // points were added/removed since the last build
+  // voxel bounding box of every point added since the last clear, kept by the ingest kernel
+  // (api.hip): int32 x 8 = {min x,y,z, max x,y,z, domain-error flag, unused}; bbox_host is a pinned
+  // mirror refreshed asynchronously after every ingest (bbox_event marks the copy)
+  DevBuf bbox_dev;
+  int32_t* bbox_host = nullptr;
+  hipEvent_t bbox_event = nullptr;
 
   // scheme of the last build
   NodeTable nodes[2];
@@ -56,6 +62,16 @@ struct octl_forest {
   DevBuf ord_idx2, xyz_ord2, pos_node2;  // compaction targets (swapped with the live arrays)
   std::vector<int64_t> level_first;      // node id of the first node of every level (+ end)
 
+  // bucket build (bucket_build.hip): the cloud partitioned into buckets of consecutive voxels
+  DevBuf part_lin[2], part_idx[2], part_xyz[2];  // u32 linear voxel key, u32 store index | scheme bit, f64 x3
+  DevBuf bk_table;     // u32 [digit][supertile] partition histogram (scanned in place)
+  DevBuf bk_tot;       // u32 [BK_ROWS][n_buckets] per-bucket totals (scanned in place)
+  DevBuf bk_vox;       // u32 [n_alive] staging: linear key of the j-th voxel of bucket b at [bucket start + j]
+  DevBuf leafinfo;     // u32 [n_alive] per leaf-ordered point: path21 | depth << 21 | flags
+  // levels of the current node table as (first, end, depth) segments, ordered by depth (parents
+  // before children); one segment per level when a single build path numbered the nodes
+  struct LevelSeg { int64_t a, b; int depth; };
+  std::vector<LevelSeg> level_segs;
   // build scratch (kept between builds to avoid re-allocation)
   DevBuf vkey, path, lin[2], val[2], hist, idxbuf[2], pathbuf[2], flags, entries, split[2],
       split_tiles[2], child_sc, pose_off_dev, scheme_dev, root_up;
@@ -83,6 +99,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                   int64_t nb, const double* hyp_dev, int32_t H, int32_t k, double thr,
                   uint8_t* mask_dev, float* plane_dev, int32_t* count_dev, int32_t* index_dev,
                   uint8_t* evaluated_dev, DevBuf& scratch);
+// the hypothesis table must hold draws from [0, 1) (np.random.random, cuda_ransac.py:39-41): anything
+// else would index outside the block in the sampling arithmetic (cuda_ransac.py:103-107)
+int ransac_check_table(octl_ctx* ctx, const double* hyp, int32_t H, int32_t k);
 // build.hip: (re)build the (leaf, pose) block table from pos_node / ord_idx
 int forest_make_blocks(octl_forest* f);
 // reads the block count (and the domain-error flag) left on the device: one synchronisation

@@ -252,8 +252,10 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
     OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)n_poses * 4));
     if ((size_t)n_poses * 4 <= 64 * 1024) {  // pinned staging: [192 KiB, 256 KiB) of ctx->pinned
       char* pin = static_cast<char*>(ctx->pinned) + 192 * 1024;
+      OCTL_TRY(pin_region_wait(ctx, 2));
       std::memcpy(pin, e0_host, (size_t)n_poses * 4);
       HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, pin, (size_t)n_poses * 4, hipMemcpyHostToDevice, st));
+      OCTL_TRY(pin_region_mark(ctx, 2));
     } else {
       HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, e0_host, (size_t)n_poses * 4,
                                   hipMemcpyHostToDevice, st));
@@ -342,6 +344,7 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "ransac before build");
   if (poses_per_batch < 1) return octl_set_error(ctx, OCTL_E_INVALID, "poses_per_batch < 1");
   if (H < 1 || H > 1024 || k < 1) return octl_set_error(ctx, OCTL_E_INVALID, "bad H or k");
+  OCTL_TRY(ransac_check_table(ctx, hypotheses, H, k));
   const int n_poses = (int)f->pose_off.size() - 1;
   if (e0 && n_e0 != n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "e0 size mismatch");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -355,9 +358,13 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
   if (f->n_blocks == 0) return OCTL_OK;
   OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
   if ((size_t)H * k * 8 <= 64 * 1024) {  // pinned staging: [128 KiB, 192 KiB) of ctx->pinned
+    // the launches below are not synchronised: a later call must not overwrite the staging area
+    // while this copy is still pending
     char* pin = static_cast<char*>(ctx->pinned) + 128 * 1024;
+    OCTL_TRY(pin_region_wait(ctx, 1));
     std::memcpy(pin, hypotheses, (size_t)H * k * 8);
     HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, pin, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+    OCTL_TRY(pin_region_mark(ctx, 1));
   } else {
     HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

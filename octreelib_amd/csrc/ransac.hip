@@ -954,6 +954,16 @@ __global__ __launch_bounds__(256) void k_block_scatter(const BlockDesc* __restri
 
 }  // namespace
 
+int ransac_check_table(octl_ctx* ctx, const double* hyp, int32_t H, int32_t k) {
+  const int64_t n = (int64_t)H * k;
+  for (int64_t i = 0; i < n; ++i)
+    if (!(hyp[i] >= 0.0 && hyp[i] < 1.0))  // also false for NaN
+      return octl_set_error(ctx, OCTL_E_INVALID,
+                            "hypothesis table entry %lld = %g is outside [0, 1): the table must hold "
+                            "np.random.random draws (cuda_ransac.py:39-41)", (long long)i, hyp[i]);
+  return OCTL_OK;
+}
+
 // Launch the kernels over nb batch entries.  `order` (device, nullable) maps batch entry ->
 // physical block.  Descriptors (virtual start, spill point) are derived on the device from the
 // sizes in batch order; blocks are then processed largest first.

@@ -117,6 +117,18 @@ __global__ __launch_bounds__(256) void k_route_pack(const double* __restrict__ x
   out_gidx[i] = gidx ? gidx[s] : index_base + s;
 }
 
+// Entries R and R+1 of a rank's row of the count exchange: its domain-error flag (set on the device by
+// k_route_dest) and the capacity, in points, of its receive buffers - every rank then knows whether
+// ANY rank failed or has to grow its buffers, and all of them take the same exit (see
+// octl_route_points).
+__global__ void k_route_status(unsigned long long* __restrict__ counts, int n_ranks,
+                               const uint32_t* __restrict__ err, unsigned long long capacity) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    counts[n_ranks] = (unsigned long long)*err;
+    counts[n_ranks + 1] = capacity;
+  }
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
 // Steps 1-2 of the routing for R destination ranks: destination of every point + counts, stable
@@ -138,7 +150,7 @@ static int route_partition(octl_ctx* ctx, const double* xyz_dev, const int64_t* 
     OCTL_TRY(devbuf_reserve(ctx, vals[b], (size_t)n1 * 4));
   }
   OCTL_TRY(devbuf_reserve(ctx, counts_d, (size_t)R * 8 + 16));
-  OCTL_TRY(devbuf_reserve(ctx, matrix_d, (size_t)R * R * 8));
+  OCTL_TRY(devbuf_reserve(ctx, matrix_d, (size_t)R * (R + 2) * 8));
   uint32_t* err = ctx->small.as<uint32_t>();
   HIP_TRY(ctx, hipMemsetAsync(counts_d.p, 0, (size_t)R * 8 + 16, st));
   HIP_TRY(ctx, hipMemsetAsync(err, 0, 4, st));
@@ -252,21 +264,32 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   } while (0)
   RT_TRY(route_partition(ctx, xyz_dev, gidx_dev, n, index_base, L, R));
   uint32_t* err = ctx->small.as<uint32_t>();
-  // --- 3. counts exchange -----------------------------------------------------------------------------
-  std::vector<int64_t> matrix((size_t)R * R, 0);
+  // --- 3. counts exchange ---------------------------------------------------------------------------------
+  // A rank that left this function alone after the exchange would leave its peers waiting for ever in
+  // the Send/Recv group below (RCCL has no timeout), so every exit between here and the group is
+  // COLLECTIVE: each row of the exchange carries the rank's domain-error flag and the capacity of its
+  // receive buffers next to its R counts; what can only fail locally (growing those buffers) is
+  // agreed on with one more all-reduce, and only in the steps in which some rank has to grow.
+  const int64_t cap_pts = (int64_t)std::min(ctx->routed_xyz.cap / 24, ctx->routed_gidx.cap / 8);
+  const int W = R + 2;  // words per row
+  std::vector<int64_t> matrix((size_t)R * W, 0);
   if (use_rccl) {
-    ncclResult_t r = g_rccl.AllGather(counts_d.p, matrix_d.p, (size_t)R, ncclInt64, comm, st);
+    hipLaunchKernelGGL(k_route_status, dim3(1), dim3(64), 0, st, counts_d.as<unsigned long long>(), R,
+                       (const uint32_t*)err, (unsigned long long)cap_pts);
+    if (hipGetLastError() != hipSuccess) return octl_set_error(ctx, OCTL_E_HIP, "route: status launch failed");
+    ncclResult_t r = g_rccl.AllGather(counts_d.p, matrix_d.p, (size_t)W, ncclInt64, comm, st);
     if (r != ncclSuccess) {
       cleanup();
       return octl_set_error(ctx, OCTL_E_COMM, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
     }
-    if (hipMemcpyAsync(matrix.data(), matrix_d.p, (size_t)R * R * 8, hipMemcpyDeviceToHost, st) !=
+    if (hipMemcpyAsync(matrix.data(), matrix_d.p, (size_t)R * W * 8, hipMemcpyDeviceToHost, st) !=
         hipSuccess) {
       cleanup();
       return octl_set_error(ctx, OCTL_E_HIP, "count download failed");
     }
   } else {
     matrix[0] = n;
+    matrix[2] = cap_pts;
   }
   uint32_t err_h = 0;
   if (hipMemcpyAsync(ctx->small_host, err, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -276,40 +299,72 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
                           hipGetErrorString(hipGetLastError()));
   }
   std::memcpy(&err_h, ctx->small_host, 4);
-  if (err_h) {
-    cleanup();
-    return octl_set_error(ctx, OCTL_E_DOMAIN, "route: non-finite coordinate or voxel out of range");
+  if (!use_rccl) matrix[1] = err_h;
+  auto cnt = [&](int from, int to) { return matrix[(size_t)from * W + to]; };
+  bool grow_any = false;
+  for (int p = 0; p < R; ++p) {  // identical on every rank: all of them return, none posts a transfer
+    if (matrix[(size_t)p * W + R] != 0) {
+      cleanup();
+      return octl_set_error(ctx, OCTL_E_DOMAIN,
+                            "route: non-finite coordinate or voxel out of range (on rank %d)", p);
+    }
+    int64_t recv_p = 0;
+    for (int q = 0; q < R; ++q) recv_p += cnt(q, p);
+    if (recv_p >= ((int64_t)1 << 31)) {
+      cleanup();
+      return octl_set_error(ctx, OCTL_E_INVALID, "rank %d receives more than 2^31-1 points", p);
+    }
+    grow_any = grow_any || std::max<int64_t>(recv_p, 1) > matrix[(size_t)p * W + R + 1];
   }
   std::vector<int64_t> soff(R + 1, 0), roff(R + 1, 0);
   for (int p = 0; p < R; ++p) {
-    soff[p + 1] = soff[p] + matrix[(size_t)me * R + p];
-    roff[p + 1] = roff[p] + matrix[(size_t)p * R + me];
-    if (send_counts) send_counts[p] = matrix[(size_t)me * R + p];
+    soff[p + 1] = soff[p] + cnt(me, p);
+    roff[p + 1] = roff[p] + cnt(p, me);
+    if (send_counts) send_counts[p] = cnt(me, p);
   }
   const int64_t nr = roff[R];
-  if (nr >= ((int64_t)1 << 31)) {
-    cleanup();
-    return octl_set_error(ctx, OCTL_E_INVALID, "rank receives more than 2^31-1 points");
+  {
+    int rc_a = devbuf_reserve(ctx, ctx->routed_xyz, (size_t)std::max<int64_t>(nr, 1) * 24);
+    if (rc_a == OCTL_OK) rc_a = devbuf_reserve(ctx, ctx->routed_gidx, (size_t)std::max<int64_t>(nr, 1) * 8);
+    if (use_rccl && grow_any) {
+      int64_t* flag_d = reinterpret_cast<int64_t*>(ctx->small.as<uint32_t>() + 512);
+      int64_t* flag_h = static_cast<int64_t*>(ctx->small_host);
+      *flag_h = rc_a == OCTL_OK ? 0 : 1;
+      ncclResult_t r = ncclSuccess;
+      if (hipMemcpyAsync(flag_d, flag_h, 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+          (r = g_rccl.AllReduce(flag_d, flag_d, 1, ncclInt64, ncclMax, comm, st)) != ncclSuccess ||
+          hipMemcpyAsync(flag_h, flag_d, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipStreamSynchronize(st) != hipSuccess) {
+        cleanup();
+        return octl_set_error(ctx, OCTL_E_COMM, "route: status all-reduce failed");
+      }
+      if (*flag_h != 0 && rc_a == OCTL_OK)
+        rc_a = octl_set_error(ctx, OCTL_E_NOMEM, "route: another rank could not grow its receive buffers");
+    }
+    if (rc_a != OCTL_OK) {
+      cleanup();
+      return rc_a;
+    }
   }
-  RT_TRY(devbuf_reserve(ctx, ctx->routed_xyz, (size_t)std::max<int64_t>(nr, 1) * 24));
-  RT_TRY(devbuf_reserve(ctx, ctx->routed_gidx, (size_t)std::max<int64_t>(nr, 1) * 8));
   // --- 4. the all-to-all ----------------------------------------------------------------------------------
+  hipError_t self_rc = hipSuccess;
   {
     KTimer t(ctx, "route_alltoall");
-    const int64_t self = matrix[(size_t)me * R + me];
+    const int64_t self = cnt(me, me);
     if (self > 0 && !self_rccl) {
-      (void)hipMemcpyAsync(ctx->routed_xyz.as<double>() + 3 * roff[me],
-                           send_xyz.as<double>() + 3 * soff[me], (size_t)self * 24,
-                           hipMemcpyDeviceToDevice, st);
-      (void)hipMemcpyAsync(ctx->routed_gidx.as<int64_t>() + roff[me],
-                           send_gidx.as<int64_t>() + soff[me], (size_t)self * 8,
-                           hipMemcpyDeviceToDevice, st);
+      self_rc = hipMemcpyAsync(ctx->routed_xyz.as<double>() + 3 * roff[me],
+                               send_xyz.as<double>() + 3 * soff[me], (size_t)self * 24,
+                               hipMemcpyDeviceToDevice, st);
+      if (self_rc == hipSuccess)
+        self_rc = hipMemcpyAsync(ctx->routed_gidx.as<int64_t>() + roff[me],
+                                 send_gidx.as<int64_t>() + soff[me], (size_t)self * 8,
+                                 hipMemcpyDeviceToDevice, st);
     }
     if (use_rccl) {
       ncclResult_t r = g_rccl.GroupStart();
       for (int p = 0; p < R && r == ncclSuccess; ++p) {
         if (p == me && !self_rccl) continue;
-        const int64_t sc = matrix[(size_t)me * R + p], rcnt = matrix[(size_t)p * R + me];
+        const int64_t sc = cnt(me, p), rcnt = cnt(p, me);
         if (sc > 0) {
           r = g_rccl.Send(send_xyz.as<double>() + 3 * soff[p], (size_t)sc * 3, ncclDouble, p, comm, st);
           if (r == ncclSuccess)
@@ -331,7 +386,9 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
       }
     }
   }
-  if (hipStreamSynchronize(st) != hipSuccess) {
+  // (the transfers of the group are posted by now on every rank: a local failure below no longer
+  //  leaves a peer waiting)
+  if (hipStreamSynchronize(st) != hipSuccess || self_rc != hipSuccess) {
     cleanup();
     return octl_set_error(ctx, OCTL_E_HIP, "route: all-to-all stream failed");
   }

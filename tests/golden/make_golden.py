@@ -18,6 +18,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "tools", "refshim"))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))  # octreelib_amd.synthetic (scene generator)
 import refshim  # noqa: E402
 
 refshim.install()
@@ -266,9 +267,88 @@ def gen_grid_ransac():
     _save("grid_ransac_e2e.npz", **out)
 
 
+# --------------------------------------------------------------------------------------
+# G3b: RANSAC operator on blocks cut from the BENCHMARK scene's own leaves, with the kernel's
+#      shared best_plane / max_inliers_number (cuda_ransac.py:125-146) recorded per block -
+#      observables the upstream API never returns (evaluate() hands back the mask only).
+# --------------------------------------------------------------------------------------
+def _bench_scene_leaves(dims, k_split, seed_stream):
+    """Leaves (point arrays, in the reference's own order) of the benchmark's planar scene,
+    subdivided by the reference itself."""
+    from octreelib_amd import synthetic  # the product's scene generator (pure NumPy)
+
+    n = int(np.prod(dims)) * 305
+    pts = synthetic.planar_cloud(n, dims, seed=1, stream=seed_stream)
+    g = Grid(GridConfig(voxel_edge_length=1))
+    g.insert_points(0, pts)
+    if k_split is not None:
+        g.subdivide(crit(k_split))
+    return [np.ascontiguousarray(v.get_points(), dtype=np.float64) for v in g.get_leaf_points(0)]
+
+
+def _evaluate_recorded(cloud, sizes, H, k, thr, seed):
+    np.random.seed(seed)
+    table = np.random.random((min(H, 1024), k))
+    np.random.seed(seed)
+    r = CudaRansac(threshold=thr, hypotheses_number=H, initial_points_number=k)
+    refshim.RECORD = []
+    mask = r.evaluate(cloud, sizes)
+    rec, refshim.RECORD = refshim.RECORD, None
+    assert len(rec) == len(sizes)
+    plane = np.zeros((len(sizes), 4), dtype=np.float32)
+    count = np.full(len(sizes), -1, dtype=np.int32)  # -1: the block returned before scoring (n < k)
+    for b, shared in enumerate(rec):
+        if shared:
+            plane[b] = shared[0]
+            count[b] = shared[1][0]
+    return table, mask, plane, count
+
+
+def gen_ransac_thick():
+    rng = np.random.default_rng(61)
+    leaves = _bench_scene_leaves((4, 4, 4), 64, 90)
+    by_size = {}
+    for lf in leaves:
+        by_size.setdefault(len(lf), []).append(lf)
+    sizes_present = sorted(z for z in by_size if z >= 6)
+    per = -(-300 // len(sizes_present))
+    blocks = []
+    for z in sizes_present:
+        pick = rng.permutation(len(by_size[z]))[:per]
+        blocks.extend(by_size[z][i] for i in pick)
+    for z in sorted(z for z in by_size if z < 6)[:3]:  # n < k blocks (mask stays False)
+        blocks.append(by_size[z][0])
+    # larger leaves: K = 200 over ~305-point voxels, and two unsplit voxels (n > 255)
+    big = [lf for lf in _bench_scene_leaves((2, 2, 2), 200, 91) if 65 <= len(lf) <= 200]
+    blocks.extend(big[i] for i in rng.permutation(len(big))[:6])
+    blocks.extend(_bench_scene_leaves((2, 1, 1), None, 92)[:2])
+    order = rng.permutation(len(blocks))
+    blocks = [blocks[i] for i in order]
+    cloud = np.vstack(blocks)
+    sizes = np.array([len(b) for b in blocks], dtype=np.int32)
+    table, mask, plane, count = _evaluate_recorded(cloud, sizes, 1024, 6, 0.01, 2024)
+    _save("ransac_bench_leaves_h1024.npz", cloud=cloud, block_sizes=sizes, hypotheses=table,
+          threshold=np.float64(0.01), seed=np.int64(2024), mask=mask, ref_plane=plane,
+          ref_max_inliers=count)
+    # H = 256 on a subset
+    sub = [blocks[i] for i in rng.permutation(len(blocks))[:72]]
+    cloud = np.vstack(sub)
+    sizes = np.array([len(b) for b in sub], dtype=np.int32)
+    table, mask, plane, count = _evaluate_recorded(cloud, sizes, 256, 6, 0.01, 2025)
+    _save("ransac_bench_leaves_h256.npz", cloud=cloud, block_sizes=sizes, hypotheses=table,
+          threshold=np.float64(0.01), seed=np.int64(2025), mask=mask, ref_plane=plane,
+          ref_max_inliers=count)
+
+
+GENERATORS = {
+    "octree": gen_octree,
+    "grid": gen_grid,
+    "manager": gen_manager,
+    "ransac": gen_ransac,
+    "grid_ransac": gen_grid_ransac,
+    "ransac_thick": gen_ransac_thick,   # ~10 minutes: 380 blocks x up to 1024 simulated threads
+}
+
 if __name__ == "__main__":
-    gen_octree()
-    gen_grid()
-    gen_manager()
-    gen_ransac()
-    gen_grid_ransac()
+    for name in (sys.argv[1:] or list(GENERATORS)):
+        GENERATORS[name]()

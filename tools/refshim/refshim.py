@@ -60,6 +60,13 @@ class _Block:
 
 _atomic_lock = threading.Lock()
 
+# Observables the upstream API never returns (CudaRansac.evaluate only hands back the mask,
+# cuda_ransac.py:80-81): when RECORD is a list, every launched block appends the final contents
+# of its shared arrays in declaration order - for the RANSAC kernel (cuda_ransac.py:125-128)
+# [best_plane f32[4], max_inliers_number i32[1], mutex i32[1]]; a block that returned before
+# declaring them (n < k, cuda_ransac.py:96-97) appends an empty list.
+RECORD = None
+
 
 class _DeviceArray(np.ndarray):
     def copy_to_host(self):
@@ -145,6 +152,8 @@ class _Kernel:
                     th.join()
                 if errors:
                     raise errors[0]
+                if RECORD is not None:
+                    RECORD.append([np.array(blk.shared[key]) for key in sorted(blk.shared)])
 
         return launch
 
