@@ -636,14 +636,17 @@ def main():
 # algorithmic HBM bytes per point of the streaming kernels of insert + subdivide (reads + unavoidable
 # writes of what each one produces), keyed by the library's timer names
 BUILD_ALG_BYTES = {
+    "ingest": 24 + 24 + 1,            # copy into the store + alive flag (bounding box on the fly)
+    "part_hist": 24 + 1,              # xyz -> bucket histogram
+    "part_scatter": 24 + 1 + 32,      # xyz -> 32-byte record (xyz, voxel | child digits, index) in its bucket
+    "bucket_build": 32 + 4 + 4 + 24,  # records -> leafinfo, permutation, leaf-ordered coordinates
+    "bucket_nodes": 4 + 4 + 4,        # leafinfo, permutation -> position -> leaf (+ nodes, blocks: small)
+    # general path (not on the benchmarked step)
     "keygen": 24 + 16,
     "linkey": 8 + 12,
     "sort_hist": 8,
     "sort_scatter": 12 + 12,
-    "voxel_build_a": 4 + 24 + 4 + 24 + 4,
-    "voxel_build_b": 4 + 4,
     "finalize": 4 + 24 + 4 + 24,
-    "apply_mask": 1 + 4 + 24 + 4 + 4 + 24 + 4,
 }
 
 

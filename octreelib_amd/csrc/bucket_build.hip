@@ -33,10 +33,8 @@
 namespace {
 
 constexpr int PT_THREADS = 256;
-constexpr int PT_IPT = 16;
-constexpr int PT_TILE = PT_THREADS * PT_IPT;     // 4096 items per tile
-constexpr int PT_ST_TILES = 4;                   // tiles per supertile (one workgroup, one table column)
-constexpr int PT_ST = PT_TILE * PT_ST_TILES;     // 16384 items
+// a workgroup partitions one SUPERTILE (one column of the histogram table) tile by tile; the number
+// of tiles per supertile is chosen at run time so that one round of workgroups covers the cloud
 constexpr int PT_BITS = 12;
 constexpr int PT_BINS = 1 << PT_BITS;            // buckets
 
@@ -65,36 +63,106 @@ struct LinParams {
   int shift;         // bucket = lin >> shift
 };
 
+// ---------------------------------------------------------------------------------------------
+// partition
+// ---------------------------------------------------------------------------------------------
+// One partitioned point: 32 bytes, written and read as two 16-byte accesses.  (Five separate stores
+// per point - key, index, three coordinates - cost one partial-sector write each: measured 1.08 GB
+// written for 0.32 GB of records.)
+struct __attribute__((aligned(32))) PartRec {
+  double x, y, z;
+  uint32_t vp;    // voxel inside the bucket << 19 | first 6 child digits << 1 | bad point
+  uint32_t idx;   // store index | bit 31: the pose drives the scheme
+};
+// The child digits are computed by the partition kernel, whose waves otherwise wait for their
+// scattered stores: the arithmetic is free there, in the bucket kernel it was a third of the VALU work.
+constexpr int PATH_EAGER = 6;          // child digits carried by the record; deeper ones on demand
+
+__device__ __forceinline__ double floor_div_fast(double a, double L) {
+  return L == 1.0 ? floor(a) : floor_div_exact(a, L);  // (floor_div_exact(a, 1) == floor(a))
+}
+
+// child digits of levels [l0, l1) below the cube (c, e): the exact comparisons of compute_path in
+// build.hip (octree/octree.py:73-75,94-97,181-191) - the reference's floor((p - corner) / (edge / 2))
+// in {0, 1} restated as comparisons on the same rounded difference.  All levels from 0 are walked
+// (the corner of level l follows from the digits above it); digits below l0 are not returned.
+// *bad when the point is not inside the cube at some level.
+__device__ __forceinline__ uint32_t path_levels(double px, double py, double pz, double cx, double cy,
+                                                double cz, double e, int l1, bool* bad) {
+  uint32_t path = 0;
+  double h = e / 2.0;
+#pragma unroll 1
+  for (int j = 0; j < l1; ++j) {
+    const double ax = px - cx, ay = py - cy, az = pz - cz;
+    const bool ok = (ax >= 0.0) && (ax < e) && (ay >= 0.0) && (ay < e) && (az >= 0.0) && (az < e);
+    if (!ok) {
+      *bad = true;
+      return path;
+    }
+    const bool bx = ax >= h, by = ay >= h, bz = az >= h;
+    path |= ((bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u)) << (18 - 3 * j);
+    cx = cx + (bx ? h : 0.0);
+    cy = cy + (by ? h : 0.0);
+    cz = cz + (bz ? h : 0.0);
+    e = h;
+    h = e / 2.0;
+  }
+  return path;
+}
+
 // top-level voxel of a point: floor((p - corner) / L) with corner = 0 (grid.py:72-76), as a compact
 // linear key in lexicographic (x, y, z) order - the order of np.unique(axis=0) (grid.py:79-81)
 __device__ __forceinline__ uint32_t lin_of(const LinParams& lp, double x, double y, double z) {
   if (lp.mode != 0) return 0u;
-  const int qx = (int)floor_div_exact(x, lp.L), qy = (int)floor_div_exact(y, lp.L),
-            qz = (int)floor_div_exact(z, lp.L);
+  const int qx = (int)floor_div_fast(x, lp.L), qy = (int)floor_div_fast(y, lp.L),
+            qz = (int)floor_div_fast(z, lp.L);
   return ((uint32_t)(qx - lp.minx) * lp.ny + (uint32_t)(qy - lp.miny)) * lp.nz + (uint32_t)(qz - lp.minz);
 }
 
-// ---------------------------------------------------------------------------------------------
-// partition
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PT_THREADS) void k_part_hist(const double* __restrict__ xyz,
+// the same, plus the corner of the voxel as the reference's OctreeManager holds it:
+// np.array(voxel_coords) = int64(q * L) (grid.py:72-76,96-105)
+__device__ __forceinline__ uint32_t lin_corner_of(const LinParams& lp, double x, double y, double z,
+                                                  double& cx, double& cy, double& cz) {
+  if (lp.mode != 0) {
+    cx = lp.c0x;
+    cy = lp.c0y;
+    cz = lp.c0z;
+    return 0u;
+  }
+  const double fx = floor_div_fast(x, lp.L), fy = floor_div_fast(y, lp.L), fz = floor_div_fast(z, lp.L);
+  cx = (double)(long long)(fx * lp.L);
+  cy = (double)(long long)(fy * lp.L);
+  cz = (double)(long long)(fz * lp.L);
+  return ((uint32_t)((int)fx - lp.minx) * lp.ny + (uint32_t)((int)fy - lp.miny)) * lp.nz +
+         (uint32_t)((int)fz - lp.minz);
+}
+
+constexpr int PH_THREADS = 1024;
+__global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restrict__ xyz,
                                                           const uint8_t* __restrict__ alive, int64_t N,
                                                           LinParams lp, uint32_t nst, uint32_t nd,
-                                                          uint32_t* __restrict__ table) {
+                                                          int64_t st_items, uint32_t* __restrict__ table) {
   __shared__ uint32_t hist[PT_BINS];
-  for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS) hist[d] = 0;
+  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) hist[d] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * PT_ST;
-#pragma unroll 4
-  for (int r = 0; r < PT_ST / PT_THREADS; ++r) {
-    const int64_t i = base + (int64_t)r * PT_THREADS + threadIdx.x;  // coalesced; order is irrelevant here
-    if (i < N && alive[i]) {
-      const uint32_t lin = lin_of(lp, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-      atomicAdd(&hist[lin >> lp.shift], 1u);
+  const int64_t base = (int64_t)blockIdx.x * st_items;
+  // two points per thread and step: 48 contiguous bytes as three 16-byte loads (the store is
+  // 16-byte aligned and base is even)
+  const int64_t lim = min(N, base + st_items);  // (st_items is even)
+#pragma unroll 2
+  for (int64_t i = base + 2 * (int64_t)threadIdx.x; i < lim; i += 2 * PH_THREADS) {
+    if (i + 1 < N) {
+      const double2* s2 = reinterpret_cast<const double2*>(xyz + 3 * i);
+      const double2 a = s2[0], b = s2[1], c = s2[2];
+      const uint16_t al = *reinterpret_cast<const uint16_t*>(alive + i);
+      if (al & 0xFF) atomicAdd(&hist[lin_of(lp, a.x, a.y, b.x) >> lp.shift], 1u);
+      if (al >> 8) atomicAdd(&hist[lin_of(lp, b.y, c.x, c.y) >> lp.shift], 1u);
+    } else if (i < N && alive[i]) {
+      atomicAdd(&hist[lin_of(lp, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]) >> lp.shift], 1u);
     }
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS) table[(size_t)d * nst + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table[(size_t)d * nst + blockIdx.x] = hist[d];
 }
 
 // stable rank inside one wave's stream with 16-bit counters: a wave's counters are touched by that
@@ -114,18 +182,20 @@ __device__ __forceinline__ uint32_t wave_rank_u16(uint32_t digit, bool valid, ui
   return old + rank_in_round;
 }
 
+template <int PT_IPT>
 __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     const double* __restrict__ xyz, const uint8_t* __restrict__ alive, int64_t N, LinParams lp,
-    uint32_t nst, uint32_t nd, const uint32_t* __restrict__ table_scanned,
+    uint32_t nst, uint32_t nd, int st_tiles, const uint32_t* __restrict__ table_scanned,
     const int64_t* __restrict__ pose_off, int n_poses, const uint8_t* __restrict__ scheme,
-    uint32_t* __restrict__ out_lin, uint32_t* __restrict__ out_idx, double* __restrict__ out_xyz) {
+    PartRec* __restrict__ out) {
   __shared__ uint32_t base[PT_BINS];                 // running destination of every bucket
   __shared__ uint16_t cnt[PT_THREADS / 64][PT_BINS]; // per wave, per tile
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
     base[d] = table_scanned[(size_t)d * nst + blockIdx.x];
-  for (int t = 0; t < PT_ST_TILES; ++t) {
-    const int64_t tbase = (int64_t)blockIdx.x * PT_ST + (int64_t)t * PT_TILE;
+  constexpr int PT_TILE = PT_THREADS * PT_IPT;
+  for (int t = 0; t < st_tiles; ++t) {
+    const int64_t tbase = ((int64_t)blockIdx.x * st_tiles + t) * PT_TILE;
     if (tbase >= N) break;
     for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS) {
 #pragma unroll
@@ -136,18 +206,30 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     // == memory order, so the partition is stable
     const int64_t wbase = tbase + (int64_t)wave * (64 * PT_IPT);
     double x[PT_IPT], y[PT_IPT], z[PT_IPT];
-    uint32_t lin[PT_IPT], rank[PT_IPT];
+    uint32_t lin[PT_IPT], rank[PT_IPT], pbits[PT_IPT];
+    uint8_t live[PT_IPT];
+    // every load of the tile is issued before the first use: a load behind `if (alive[i])` waits for
+    // the flag first, and 16 rounds of two dependent HBM latencies were 50 us per tile
+#pragma unroll
+    for (int r = 0; r < PT_IPT; ++r) {
+      const int64_t i = min(wbase + r * 64 + lane, N - 1);
+      live[r] = alive[i];
+      x[r] = xyz[3 * i];
+      y[r] = xyz[3 * i + 1];
+      z[r] = xyz[3 * i + 2];
+    }
 #pragma unroll
     for (int r = 0; r < PT_IPT; ++r) {
       const int64_t i = wbase + r * 64 + lane;
-      const bool valid = i < N && alive[i];
+      const bool valid = i < N && live[r];
       lin[r] = 0;
-      x[r] = y[r] = z[r] = 0.0;
+      pbits[r] = 0;
       if (valid) {
-        x[r] = xyz[3 * i];
-        y[r] = xyz[3 * i + 1];
-        z[r] = xyz[3 * i + 2];
-        lin[r] = lin_of(lp, x[r], y[r], z[r]);
+        double cx, cy, cz;
+        lin[r] = lin_corner_of(lp, x[r], y[r], z[r], cx, cy, cz);
+        bool bad = false;
+        const uint32_t path = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
+        pbits[r] = ((path >> 3) << 1) | (bad ? 1u : 0u);
       }
       rank[r] = wave_rank_u16<PT_BITS>(lin[r] >> lp.shift, valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
     }
@@ -187,11 +269,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
         } else {
           v |= 0x80000000u;
         }
-        out_lin[dst] = lin[r];
-        out_idx[dst] = v;
-        out_xyz[3 * (size_t)dst] = x[r];
-        out_xyz[3 * (size_t)dst + 1] = y[r];
-        out_xyz[3 * (size_t)dst + 2] = z[r];
+        uint4* o = reinterpret_cast<uint4*>(out + dst);
+        const uint64_t xb = (uint64_t)__double_as_longlong(x[r]), yb = (uint64_t)__double_as_longlong(y[r]),
+                       zb = (uint64_t)__double_as_longlong(z[r]);
+        o[0] = uint4{(uint32_t)xb, (uint32_t)(xb >> 32), (uint32_t)yb, (uint32_t)(yb >> 32)};
+        const uint32_t vl = lin[r] & ((1u << lp.shift) - 1u);
+        o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), (vl << 19) | pbits[r], v};
       }
     }
     __syncthreads();
@@ -205,7 +288,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS radix sort pass (stable, 8-bit digit) over n <= BB_CAP keys, wave-striped ownership
+// helpers of the bucket kernel
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v) {
   const int lane = threadIdx.x & 63;
@@ -236,75 +319,6 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t* total, 
   return basev + inc - v;
 }
 
-template <typename T>
-__device__ __forceinline__ void lds_sort_pass(const T* __restrict__ src, T* __restrict__ dst, int n,
-                                              int shift, uint32_t (*cnt)[256], uint32_t* scratch) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int w = 0; w < BB_THREADS / 64; ++w) cnt[w][threadIdx.x] = 0;
-  __syncthreads();
-  T key[BB_IPT];
-  uint32_t rank[BB_IPT];
-#pragma unroll
-  for (int r = 0; r < BB_IPT; ++r) {
-    const int i = wave * (64 * BB_IPT) + r * 64 + lane;
-    const bool valid = i < n;
-    key[r] = valid ? src[i] : (T)0;
-    const uint32_t d = (uint32_t)(key[r] >> shift) & 0xFFu;
-    rank[r] = wave_stable_rank<8>(d, valid, cnt[wave]);
-  }
-  __syncthreads();
-  {
-    const int d = threadIdx.x;
-    uint32_t tot = 0;
-#pragma unroll
-    for (int w = 0; w < BB_THREADS / 64; ++w) tot += cnt[w][d];
-    uint32_t all;
-    uint32_t run = block_excl_add(tot, &all, scratch);
-#pragma unroll
-    for (int w = 0; w < BB_THREADS / 64; ++w) {
-      const uint32_t c = cnt[w][d];
-      cnt[w][d] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < BB_IPT; ++r) {
-    const int i = wave * (64 * BB_IPT) + r * 64 + lane;
-    if (i < n) {
-      const uint32_t d = (uint32_t)(key[r] >> shift) & 0xFFu;
-      dst[cnt[wave][d] + rank[r]] = key[r];
-    }
-  }
-  __syncthreads();
-}
-
-// child digits of BB_LEVELS levels below the cube (c, e): the exact comparisons of compute_path in
-// build.hip (octree/octree.py:73-75,94-97,181-191); *bad when the point is not inside the cube
-__device__ __forceinline__ uint32_t path21_of(double px, double py, double pz, double cx, double cy,
-                                              double cz, double e, bool* bad) {
-  uint32_t path = 0;
-  double h = e / 2.0;
-#pragma unroll 1
-  for (int j = 0; j < BB_LEVELS; ++j) {
-    const double ax = px - cx, ay = py - cy, az = pz - cz;
-    const bool ok = (ax >= 0.0) && (ax < e) && (ay >= 0.0) && (ay < e) && (az >= 0.0) && (az < e);
-    if (!ok) {
-      *bad = true;
-      return path;
-    }
-    const bool bx = ax >= h, by = ay >= h, bz = az >= h;
-    path |= ((bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u)) << (18 - 3 * j);
-    cx = cx + (bx ? h : 0.0);
-    cy = cy + (by ? h : 0.0);
-    cz = cz + (bz ? h : 0.0);
-    e = h;
-    h = e / 2.0;
-  }
-  return path;
-}
-
 __device__ __forceinline__ int find_slot_dev(const int64_t* __restrict__ pose_off, int n_poses,
                                              int64_t idx) {
   int lo = 0, hi = n_poses;
@@ -325,301 +339,418 @@ struct BkParams {
   int all_scheme;
 };
 
+__device__ __forceinline__ void load_rec(const PartRec* __restrict__ p, double& x, double& y, double& z,
+                                         uint32_t& lin, uint32_t& idx) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  x = __longlong_as_double((long long)(((uint64_t)a.y << 32) | a.x));
+  y = __longlong_as_double((long long)(((uint64_t)a.w << 32) | a.z));
+  z = __longlong_as_double((long long)(((uint64_t)b.y << 32) | b.x));
+  lin = b.z;
+  idx = b.w;
+}
+
 // ---------------------------------------------------------------------------------------------
 // one workgroup per bucket
 // ---------------------------------------------------------------------------------------------
-// Key of a point inside its bucket (64 bit): [33+s .. 33) voxel inside the bucket | [33 .. 12) path21
-// | [12 .. 0) slot = position in the partitioned bucket (insertion order); bit 62 = pose is in the
-// scheme, bit 63 = bad point.  Sorting on bits [12, 33+s) orders the points by (voxel, path); a node
-// of level l is a run of keys with equal top s + 3l sort bits.
-__global__ __launch_bounds__(BB_THREADS) void k_bucket_build(
-    const uint32_t* __restrict__ part_lin, const uint32_t* __restrict__ part_idx,
-    const double* __restrict__ part_xyz, const uint32_t* __restrict__ table, BkParams P,
+// The subdivision of every voxel of the bucket (OctreeNode.subdivide, octree/octree.py:20-32: a node
+// splits while its scheme-pose count exceeds K) is found WITHOUT moving points: level by level the
+// still undecided points add themselves to an LDS histogram over (node ordinal, child digit); bins
+// above K become the nodes of the next level and get ordinals from a block scan.  Nothing is sorted
+// until every point knows its leaf depth d; then ONE stable LDS radix sort by (voxel, first d digits)
+// puts the bucket in the final order - voxel, leaf path, insertion order inside the leaf - and the
+// outputs are written with coalesced stores.
+constexpr int BB_BINS = 8192;          // histogram bins per level (nodes of a level x 8)
+constexpr uint32_t NOT_OVER = 0xFFFFFFFFu;
+
+// One chunk of a bucket: n <= BB_CAP points (a run of whole voxels), records part[SRC[i]] (CHUNKED)
+// or part[i]; outputs at positions out_base + [0, n), voxel staging records from vox_stage on.
+// Returns 0 or the BF_* flags that send the build down the general path.
+template <bool CHUNKED>
+__device__ __forceinline__ uint32_t bucket_chunk(
+    const PartRec* __restrict__ part, const uint16_t* __restrict__ SRC, const int n, const uint32_t out_base,
+    const uint32_t vox_stage, const uint32_t lin0, const BkParams& P, const int64_t* __restrict__ pose_off,
+    uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord, uint32_t* __restrict__ leafinfo,
+    uint32_t* __restrict__ bk_vox, uint32_t* s_bins, uint16_t (*s_slot)[BB_CAP], uint32_t (*s_cnt)[256],
+    uint32_t* s_scr, uint32_t* s_tot) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int s = P.lp.shift;
+  // wave w owns items [w * per_wave, (w+1) * per_wave) in `rounds` rounds of 64 consecutive items:
+  // item order == (wave, round, lane) order, which the stable ranks below rely on
+  const int rounds = (n + BB_THREADS - 1) / BB_THREADS;  // <= 16
+  const int per_wave = rounds * 64;
+
+  // ---- 1. points -> (voxel inside the bucket, child digits) ----------------------------------------------
+  // pth: bits 0..20 child digits (level j at bits 20-3j..18-3j), bit 30 bad point, bit 31 scheme pose
+  // stt: bit 31 undecided; undecided: bits 0..15 ordinal of the point's node among the overfull nodes of
+  //      the current level; decided: bits 16..19 leaf depth
+  uint32_t pth[BB_IPT], vlv[BB_IPT], stt[BB_IPT];
+  bool bad_any = false;
+#pragma unroll
+  for (int r = 0; r < BB_IPT; ++r) {
+    pth[r] = 0;
+    vlv[r] = 0;
+    stt[r] = 0;
+    if (r < rounds) {
+      const int i = wave * per_wave + r * 64 + lane;
+      if (i < n) {
+        // (16-byte loads: the second half of the record holds voxel, child digits and index)
+        const uint4 w4 = reinterpret_cast<const uint4*>(part + (CHUNKED ? (int)SRC[i] : i))[1];
+        const uint2 w = uint2{w4.z, w4.w};
+        const bool bad = w.x & 1u;
+        pth[r] = (((w.x >> 1) & 0x3FFFFu) << 3) | (w.y & 0x80000000u) | (bad ? 0x40000000u : 0u);
+        vlv[r] = w.x >> 19;
+        stt[r] = 0x80000000u;
+        bad_any = bad_any || bad;
+      }
+    }
+  }
+
+  // ---- 2. level 0: the voxels ------------------------------------------------------------------------------------
+  // bin = voxel inside the bucket; low half: scheme-pose points, high half: all points
+  const int nbins0 = 1 << s;
+  for (int d = tid; d < nbins0; d += BB_THREADS) s_bins[d] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < BB_IPT; ++r)
+    if (stt[r] >> 31) atomicAdd(&s_bins[vlv[r]], 0x10000u + (pth[r] >> 31));
+  __syncthreads();
+  uint32_t n_over;
+  {
+    const int per = (nbins0 + BB_THREADS - 1) / BB_THREADS;
+    uint32_t mine = 0;  // low half: voxels, high half: overfull voxels
+    for (int q = 0; q < per; ++q) {
+      const int d = tid * per + q;
+      if (d < nbins0) {
+        const uint32_t c = s_bins[d];
+        mine += ((c >> 16) ? 1u : 0u) + ((P.K >= 0 && (int64_t)(c & 0xFFFFu) > P.K) ? 0x10000u : 0u);
+      }
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_add(mine, &tot, s_scr);
+    for (int q = 0; q < per; ++q) {
+      const int d = tid * per + q;
+      if (d < nbins0) {
+        const uint32_t c = s_bins[d];
+        if (c >> 16) {  // staging of the j-th voxel of this bucket: linear key and point count
+          bk_vox[2 * ((size_t)vox_stage + (run & 0xFFFFu))] = lin0 + (uint32_t)d;
+          bk_vox[2 * ((size_t)vox_stage + (run & 0xFFFFu)) + 1] = c >> 16;
+          run += 1u;
+        }
+        const bool over = P.K >= 0 && (int64_t)(c & 0xFFFFu) > P.K;
+        s_bins[d] = over ? (run >> 16) : NOT_OVER;
+        if (over) run += 0x10000u;
+      }
+    }
+    n_over = tot >> 16;
+    if (tid == 0) {
+      s_tot[BK_NVOX] += tot & 0xFFFFu;
+      s_tot[BK_NINT] += n_over;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < BB_IPT; ++r) {
+    if (stt[r] >> 31) {
+      const uint32_t v = s_bins[vlv[r]];
+      stt[r] = v == NOT_OVER ? 0u : (0x80000000u | v);
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. deeper levels: bins = (overfull node of the level above, child digit) -----------------------------
+  int dmax = 0;
+  uint32_t flags = __any(bad_any) ? BF_BAD : 0u;
+#pragma unroll 1
+  for (int l = 1; n_over > 0; ++l) {
+    if (l > BB_LEVELS) {  // a node of level 7 still exceeds K: deeper than the 21-bit paths reach
+      flags |= BF_DEEP;
+#pragma unroll
+      for (int r = 0; r < BB_IPT; ++r)
+        if (stt[r] >> 31) stt[r] = (uint32_t)BB_LEVELS << 16;
+      break;
+    }
+    const int nbl = 8 * (int)n_over;
+    if (nbl > BB_BINS) {  // tiny K with many points: more nodes per level than the histogram holds
+      flags |= BF_OVERFLOW;
+      break;
+    }
+    dmax = l;
+    if (l - 1 == PATH_EAGER) {
+      // the digits computed up front are used up: the points that go deeper get all 7 levels
+#pragma unroll
+      for (int r = 0; r < BB_IPT; ++r) {
+        if (stt[r] >> 31) {
+          const int i = wave * per_wave + r * 64 + lane;
+          double x, y, z, cx, cy, cz;
+          uint32_t vp, idx;
+          load_rec(part + (CHUNKED ? (int)SRC[i] : i), x, y, z, vp, idx);
+          (void)lin_corner_of(P.lp, x, y, z, cx, cy, cz);
+          bool bad = false;
+          const uint32_t path = path_levels(x, y, z, cx, cy, cz, P.lp.L, BB_LEVELS, &bad);
+          pth[r] = (pth[r] & 0x80000000u) | path | (bad ? 0x40000000u : 0u);
+          bad_any = bad_any || bad;
+        }
+      }
+      if (__any(bad_any)) flags |= BF_BAD;
+    }
+    for (int d = tid; d < nbl; d += BB_THREADS) s_bins[d] = 0;
+    __syncthreads();
+    const int dsh = 18 - 3 * (l - 1);
+#pragma unroll
+    for (int r = 0; r < BB_IPT; ++r)
+      if ((stt[r] >> 31) && (pth[r] >> 31))
+        atomicAdd(&s_bins[(stt[r] & 0xFFFFu) * 8u + ((pth[r] >> dsh) & 7u)], 1u);
+    __syncthreads();
+    {
+      const int per = (nbl + BB_THREADS - 1) / BB_THREADS;
+      uint32_t mine = 0;
+      for (int q = 0; q < per; ++q) {
+        const int d = tid * per + q;
+        if (d < nbl) mine += (int64_t)s_bins[d] > P.K ? 1u : 0u;
+      }
+      uint32_t tot;
+      uint32_t run = block_excl_add(mine, &tot, s_scr);
+      for (int q = 0; q < per; ++q) {
+        const int d = tid * per + q;
+        if (d < nbl) {
+          const bool over = (int64_t)s_bins[d] > P.K;
+          s_bins[d] = over ? run : NOT_OVER;
+          if (over) ++run;
+        }
+      }
+      n_over = tot;
+      if (tid == 0 && l < BB_LEVELS) s_tot[BK_NINT + l] += tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BB_IPT; ++r) {
+      if (stt[r] >> 31) {
+        const uint32_t v = s_bins[(stt[r] & 0xFFFFu) * 8u + ((pth[r] >> dsh) & 7u)];
+        stt[r] = v == NOT_OVER ? ((uint32_t)l << 16) : (0x80000000u | v);
+      }
+    }
+    __syncthreads();
+  }
+  const int kshift = 3 * dmax;          // key = voxel << kshift | first d digits, left aligned in dmax digits
+  const int kbits = s + kshift;
+  if (kbits > 32) flags |= BF_OVERFLOW;
+  if (flags & (BF_OVERFLOW | BF_DEEP | BF_BAD)) return flags;  // the host runs the general path instead
+
+  // ---- 4. sort keys ------------------------------------------------------------------------------------------------
+  uint32_t* KEY = s_bins;
+  uint32_t* INFO = s_bins + BB_CAP;
+#pragma unroll
+  for (int r = 0; r < BB_IPT; ++r) {
+    if (r < rounds) {
+      const int i = wave * per_wave + r * 64 + lane;
+      if (i < n) {
+        const uint32_t d = (stt[r] >> 16) & 15u;
+        const uint32_t path = pth[r] & PATH_MASK;
+        const uint32_t trunc = d == 0 ? 0u : ((path >> (21 - 3 * d)) << (3 * (dmax - (int)d)));
+        KEY[i] = (kshift ? (vlv[r] << kshift) : vlv[r]) | trunc;
+        INFO[i] = path | (d << 21);
+      }
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  if (kbits == 0) {
+    for (int i = tid; i < n; i += BB_THREADS) s_slot[0][i] = (uint16_t)i;
+    __syncthreads();
+  }
+  for (int sh = 0; sh < kbits; sh += 8) {
+    const bool first = sh == 0;
+#pragma unroll
+    for (int w = 0; w < BB_THREADS / 64; ++w) s_cnt[w][tid] = 0;
+    __syncthreads();
+    uint32_t rank[BB_IPT];
+    uint16_t item[BB_IPT];
+    uint8_t dig[BB_IPT];
+#pragma unroll
+    for (int r = 0; r < BB_IPT; ++r) {
+      rank[r] = 0;
+      item[r] = 0;
+      dig[r] = 0;
+      if (r < rounds) {
+        const int i = wave * per_wave + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t it = valid ? (first ? (uint32_t)i : (uint32_t)s_slot[cur][i]) : 0u;
+        const uint32_t d = valid ? (KEY[it] >> sh) & 0xFFu : 0u;
+        item[r] = (uint16_t)it;
+        dig[r] = (uint8_t)d;
+        rank[r] = wave_stable_rank<8>(d, valid, s_cnt[wave]);
+      }
+    }
+    __syncthreads();
+    {
+      const int d = tid;
+      uint32_t tot = 0;
+#pragma unroll
+      for (int w = 0; w < BB_THREADS / 64; ++w) tot += s_cnt[w][d];
+      uint32_t all;
+      uint32_t run = block_excl_add(tot, &all, s_scr);
+#pragma unroll
+      for (int w = 0; w < BB_THREADS / 64; ++w) {
+        const uint32_t c = s_cnt[w][d];
+        s_cnt[w][d] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    const int dst_buf = first ? 0 : (cur ^ 1);
+#pragma unroll
+    for (int r = 0; r < BB_IPT; ++r) {
+      if (r < rounds) {
+        const int i = wave * per_wave + r * 64 + lane;
+        if (i < n) s_slot[dst_buf][s_cnt[wave][dig[r]] + rank[r]] = item[r];
+      }
+    }
+    __syncthreads();
+    cur = dst_buf;
+  }
+  const uint16_t* __restrict__ RS = s_slot[cur];
+
+  // ---- 5. outputs (coalesced) ------------------------------------------------------------------------------------
+  uint32_t nblk = 0;
+#pragma unroll 4
+  for (int r = 0; r < BB_IPT; ++r) {
+    const int f = r * BB_THREADS + tid;
+    if (f < n) {
+      const uint32_t it = RS[f];
+      const uint32_t key = KEY[it];
+      const uint32_t pit = f > 0 ? (uint32_t)RS[f - 1] : 0u;
+      const uint32_t pkey = f > 0 ? KEY[pit] : ~key;
+      const bool leaf_head = key != pkey;
+      const bool vox_head = f == 0 || (key >> kshift) != (pkey >> kshift);
+      double x, y, z;
+      uint32_t vp, idx;
+      load_rec(part + (CHUNKED ? (uint32_t)SRC[it] : it), x, y, z, vp, idx);
+      idx &= IDX_MASK;
+      bool blk_head = leaf_head;
+      if (!leaf_head && P.n_poses > 1) {
+        const uint32_t pidx = part[CHUNKED ? (uint32_t)SRC[pit] : pit].idx & IDX_MASK;
+        blk_head = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, pidx);
+      }
+      nblk += blk_head ? 1u : 0u;
+      const size_t o = (size_t)out_base + f;
+      leafinfo[o] = INFO[it] | (vox_head ? LI_VHEAD : 0u) | (blk_head ? LI_BHEAD : 0u);
+      ord_idx[o] = idx;
+      xyz_ord[3 * o] = x;
+      xyz_ord[3 * o + 1] = y;
+      xyz_ord[3 * o + 2] = z;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) nblk += __shfl_xor(nblk, off);
+  if (lane == 0 && nblk) atomicAdd(&s_tot[BK_NBLK], nblk);
+  __syncthreads();  // the LDS arrays are free for the next chunk
+  return 0u;
+}
+
+constexpr int BB_MAX_CHUNKS = 64;
+
+__global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
+    const PartRec* __restrict__ part, const uint32_t* __restrict__ table, BkParams P,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
     uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_tot) {
-  __shared__ uint64_t s_key[2][BB_CAP];
+  __shared__ uint32_t s_bins[BB_BINS];            // pyramid bins; afterwards KEY[BB_CAP] | INFO[BB_CAP]
+  __shared__ uint16_t s_slot[2][BB_CAP];          // sort buffers: positions -> item
   __shared__ uint32_t s_cnt[BB_THREADS / 64][256];
   __shared__ uint32_t s_scr[8];
   __shared__ uint32_t s_tot[BK_ROWS];
+  // buckets with more than BB_CAP points are cut into chunks of whole voxels
+  __shared__ uint16_t s_src[BB_CAP];              // chunk item -> record of the bucket
+  __shared__ uint8_t s_chunk[1 << PT_BITS];       // voxel inside the bucket -> chunk
+  __shared__ uint32_t s_cofs[BB_MAX_CHUNKS];      // first output position of the chunk
+  __shared__ uint16_t s_csize[BB_MAX_CHUNKS], s_cvox[BB_MAX_CHUNKS];
+  __shared__ int s_nchunks;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t b = blockIdx.x;
   const uint32_t start = table[(size_t)b * P.nst];
   const uint32_t end = (b + 1 < P.nb) ? table[(size_t)(b + 1) * P.nst] : P.n_alive;
   const int n = (int)(end - start);
   if (tid < BK_ROWS) s_tot[tid] = 0;
-  if (n == 0 || n > BB_CAP) {
-    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = (tid == BK_FLAGS && n > BB_CAP) ? BF_OVERFLOW : 0u;
+  if (n == 0 || n > 65535) {
+    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = (tid == BK_FLAGS && n > 0) ? BF_OVERFLOW : 0u;
     return;
   }
+  __syncthreads();
   const int s = P.lp.shift;
   const uint32_t lin0 = b << s;
-
-  // ---- 1. keys ----------------------------------------------------------------------------------------
-  bool bad_any = false;
-#pragma unroll 4
-  for (int r = 0; r < BB_IPT; ++r) {
-    const int i = wave * (64 * BB_IPT) + r * 64 + lane;
-    if (i < n) {
-      const size_t g = (size_t)start + i;
-      const uint32_t lin = part_lin[g];
-      const double x = part_xyz[3 * g], y = part_xyz[3 * g + 1], z = part_xyz[3 * g + 2];
-      double cx = P.lp.c0x, cy = P.lp.c0y, cz = P.lp.c0z;
-      if (P.lp.mode == 0) {
-        // the manager's corner is np.array(voxel_coords): int64(q * L) (grid.py:72-76,96-105)
-        cx = (double)(long long)(floor_div_exact(x, P.lp.L) * P.lp.L);
-        cy = (double)(long long)(floor_div_exact(y, P.lp.L) * P.lp.L);
-        cz = (double)(long long)(floor_div_exact(z, P.lp.L) * P.lp.L);
-      }
-      bool bad = false;
-      const uint32_t path = path21_of(x, y, z, cx, cy, cz, P.lp.L, &bad);
-      uint64_t k = ((uint64_t)(lin - lin0) << 33) | ((uint64_t)path << 12) | (uint64_t)i;
-      if (part_idx[g] >> 31) k |= 1ull << 62;
-      if (bad) k |= 1ull << 63;
-      bad_any = bad_any || bad;
-      s_key[0][i] = k;
-    }
-  }
-  __syncthreads();
-
-  // ---- 2. sort by (voxel, path) -------------------------------------------------------------------------
-  // K < 0 never splits: the path does not matter, only the voxel
-  const int lo_bit = P.K < 0 ? 33 : 12;
-  const int hi_bit = 33 + s;
-  int cur = 0;
-  for (int sh = lo_bit; sh < hi_bit; sh += 8) {
-    lds_sort_pass<uint64_t>(s_key[cur], s_key[cur ^ 1], n, sh, s_cnt, s_scr);
-    cur ^= 1;
-  }
-  const uint64_t* __restrict__ KS = s_key[cur];
-  char* KT = reinterpret_cast<char*>(s_key[cur ^ 1]);
-  // scratch carved out of the other key buffer
-  int8_t* c8 = reinterpret_cast<int8_t*>(KT);                       // [0, n]: common levels with j-1
-  uint16_t* pfx = reinterpret_cast<uint16_t*>(KT + 4608);           // [0, n]: scheme points before j
-  uint16_t* lf16 = reinterpret_cast<uint16_t*>(KT + 4608 + 8704);   // leaf ordinal of sorted position j
-
-  // ---- 3. structure -----------------------------------------------------------------------------------------
-  // c[j] = number of leading levels (0..7) that sorted element j shares with j-1, -1 across voxels;
-  // c[0] = c[n] = -1.  Blocked ownership from here on: thread t owns positions [16t, 16t+16).
-  for (int j = tid; j <= n; j += BB_THREADS) {
-    int c = -1;
-    if (j > 0 && j < n) {
-      const uint64_t x = ((KS[j] ^ KS[j - 1]) >> 12) & ((1ull << (21 + 12)) - 1ull);
-      if ((x >> 21) == 0) {
-        const uint32_t xp = (uint32_t)x & PATH_MASK;
-        c = xp == 0 ? 7 : (20 - (31 - __clz((int)xp))) / 3;
-      }
-    }
-    c8[j] = (int8_t)c;
-  }
-  const int j0 = tid * BB_IPT;
-  uint64_t key[BB_IPT];
-#pragma unroll
-  for (int e = 0; e < BB_IPT; ++e) key[e] = (j0 + e < n) ? KS[j0 + e] : 0ull;
-  if (!P.all_scheme) {
-    uint32_t mine = 0;
-#pragma unroll
-    for (int e = 0; e < BB_IPT; ++e) mine += (j0 + e < n) ? (uint32_t)((key[e] >> 62) & 1ull) : 0u;
-    uint32_t all;
-    uint32_t run = block_excl_add(mine, &all, s_scr);
-#pragma unroll
-    for (int e = 0; e < BB_IPT; ++e) {
-      if (j0 + e <= n) pfx[j0 + e] = (uint16_t)run;
-      run += (j0 + e < n) ? (uint32_t)((key[e] >> 62) & 1ull) : 0u;
-    }
-    if (tid == BB_THREADS - 1 && n == BB_CAP) pfx[n] = (uint16_t)run;
-  }
-  __syncthreads();
-
-  uint32_t act = 0;  // bit e: element e has not reached its leaf yet
-#pragma unroll
-  for (int e = 0; e < BB_IPT; ++e) act |= (j0 + e < n) ? (1u << e) : 0u;
-  uint32_t dep_pk[2] = {0, 0};       // 4 bits per element: leaf depth
-  uint32_t first_leaf = 0;           // bit e: the element's leaf starts its voxel
-  uint16_t vlo[BB_IPT], vcnt[BB_IPT];
-  uint32_t nint_loc[BB_LEVELS];
-#pragma unroll
-  for (int l = 0; l < BB_LEVELS; ++l) nint_loc[l] = 0;
-  bool deep = false;
-#pragma unroll 1
-  for (int l = 0; l <= BB_LEVELS; ++l) {
-    // heads of level l: positions i with c[i] < l.  lo(j) = last head <= j, hi(j) = first head > j.
-    int8_t cc[BB_IPT + 1];
-#pragma unroll
-    for (int e = 0; e <= BB_IPT; ++e) cc[e] = (j0 + e <= n) ? c8[j0 + e] : (int8_t)-1;
-    int last = -1, first = 0x7FFF;
-#pragma unroll
-    for (int e = 0; e < BB_IPT; ++e) {
-      if (cc[e] < l) {
-        last = j0 + e;
-        if (first == 0x7FFF) first = j0 + e;
-      }
-    }
-    // exclusive max-scan of `last` over lower threads, exclusive min-scan of `first` over higher ones
-    int pl = last, nf = first;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int a = __shfl_up(pl, off), bq = __shfl_down(nf, off);
-      if (lane >= off) pl = max(pl, a);
-      if (lane + off < 64) nf = min(nf, bq);
-    }
-    int* sw = reinterpret_cast<int*>(s_scr);
-    if (lane == 63) sw[wave] = pl;
-    if (lane == 0) sw[4 + wave] = nf;
+  const PartRec* __restrict__ recs = part + start;
+  uint32_t fl = 0;
+  if (n <= BB_CAP) {
+    fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
+                             bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot);
+  } else {
+    // ---- plan: points per voxel, then greedy runs of voxels with at most BB_CAP points ------------------
+    const int nbins0 = 1 << s;
+    for (int d = tid; d < nbins0; d += BB_THREADS) s_bins[d] = 0;
     __syncthreads();
-    int carry_lo = -1, carry_hi = 0x7FFF;
-#pragma unroll
-    for (int w = 0; w < BB_THREADS / 64; ++w) {
-      if (w < wave) carry_lo = max(carry_lo, sw[w]);
-      if (w > wave) carry_hi = min(carry_hi, sw[4 + w]);
-    }
-    {
-      const int a = __shfl_up(pl, 1), bq = __shfl_down(nf, 1);
-      carry_lo = max(carry_lo, lane > 0 ? a : -1);
-      carry_hi = min(carry_hi, lane < 63 ? bq : 0x7FFF);
-    }
-    carry_hi = min(carry_hi, n);
-    int lo_e[BB_IPT], hi_e[BB_IPT];
-    int run = carry_lo;
-#pragma unroll
-    for (int e = 0; e < BB_IPT; ++e) {
-      if (cc[e] < l) run = j0 + e;
-      lo_e[e] = run;
-    }
-    run = carry_hi;
-#pragma unroll
-    for (int e = BB_IPT - 1; e >= 0; --e) {
-      hi_e[e] = (cc[e + 1] < l) ? j0 + e + 1 : run;
-      run = hi_e[e];
-    }
-    bool any_split = false;
-#pragma unroll
-    for (int e = 0; e < BB_IPT; ++e) {
-      if (l == 0) {
-        vlo[e] = (uint16_t)lo_e[e];
-        vcnt[e] = (uint16_t)(min(hi_e[e], n) - lo_e[e]);
-      }
-      if (act & (1u << e)) {
-        const int lo = lo_e[e], hi = min(hi_e[e], n);
-        const int64_t cntv = P.all_scheme ? (int64_t)(hi - lo) : (int64_t)(pfx[hi] - pfx[lo]);
-        const bool split = P.K >= 0 && cntv > P.K;
-        if (split && l < BB_LEVELS) {
-          if (j0 + e == lo) nint_loc[l < BB_LEVELS ? l : 0] += 1;
-          any_split = true;
-        } else {
-          if (split) deep = true;  // level 7 and still too many points: not representable here
-          act &= ~(1u << e);
-          dep_pk[e >> 3] |= (uint32_t)l << (4 * (e & 7));
-          if (lo == (int)vlo[e]) first_leaf |= 1u << e;
+    for (int i = tid; i < n; i += BB_THREADS)
+      atomicAdd(&s_bins[reinterpret_cast<const uint4*>(recs + i)[1].z >> 19], 1u);
+    __syncthreads();
+    if (tid == 0) {
+      // (one lane, <= 4096 bins: this is the rare path of a skewed bucket)
+      int c = 0, size = 0, vox = 0;
+      uint32_t cum = 0;
+      bool fits = true;
+      s_cofs[0] = 0;
+      s_cvox[0] = 0;
+      for (int d = 0; d < nbins0; ++d) {
+        const int cnt = (int)s_bins[d];
+        if (cnt > BB_CAP) fits = false;  // a single voxel beyond the LDS capacity: general path
+        if (cnt > 0 && size + cnt > BB_CAP) {
+          s_csize[c] = (uint16_t)size;
+          if (++c >= BB_MAX_CHUNKS) {
+            fits = false;
+            c = BB_MAX_CHUNKS - 1;
+          }
+          size = 0;
+          s_cofs[c] = cum;
+          s_cvox[c] = (uint16_t)vox;
+        }
+        s_chunk[d] = (uint8_t)c;
+        if (cnt > 0) {
+          size += cnt;
+          cum += (uint32_t)cnt;
+          ++vox;
         }
       }
+      s_csize[c] = (uint16_t)size;
+      s_nchunks = fits ? c + 1 : 0;
     }
-    if (!__syncthreads_or(any_split ? 1 : 0)) break;
-  }
-
-  // ---- 4. leaf / voxel ordinals, totals -------------------------------------------------------------------
-  uint32_t heads = 0;  // low half: leaf heads, high half: voxel heads among my elements
-  uint32_t lh_bits = 0, vh_bits = 0;
+    __syncthreads();
+    const int nchunks = s_nchunks;
+    if (nchunks == 0) fl = BF_OVERFLOW;
+    for (int c = 0; c < nchunks && fl == 0; ++c) {
+      // stable compaction of the chunk's records: SRC[k] = k-th record of the bucket whose voxel is in the chunk
+      uint32_t basec = 0;
+      for (int i0 = 0; i0 < n; i0 += BB_THREADS) {
+        const int i = i0 + tid;
+        const bool sel = i < n && s_chunk[reinterpret_cast<const uint4*>(recs + i)[1].z >> 19] == (uint8_t)c;
+        const uint64_t m = __ballot(sel);
+        if (lane == 0) s_scr[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = basec, tot = 0;
 #pragma unroll
-  for (int e = 0; e < BB_IPT; ++e) {
-    if (j0 + e < n) {
-      const int d = (int)((dep_pk[e >> 3] >> (4 * (e & 7))) & 15u);
-      const int c = (int)c8[j0 + e];
-      if (c < d) lh_bits |= 1u << e;
-      if (c < 0) vh_bits |= 1u << e;
-    }
-  }
-  heads = (uint32_t)__popc(lh_bits) | ((uint32_t)__popc(vh_bits) << 16);
-  uint32_t tot_heads;
-  uint32_t hrun = block_excl_add(heads, &tot_heads, s_scr);
-  const int n_leaves = (int)(tot_heads & 0xFFFFu);
-  uint32_t lrun = hrun & 0xFFFFu, vrun = hrun >> 16;
-#pragma unroll
-  for (int e = 0; e < BB_IPT; ++e) {
-    if (j0 + e < n) {
-      if (lh_bits & (1u << e)) ++lrun;
-      if (vh_bits & (1u << e)) {
-        // staging of the j-th voxel of this bucket: linear key and point count
-        const uint32_t vl = (uint32_t)((key[e] >> 33) & 0xFFFu);
-        bk_vox[2 * ((size_t)start + vrun)] = lin0 + vl;
-        bk_vox[2 * ((size_t)start + vrun) + 1] = (uint32_t)vcnt[e];
-        ++vrun;
+        for (int w = 0; w < BB_THREADS / 64; ++w) {
+          if (w < wave) off += s_scr[w];
+          tot += s_scr[w];
+        }
+        if (sel) s_src[off + (uint32_t)__popcll(m & lanemask_lt())] = (uint16_t)i;
+        basec += tot;
+        __syncthreads();
       }
-      lf16[j0 + e] = (uint16_t)(lrun - 1u);
+      fl = bucket_chunk<true>(recs, s_src, (int)s_csize[c], start + s_cofs[c], start + s_cvox[c], lin0, P,
+                              pose_off, ord_idx, xyz_ord, leafinfo, bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot);
     }
   }
-  {
-    // per-level internal node counts, bad / deep flags
-#pragma unroll
-    for (int l = 0; l < BB_LEVELS; ++l) {
-      uint32_t v = nint_loc[l];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0 && v) atomicAdd(&s_tot[BK_NINT + l], v);
-    }
-    const uint32_t fl = (__any(deep) ? BF_DEEP : 0u) | (__any(bad_any) ? BF_BAD : 0u);
-    if (lane == 0 && fl) atomicOr(&s_tot[BK_FLAGS], fl);
-    if (tid == 0) s_tot[BK_NVOX] = tot_heads >> 16;
+  if (fl) {
+    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = tid == BK_FLAGS ? fl : 0u;
+    return;
   }
-  __syncthreads();  // lf16 complete; every read of KS / c8 is done
-
-  // ---- 5. back to insertion order: INFO[slot], (leaf ordinal, slot) words ------------------------------------
-  uint32_t* INFO = reinterpret_cast<uint32_t*>(s_key[cur]);             // [BB_CAP]
-  uint32_t* SB0 = reinterpret_cast<uint32_t*>(s_key[cur]) + BB_CAP;     // [BB_CAP]
-  uint32_t* SB1 = reinterpret_cast<uint32_t*>(s_key[cur ^ 1]);          // [BB_CAP] (over c8 / pfx: dead)
-  uint16_t lf_loc[BB_IPT];
-#pragma unroll
-  for (int e = 0; e < BB_IPT; ++e) lf_loc[e] = (j0 + e < n) ? lf16[j0 + e] : (uint16_t)0;
-  __syncthreads();
-#pragma unroll
-  for (int e = 0; e < BB_IPT; ++e) {
-    if (j0 + e < n) {
-      const uint32_t slot = (uint32_t)(key[e] & 0xFFFull);
-      const uint32_t d = (dep_pk[e >> 3] >> (4 * (e & 7))) & 15u;
-      const uint32_t path = (uint32_t)(key[e] >> 12) & PATH_MASK;
-      INFO[slot] = path | (d << 21) | ((first_leaf >> e) & 1u ? (1u << 30) : 0u);
-      SB0[slot] = ((uint32_t)lf_loc[e] << 12) | slot;
-    }
-  }
-  __syncthreads();
-  // ---- 6. stable sort by leaf ordinal from insertion order ---------------------------------------------------
-  uint32_t* sb[2] = {SB0, SB1};
-  int sc = 0;
-  for (int sh = 12; sh < 12 + 13 && (sh == 12 || (n_leaves - 1) >> (sh - 12)); sh += 8) {
-    lds_sort_pass<uint32_t>(sb[sc], sb[sc ^ 1], n, sh, s_cnt, s_scr);
-    sc ^= 1;
-  }
-  const uint32_t* __restrict__ RS = sb[sc];
-
-  // ---- 7. outputs (coalesced) ------------------------------------------------------------------------------------
-  uint32_t nblk = 0;
-#pragma unroll 4
-  for (int r = 0; r < BB_IPT; ++r) {
-    const int f = r * BB_THREADS + tid;
-    if (f < n) {
-      const uint32_t w = RS[f];
-      const uint32_t slot = w & 0xFFFu;
-      const uint32_t info = INFO[slot];
-      const bool leaf_head = f == 0 || (RS[f - 1] >> 12) != (w >> 12);
-      const size_t g = (size_t)start + slot;
-      const uint32_t idx = part_idx[g] & IDX_MASK;
-      bool blk_head = leaf_head;
-      if (!leaf_head && P.n_poses > 1) {
-        const uint32_t pidx = part_idx[(size_t)start + (RS[f - 1] & 0xFFFu)] & IDX_MASK;
-        blk_head = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, pidx);
-      }
-      nblk += blk_head ? 1u : 0u;
-      const size_t o = (size_t)start + f;
-      leafinfo[o] = (info & 0xFFFFFFu) | ((leaf_head && (info >> 30 & 1u)) ? LI_VHEAD : 0u) |
-                    (blk_head ? LI_BHEAD : 0u);
-      ord_idx[o] = idx;
-      xyz_ord[3 * o] = part_xyz[3 * g];
-      xyz_ord[3 * o + 1] = part_xyz[3 * g + 1];
-      xyz_ord[3 * o + 2] = part_xyz[3 * g + 2];
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) nblk += __shfl_xor(nblk, off);
-  if (lane == 0 && nblk) atomicAdd(&s_tot[BK_NBLK], nblk);
   __syncthreads();
   if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = s_tot[tid];
 }
@@ -632,52 +763,62 @@ __global__ __launch_bounds__(BB_THREADS) void k_bucket_build(
 // level 0 in voxel order, then level 1, ...); row BK_NBLK -> first block.  Totals -> small[].
 __global__ __launch_bounds__(1024) void k_bucket_scan(uint32_t* __restrict__ bk_tot, uint32_t nb,
                                                       uint32_t* __restrict__ small) {
-  __shared__ uint32_t s_w[16];
-  __shared__ uint32_t s_carry;
+  constexpr int ROWS = BK_FLAGS;  // rows 0 .. BK_FLAGS-1 are scanned, row BK_FLAGS is OR-ed
+  __shared__ uint32_t s_w[ROWS][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t level_base = 0, flags = 0;
-  for (int row = 0; row < BK_ROWS; ++row) {
-    if (tid == 0) s_carry = (row >= BK_NINT && row < BK_NINT + BB_LEVELS) ? level_base : 0u;
-    __syncthreads();
-    uint32_t row_total = 0;
-    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
-      const uint32_t bb = b0 + tid;
-      const uint32_t v = bb < nb ? bk_tot[(size_t)row * nb + bb] : 0u;
-      if (row == BK_FLAGS) {
-        flags |= v;
-        continue;
-      }
-      uint32_t inc = v;
+  // thread t owns buckets [4t, 4t+4) of every row: all loads in flight at once, ONE barrier
+  uint32_t v[ROWS][4], fl = 0;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-      }
-      if (lane == 63) s_w[wave] = inc;
-      __syncthreads();
-      uint32_t basev = s_carry, tot = 0;
-      for (int w = 0; w < 16; ++w) {
-        if (w < wave) basev += s_w[w];
-        tot += s_w[w];
-      }
-      if (bb < nb) bk_tot[(size_t)row * nb + bb] = basev + inc - v;
-      row_total += tot;
-      __syncthreads();
-      if (tid == 0) s_carry += tot;
-      __syncthreads();
-    }
-    if (row == BK_FLAGS) {
+  for (int row = 0; row <= ROWS; ++row) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) flags |= __shfl_xor(flags, off);
-      if (lane == 0 && flags) atomicOr(&small[SM_BK_FLAGS], flags);
-    } else if (tid == 0) {
-      if (row == BK_NVOX) small[SM_NVOX] = row_total;
-      if (row == BK_NBLK) small[SM_NBLOCKS] = row_total;
-      if (row >= BK_NINT && row < BK_NINT + BB_LEVELS) small[SM_BK_LEVEL + (row - BK_NINT)] = row_total;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t bb = 4u * tid + j;
+      const uint32_t x = bb < nb ? bk_tot[(size_t)row * nb + bb] : 0u;
+      if (row < ROWS) v[row < ROWS ? row : 0][j] = x; else fl |= x;
     }
-    if (row >= BK_NINT && row < BK_NINT + BB_LEVELS) level_base += row_total;
-    __syncthreads();
   }
+  uint32_t inc[ROWS], mine[ROWS];
+#pragma unroll
+  for (int row = 0; row < ROWS; ++row) {
+    mine[row] = v[row][0] + v[row][1] + v[row][2] + v[row][3];
+    uint32_t x = mine[row];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(x, off);
+      if (lane >= off) x += t;
+    }
+    inc[row] = x;
+    if (lane == 63) s_w[row][wave] = x;
+  }
+  __syncthreads();
+  uint32_t level_base = 0;
+#pragma unroll
+  for (int row = 0; row < ROWS; ++row) {
+    uint32_t basev = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t sv = s_w[row][w];
+      if (w < wave) basev += sv;
+      tot += sv;
+    }
+    const bool is_level = row >= BK_NINT && row < BK_NINT + BB_LEVELS;
+    uint32_t run = basev + inc[row] - mine[row] + (is_level ? level_base : 0u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t bb = 4u * tid + j;
+      if (bb < nb) bk_tot[(size_t)row * nb + bb] = run;
+      run += v[row][j];
+    }
+    if (tid == 0) {
+      if (row == BK_NVOX) small[SM_NVOX] = tot;
+      if (row == BK_NBLK) small[SM_NBLOCKS] = tot;
+      if (is_level) small[SM_BK_LEVEL + (row - BK_NINT)] = tot;
+    }
+    if (is_level) level_base += tot;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) fl |= __shfl_xor(fl, off);
+  if (lane == 0 && fl) atomicOr(&small[SM_BK_FLAGS], fl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -711,7 +852,7 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
   const uint32_t start = table[(size_t)b * P.nst];
   const uint32_t end = (b + 1 < P.nb) ? table[(size_t)(b + 1) * P.nst] : P.n_alive;
   const int n = (int)(end - start);
-  if (n == 0 || n > BB_CAP) return;
+  if (n == 0) return;
   const int64_t V = (int64_t)small[SM_NVOX];
   int64_t n_int = 0;
 #pragma unroll
@@ -871,9 +1012,8 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   hipStream_t st = ctx->stream;
   *done = 0;
   const int64_t N = f->n_store, n_alive = f->n_alive;
-  // (OCTL_NO_VOXEL_BUILD: tests compare this path with the level-synchronous one)
-  if (n_alive <= 0 || !f->bbox_dev.p || getenv("OCTL_NO_BUCKET_BUILD") || getenv("OCTL_NO_VOXEL_BUILD"))
-    return OCTL_OK;
+  // (OCTL_NO_BUCKET_BUILD: tests compare this path with the level-synchronous one)
+  if (n_alive <= 0 || !f->bbox_dev.p || getenv("OCTL_NO_BUCKET_BUILD")) return OCTL_OK;
   const int n_poses = (int)f->pose_off.size() - 1;
   // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
   HIP_TRY(ctx, hipEventSynchronize(f->bbox_event));
@@ -909,11 +1049,21 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   lp.nz = (uint32_t)nz;
   lp.shift = s;
   uint32_t* small = ctx->small.as<uint32_t>();
-  const uint32_t nst = (uint32_t)ceil_div(N, PT_ST);
+  // supertiles: one round of workgroups (2 per CU) over the cloud, at most 16 tiles each
+  int cus = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  static const int pt_ipt = getenv("OCTL_PT_IPT") ? atoi(getenv("OCTL_PT_IPT")) : 16;
+  const int tile = PT_THREADS * (pt_ipt == 8 ? 8 : 16);
+  const int wg_per_cu = pt_ipt == 8 ? 3 : 2;
+  const int st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(N, tile), (int64_t)cus * wg_per_cu)));
+  const int64_t st_items = (int64_t)st_tiles * tile;
+  const uint32_t nst = (uint32_t)ceil_div(N, st_items);
   // ---- scratch ------------------------------------------------------------------------------------------------
-  OCTL_TRY(devbuf_reserve(ctx, f->part_lin[0], (size_t)n_alive * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->part_idx[0], (size_t)n_alive * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)n_alive * 24));
+  OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)n_alive * sizeof(PartRec)));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_table, ((size_t)nb * nst + 8) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, (size_t)BK_ROWS * nb * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 8));
@@ -930,8 +1080,8 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   // ---- partition ----------------------------------------------------------------------------------------------
   {
     KTimer t(ctx, "part_hist");
-    hipLaunchKernelGGL(k_part_hist, dim3(nst), dim3(PT_THREADS), 0, st, (const double*)f->xyz.as<double>(),
-                       (const uint8_t*)f->alive.as<uint8_t>(), N, lp, nst, nb, table);
+    hipLaunchKernelGGL(k_part_hist, dim3(nst), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+                       (const uint8_t*)f->alive.as<uint8_t>(), N, lp, nst, nb, st_items, table);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -940,11 +1090,18 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   }
   {
     KTimer t(ctx, "part_scatter");
-    hipLaunchKernelGGL(k_part_scatter, dim3(nst), dim3(PT_THREADS), 0, st,
-                       (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
-                       nst, nb, (const uint32_t*)table, (const int64_t*)f->pose_off_dev.as<int64_t>(),
-                       n_poses, a.scheme_dev, f->part_lin[0].as<uint32_t>(), f->part_idx[0].as<uint32_t>(),
-                       f->part_xyz[0].as<double>());
+    if (pt_ipt == 8)
+      hipLaunchKernelGGL(k_part_scatter<8>, dim3(nst), dim3(PT_THREADS), 0, st,
+                         (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
+                         nst, nb, st_tiles, (const uint32_t*)table,
+                         (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
+                         f->part_xyz[0].as<PartRec>());
+    else
+      hipLaunchKernelGGL(k_part_scatter<16>, dim3(nst), dim3(PT_THREADS), 0, st,
+                         (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
+                         nst, nb, st_tiles, (const uint32_t*)table,
+                         (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
+                         f->part_xyz[0].as<PartRec>());
     HIP_TRY(ctx, hipGetLastError());
   }
   // ---- buckets ------------------------------------------------------------------------------------------------
@@ -959,9 +1116,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   {
     KTimer t(ctx, "bucket_build");
     hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st,
-                       (const uint32_t*)f->part_lin[0].as<uint32_t>(),
-                       (const uint32_t*)f->part_idx[0].as<uint32_t>(),
-                       (const double*)f->part_xyz[0].as<double>(), (const uint32_t*)table, bp,
+                       (const PartRec*)f->part_xyz[0].as<PartRec>(), (const uint32_t*)table, bp,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(),
                        f->bk_tot.as<uint32_t>());

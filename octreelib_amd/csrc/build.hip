@@ -7,6 +7,10 @@
 //   OctreeNode.insert_points    octree/octree.py:67-100  child index arithmetic
 //   OctreeNode._generate_children octree/octree.py:177-191 child corners / edges
 //
+// This is the GENERAL path: schemes with history, keep_scheme re-placement, voxels with more points than
+// the bucket build of bucket_build.hip sorts in LDS (a bare Octree / OctreeManager with millions of
+// points in one cube), trees deeper than 7 levels, points outside their cube.  A fresh forest is
+// built by bucket_build.hip (step 0 of forest_build).
 // Pipeline (all kernels HBM-bound integer/compare work; nothing here is a contraction):
 //   k_keygen      xyz -> packed voxel key + 21-level child-digit path (reference arithmetic
 //                 restated as exact f64 comparisons), voxel bounding box
@@ -1073,29 +1077,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   int level = 0;
   std::vector<int64_t> level_first{0, V};
 
-  // ---- 3b. voxel-local build: one wave per top-level voxel (voxel_build.hip) -------------------------
-  // a K-driven scheme without history; any voxel that does not fit sends the whole build down the
-  // level-synchronous path below
-  bool voxel_done = false;
-  if (!keep_scheme && K >= 0 && old_internal == 0 && n_alive > 0 && V > 0 &&
-      getenv("OCTL_NO_VOXEL_BUILD") == nullptr) {
-    VoxelBuildArgs va{val_sorted, n_alive, V, K, cur_epoch, max_depth};
-    int done = 0, lv = 0;
-    int64_t ni = 0;
-    std::vector<int64_t> lf;
-    OCTL_TRY(forest_voxel_build(f, va, nt, &done, &lf, &ni, &lv));
-    if (done) {
-      voxel_done = true;
-      level_first.swap(lf);
-      n_internal = ni;
-      level = lv;
-      nd = node_ptrs(nt);
-    }
-  }
-
   int32_t* pos_node = nullptr;
-  if (!voxel_done) {
-  trace.mark("voxel-local build");
   // ---- 4. level-0 buffers ---------------------------------------------------------------------------
   for (int b = 0; b < 2; ++b) {
     OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 4));
@@ -1254,7 +1236,6 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       HIP_TRY(ctx, hipGetLastError());
     }
   }
-  }  // !voxel_done
   trace.mark("finalize (enqueue)");
   int64_t n_blocks = 0;
   const int64_t n_ord_before = f->n_ord;

@@ -1,5 +1,5 @@
-// Declarations shared by the two build paths (build.hip: level-synchronous global path,
-// voxel_build.hip: one wave per top-level voxel).
+// Declarations shared by the two build paths (build.hip: level-synchronous general path,
+// bucket_build.hip: one MSD partition + one workgroup per bucket of voxels).
 #pragma once
 #include "forest.h"
 
@@ -14,9 +14,6 @@ enum {
   SM_NTILES = 14,   // tiles of the next level
   SM_ETOTAL = 15,   // total of the scanned tile histogram
   SM_NBLOCKS = 16,
-  SM_VB_FALLBACK = 17,  // voxel build: some voxel does not fit (too many points / too deep / bad point)
-  SM_VB_DEPTH = 18,     // voxel build: deepest leaf
-  SM_VB_INTERNAL = 19,  // voxel build: internal nodes in total
   // 20: kept count of apply_mask, 21: slot-voxel count, 24: debug scan total
   SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
@@ -44,21 +41,6 @@ static inline NodePtrs node_ptrs(NodeTable& t) {
   p.edge = t.edge.as<double>();
   return p;
 }
-
-// voxel_build.hip: complete build of every top-level voxel by one wave each (K-driven scheme, no
-// previous internal nodes).  Returns OCTL_OK with *done = 1 when the scheme, the leaf-ordered
-// arrays and pos_node are complete; *done = 0 when some voxel does not fit and the caller must
-// run the level-synchronous path instead (nothing the caller relies on has been modified).
-struct VoxelBuildArgs {
-  const uint32_t* val_sorted;  // store index | scheme bit, sorted by voxel
-  int64_t n_alive;
-  int64_t V;
-  int64_t K;
-  int cur_epoch;
-  int max_depth;
-};
-int forest_voxel_build(octl_forest* f, const VoxelBuildArgs& a, NodeTable& nt, int* done,
-                       std::vector<int64_t>* level_first, int64_t* n_internal, int* levels);
 
 // bucket_build.hip: complete build of a fresh forest (K-driven scheme or K < 0, no previous scheme) by
 // one MSD partition into buckets of consecutive voxels + one workgroup per bucket.  *done = 0 when

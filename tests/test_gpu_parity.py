@@ -860,9 +860,9 @@ def test_voxel_local_build_equals_level_synchronous_build(monkeypatch, scheme):
         f.close()
         return out
 
-    monkeypatch.delenv("OCTL_NO_VOXEL_BUILD", raising=False)
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
     a = build()
-    monkeypatch.setenv("OCTL_NO_VOXEL_BUILD", "1")
+    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
     b = build()
     assert a[5] == b[5] and a[5] >= 2
     for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
@@ -915,13 +915,68 @@ def test_voxel_local_build_random_voxels_vs_level_synchronous_build(monkeypatch,
         f.close()
         return out, names
 
-    monkeypatch.delenv("OCTL_NO_VOXEL_BUILD", raising=False)
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
     a, names_a = build()
-    monkeypatch.setenv("OCTL_NO_VOXEL_BUILD", "1")
+    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
     b, names_b = build()
-    assert "bucket_build" in names_a and "bucket_build" not in names_b and "voxel_build_a" not in names_b
+    assert "bucket_build" in names_a and "bucket_build" not in names_b
     if not deep and K >= 8:
         assert "level_hist" not in names_a    # the bucket path did the whole build
+    assert a[5] == b[5]
+    for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bucket_build_mixed_voxel_populations_vs_level_synchronous_build(monkeypatch, seed):
+    """Skewed scenes: most voxels hold a few hundred points, some 600 .. 3000 (more than one wavefront's
+    512, up to the 4096 a workgroup sorts in LDS), a few are empty; buckets of consecutive voxels
+    overflow and are cut into chunks of whole voxels.  Node tables, blocks, permutation, coordinates and
+    leaf order must be bit-identical to the level-synchronous path, and the bucket path must have done
+    the whole build."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    rng = np.random.default_rng(900 + seed)
+    dims = rng.integers(3, 7, 3)
+    K = int(rng.choice([16, 64, 300, 1000]))
+    parts = []
+    for c in np.argwhere(np.ones(dims)):
+        r = rng.random()
+        m = 0 if r < 0.05 else (int(rng.integers(600, 3001)) if r < 0.30 else int(rng.integers(1, 400)))
+        pts = rng.random((m, 3))
+        if m and rng.random() < 0.3:
+            pts[: m // 2] = rng.random(3) * 0.9 + rng.random((m // 2, 3)) * 0.1
+        parts.append(pts + c)
+    cloud = np.unique(np.vstack(parts), axis=0)
+    rng.shuffle(cloud)
+    cut = int(len(cloud) * rng.uniform(0.3, 0.7))
+    poses = [cloud[:cut], cloud[cut:]] if seed % 2 else [cloud]
+    scheme = [0] if (len(poses) == 2 and seed % 4 == 1) else None
+    ctx = nat.get_context()
+
+    def build():
+        f = Forest(0, np.zeros(3), 1.0)
+        for c in poses:
+            f.add_pose(c)
+        ctx.set_profiling(True)
+        f.subdivide(K, scheme)
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        out = ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()},
+               f.perm.copy(), f.xyz.copy(), f.order.copy(), int(f.info.n_levels))
+        f.close()
+        return out, names
+
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    a, names_a = build()
+    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    b, names_b = build()
+    assert "bucket_build" in names_a and "level_hist" not in names_a
+    assert "bucket_build" not in names_b
     assert a[5] == b[5]
     for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
         assert np.array_equal(a[0][k], b[0][k]), k
