@@ -308,24 +308,29 @@ class Workload:
         self.ctx.check(self.lib.octl_dev_free(self.ctx.handle, self.d_xyz))
 
 
+_OWNED = {}
+
+
+def owned_voxels(dims, n_ranks):
+    """Linear ids (x slowest) of the voxels of the scene that rank 0 of n_ranks owns."""
+    key = (tuple(dims), n_ranks)
+    if key not in _OWNED:
+        from octreelib_amd.distributed import voxel_owner_np
+
+        d = np.asarray(dims, dtype=np.int64)
+        lin = np.arange(int(d.prod()), dtype=np.int64)
+        q = np.stack([lin // (d[1] * d[2]), (lin // d[2]) % d[1], lin % d[2]], axis=1)
+        _OWNED[key] = lin[voxel_owner_np(q, n_ranks) == 0]
+    return _OWNED[key]
+
+
 def shard_cloud(m, dims, cloud, stream, n_ranks):
     """m points of the scene that all lie in voxels owned by rank 0 of n_ranks: what one rank holds
-    after the all-to-all.  Points are drawn over the whole scene and those of other owners are
-    rejected, so the density per owned voxel is the scene's."""
-    from octreelib_amd.distributed import voxel_indices_np, voxel_owner_np
-
-    out, have, sub = [], 0, 0
-    while have < m:
-        want = int((m - have) * n_ranks * 1.02) + 1024
-        want = min(want, 4 * GEN_CHUNK)
-        s = stream * 64 + sub
-        pts = (synthetic.planar_cloud(want, dims, seed=1, stream=s) if cloud == "planar"
-               else synthetic.uniform_cloud(want, dims, seed=1000 + s))
-        keep = pts[voxel_owner_np(voxel_indices_np(pts, 1.0), n_ranks) == 0]
-        out.append(keep[: m - have])
-        have += len(out[-1])
-        sub += 1
-    return np.vstack(out)
+    after the all-to-all (uniform over the owned voxels, so the density per voxel is the scene's)."""
+    vox = owned_voxels(dims, n_ranks)
+    if cloud == "planar":
+        return synthetic.planar_cloud(m, dims, seed=1, stream=stream, voxels=vox)
+    return synthetic.uniform_cloud(m, dims, seed=1000 + stream, voxels=vox)
 
 
 def main():

@@ -11,16 +11,18 @@
 // node's points at every level.  A device radix sort by voxel followed by a per-voxel gather reads the
 // 24-byte points at random: 128-byte lines for 24 useful bytes (measured 147 B per point).  Here the
 // points move through HBM once:
-//   k_part_hist / k_part_scatter   MSD partition of (linear voxel key, index, xyz) into <= 4096
-//                                  BUCKETS of consecutive voxels (one 12-bit digit, LDS histograms,
-//                                  wave64 ballot ranks: stable) - the only scatter of coordinates;
+//   k_part_hist / k_part_scatter   partition of (voxel, child digits, index, xyz) records into BUCKETS of
+//                                  consecutive voxels: one stable pass on a 12-bit digit (LDS
+//                                  histograms, wave64 ballot ranks) for up to 4096 buckets - the only
+//                                  scatter of coordinates - and a second one on the next 12 bits for
+//                                  clouds that need more buckets (> 10 M points);
 //   k_bucket_build                 one workgroup per bucket (<= 4096 points, a few voxels): the bucket
 //                                  is sorted in LDS by (voxel, 21-bit child-digit path), the leaf of
 //                                  every point follows from segment scans over the sorted keys (a node
 //                                  splits while its scheme-pose count exceeds K), a second LDS sort
 //                                  restores insertion order inside the leaves, and the leaf-ordered
 //                                  permutation + coordinates are written with coalesced stores;
-//   k_bucket_scan                  bucket totals -> voxel / node / block numbering bases;
+//   one exclusive scan             bucket totals -> voxel / node / block numbering bases;
 //   k_bucket_nodes                 one wavefront per bucket: scheme nodes in the level-major numbering
 //                                  of the level-synchronous path, position -> leaf map, block table.
 // Everything is HBM-bound integer / compare work; the f64 arithmetic is the reference's own
@@ -45,7 +47,7 @@ constexpr int BB_LEVELS = 7;                     // child digits per point (21 b
 constexpr uint32_t PATH_MASK = 0x1FFFFFu;
 
 // rows of the per-bucket totals table bk_tot[row][bucket]
-enum { BK_NVOX = 0, BK_NINT = 1 /* .. 7 */, BK_NBLK = 8, BK_FLAGS = 9, BK_ROWS = 10 };
+enum { BK_NVOX = 0, BK_NINT = 1 /* .. 7 */, BK_NBLK = 8, BK_ROWS = 9 };
 // leafinfo word of a leaf-ordered point
 constexpr uint32_t LI_VHEAD = 1u << 24;   // first point of its top-level voxel
 constexpr uint32_t LI_BHEAD = 1u << 25;   // first point of its (leaf, pose) block
@@ -61,7 +63,15 @@ struct LinParams {
   int minx, miny, minz;  // voxel bounding box
   uint32_t ny, nz;
   int shift;         // bucket = lin >> shift
+  // digit of the current partition pass: (lin >> dshift) & dmask.  One pass: the bucket itself.  More
+  // than 4096 buckets: two stable passes, the low 12 bits of the bucket first, then the rest.
+  int dshift;
+  uint32_t dmask;
+  int raw_vp;        // 1: this pass is not the last one, records carry the full linear key
 };
+__device__ __forceinline__ uint32_t digit_of(const LinParams& lp, uint32_t lin) {
+  return (lin >> lp.dshift) & lp.dmask;
+}
 
 // ---------------------------------------------------------------------------------------------
 // partition
@@ -155,12 +165,28 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
       const double2* s2 = reinterpret_cast<const double2*>(xyz + 3 * i);
       const double2 a = s2[0], b = s2[1], c = s2[2];
       const uint16_t al = *reinterpret_cast<const uint16_t*>(alive + i);
-      if (al & 0xFF) atomicAdd(&hist[lin_of(lp, a.x, a.y, b.x) >> lp.shift], 1u);
-      if (al >> 8) atomicAdd(&hist[lin_of(lp, b.y, c.x, c.y) >> lp.shift], 1u);
+      if (al & 0xFF) atomicAdd(&hist[digit_of(lp, lin_of(lp, a.x, a.y, b.x))], 1u);
+      if (al >> 8) atomicAdd(&hist[digit_of(lp, lin_of(lp, b.y, c.x, c.y))], 1u);
     } else if (i < N && alive[i]) {
-      atomicAdd(&hist[lin_of(lp, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]) >> lp.shift], 1u);
+      atomicAdd(&hist[digit_of(lp, lin_of(lp, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]))], 1u);
     }
   }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table[(size_t)d * nst + blockIdx.x] = hist[d];
+}
+
+// second pass: the records of the first pass (they carry the full linear key)
+struct PartRec;
+__global__ __launch_bounds__(PH_THREADS) void k_part_hist_rec(const uint4* __restrict__ recs, int64_t N,
+                                                              LinParams lp, uint32_t nst, uint32_t nd,
+                                                              int64_t st_items, uint32_t* __restrict__ table) {
+  __shared__ uint32_t hist[PT_BINS];
+  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) hist[d] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * st_items;
+  const int64_t lim = min(N, base + st_items);
+  for (int64_t i = base + threadIdx.x; i < lim; i += PH_THREADS)
+    atomicAdd(&hist[digit_of(lp, recs[2 * i + 1].z)], 1u);
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table[(size_t)d * nst + blockIdx.x] = hist[d];
 }
@@ -182,7 +208,7 @@ __device__ __forceinline__ uint32_t wave_rank_u16(uint32_t digit, bool valid, ui
   return old + rank_in_round;
 }
 
-template <int PT_IPT>
+template <int PT_IPT, bool FROM_REC>
 __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     const double* __restrict__ xyz, const uint8_t* __restrict__ alive, int64_t N, LinParams lp,
     uint32_t nst, uint32_t nd, int st_tiles, const uint32_t* __restrict__ table_scanned,
@@ -206,32 +232,47 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     // == memory order, so the partition is stable
     const int64_t wbase = tbase + (int64_t)wave * (64 * PT_IPT);
     double x[PT_IPT], y[PT_IPT], z[PT_IPT];
-    uint32_t lin[PT_IPT], rank[PT_IPT], pbits[PT_IPT];
+    uint32_t lin[PT_IPT], rank[PT_IPT], pbits[PT_IPT], idxv[PT_IPT];
     uint8_t live[PT_IPT];
     // every load of the tile is issued before the first use: a load behind `if (alive[i])` waits for
     // the flag first, and 16 rounds of two dependent HBM latencies were 50 us per tile
 #pragma unroll
     for (int r = 0; r < PT_IPT; ++r) {
       const int64_t i = min(wbase + r * 64 + lane, N - 1);
-      live[r] = alive[i];
-      x[r] = xyz[3 * i];
-      y[r] = xyz[3 * i + 1];
-      z[r] = xyz[3 * i + 2];
+      if (FROM_REC) {
+        const uint4* q = reinterpret_cast<const uint4*>(xyz) + 2 * i;
+        const uint4 a = q[0], b = q[1];
+        x[r] = __longlong_as_double((long long)(((uint64_t)a.y << 32) | a.x));
+        y[r] = __longlong_as_double((long long)(((uint64_t)a.w << 32) | a.z));
+        z[r] = __longlong_as_double((long long)(((uint64_t)b.y << 32) | b.x));
+        lin[r] = b.z;
+        idxv[r] = b.w;
+        live[r] = 1;
+      } else {
+        live[r] = alive[i];
+        x[r] = xyz[3 * i];
+        y[r] = xyz[3 * i + 1];
+        z[r] = xyz[3 * i + 2];
+        idxv[r] = 0;
+      }
     }
 #pragma unroll
     for (int r = 0; r < PT_IPT; ++r) {
       const int64_t i = wbase + r * 64 + lane;
       const bool valid = i < N && live[r];
-      lin[r] = 0;
+      if (!FROM_REC) lin[r] = 0;
       pbits[r] = 0;
       if (valid) {
         double cx, cy, cz;
-        lin[r] = lin_corner_of(lp, x[r], y[r], z[r], cx, cy, cz);
-        bool bad = false;
-        const uint32_t path = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
-        pbits[r] = ((path >> 3) << 1) | (bad ? 1u : 0u);
+        const uint32_t l = lin_corner_of(lp, x[r], y[r], z[r], cx, cy, cz);
+        if (!FROM_REC) lin[r] = l;
+        if (!lp.raw_vp) {
+          bool bad = false;
+          const uint32_t path = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
+          pbits[r] = ((path >> 3) << 1) | (bad ? 1u : 0u);
+        }
       }
-      rank[r] = wave_rank_u16<PT_BITS>(lin[r] >> lp.shift, valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
+      rank[r] = wave_rank_u16<PT_BITS>(digit_of(lp, lin[r]), valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
     }
     __syncthreads();
     // per bucket: exclusive offsets of the waves inside this tile; the tile's total moves the running
@@ -256,10 +297,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     for (int r = 0; r < PT_IPT; ++r) {
       if (rank[r] >> 31) {
         const int64_t i = wbase + r * 64 + lane;
-        const uint32_t d = lin[r] >> lp.shift;
+        const uint32_t d = digit_of(lp, lin[r]);
         const uint32_t dst = base[d] + cnt[wave][d] + (rank[r] & 0x7FFFFFFFu);
         uint32_t v = (uint32_t)i;
-        if (scheme) {
+        if (FROM_REC) {
+          v = idxv[r];
+        } else if (scheme) {
           int lo = 0, hi = n_poses;
           while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -274,7 +317,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
                        zb = (uint64_t)__double_as_longlong(z[r]);
         o[0] = uint4{(uint32_t)xb, (uint32_t)(xb >> 32), (uint32_t)yb, (uint32_t)(yb >> 32)};
         const uint32_t vl = lin[r] & ((1u << lp.shift) - 1u);
-        o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), (vl << 19) | pbits[r], v};
+        o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), lp.raw_vp ? lin[r] : ((vl << 19) | pbits[r]), v};
       }
     }
     __syncthreads();
@@ -285,6 +328,26 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     }
     // (the next tile reads base only after the barrier that follows its counter reset)
   }
+}
+
+// first record of every bucket after a two-pass partition (one pass: the scanned table has them):
+// bstart[b] for b in [0, nb], from the sorted records' own coordinates
+__global__ __launch_bounds__(256) void k_bucket_bounds(const uint4* __restrict__ recs, uint32_t n,
+                                                       LinParams lp, uint32_t nb,
+                                                       uint32_t* __restrict__ bstart) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  auto bucket_at = [&](uint32_t j) {
+    const uint4 a = recs[2 * (size_t)j], b = recs[2 * (size_t)j + 1];
+    return lin_of(lp, __longlong_as_double((long long)(((uint64_t)a.y << 32) | a.x)),
+                  __longlong_as_double((long long)(((uint64_t)a.w << 32) | a.z)),
+                  __longlong_as_double((long long)(((uint64_t)b.y << 32) | b.x))) >> lp.shift;
+  };
+  const uint32_t bi = bucket_at(i);
+  const uint32_t first = i == 0 ? 0u : bucket_at(i - 1) + 1u;  // buckets (prev, bi] start here
+  for (uint32_t bb = first; bb <= bi; ++bb) bstart[bb] = i;
+  if (i == n - 1)
+    for (uint32_t bb = bi + 1; bb <= nb; ++bb) bstart[bb] = n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,7 +395,7 @@ __device__ __forceinline__ int find_slot_dev(const int64_t* __restrict__ pose_of
 struct BkParams {
   LinParams lp;
   int64_t K;
-  uint32_t nst;       // stride of the partition table
+  uint32_t bstride;   // first record of bucket b = bstart[b * bstride]
   uint32_t nb;        // buckets
   uint32_t n_alive;
   int n_poses;
@@ -651,9 +714,10 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 constexpr int BB_MAX_CHUNKS = 64;
 
 __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
-    const PartRec* __restrict__ part, const uint32_t* __restrict__ table, BkParams P,
+    const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
-    uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_tot) {
+    uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_tot,
+    uint32_t* __restrict__ small) {
   __shared__ uint32_t s_bins[BB_BINS];            // pyramid bins; afterwards KEY[BB_CAP] | INFO[BB_CAP]
   __shared__ uint16_t s_slot[2][BB_CAP];          // sort buffers: positions -> item
   __shared__ uint32_t s_cnt[BB_THREADS / 64][256];
@@ -667,12 +731,13 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
   __shared__ int s_nchunks;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t b = blockIdx.x;
-  const uint32_t start = table[(size_t)b * P.nst];
-  const uint32_t end = (b + 1 < P.nb) ? table[(size_t)(b + 1) * P.nst] : P.n_alive;
+  const uint32_t start = bstart[(size_t)b * P.bstride];
+  const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   const int n = (int)(end - start);
   if (tid < BK_ROWS) s_tot[tid] = 0;
   if (n == 0 || n > 65535) {
-    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = (tid == BK_FLAGS && n > 0) ? BF_OVERFLOW : 0u;
+    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
+    if (tid == 0 && n > 0) atomicOr(&small[SM_BK_FLAGS], BF_OVERFLOW);
     return;
   }
   __syncthreads();
@@ -747,8 +812,9 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
                               pose_off, ord_idx, xyz_ord, leafinfo, bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot);
     }
   }
-  if (fl) {
-    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = tid == BK_FLAGS ? fl : 0u;
+  if (fl) {  // the host runs the general path instead
+    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
+    if (tid == 0) atomicOr(&small[SM_BK_FLAGS], fl);
     return;
   }
   __syncthreads();
@@ -756,69 +822,22 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
 }
 
 // ---------------------------------------------------------------------------------------------
-// bucket totals -> numbering bases (one workgroup; nb <= 4096)
+// bucket totals -> numbering bases
 // ---------------------------------------------------------------------------------------------
-// In place: row BK_NVOX -> first voxel (root) of every bucket; rows BK_NINT+l -> first internal node of
-// level l of every bucket in the LEVEL-MAJOR order of the level-synchronous path (all internal nodes of
-// level 0 in voxel order, then level 1, ...); row BK_NBLK -> first block.  Totals -> small[].
-__global__ __launch_bounds__(1024) void k_bucket_scan(uint32_t* __restrict__ bk_tot, uint32_t nb,
-                                                      uint32_t* __restrict__ small) {
-  constexpr int ROWS = BK_FLAGS;  // rows 0 .. BK_FLAGS-1 are scanned, row BK_FLAGS is OR-ed
-  __shared__ uint32_t s_w[ROWS][16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // thread t owns buckets [4t, 4t+4) of every row: all loads in flight at once, ONE barrier
-  uint32_t v[ROWS][4], fl = 0;
-#pragma unroll
-  for (int row = 0; row <= ROWS; ++row) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t bb = 4u * tid + j;
-      const uint32_t x = bb < nb ? bk_tot[(size_t)row * nb + bb] : 0u;
-      if (row < ROWS) v[row < ROWS ? row : 0][j] = x; else fl |= x;
-    }
+// ONE exclusive scan over the row-major table bk_tot[row][bucket] numbers everything: inside row
+// BK_NVOX the prefix is the first voxel (root) of a bucket; rows BK_NINT .. BK_NINT+6 follow each other,
+// so the prefix minus the value at the head of row BK_NINT is the first internal node of level l of a
+// bucket in the LEVEL-MAJOR order of the level-synchronous path (all internal nodes of level 0 in voxel
+// order, then level 1, ...); row BK_NBLK minus its head is the first block.  The row heads are the totals.
+__global__ void k_bucket_totals(const uint32_t* __restrict__ scanned, uint32_t nb,
+                                const uint32_t* __restrict__ grand_total, uint32_t* __restrict__ small) {
+  const int t = threadIdx.x;
+  if (t == 0) small[SM_NVOX] = scanned[(size_t)BK_NINT * nb];
+  if (t < BB_LEVELS) {
+    const uint32_t a = scanned[(size_t)(BK_NINT + t) * nb], bq = scanned[(size_t)(BK_NINT + t + 1) * nb];
+    small[SM_BK_LEVEL + t] = bq - a;
   }
-  uint32_t inc[ROWS], mine[ROWS];
-#pragma unroll
-  for (int row = 0; row < ROWS; ++row) {
-    mine[row] = v[row][0] + v[row][1] + v[row][2] + v[row][3];
-    uint32_t x = mine[row];
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(x, off);
-      if (lane >= off) x += t;
-    }
-    inc[row] = x;
-    if (lane == 63) s_w[row][wave] = x;
-  }
-  __syncthreads();
-  uint32_t level_base = 0;
-#pragma unroll
-  for (int row = 0; row < ROWS; ++row) {
-    uint32_t basev = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const uint32_t sv = s_w[row][w];
-      if (w < wave) basev += sv;
-      tot += sv;
-    }
-    const bool is_level = row >= BK_NINT && row < BK_NINT + BB_LEVELS;
-    uint32_t run = basev + inc[row] - mine[row] + (is_level ? level_base : 0u);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t bb = 4u * tid + j;
-      if (bb < nb) bk_tot[(size_t)row * nb + bb] = run;
-      run += v[row][j];
-    }
-    if (tid == 0) {
-      if (row == BK_NVOX) small[SM_NVOX] = tot;
-      if (row == BK_NBLK) small[SM_NBLOCKS] = tot;
-      if (is_level) small[SM_BK_LEVEL + (row - BK_NINT)] = tot;
-    }
-    if (is_level) level_base += tot;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) fl |= __shfl_xor(fl, off);
-  if (lane == 0 && fl) atomicOr(&small[SM_BK_FLAGS], fl);
+  if (t == 8) small[SM_NBLOCKS] = *grand_total - scanned[(size_t)BK_NBLK * nb];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -834,13 +853,13 @@ __device__ __forceinline__ uint32_t digit_at(uint32_t path21, int level) {
 
 struct NodeParams {
   LinParams lp;
-  uint32_t nst, nb, n_alive;
+  uint32_t bstride, nb, n_alive;
   int n_poses, all_scheme, cur_epoch;
   int64_t node_cap;   // capacity of the node table (nodes); a larger table is needed -> overflow flag
 };
 
 __global__ __launch_bounds__(256) void k_bucket_nodes(
-    NodePtrs nd, NodeParams P, const uint32_t* __restrict__ table, const uint32_t* __restrict__ bk_base,
+    NodePtrs nd, NodeParams P, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bk_base,
     const uint32_t* __restrict__ leafinfo,
     const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bk_vox,
     const int64_t* __restrict__ pose_off, int32_t* __restrict__ pos_node, uint64_t* __restrict__ vlin,
@@ -849,14 +868,13 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t b = blockIdx.x * 4 + wave;
   if (b >= P.nb) return;  // no workgroup barrier below: waves are independent
-  const uint32_t start = table[(size_t)b * P.nst];
-  const uint32_t end = (b + 1 < P.nb) ? table[(size_t)(b + 1) * P.nst] : P.n_alive;
+  const uint32_t start = bstart[(size_t)b * P.bstride];
+  const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   const int n = (int)(end - start);
   if (n == 0) return;
-  const int64_t V = (int64_t)small[SM_NVOX];
-  int64_t n_int = 0;
-#pragma unroll
-  for (int l = 0; l < BB_LEVELS; ++l) n_int += small[SM_BK_LEVEL + l];
+  const uint32_t head_int = bk_base[(size_t)BK_NINT * P.nb], head_blk = bk_base[(size_t)BK_NBLK * P.nb];
+  const int64_t V = (int64_t)head_int;                     // total of row BK_NVOX
+  const int64_t n_int = (int64_t)(head_blk - head_int);    // total of the level rows
   if (V + 8 * n_int > P.node_cap) {
     if (lane == 0) atomicOr(&small[SM_BK_FLAGS], 0x100u);  // the host grows the table and launches again
     return;
@@ -864,8 +882,8 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
   const uint32_t vbase = bk_base[(size_t)BK_NVOX * P.nb + b];
   uint32_t lbase[BB_LEVELS];
 #pragma unroll
-  for (int l = 0; l < BB_LEVELS; ++l) lbase[l] = bk_base[(size_t)(BK_NINT + l) * P.nb + b];
-  const uint32_t bbase = bk_base[(size_t)BK_NBLK * P.nb + b];
+  for (int l = 0; l < BB_LEVELS; ++l) lbase[l] = bk_base[(size_t)(BK_NINT + l) * P.nb + b] - head_int;
+  const uint32_t bbase = bk_base[(size_t)BK_NBLK * P.nb + b] - head_blk;
 
   uint32_t vcarry = 0, bcarry = 0;
   uint32_t carry[BB_LEVELS], tail_pref[BB_LEVELS];
@@ -1028,13 +1046,15 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
                  nz = (uint64_t)(bb[5] - bb[2] + 1);
   if (nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32)) return OCTL_OK;  // keys would not fit 32 bits
   const uint64_t R = nx * ny * nz;
-  // buckets: runs of 2^s consecutive voxel keys, sized for ~2500 points on average
+  // buckets: runs of 2^s consecutive voxel keys, sized for ~2500 points on average (at most 2^24)
+  // (OCTL_BUCKET_POINTS: tests force many small buckets - and with them the two-pass partition - on small clouds)
+  const uint64_t target = getenv("OCTL_BUCKET_POINTS") ? std::max(1, atoi(getenv("OCTL_BUCKET_POINTS"))) : 2560;
   uint64_t want = 1;
-  while (want < PT_BINS && want * 2560 < (uint64_t)n_alive) want <<= 1;
-  if (want * 2560 < (uint64_t)n_alive && R > (uint64_t)PT_BINS) return OCTL_OK;  // needs two levels: not yet
+  while (want < ((uint64_t)PT_BINS << PT_BITS) && want * target < (uint64_t)n_alive) want <<= 1;
   const int s = std::min(12, std::max(0, ceil_log2_u64(R) - ceil_log2_u64(want)));
-  if (((R - 1) >> s) + 1 > (uint64_t)PT_BINS) return OCTL_OK;  // a sparse scene: more than 2^24 voxel keys
+  if (((R - 1) >> s) + 1 > ((uint64_t)PT_BINS << PT_BITS)) return OCTL_OK;  // a sparse scene: too many keys
   const uint32_t nb = (uint32_t)(((R - 1) >> s) + 1);
+  const bool two_pass = nb > (uint32_t)PT_BINS;
 
   LinParams lp;
   lp.mode = f->mode;
@@ -1056,16 +1076,23 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  static const int pt_ipt = getenv("OCTL_PT_IPT") ? atoi(getenv("OCTL_PT_IPT")) : 16;
-  const int tile = PT_THREADS * (pt_ipt == 8 ? 8 : 16);
-  const int wg_per_cu = pt_ipt == 8 ? 3 : 2;
-  const int st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(N, tile), (int64_t)cus * wg_per_cu)));
-  const int64_t st_items = (int64_t)st_tiles * tile;
-  const uint32_t nst = (uint32_t)ceil_div(N, st_items);
+  constexpr int PT_IPT = 16;
+  constexpr int tile = PT_THREADS * PT_IPT;
+  auto supertiles = [&](int64_t items, int* st_tiles) {
+    *st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(items, tile), (int64_t)cus * 2)));
+    return (uint32_t)ceil_div(items, (int64_t)*st_tiles * tile);
+  };
+  int st_tiles_a = 1, st_tiles_b = 1;
+  const uint32_t nst_a = supertiles(N, &st_tiles_a);
+  const uint32_t nst_b = two_pass ? supertiles(n_alive, &st_tiles_b) : 0;
+  const uint32_t nd_a = two_pass ? (uint32_t)PT_BINS : nb;             // digits of the first pass
+  const uint32_t nd_b = two_pass ? ((nb - 1) >> PT_BITS) + 1 : 0;      // digits of the second pass
   // ---- scratch ------------------------------------------------------------------------------------------------
   OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)n_alive * sizeof(PartRec)));
-  OCTL_TRY(devbuf_reserve(ctx, f->bk_table, ((size_t)nb * nst + 8) * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, (size_t)BK_ROWS * nb * 4));
+  if (two_pass) OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[1], (size_t)n_alive * sizeof(PartRec)));
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_table,
+                          (std::max((size_t)nd_a * nst_a, (size_t)nd_b * nst_b) + (two_pass ? nb + 1 : 0) + 16) * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, ((size_t)BK_ROWS * nb + 8) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 8));
   OCTL_TRY(devbuf_reserve(ctx, f->leafinfo, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_alive * 4));
@@ -1078,53 +1105,90 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   uint32_t* table = f->bk_table.as<uint32_t>();
   HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_FLAGS, 0, 4, st));
   // ---- partition ----------------------------------------------------------------------------------------------
+  lp.dshift = s;
+  lp.dmask = two_pass ? (uint32_t)(PT_BINS - 1) : 0xFFFFFFFFu;
+  lp.raw_vp = two_pass ? 1 : 0;
   {
     KTimer t(ctx, "part_hist");
-    hipLaunchKernelGGL(k_part_hist, dim3(nst), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
-                       (const uint8_t*)f->alive.as<uint8_t>(), N, lp, nst, nb, st_items, table);
+    hipLaunchKernelGGL(k_part_hist, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+                       (const uint8_t*)f->alive.as<uint8_t>(), N, lp, nst_a, nd_a,
+                       (int64_t)st_tiles_a * tile, table);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
     KTimer t(ctx, "part_scan");
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, table, table, (int64_t)nb * nst, nullptr));
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, table, table, (int64_t)nd_a * nst_a, nullptr));
   }
   {
     KTimer t(ctx, "part_scatter");
-    if (pt_ipt == 8)
-      hipLaunchKernelGGL(k_part_scatter<8>, dim3(nst), dim3(PT_THREADS), 0, st,
-                         (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
-                         nst, nb, st_tiles, (const uint32_t*)table,
-                         (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
-                         f->part_xyz[0].as<PartRec>());
-    else
-      hipLaunchKernelGGL(k_part_scatter<16>, dim3(nst), dim3(PT_THREADS), 0, st,
-                         (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
-                         nst, nb, st_tiles, (const uint32_t*)table,
-                         (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
-                         f->part_xyz[0].as<PartRec>());
+    hipLaunchKernelGGL((k_part_scatter<PT_IPT, false>), dim3(nst_a), dim3(PT_THREADS), 0, st,
+                       (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
+                       nst_a, nd_a, st_tiles_a, (const uint32_t*)table,
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
+                       f->part_xyz[0].as<PartRec>());
     HIP_TRY(ctx, hipGetLastError());
+  }
+  const PartRec* recs = f->part_xyz[0].as<PartRec>();
+  const uint32_t* bstart = table;
+  uint32_t bstride = nst_a;
+  if (two_pass) {
+    // second (more significant) digit over the records of the first pass, then the bucket bounds
+    lp.dshift = s + PT_BITS;
+    lp.dmask = 0xFFFFFFFFu;
+    lp.raw_vp = 0;
+    {
+      KTimer t(ctx, "part_hist");
+      hipLaunchKernelGGL(k_part_hist_rec, dim3(nst_b), dim3(PH_THREADS), 0, st,
+                         (const uint4*)f->part_xyz[0].as<uint4>(), n_alive, lp, nst_b, nd_b,
+                         (int64_t)st_tiles_b * tile, table);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    {
+      KTimer t(ctx, "part_scan");
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, table, table, (int64_t)nd_b * nst_b, nullptr));
+    }
+    {
+      KTimer t(ctx, "part_scatter");
+      hipLaunchKernelGGL((k_part_scatter<PT_IPT, true>), dim3(nst_b), dim3(PT_THREADS), 0, st,
+                         (const double*)f->part_xyz[0].as<double>(), (const uint8_t*)nullptr, n_alive, lp,
+                         nst_b, nd_b, st_tiles_b, (const uint32_t*)table, (const int64_t*)nullptr, 0,
+                         (const uint8_t*)nullptr, f->part_xyz[1].as<PartRec>());
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    uint32_t* bounds = table + (((size_t)nd_b * nst_b + 3) & ~(size_t)3);
+    {
+      KTimer t(ctx, "bucket_bounds");
+      hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)ceil_div(n_alive, 256)), dim3(256), 0, st,
+                         (const uint4*)f->part_xyz[1].as<uint4>(), (uint32_t)n_alive, lp, nb, bounds);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    recs = f->part_xyz[1].as<PartRec>();
+    bstart = bounds;
+    bstride = 1;
   }
   // ---- buckets ------------------------------------------------------------------------------------------------
   BkParams bp;
   bp.lp = lp;
   bp.K = a.K;
-  bp.nst = nst;
+  bp.bstride = bstride;
   bp.nb = nb;
   bp.n_alive = (uint32_t)n_alive;
   bp.n_poses = n_poses;
   bp.all_scheme = a.scheme_dev ? 0 : 1;
+  uint32_t* bk_tot = f->bk_tot.as<uint32_t>();
   {
     KTimer t(ctx, "bucket_build");
-    hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st,
-                       (const PartRec*)f->part_xyz[0].as<PartRec>(), (const uint32_t*)table, bp,
+    hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(),
-                       f->bk_tot.as<uint32_t>());
+                       bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
     KTimer t(ctx, "bucket_scan");
-    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, f->bk_tot.as<uint32_t>(), nb, small);
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, bk_tot, bk_tot, (int64_t)BK_ROWS * nb, small + SM_BK_TOTAL));
+    hipLaunchKernelGGL(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_tot, nb,
+                       (const uint32_t*)(small + SM_BK_TOTAL), small);
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t sm[64];
@@ -1152,7 +1216,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   HIP_TRY(ctx, hipMemsetAsync(nd.epoch, 0, (size_t)total * 4, st));
   NodeParams np;
   np.lp = lp;
-  np.nst = nst;
+  np.bstride = bstride;
   np.nb = nb;
   np.n_alive = (uint32_t)n_alive;
   np.n_poses = n_poses;
@@ -1162,7 +1226,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   {
     KTimer t(ctx, "bucket_nodes");
     hipLaunchKernelGGL(k_bucket_nodes, dim3((unsigned)ceil_div(nb, 4)), dim3(256), 0, st, nd, np,
-                       (const uint32_t*)table, (const uint32_t*)f->bk_tot.as<uint32_t>(),
+                       bstart, (const uint32_t*)f->bk_tot.as<uint32_t>(),
                        (const uint32_t*)f->leafinfo.as<uint32_t>(),
                        (const uint32_t*)f->ord_idx.as<uint32_t>(), (const uint32_t*)f->bk_vox.as<uint32_t>(),
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->pos_node.as<int32_t>(),

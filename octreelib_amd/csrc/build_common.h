@@ -16,6 +16,7 @@ enum {
   SM_NBLOCKS = 16,
   // 20: kept count of apply_mask, 21: slot-voxel count, 24: debug scan total
   SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
+  SM_BK_TOTAL = 26,     // bucket build: grand total of the scanned bucket table
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
   // 64..: slot histogram, 512..: allreduce
 };

@@ -9,16 +9,23 @@ import numpy as np
 __all__ = ["uniform_cloud", "planar_cloud"]
 
 
-def uniform_cloud(n: int, dims=(32, 32, 32), seed: int = 0) -> np.ndarray:
+def uniform_cloud(n: int, dims=(32, 32, 32), seed: int = 0, voxels=None) -> np.ndarray:
+    """n uniform points over the scene; `voxels` (linear ids, x slowest) restricts them to those voxels."""
     rng = np.random.default_rng(seed)
-    return rng.random((n, 3)) * np.asarray(dims, dtype=np.float64)
+    if voxels is None:
+        return rng.random((n, 3)) * np.asarray(dims, dtype=np.float64)
+    dims = np.asarray(dims, dtype=np.int64)
+    lin = np.asarray(voxels, dtype=np.int64)[rng.integers(0, len(voxels), n)]
+    q = np.stack([lin // (dims[1] * dims[2]), (lin // dims[2]) % dims[1], lin % dims[2]], axis=1)
+    return rng.random((n, 3)) + q.astype(np.float64)
 
 
 def planar_cloud(n: int, dims=(32, 32, 32), seed: int = 1, stream: int = 0,
-                 inlier_fraction: float = 0.8, sigma: float = 0.005, box=None) -> np.ndarray:
+                 inlier_fraction: float = 0.8, sigma: float = 0.005, box=None, voxels=None) -> np.ndarray:
     """n points over a grid of dims[0] x dims[1] x dims[2] voxels of 1 m.  The plane of every
     voxel depends only on `seed`, so different `stream`s (ranks) draw different points of the
-    SAME scene.  `box` = (lo, hi) integer voxel bounds restricts the points to a sub-box."""
+    SAME scene.  `box` = (lo, hi) integer voxel bounds restricts the points to a sub-box;
+    `voxels` (linear ids, x slowest) to a set of voxels (e.g. the voxels one rank owns)."""
     dims = np.asarray(dims, dtype=np.int64)
     V = int(dims.prod())
     ab = np.random.default_rng(seed).uniform(-0.4, 0.4, (V, 2))
@@ -27,8 +34,12 @@ def planar_cloud(n: int, dims=(32, 32, 32), seed: int = 1, stream: int = 0,
         lo, hi = np.zeros(3, dtype=np.int64), dims
     else:
         lo, hi = np.asarray(box[0], dtype=np.int64), np.asarray(box[1], dtype=np.int64)
-    q = np.stack([rng.integers(lo[a], hi[a], n) for a in range(3)], axis=1)
-    lin = (q[:, 0] * dims[1] + q[:, 1]) * dims[2] + q[:, 2]
+    if voxels is not None:
+        lin = np.asarray(voxels, dtype=np.int64)[rng.integers(0, len(voxels), n)]
+        q = np.stack([lin // (dims[1] * dims[2]), (lin // dims[2]) % dims[1], lin % dims[2]], axis=1)
+    else:
+        q = np.stack([rng.integers(lo[a], hi[a], n) for a in range(3)], axis=1)
+        lin = (q[:, 0] * dims[1] + q[:, 1]) * dims[2] + q[:, 2]
     local = rng.random((n, 3))
     inl = rng.random(n) < inlier_fraction
     a, b = ab[lin, 0], ab[lin, 1]

@@ -985,6 +985,55 @@ def test_bucket_build_mixed_voxel_populations_vs_level_synchronous_build(monkeyp
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_bucket_build_two_pass_partition_vs_level_synchronous_build(monkeypatch, seed):
+    """More than 4096 buckets (forced here on a small cloud over ~10 k voxels; at full size: more than
+    ~10 M points per GPU, e.g. one rank of the 10^9-point configuration): the partition runs two stable
+    passes and the bucket bounds come from the sorted records.  Everything must be bit-identical to the
+    level-synchronous path."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    rng = np.random.default_rng(1200 + seed)
+    dims = np.array([24, 20, 22]) + rng.integers(0, 4, 3)
+    n = 150_000
+    q = np.stack([rng.integers(0, dims[a], n) for a in range(3)], axis=1)
+    keep = rng.random(n) < np.where((q.sum(axis=1) % 7) == 0, 1.0, 0.25)   # some voxels 4x denser
+    cloud = np.unique((rng.random((n, 3)) + q)[keep] - np.array([3.0, 0.0, 5.0]), axis=0)
+    rng.shuffle(cloud)
+    poses = [cloud[: len(cloud) // 2], cloud[len(cloud) // 2:]]
+    K = int(rng.choice([3, 8, 20]))
+    ctx = nat.get_context()
+
+    def build():
+        f = Forest(0, np.zeros(3), 1.0)
+        for c in poses:
+            f.add_pose(c)
+        ctx.set_profiling(True)
+        f.subdivide(K, [1] if seed == 1 else None)
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        out = ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()},
+               f.perm.copy(), f.xyz.copy(), f.order.copy(), int(f.info.n_levels), f.voxels.copy())
+        f.close()
+        return out, names
+
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    monkeypatch.setenv("OCTL_BUCKET_POINTS", "4")
+    a, names_a = build()
+    monkeypatch.delenv("OCTL_BUCKET_POINTS")
+    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    b, names_b = build()
+    assert "bucket_bounds" in names_a and "level_hist" not in names_a   # two passes, whole build
+    assert "bucket_build" not in names_b
+    assert a[5] == b[5] and np.array_equal(a[6], b[6])
+    for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
 def test_grid_get_points_follows_voxel_creation_order():
     """Grid.get_points walks ALL managers in the order they were first created (the dict order of
     Grid.__octrees, grid.py:56,100-109,240-242), not in lexicographic voxel order: a voxel first
