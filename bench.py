@@ -315,12 +315,9 @@ def owned_voxels(dims, n_ranks):
     """Linear ids (x slowest) of the voxels of the scene that rank 0 of n_ranks owns."""
     key = (tuple(dims), n_ranks)
     if key not in _OWNED:
-        from octreelib_amd.distributed import voxel_owner_np
+        from octreelib_amd.distributed import owned_voxel_ids
 
-        d = np.asarray(dims, dtype=np.int64)
-        lin = np.arange(int(d.prod()), dtype=np.int64)
-        q = np.stack([lin // (d[1] * d[2]), (lin // d[2]) % d[1], lin % d[2]], axis=1)
-        _OWNED[key] = lin[voxel_owner_np(q, n_ranks) == 0]
+        _OWNED[key] = owned_voxel_ids(dims, 0, n_ranks)
     return _OWNED[key]
 
 

@@ -20,7 +20,7 @@ import numpy as np
 from octreelib_amd import _native as nat
 from octreelib_amd._engine import Forest
 
-__all__ = ["voxel_owner_np", "voxel_indices_np", "ShardedGrid"]
+__all__ = ["voxel_owner_np", "voxel_indices_np", "owned_voxel_ids", "ShardedGrid"]
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
@@ -44,6 +44,15 @@ def voxel_owner_np(q: np.ndarray, n_ranks: int) -> np.ndarray:
         h = h * np.uint64(0x94D049BB133111EB)
         h = h ^ (h >> np.uint64(31))
     return (h % np.uint64(max(n_ranks, 1))).astype(np.int32)
+
+
+def owned_voxel_ids(dims, rank: int, n_ranks: int) -> np.ndarray:
+    """Linear ids (x slowest) of the voxels of a dims[0] x dims[1] x dims[2] scene anchored at the
+    origin that `rank` of `n_ranks` owns."""
+    d = np.asarray(dims, dtype=np.int64)
+    lin = np.arange(int(d.prod()), dtype=np.int64)
+    q = np.stack([lin // (d[1] * d[2]), (lin // d[2]) % d[1], lin % d[2]], axis=1)
+    return lin[voxel_owner_np(q, n_ranks) == rank]
 
 
 class ShardedGrid:

@@ -36,13 +36,12 @@ def _check_structure(f, n_total, K, scheme_all=True):
     per_node = np.bincount(blk["node"], weights=blk["size"], minlength=len(leaf)).astype(np.int64)
     if scheme_all:
         assert per_node[leaf].max() <= K
-        # points under an internal node = sum over its subtree: accumulate bottom-up
+        # points under an internal node = sum over its subtree: accumulate bottom-up, level by level
         tot = per_node.copy()
-        order = np.argsort(-nd["depth"], kind="stable")
         par = nd["parent"]
-        for i in order:
-            if par[i] >= 0:
-                tot[par[i]] += tot[i]
+        for d in range(int(nd["depth"].max()), 0, -1):
+            ids = np.nonzero(nd["depth"] == d)[0]
+            np.add.at(tot, par[ids], tot[ids])
         assert (tot[~leaf] > K).all()
     # 4. n_nodes = roots + 8 * internal
     assert len(leaf) == len(f.voxels) + 8 * int((~leaf).sum())
