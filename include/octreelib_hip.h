@@ -97,11 +97,14 @@ int octl_forest_clear(octl_forest* f);
 /* Append the cloud of a new pose slot (host pointer, copied to the device).  Returns the
  * slot through *slot.  Replaces Grid.insert_points' storage step.                        */
 int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* slot);
-/* Same, from a device pointer (device-to-device copy; no PCIe).                           */
+/* Same, from a device pointer (device-to-device copy fused with the bounding-box pass; no PCIe).  The
+ * source is consumed in stream order: it must stay unchanged until the next synchronising call on
+ * the context (octl_forest_build, octl_ctx_sync, ...).                                      */
 int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n,
                                 int32_t* slot);
-/* Append more points to an EXISTING pose slot (only meaningful in mode 1, where the
- * reference allows OctreeManager.insert_points twice for one pose).                       */
+/* Append more points to an EXISTING pose slot, any slot (OctreeManager.insert_points on a pose that
+ * already has an octree, octree_manager.py:161-171; Octree.insert_points, octree.py:235-239).  The
+ * points of later poses move up in the pose-major store.                                       */
 int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n);
 
 typedef struct octl_build_info {
@@ -197,8 +200,14 @@ int octl_forest_get_mask(octl_forest* f, int64_t cap, uint8_t* mask, int64_t* n)
  * octree.py:137-142): compacts the leaf-ordered arrays, updates the block table and marks
  * the points dead for later builds.  Returns the surviving point count.                    */
 int octl_forest_apply_mask(octl_forest* f, int64_t* n_alive);
+/* OctreeNode.filter (octree/octree.py:102-112) for point-count predicates, on the device: every leaf of
+ * the poses with slot_sel[slot] != 0 whose point count is outside [lo, hi] is emptied (its points
+ * leave the tree), followed by the same compaction as apply_mask.  A criterion `len(points) >= c` is
+ * [c, INT64_MAX], `len(points) < c` is [0, c-1], several criteria intersect.                    */
+int octl_forest_filter_count(octl_forest* f, const uint8_t* slot_sel, int32_t n_sel, int64_t lo,
+                             int64_t hi, int64_t* n_alive);
 /* Drop points by an explicit host mask over storage positions (filter / map_leaf_points
- * paths of the Python layer).                                                              */
+ * paths of the Python layer for arbitrary callables).                                       */
 int octl_forest_apply_host_mask(octl_forest* f, const uint8_t* mask, int64_t n,
                                 int64_t* n_alive);
 

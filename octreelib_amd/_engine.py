@@ -450,6 +450,17 @@ class Forest:
         self.n_ord = n.value
         self._invalidate()
 
+    def filter_count(self, slots, lo: int, hi: int):
+        """Empty every leaf of the given slots whose point count is outside [lo, hi] (device)."""
+        self.ensure_built()
+        sel = np.zeros(max(self.n_slots, 1), dtype=np.uint8)
+        sel[list(slots)] = 1
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.octl_forest_filter_count(self.handle, nat.ptr(sel), self.n_slots, int(lo),
+                                                         int(min(hi, (1 << 63) - 1)), C.byref(n)))
+        self.n_ord = n.value
+        self._invalidate()
+
     def apply_device_mask(self):
         n = C.c_int64(0)
         self.ctx.check(self.lib.octl_forest_apply_mask(self.handle, C.byref(n)))

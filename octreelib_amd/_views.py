@@ -148,7 +148,15 @@ def apply_mask_slot(forest, slot: int, mask):
 
 
 def filter_slots(forest, slots: Iterable[int], criteria: Sequence[Callable]):
-    """OctreeNode.filter (octree.py:102-112): a leaf whose points fail any criterion is emptied."""
+    """OctreeNode.filter (octree.py:102-112): a leaf whose points fail any criterion is emptied.
+    Point-count criteria run on the device (no download of the cloud); arbitrary callables are the
+    caller's Python code and are evaluated on the host over the leaf arrays."""
+    from octreelib_amd.criteria import try_count_interval
+
+    iv = try_count_interval(criteria)
+    if iv is not None:
+        forest.filter_count(list(slots), iv[0], iv[1])
+        return
     xyz = forest.xyz
     keep = np.ones(forest.n_ord, dtype=np.uint8)
     changed = False

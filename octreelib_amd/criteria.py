@@ -15,7 +15,8 @@ from typing import Callable, Optional, Sequence
 
 import numpy as np
 
-__all__ = ["MaxPoints", "count_threshold", "try_count_threshold", "UnsupportedCriterion"]
+__all__ = ["MaxPoints", "count_threshold", "try_count_threshold", "try_count_interval",
+           "UnsupportedCriterion"]
 
 
 class UnsupportedCriterion(NotImplementedError):
@@ -86,6 +87,73 @@ def _match_len_compare(fn) -> Optional[int]:
     except Exception:
         return None
     return None
+
+
+_FLIP = {"<": ">", "<=": ">=", ">": "<", ">=": "<=", "==": "==", "!=": "!="}
+_INT_MAX = (1 << 63) - 1
+
+
+def _match_len_interval(fn):
+    """(lo, hi) if `fn` is `len(p) OP c` or `c OP len(p)` with OP in < <= > >= ==: the predicate holds
+    exactly when lo <= len(p) <= hi.  None otherwise."""
+    if isinstance(fn, MaxPoints):
+        return fn.k + 1, _INT_MAX
+    code = getattr(fn, "__code__", None)
+    if code is None or code.co_argcount != 1:
+        return None
+    skip = {"RESUME", "PRECALL", "PUSH_NULL", "CACHE", "COPY_FREE_VARS", "NOP"}
+    ins = [i for i in dis.get_instructions(fn) if i.opname not in skip]
+    arg = code.co_varnames[0]
+
+    def is_len_call(seq):
+        return (len(seq) == 3 and seq[0].opname == "LOAD_GLOBAL" and seq[0].argval == "len"
+                and seq[1].opname == "LOAD_FAST" and seq[1].argval == arg
+                and seq[2].opname in ("CALL_FUNCTION", "CALL"))
+
+    if len(ins) != 6 or ins[-1].opname != "RETURN_VALUE" or ins[-2].opname != "COMPARE_OP":
+        return None
+    op = ins[-2].argval
+    try:
+        if is_len_call(ins[0:3]):
+            c = _resolve(fn, ins[3])
+        elif is_len_call(ins[1:4]):
+            c = _resolve(fn, ins[0])
+            op = _FLIP.get(op)
+        else:
+            return None
+        c = float(c)
+    except Exception:
+        return None
+    if op == ">":
+        return int(np.floor(c)) + 1, _INT_MAX
+    if op == ">=":
+        return int(np.ceil(c)), _INT_MAX
+    if op == "<":
+        return 0, int(np.ceil(c)) - 1
+    if op == "<=":
+        return 0, int(np.floor(c))
+    if op == "==" and c == int(c):
+        return int(c), int(c)
+    return None
+
+
+def try_count_interval(criteria: Sequence[Callable]):
+    """(lo, hi) such that all(criterion(points)) == (lo <= len(points) <= hi) when every criterion is a
+    point-count comparison (they then run on the device, octl_forest_filter_count); None otherwise."""
+    lo, hi = 0, _INT_MAX
+    for c in criteria:
+        iv = _match_len_interval(c)
+        if iv is None:
+            return None
+        # double-check by probing around the bounds
+        try:
+            for n in {max(iv[0] - 1, 0), iv[0], min(iv[1], iv[0] + 3), min(iv[1] + 1, iv[0] + 4)}:
+                if bool(c(np.zeros((n, 3)))) != (iv[0] <= n <= iv[1]):
+                    return None
+        except Exception:
+            return None
+        lo, hi = max(lo, iv[0]), min(hi, iv[1])
+    return lo, hi
 
 
 def _probe(fn, k: int) -> bool:

@@ -126,6 +126,21 @@ __global__ __launch_bounds__(256) void k_compact_ord(
   }
 }
 
+// OctreeNode.filter for count predicates (octree.py:102-112): a leaf of a selected pose whose point
+// count lies outside [lo, hi] is emptied - one wavefront per block clears its mask bytes
+__global__ __launch_bounds__(256) void k_filter_blocks(const uint32_t* __restrict__ blk_start,
+                                                       const int32_t* __restrict__ blk_size,
+                                                       const int32_t* __restrict__ blk_slot, int64_t nb,
+                                                       const uint8_t* __restrict__ slot_sel, int64_t lo,
+                                                       int64_t hi, uint8_t* __restrict__ mask) {
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nb) return;
+  const int64_t n = blk_size[b];
+  if (!slot_sel[blk_slot[b]] || (n >= lo && n <= hi)) return;
+  const int64_t s0 = blk_start[b];
+  for (int64_t i = threadIdx.x & 63; i < n; i += 64) mask[s0 + i] = 0;
+}
+
 // voxels in which a pose slot has at least one block
 __global__ __launch_bounds__(256) void k_slot_voxel_flags(const int32_t* __restrict__ blk_node,
                                                           const int32_t* __restrict__ blk_slot,
@@ -360,14 +375,31 @@ int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n
 
 int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n) {
   if (!f) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
   const int n_poses = (int)f->pose_off.size() - 1;
-  if (slot != n_poses - 1)
-    return octl_set_error(f->ctx, OCTL_E_INVALID,
-                          "only the most recently added pose can be extended (pose-major store)");
-  OCTL_TRY(store_append(f, xyz, n, false));
+  if (slot < 0 || slot >= n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "bad pose slot");
+  const int64_t tail = f->n_store - f->pose_off[slot + 1];  // points of the later poses
+  OCTL_TRY(store_append(f, xyz, n, false));  // lands behind everything (bounding box, alive flags)
+  if (tail > 0 && n > 0) {
+    // The store is pose-major: rotate the new points in front of the later poses' points (they were
+    // appended at the end).  Two device copies through the partition scratch; the next build
+    // re-derives every table from the store.
+    hipStream_t st = ctx->stream;
+    const int64_t at = f->pose_off[slot + 1];
+    OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)tail * 25));
+    char* tmp = static_cast<char*>(f->part_xyz[0].p);
+    double* xs = f->xyz.as<double>();
+    uint8_t* al = f->alive.as<uint8_t>();
+    HIP_TRY(ctx, hipMemcpyAsync(tmp, xs + 3 * at, (size_t)tail * 24, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(tmp + (size_t)tail * 24, al + at, (size_t)tail, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(xs + 3 * at, xs + 3 * f->n_store, (size_t)n * 24, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(al + at, al + f->n_store, (size_t)n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(xs + 3 * (at + n), tmp, (size_t)tail * 24, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(al + at + n, tmp + (size_t)tail * 24, (size_t)tail, hipMemcpyDeviceToDevice, st));
+  }
   f->n_store += n;
   f->n_alive += n;
-  f->pose_off.back() = f->n_store;
+  for (int p = slot + 1; p <= n_poses; ++p) f->pose_off[p] += n;
   f->store_dirty = true;
   return OCTL_OK;
 }
@@ -630,6 +662,30 @@ int octl_forest_apply_mask(octl_forest* f, int64_t* n_alive) {
   if (!f) return OCTL_E_INVALID;
   if (!f->built) return octl_set_error(f->ctx, OCTL_E_STATE, "apply_mask before build");
   OCTL_TRY(ensure_mask(f));
+  return apply_device_mask(f, n_alive);
+}
+
+int octl_forest_filter_count(octl_forest* f, const uint8_t* slot_sel, int32_t n_sel, int64_t lo,
+                             int64_t hi, int64_t* n_alive) {
+  if (!f || !slot_sel) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "filter before build");
+  const int n_poses = (int)f->pose_off.size() - 1;
+  if (n_sel != n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "slot selection has %d entries for %d poses", n_sel, n_poses);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  OCTL_TRY(ensure_mask(f));
+  if (f->n_blocks > 0) {
+    OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)std::max(n_poses, 1)));
+    HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, slot_sel, (size_t)n_poses, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));  // (a pageable source)
+    KTimer t(ctx, "filter");
+    hipLaunchKernelGGL(k_filter_blocks, dim3((unsigned)ceil_div(f->n_blocks, 4)), dim3(256), 0, st,
+                       (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(),
+                       (const int32_t*)f->blk_slot.as<int32_t>(), f->n_blocks,
+                       (const uint8_t*)f->scheme_dev.as<uint8_t>(), lo, hi, f->mask.as<uint8_t>());
+    HIP_TRY(ctx, hipGetLastError());
+  }
   return apply_device_mask(f, n_alive);
 }
 

@@ -135,38 +135,44 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
   // RN(c*zh + RN(c*zl)) with zh + zl = 1/k to ~2^-106 IS the correctly rounded quotient:
   // one multiply + one FMA instead of the 11-instruction IEEE division sequence.
   div3_by_small_int(cx, cy, cz, k);
+  // util.py:48-57.  The reference starts every sum at 0.0: for the squares 0.0 + r*r == r*r exactly
+  // (a square is never -0), so their first add is dropped; a cross product CAN be -0 and 0.0 + (-0) is
+  // +0, so the cross terms keep it (axis-aligned samples reach the sign of a zero plane coefficient).
   double xx = 0.0, xy = 0.0, xz = 0.0, yy = 0.0, yz = 0.0, zz = 0.0;
 #pragma unroll
-  for (int i = 0; i < (KT > 0 ? KT : KMAX); ++i) {  // util.py:48-57
+  for (int i = 0; i < (KT > 0 ? KT : KMAX); ++i) {
     if (i < k) {
       const double rx = sx[i] - cx;
       const double ry = sy[i] - cy;
       const double rz = sz[i] - cz;
-      xx += rx * rx;
+      if (i == 0) {
+        xx = rx * rx;
+        yy = ry * ry;
+        zz = rz * rz;
+      } else {
+        xx += rx * rx;
+        yy += ry * ry;
+        zz += rz * rz;
+      }
       xy += rx * ry;
       xz += rx * rz;
-      yy += ry * ry;
       yz += ry * rz;
-      zz += rz * rz;
     }
   }
   const double det_x = yy * zz - yz * yz;  // util.py:59-61
   const double det_y = xx * zz - xz * xz;
   const double det_z = xx * yy - xy * xy;
-  double ax, ay, az;
-  if (det_x > det_y && det_x > det_z) {  // util.py:63-74
-    ax = det_x;
-    ay = xz * yz - xy * zz;
-    az = xy * yz - xz * yy;
-  } else if (det_y > det_z) {
-    ax = xz * yz - xy * zz;
-    ay = det_y;
-    az = xy * xz - yz * xx;
-  } else {
-    ax = xy * yz - xz * yy;
-    ay = xy * xz - yz * xx;
-    az = det_z;
-  }
+  // util.py:63-74: the three cofactors that the branches share, then selects instead of a three-way
+  // branch (lanes of a wave take all three, so every branch body was executed anyway):
+  //   x: (det_x, A, B)   y: (A, det_y, C)   z: (B, C, det_z)
+  const double cA = xz * yz - xy * zz;
+  const double cB = xy * yz - xz * yy;
+  const double cC = xy * xz - yz * xx;
+  const bool is_x = det_x > det_y && det_x > det_z;
+  const bool is_y = !is_x && det_y > det_z;
+  double ax = is_x ? det_x : (is_y ? cA : cB);
+  double ay = is_x ? cA : (is_y ? det_y : cC);
+  double az = is_x ? cB : (is_y ? cC : det_z);
 #if RS_FAST_DIV
   const double norm = sqrt_rn_guarded(ax * ax + ay * ay + az * az);  // util.py:76
 #else

@@ -43,6 +43,18 @@ class Grid(GridBase):
                 "voxel_edge_length must be a positive integer value: the reference truncates "
                 "voxel coordinates with astype(int) (grid.py:72-76), merging fractional voxels"
             )
+        # the reference's plug seam (grid_base.py:66-87, grid.py:100-106): it instantiates
+        # octree_manager_type(octree_type, octree_config, corner, L) per top-level voxel.  Here the whole
+        # grid is ONE device-resident forest; a user-supplied subclass would never be instantiated, so it
+        # is refused instead of being silently ignored.
+        from octreelib_amd.octree import Octree
+        from octreelib_amd.octree_manager import OctreeManager
+
+        if grid_config.octree_manager_type is not OctreeManager or grid_config.octree_type is not Octree:
+            raise NotImplementedError(
+                "GridConfig.octree_manager_type / octree_type other than octreelib_amd's own OctreeManager / "
+                "Octree are not supported: the device-resident grid does not instantiate per-voxel managers"
+            )
         self._forest = Forest(0, corner, float(L))
         self._slots: Dict[int, int] = {}  # pose number -> slot
 

@@ -36,12 +36,7 @@ class OctreeManager(VoxelBase):
         if pose_number not in self._slots:
             self._slots[pose_number] = self._forest.add_pose(points)
         else:
-            slot = self._slots[pose_number]
-            if slot != self._forest.n_slots - 1:
-                raise NotImplementedError(
-                    "points can only be appended to the most recently inserted pose"
-                )
-            self._forest.extend_pose(slot, points)
+            self._forest.extend_pose(self._slots[pose_number], points)
 
     # octree_manager.py:36-66
     def subdivide(self, subdivision_criteria: List[Callable], pose_numbers: Optional[List[int]] = None):

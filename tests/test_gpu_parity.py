@@ -839,8 +839,112 @@ def test_manager_apply_mask_filter_and_map_per_pose():
         assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == [om.n_nodes(p), om.n_leaves(p), om.n_points(p)]
 
 
+def test_grid_filter_count_criteria_on_device_vs_oracle_and_host_path():
+    """Grid.filter with point-count criteria (octree.py:102-112 through grid.py:260-267) runs as a device
+    kernel over the block table + compaction - no download of the cloud; the result equals the oracle's
+    and the host path's (the same predicate hidden from the recogniser)."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(77)
+    poses = [rng.random((3000, 3)) * 3.0, rng.random((2000, 3)) * 3.0 - 1.0]
+    ctx = nat.get_context()
+
+    def make():
+        g = Grid(GridConfig(voxel_edge_length=1))
+        for p, c in enumerate(poses):
+            g.insert_points(p, c)
+        g.subdivide(crit(20))
+        return g
+
+    for criteria, lo, hi in (([lambda pts: len(pts) >= 5], 5, None), ([lambda pts: len(pts) < 9], None, 8),
+                             ([lambda pts: len(pts) > 2, lambda pts: 12 >= len(pts)], 3, 12)):
+        g = make()
+        ctx.set_profiling(True)
+        g.filter(criteria)
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        assert "filter" in names                       # the device kernel ran
+        assert g._forest._xyz is None                  # ... and nothing was downloaded for it
+        og = onp.OGrid(1)
+        for p, c in enumerate(poses):
+            og.insert_points(p, c)
+        og.subdivide(20)
+        for key, m in og.managers.items():
+            for t in m.octrees.values():
+                for v in t.leaves():
+                    n = len(v.idx)
+                    if (lo is not None and n < lo) or (hi is not None and n > hi):
+                        v.idx = np.empty(0, dtype=np.int64)
+        h = make()
+        opaque = [(lambda f: (lambda pts: bool(f(pts)) and True))(f) for f in criteria]  # not recognisable
+        h.filter(opaque)
+        for p in range(2):
+            index = index_map(poses[p])
+            got = canon_from_list(views_table(g.get_leaf_points(p), index))
+            assert_same_leaves(got, _oracle_pose_table(og, p))
+            assert_same_leaves(canon_from_list(views_table(h.get_leaf_points(p), index)), got)
+            assert [g.n_leaves(p), g.n_points(p)] == [og.n_leaves(p), og.n_points(p)]
+
+
+def test_grid_refuses_foreign_manager_and_octree_types():
+    """The reference's plug seam (grid_base.py:66-87, grid.py:100-106): a type that is not a subclass is a
+    TypeError (message asserted upstream), a subclass that this build cannot honour is refused loudly."""
+    from octreelib_amd.grid import Grid, GridConfig
+    from octreelib_amd.octree import Octree
+    from octreelib_amd.octree_manager import OctreeManager
+
+    class MyManager(OctreeManager):
+        pass
+
+    class MyOctree(Octree):
+        pass
+
+    with pytest.raises(NotImplementedError, match="octree_manager_type"):
+        Grid(GridConfig(octree_manager_type=MyManager))
+    with pytest.raises(NotImplementedError, match="octree_type"):
+        Grid(GridConfig(octree_type=MyOctree))
+    Grid(GridConfig(octree_manager_type=OctreeManager, octree_type=Octree))
+
+
+def test_manager_insert_points_into_any_existing_pose_vs_oracle():
+    """OctreeManager.insert_points on a pose that already has an octree appends to it and lets the new
+    points descend the current scheme (octree_manager.py:161-171) - for ANY pose, not only the most
+    recently inserted one."""
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(91)
+    poses = [rng.random((500, 3)), rng.random((400, 3)), rng.random((300, 3))]
+    extra = {0: rng.random((151, 3)), 1: rng.random((80, 3))}
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 1.0)
+    om = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(3):
+        m.insert_points(p, poses[p])
+        om.insert_points(p, poses[p])
+    m.subdivide(crit(25))
+    om.subdivide(25)
+    for p in (0, 1):       # neither is the last pose; 151 points: an odd offset for the later poses
+        m.insert_points(p, extra[p])
+        om.insert_points(p, extra[p])
+    allp = [np.vstack([poses[0], extra[0]]), np.vstack([poses[1], extra[1]]), poses[2]]
+    for p in range(3):
+        index = index_map(allp[p])
+        got = canon_from_list(views_table(m.get_leaf_points(True, p), index))
+        assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(om.octrees[p])))
+        assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == [om.n_nodes(p), om.n_leaves(p), om.n_points(p)]
+    m.subdivide(crit(10))
+    om.subdivide(10)
+    for p in range(3):
+        index = index_map(allp[p])
+        got = canon_from_list(views_table(m.get_leaf_points(True, p), index))
+        assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(om.octrees[p])))
+
+
 # ------------------------------------------------------------------------------------------------
-# the two build paths (one wave per voxel / level-synchronous) must produce identical tables
+# the two build paths (bucket build / level-synchronous) must produce identical tables
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("scheme", [None, [0]])
 def test_voxel_local_build_equals_level_synchronous_build(monkeypatch, scheme):
