@@ -158,6 +158,12 @@ int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* 
  * node and block tables.                                                                     */
 int octl_forest_get_slot_voxels(octl_forest* f, int32_t slot, int64_t cap, int32_t* voxel_ranks,
                                 int64_t* n);
+/* Counters of one pose without fetching the tables (octree.py:144-175, octree_manager.py:132-159,
+ * grid.py:343-362): points and non-empty leaves of the slot, reduced on the device ...            */
+int octl_forest_slot_counts(octl_forest* f, int32_t slot, int64_t* n_points, int64_t* n_leaves);
+/* ... and the internal scheme nodes of every top-level voxel (V int32): n_nodes of a pose is the sum of
+ * 1 + 8 * internal over the voxels the pose was inserted into.                                     */
+int octl_forest_internal_per_voxel(octl_forest* f, int64_t cap, int32_t* counts, int64_t* n_voxels);
 /* Leaf-ordered point permutation: perm[i] = index of the point at storage position i in
  * the concatenation of all pose clouds in slot order (pose-local index = perm - offset of
  * its slot).  Within a block the order is ascending (stable).                              */

@@ -62,6 +62,8 @@ class Forest:
         self._xyz = None
         self._perm = None
         self._slot_blocks = None
+        self._counts = None
+        self._internal = None
 
     # -- points -----------------------------------------------------------------------------
     def add_pose(self, points) -> int:
@@ -416,17 +418,33 @@ class Forest:
         return self._perm
 
     # -- counters (reference: octree.py:144-175, octree_manager.py:132-159, grid.py:343-362) ---
+    def _slot_counts(self, slot: int):
+        """(points, non-empty leaves) of a slot, reduced on the device (no table download)."""
+        self.ensure_built()
+        if self._counts is None:
+            self._counts = {}
+        if slot not in self._counts:
+            a, b = C.c_int64(0), C.c_int64(0)
+            self.ctx.check(self.lib.octl_forest_slot_counts(self.handle, int(slot), C.byref(a), C.byref(b)))
+            self._counts[slot] = (a.value, b.value)
+        return self._counts[slot]
+
     def n_points(self, slot: int) -> int:
-        b = self.blocks
-        return int(b["size"][b["slot"] == slot].sum())
+        return self._slot_counts(slot)[0]
 
     def n_leaves(self, slot: int) -> int:
-        return int((self.blocks["slot"] == slot).sum())
+        return self._slot_counts(slot)[1]
 
     def internal_per_voxel(self) -> np.ndarray:
-        nd = self.nodes
-        internal = nd["first_child"] >= 0
-        return np.bincount(nd["voxel"][internal], minlength=len(self.voxels))
+        self.ensure_built()
+        if self._internal is None:
+            n = C.c_int64(0)
+            self.ctx.check(self.lib.octl_forest_internal_per_voxel(self.handle, 0, None, C.byref(n)))
+            out = np.zeros(n.value, dtype=np.int32)
+            if n.value:
+                self.ctx.check(self.lib.octl_forest_internal_per_voxel(self.handle, n.value, nat.ptr(out), C.byref(n)))
+            self._internal = out.astype(np.int64)
+        return self._internal
 
     def slot_voxel_ranks(self, slot: int) -> np.ndarray:
         """Current voxel ranks of the voxels the slot was inserted into (lexicographic)."""
@@ -434,7 +452,8 @@ class Forest:
         keys = self.slot_voxel_keys[slot]
         if keys is None or len(keys) == 0:
             return np.empty(0, dtype=np.int64)
-        return _rank_rows(self.voxels, keys)
+        # the packed codes order like the (x, y, z) rows: one searchsorted over int64
+        return np.searchsorted(self._voxel_codes(self.voxels), self._voxel_codes(keys)).astype(np.int64)
 
     def n_nodes(self, slot: int) -> int:
         ranks = self.slot_voxel_ranks(slot)
@@ -515,14 +534,3 @@ def _node_paths(nd):
         if p >= 0:
             paths[i] = paths[p] + (int(i - fc[p]),)
     return paths
-
-
-def _rank_rows(table: np.ndarray, rows: np.ndarray) -> np.ndarray:
-    """Index in the lexicographically sorted (V,3) int64 `table` of every row of `rows`."""
-    if len(rows) == 0:
-        return np.empty(0, dtype=np.int64)
-    dt = np.dtype([("x", np.int64), ("y", np.int64), ("z", np.int64)])
-    t = np.ascontiguousarray(table).view(dt).reshape(-1)
-    r = np.ascontiguousarray(rows).view(dt).reshape(-1)
-    idx = np.searchsorted(t, r)
-    return idx.astype(np.int64)

@@ -72,6 +72,8 @@ SIGNATURES = {
     "octl_forest_get_voxels": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_forest_get_blocks": (C.c_int, [_p, _i64, _p, _p, _p, _p, _pi64]),
     "octl_forest_get_slot_voxels": (C.c_int, [_p, _i32, _i64, _p, _pi64]),
+    "octl_forest_slot_counts": (C.c_int, [_p, _i32, _pi64, _pi64]),
+    "octl_forest_internal_per_voxel": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_forest_get_perm": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_forest_get_points": (C.c_int, [_p, _i64, _i64, _p]),
     "octl_forest_ransac": (C.c_int, [_p, _p, _i64, _p, _i32, _i32, _f64, _p, _p, _p]),

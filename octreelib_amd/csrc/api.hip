@@ -141,6 +141,43 @@ __global__ __launch_bounds__(256) void k_filter_blocks(const uint32_t* __restric
   for (int64_t i = threadIdx.x & 63; i < n; i += 64) mask[s0 + i] = 0;
 }
 
+// counters of one pose (octree.py:144-175, grid.py:343-362) without fetching the block table:
+// out[0] = points, out[1] = non-empty leaves of the slot
+__global__ __launch_bounds__(256) void k_slot_counts(const int32_t* __restrict__ blk_slot,
+                                                     const int32_t* __restrict__ blk_size, int64_t nb,
+                                                     int32_t slot, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long part[2][4];
+  unsigned long long pts = 0, lv = 0;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += (int64_t)gridDim.x * blockDim.x) {
+    if (blk_slot[b] == slot) {
+      pts += (unsigned long long)blk_size[b];
+      lv += 1;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    pts += __shfl_xor(pts, off);
+    lv += __shfl_xor(lv, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    part[0][threadIdx.x >> 6] = pts;
+    part[1][threadIdx.x >> 6] = lv;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const unsigned long long t = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+    if (t) atomicAdd(&out[threadIdx.x], t);
+  }
+}
+
+// internal scheme nodes per top-level voxel (n_nodes of a pose = sum over its voxels of 1 + 8 * internal)
+__global__ __launch_bounds__(256) void k_internal_per_voxel(const int32_t* __restrict__ first_child,
+                                                            const int32_t* __restrict__ voxel, int64_t n,
+                                                            int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && first_child[i] >= 0) atomicAdd(&out[voxel[i]], 1);
+}
+
 // voxels in which a pose slot has at least one block
 __global__ __launch_bounds__(256) void k_slot_voxel_flags(const int32_t* __restrict__ blk_node,
                                                           const int32_t* __restrict__ blk_slot,
@@ -312,8 +349,8 @@ void octl_forest_destroy(octl_forest* f) {
   if (!f) return;
   (void)hipSetDevice(f->ctx->device);
   (void)hipStreamSynchronize(f->ctx->stream);
-  nodes_free(f->nodes[0]);
-  nodes_free(f->nodes[1]);
+  nodes_free(f->ctx, f->nodes[0]);
+  nodes_free(f->ctx, f->nodes[1]);
   if (f->bbox_host) (void)hipHostFree(f->bbox_host);
   if (f->bbox_event) (void)hipEventDestroy(f->bbox_event);
   for (DevBuf* b :
@@ -325,7 +362,7 @@ void octl_forest_destroy(octl_forest* f) {
         &f->hist, &f->idxbuf[0], &f->idxbuf[1], &f->pathbuf[0], &f->pathbuf[1], &f->flags,
         &f->entries, &f->split[0], &f->split[1], &f->split_tiles[0], &f->split_tiles[1],
         &f->child_sc, &f->pose_off_dev, &f->scheme_dev, &f->root_up, &f->vlin_dev})
-    devbuf_free(*b);
+    devbuf_release(f->ctx, *b);
   delete f;
 }
 
@@ -564,6 +601,50 @@ int octl_forest_get_slot_voxels(octl_forest* f, int32_t slot, int64_t cap, int32
     HIP_TRY(ctx, hipMemcpyAsync(voxel_ranks, out, (size_t)m * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
   }
+  return OCTL_OK;
+}
+
+int octl_forest_slot_counts(octl_forest* f, int32_t slot, int64_t* n_points, int64_t* n_leaves) {
+  if (!f || !n_points || !n_leaves) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  const int n_poses = (int)f->pose_off.size() - 1;
+  if (slot < 0 || slot >= n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "bad pose slot");
+  *n_points = *n_leaves = 0;
+  if (f->n_blocks <= 0) return OCTL_OK;
+  hipStream_t st = ctx->stream;
+  unsigned long long* out = reinterpret_cast<unsigned long long*>(ctx->small.as<uint32_t>() + 28);
+  HIP_TRY(ctx, hipMemsetAsync(out, 0, 16, st));
+  hipLaunchKernelGGL(k_slot_counts, dim3((unsigned)std::min<int64_t>(1024, ceil_div(f->n_blocks, 256))), dim3(256),
+                     0, st, (const int32_t*)f->blk_slot.as<int32_t>(), (const int32_t*)f->blk_size.as<int32_t>(),
+                     f->n_blocks, slot, out);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, out, 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  unsigned long long r[2];
+  std::memcpy(r, ctx->small_host, 16);
+  *n_points = (int64_t)r[0];
+  *n_leaves = (int64_t)r[1];
+  return OCTL_OK;
+}
+
+int octl_forest_internal_per_voxel(octl_forest* f, int64_t cap, int32_t* counts, int64_t* n_voxels) {
+  if (!f || !n_voxels) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  *n_voxels = f->n_voxels;
+  const int64_t V = std::min<int64_t>(cap, f->n_voxels);
+  if (V <= 0 || !counts) return OCTL_OK;
+  hipStream_t st = ctx->stream;
+  NodeTable& t = f->nodes[f->cur];
+  OCTL_TRY(devbuf_reserve(ctx, f->rs_scratch, (size_t)f->n_voxels * 4));
+  HIP_TRY(ctx, hipMemsetAsync(f->rs_scratch.p, 0, (size_t)f->n_voxels * 4, st));
+  hipLaunchKernelGGL(k_internal_per_voxel, dim3(grid_for(t.n)), dim3(256), 0, st,
+                     (const int32_t*)t.first_child.as<int32_t>(), (const int32_t*)t.voxel.as<int32_t>(), t.n,
+                     f->rs_scratch.as<int32_t>());
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(counts, f->rs_scratch.p, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
   return OCTL_OK;
 }
 

@@ -677,10 +677,10 @@ int nodes_reserve(octl_ctx* ctx, NodeTable& t, int64_t cap) {
   return OCTL_OK;
 }
 
-void nodes_free(NodeTable& t) {
+void nodes_free(octl_ctx* ctx, NodeTable& t) {
   for (DevBuf* b : {&t.start, &t.count, &t.scount, &t.depth, &t.voxel, &t.parent, &t.first_child,
                     &t.old_id, &t.epoch, &t.corner, &t.edge})
-    devbuf_free(*b);
+    devbuf_release(ctx, *b);
   t.cap = t.n = 0;
 }
 

@@ -53,6 +53,10 @@ struct octl_ctx {
   // one event per staging region ([0,128K) build, [128K,192K) hypothesis table, [192K,256K) pose
   // epochs): recorded after the region's H2D copy, waited for before the region is written again
   hipEvent_t pin_event[3] = {nullptr, nullptr, nullptr};
+  // device blocks handed back by destroyed forests, kept for the next one: a fresh Grid per scan
+  // otherwise pays ~10 ms of hipMalloc / hipFree per build for its dozen large buffers
+  std::vector<DevBuf> pool;
+  size_t pool_bytes = 0;
   // RCCL (route.hip)
   void* comm = nullptr;
   int n_ranks = 1, rank = 0;
@@ -86,6 +90,8 @@ int pin_region_mark(octl_ctx* ctx, int r);
 // grow-only device buffer; contents are NOT preserved unless keep != 0
 int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep = 0);
 void devbuf_free(DevBuf& b);
+// hand a block back to the context's pool (the stream must have finished with it) instead of freeing it
+void devbuf_release(octl_ctx* ctx, DevBuf& b);
 
 // RAII timer: records hipEvents around the launches in its scope when profiling is on
 struct KTimer {

@@ -17,7 +17,27 @@ int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
   if (bytes <= b.cap) return OCTL_OK;
   size_t want = bytes + bytes / 4 + 256;  // grow with slack so level loops rarely realloc
   void* np = nullptr;
-  hipError_t e = hipMalloc(&np, want);
+  hipError_t e = hipSuccess;
+  // the smallest pooled block that fits without wasting more than the request again
+  int best = -1;
+  for (int i = 0; i < (int)ctx->pool.size(); ++i)
+    if (ctx->pool[i].cap >= bytes && ctx->pool[i].cap <= 2 * want &&
+        (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap))
+      best = i;
+  if (best >= 0) {
+    np = ctx->pool[best].p;
+    want = ctx->pool[best].cap;
+    ctx->pool_bytes -= want;
+    ctx->pool.erase(ctx->pool.begin() + best);
+  } else {
+    e = hipMalloc(&np, want);
+    if (e != hipSuccess && !ctx->pool.empty()) {  // give the pool back to the allocator and try again
+      for (auto& pb : ctx->pool) (void)hipFree(pb.p);
+      ctx->pool.clear();
+      ctx->pool_bytes = 0;
+      e = hipMalloc(&np, want);
+    }
+  }
   if (e != hipSuccess)
     return octl_set_error(ctx, OCTL_E_NOMEM, "hipMalloc(%zu) failed: %s", want,
                           hipGetErrorString(e));
@@ -32,10 +52,23 @@ int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
     // the old block may still be referenced by queued kernels
     (void)hipStreamSynchronize(ctx->stream);
   }
-  if (b.p) (void)hipFree(b.p);
+  if (b.p) devbuf_release(ctx, b);  // (the stream has been synchronised above)
   b.p = np;
   b.cap = want;
   return OCTL_OK;
+}
+
+void devbuf_release(octl_ctx* ctx, DevBuf& b) {
+  if (!b.p) return;
+  // small blocks and an over-full pool (> 48 GiB parked) go straight back to the allocator
+  if (ctx && b.cap >= (1u << 20) && ctx->pool_bytes + b.cap <= ((size_t)48 << 30) && ctx->pool.size() < 256) {
+    ctx->pool.push_back(b);
+    ctx->pool_bytes += b.cap;
+  } else {
+    (void)hipFree(b.p);
+  }
+  b.p = nullptr;
+  b.cap = 0;
 }
 
 int pin_region_wait(octl_ctx* ctx, int r) {
@@ -148,6 +181,8 @@ void octl_ctx_destroy(octl_ctx* ctx) {
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
   for (auto ev : ctx->pin_event)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& pb : ctx->pool) (void)hipFree(pb.p);
+  ctx->pool.clear();
   for (auto& b : ctx->scan_tmp) devbuf_free(b);
   devbuf_free(ctx->scan_status);
   devbuf_free(ctx->small);

@@ -91,7 +91,7 @@ static inline void vkey_decode(uint64_t k, int64_t q[3]) {
 int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
                  int32_t keep_scheme, int32_t max_depth, octl_build_info* info);
 int nodes_reserve(octl_ctx* ctx, NodeTable& t, int64_t cap);
-void nodes_free(NodeTable& t);
+void nodes_free(octl_ctx* ctx, NodeTable& t);
 
 // ransac.hip
 int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
