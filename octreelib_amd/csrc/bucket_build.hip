@@ -53,7 +53,7 @@ constexpr uint32_t LI_VHEAD = 1u << 24;   // first point of its top-level voxel
 constexpr uint32_t LI_BHEAD = 1u << 25;   // first point of its (leaf, pose) block
 // bucket flags
 constexpr uint32_t BF_OVERFLOW = 1u;      // more than BB_CAP points
-constexpr uint32_t BF_DEEP = 2u;          // a node at level 7 still exceeds K
+constexpr uint32_t BF_DEEP = 2u;          // a node at level 6 still exceeds K
 constexpr uint32_t BF_BAD = 4u;           // a point outside its cube (exact slow path needed)
 
 struct LinParams {
@@ -526,11 +526,8 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   uint32_t flags = __any(bad_any) ? BF_BAD : 0u;
 #pragma unroll 1
   for (int l = 1; n_over > 0; ++l) {
-    if (l > BB_LEVELS) {  // a node of level 7 still exceeds K: deeper than the 21-bit paths reach
-      flags |= BF_DEEP;
-#pragma unroll
-      for (int r = 0; r < BB_IPT; ++r)
-        if (stt[r] >> 31) stt[r] = (uint32_t)BB_LEVELS << 16;
+    if (l > PATH_EAGER) {  // a node of level 6 still exceeds K: deeper than the digits the records carry
+      flags |= BF_DEEP;    // (the general path of build.hip has no depth limit)
       break;
     }
     const int nbl = 8 * (int)n_over;
@@ -539,24 +536,6 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       break;
     }
     dmax = l;
-    if (l - 1 == PATH_EAGER) {
-      // the digits computed up front are used up: the points that go deeper get all 7 levels
-#pragma unroll
-      for (int r = 0; r < BB_IPT; ++r) {
-        if (stt[r] >> 31) {
-          const int i = wave * per_wave + r * 64 + lane;
-          double x, y, z, cx, cy, cz;
-          uint32_t vp, idx;
-          load_rec(part + (CHUNKED ? (int)SRC[i] : i), x, y, z, vp, idx);
-          (void)lin_corner_of(P.lp, x, y, z, cx, cy, cz);
-          bool bad = false;
-          const uint32_t path = path_levels(x, y, z, cx, cy, cz, P.lp.L, BB_LEVELS, &bad);
-          pth[r] = (pth[r] & 0x80000000u) | path | (bad ? 0x40000000u : 0u);
-          bad_any = bad_any || bad;
-        }
-      }
-      if (__any(bad_any)) flags |= BF_BAD;
-    }
     for (int d = tid; d < nbl; d += BB_THREADS) s_bins[d] = 0;
     __syncthreads();
     const int dsh = 18 - 3 * (l - 1);
@@ -627,22 +606,16 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 #pragma unroll
     for (int w = 0; w < BB_THREADS / 64; ++w) s_cnt[w][tid] = 0;
     __syncthreads();
-    uint32_t rank[BB_IPT];
-    uint16_t item[BB_IPT];
-    uint8_t dig[BB_IPT];
+    uint16_t rank[BB_IPT];
 #pragma unroll
     for (int r = 0; r < BB_IPT; ++r) {
       rank[r] = 0;
-      item[r] = 0;
-      dig[r] = 0;
       if (r < rounds) {
         const int i = wave * per_wave + r * 64 + lane;
         const bool valid = i < n;
         const uint32_t it = valid ? (first ? (uint32_t)i : (uint32_t)s_slot[cur][i]) : 0u;
         const uint32_t d = valid ? (KEY[it] >> sh) & 0xFFu : 0u;
-        item[r] = (uint16_t)it;
-        dig[r] = (uint8_t)d;
-        rank[r] = wave_stable_rank<8>(d, valid, s_cnt[wave]);
+        rank[r] = (uint16_t)wave_stable_rank<8>(d, valid, s_cnt[wave]);
       }
     }
     __syncthreads();
@@ -666,7 +639,12 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     for (int r = 0; r < BB_IPT; ++r) {
       if (r < rounds) {
         const int i = wave * per_wave + r * 64 + lane;
-        if (i < n) s_slot[dst_buf][s_cnt[wave][dig[r]] + rank[r]] = item[r];
+        if (i < n) {
+          // (item and digit are re-read: cheaper than 32 registers held across the barriers)
+          const uint32_t it = first ? (uint32_t)i : (uint32_t)s_slot[cur][i];
+          const uint32_t d = (KEY[it] >> sh) & 0xFFu;
+          s_slot[dst_buf][s_cnt[wave][d] + rank[r]] = (uint16_t)it;
+        }
       }
     }
     __syncthreads();
@@ -713,7 +691,11 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 
 constexpr int BB_MAX_CHUNKS = 64;
 
-__global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
+// OVERSIZE = false: the buckets with at most BB_CAP points (all of them in an evenly filled scene);
+// OVERSIZE = true: a second launch that only works on the others (it needs 12 KB more LDS for its
+// chunk plan, which would cost the common kernel one workgroup per CU).
+template <bool OVERSIZE>
+__global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
     const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
     uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_tot,
@@ -724,9 +706,9 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
   __shared__ uint32_t s_scr[8];
   __shared__ uint32_t s_tot[BK_ROWS];
   // buckets with more than BB_CAP points are cut into chunks of whole voxels
-  __shared__ uint16_t s_src[BB_CAP];              // chunk item -> record of the bucket
-  __shared__ uint8_t s_chunk[1 << PT_BITS];       // voxel inside the bucket -> chunk
-  __shared__ uint32_t s_cofs[BB_MAX_CHUNKS];      // first output position of the chunk
+  __shared__ uint16_t s_src[OVERSIZE ? BB_CAP : 1];          // chunk item -> record of the bucket
+  __shared__ uint8_t s_chunk[OVERSIZE ? (1 << PT_BITS) : 1]; // voxel inside the bucket -> chunk
+  __shared__ uint32_t s_cofs[BB_MAX_CHUNKS];                 // first output position of the chunk
   __shared__ uint16_t s_csize[BB_MAX_CHUNKS], s_cvox[BB_MAX_CHUNKS];
   __shared__ int s_nchunks;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -734,6 +716,7 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
   const uint32_t start = bstart[(size_t)b * P.bstride];
   const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   const int n = (int)(end - start);
+  if (OVERSIZE ? n <= BB_CAP : n > BB_CAP) return;  // the other launch's bucket
   if (tid < BK_ROWS) s_tot[tid] = 0;
   if (n == 0 || n > 65535) {
     if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
@@ -745,7 +728,7 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_build(
   const uint32_t lin0 = b << s;
   const PartRec* __restrict__ recs = part + start;
   uint32_t fl = 0;
-  if (n <= BB_CAP) {
+  if (!OVERSIZE) {
     fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
                              bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot);
   } else {
@@ -861,8 +844,9 @@ struct NodeParams {
 __global__ __launch_bounds__(256) void k_bucket_nodes(
     NodePtrs nd, NodeParams P, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bk_base,
     const uint32_t* __restrict__ leafinfo,
-    const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bk_vox,
-    const int64_t* __restrict__ pose_off, int32_t* __restrict__ pos_node, uint64_t* __restrict__ vlin,
+    const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
+    const uint32_t* __restrict__ bk_vox, const int64_t* __restrict__ pose_off,
+    int32_t* __restrict__ pos_node, uint64_t* __restrict__ vlin,
     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot, uint32_t* __restrict__ blk_start,
     uint32_t* small) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -894,10 +878,18 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
     tail_pref[l] = 0;
     tail_act[l] = false;
   }
+  // The chunks of a bucket are a serial chain (the running ordinals): the leafinfo words are loaded two
+  // chunks ahead so that the chain does not wait for them.
+  auto load_li = [&](int f0) {
+    const int f = f0 + lane;
+    return f < n ? leafinfo[(size_t)start + f] : 0u;
+  };
+  uint32_t li_cur = load_li(0), li_nxt = load_li(64);
   for (int f0 = 0; f0 < n; f0 += 64) {
     const int f = f0 + lane;
     const bool valid = f < n;
-    const uint32_t li = valid ? leafinfo[(size_t)start + f] : 0u;
+    const uint32_t li = li_cur;
+    const uint32_t li_nx2 = load_li(f0 + 128);
     const uint32_t pw = li & PATH_MASK;
     const uint32_t dep = (li >> 21) & 7u;
     const bool vhead = valid && (li & LI_VHEAD);
@@ -907,37 +899,23 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
     const uint32_t vo = vcarry + (uint32_t)__popcll(vb & lanemask_le64()) - 1u;  // ordinal inside the bucket
     vcarry += (uint32_t)__popcll(vb);
     const int32_t v = (int32_t)(vbase + vo);
-    // root geometry (only the lanes that need it read the staging record)
-    double c0x = P.lp.c0x, c0y = P.lp.c0y, c0z = P.lp.c0z;
-    uint32_t lin = 0;
-    if (valid && P.lp.mode == 0) {
-      lin = bk_vox[2 * ((size_t)start + vo)];
-      const uint32_t qz = lin % P.lp.nz, qy = (lin / P.lp.nz) % P.lp.ny, qx = lin / (P.lp.nz * P.lp.ny);
-      // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
-      c0x = (double)(long long)((double)((int)qx + P.lp.minx) * P.lp.L);
-      c0y = (double)(long long)((double)((int)qy + P.lp.miny) * P.lp.L);
-      c0z = (double)(long long)((double)((int)qz + P.lp.minz) * P.lp.L);
-    }
-    if (vhead) {
-      const uint32_t cntv = bk_vox[2 * ((size_t)start + vo) + 1];
-      nd.start[v] = start + (uint32_t)f;
-      nd.count[v] = cntv;
-      nd.scount[v] = P.all_scheme ? cntv : 0u;
-      nd.depth[v] = 0;
-      nd.voxel[v] = v;
-      nd.parent[v] = -1;
-      nd.old_id[v] = -1;
-      nd.edge[v] = P.lp.L;
-      nd.corner[3 * (int64_t)v] = c0x;
-      nd.corner[3 * (int64_t)v + 1] = c0y;
-      nd.corner[3 * (int64_t)v + 2] = c0z;
-      vlin[v] = (uint64_t)lin;
-    }
     int32_t leaf = v;  // dep == 0: the root is the leaf
     int32_t cb_prev = 0;
+    // pass 1: ordinals of the nodes of every level, position -> leaf; the nodes that START in this
+    // chunk are remembered per level (head lanes, their child group and their own id)
+    uint64_t hmask[BB_LEVELS];
+    int32_t h_cb[BB_LEVELS], h_xid[BB_LEVELS];
+    uint64_t any_heads = vb;
 #pragma unroll
     for (int l = 0; l < BB_LEVELS; ++l) {
+      hmask[l] = 0;
+      h_cb[l] = 0;
+      h_xid[l] = 0;
       const bool actl = valid && dep > (uint32_t)l;  // inside an internal node of level l
+      if (!__any(actl)) {  // (wave uniform) nobody of this chunk is that deep
+        tail_act[l] = false;
+        continue;
+      }
       const uint32_t pref = l == 0 ? 0u : (pw >> (21 - 3 * l));
       uint32_t pp = __shfl_up(pref, 1);
       bool pa = __shfl_up(actl ? 1 : 0, 1) != 0;
@@ -957,11 +935,60 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
         if (head) {
           nd.first_child[xid] = cb;
           nd.epoch[xid] = P.cur_epoch;
+          h_cb[l] = cb;
+          h_xid[l] = xid;
+        }
+        if (dep == (uint32_t)l + 1u) leaf = cb + (int32_t)digit_at(pw, l);
+        cb_prev = cb;
+      }
+      hmask[l] = hb;
+      any_heads |= hb;
+    }
+    // pass 2, only in chunks where a voxel or a node starts: root geometry from the staging record of
+    // the lane's voxel (a dependent load - kept off the chain of the other chunks), then the nodes
+    if (any_heads) {
+      double c0x = P.lp.c0x, c0y = P.lp.c0y, c0z = P.lp.c0z;
+      uint32_t lin = 0;
+      if (P.lp.mode == 0 && ((any_heads >> lane) & 1ull)) {
+        lin = bk_vox[2 * ((size_t)start + vo)];
+        const uint32_t qz = lin % P.lp.nz, qy = (lin / P.lp.nz) % P.lp.ny, qx = lin / (P.lp.nz * P.lp.ny);
+        // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
+        c0x = (double)(long long)((double)((int)qx + P.lp.minx) * P.lp.L);
+        c0y = (double)(long long)((double)((int)qy + P.lp.miny) * P.lp.L);
+        c0z = (double)(long long)((double)((int)qz + P.lp.minz) * P.lp.L);
+      }
+      if (vhead) {
+        const uint32_t cntv = bk_vox[2 * ((size_t)start + vo) + 1];
+        nd.start[v] = start + (uint32_t)f;
+        nd.count[v] = cntv;
+        nd.scount[v] = P.all_scheme ? cntv : 0u;
+        nd.depth[v] = 0;
+        nd.voxel[v] = v;
+        nd.parent[v] = -1;
+        nd.old_id[v] = -1;
+        nd.edge[v] = P.lp.L;
+        nd.corner[3 * (int64_t)v] = c0x;
+        nd.corner[3 * (int64_t)v + 1] = c0y;
+        nd.corner[3 * (int64_t)v + 2] = c0z;
+        vlin[v] = (uint64_t)lin;
+      }
+      // the 8 children of every node that starts in this chunk, written by the WHOLE wave, one node at
+      // a time: lane j < 8 writes child j (one store instruction per field and node)
+#pragma unroll
+      for (int l = 0; l < BB_LEVELS; ++l) {
+        uint64_t todo = hmask[l];
+        while (todo) {
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const int32_t cbh = __shfl(h_cb[l], src);
+          const int32_t xidh = __shfl(h_xid[l], src);
+          const uint32_t pwh = (uint32_t)__shfl((int)pw, src);
+          const int32_t vh = __shfl(v, src);
+          double cx = __shfl(c0x, src), cy = __shfl(c0y, src), cz = __shfl(c0z, src), e = P.lp.L;
           // corner / edge: descend from the root with the reference's arithmetic
           // (corner + offset, edge / 2: octree.py:181-191)
-          double cx = c0x, cy = c0y, cz = c0z, e = P.lp.L;
           for (int t = 0; t < l; ++t) {
-            const uint32_t d = digit_at(pw, t);
+            const uint32_t d = digit_at(pwh, t);
             const double h = e / 2.0;
             cx = cx + ((d & 4u) ? h : 0.0);
             cy = cy + ((d & 2u) ? h : 0.0);
@@ -969,14 +996,15 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
             e = h;
           }
           const double h = e / 2.0;
-          for (int j = 0; j < 8; ++j) {
-            const int64_t c = (int64_t)cb + j;
+          if (lane < 8) {
+            const int j = lane;
+            const int64_t c = (int64_t)cbh + j;
             nd.start[c] = 0;  // ranges are only meaningful inside the level-synchronous path
             nd.count[c] = 0;
             nd.scount[c] = 0;
             nd.depth[c] = l + 1;
-            nd.voxel[c] = v;
-            nd.parent[c] = xid;
+            nd.voxel[c] = vh;
+            nd.parent[c] = xidh;
             nd.old_id[c] = -1;
             nd.edge[c] = h;
             nd.corner[3 * c + 0] = cx + ((j & 4) ? h : 0.0);
@@ -984,8 +1012,6 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
             nd.corner[3 * c + 2] = cz + ((j & 1) ? h : 0.0);
           }
         }
-        if (dep == (uint32_t)l + 1u) leaf = cb + (int32_t)digit_at(pw, l);
-        cb_prev = cb;
       }
     }
     if (valid) pos_node[(size_t)start + f] = leaf;
@@ -998,6 +1024,8 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
       blk_start[bo] = start + (uint32_t)f;
     }
     bcarry += (uint32_t)__popcll(bbm);
+    li_cur = li_nxt;
+    li_nxt = li_nx2;
   }
 }
 
@@ -1178,7 +1206,12 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   uint32_t* bk_tot = f->bk_tot.as<uint32_t>();
   {
     KTimer t(ctx, "bucket_build");
-    hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
+    hipLaunchKernelGGL(k_bucket_build<false>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
+                       f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(),
+                       bk_tot, small);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_bucket_build<true>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(),
                        bk_tot, small);
@@ -1228,7 +1261,8 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
     hipLaunchKernelGGL(k_bucket_nodes, dim3((unsigned)ceil_div(nb, 4)), dim3(256), 0, st, nd, np,
                        bstart, (const uint32_t*)f->bk_tot.as<uint32_t>(),
                        (const uint32_t*)f->leafinfo.as<uint32_t>(),
-                       (const uint32_t*)f->ord_idx.as<uint32_t>(), (const uint32_t*)f->bk_vox.as<uint32_t>(),
+                       (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
+                       (const uint32_t*)f->bk_vox.as<uint32_t>(),
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->pos_node.as<int32_t>(),
                        f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
                        f->blk_start.as<uint32_t>(), small);
