@@ -73,7 +73,7 @@ def main():
     json.dump({"_note": "SQ counters per launch (sum over XCDs); SQ_* cycle counters are quad-cycles; "
                         "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8)",
                "kernels": rows}, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
-    for k in ("k_ransac", "k_keygen", "k_finalize", "k_lv_scatter"):
+    for k in ("k_ransac", "k_ingest", "k_part_hist", "k_part_scatter", "k_bucket_build", "k_bucket_nodes", "k_compact_ord"):
         if k in rows:
             print(k, json.dumps(rows[k]))
         if k in out["kernels"]:
