@@ -113,3 +113,21 @@ def test_voxel_owner_host_mirror_matches_library():
     # reasonably balanced over 8 ranks
     counts = np.bincount(voxel_owner_np(np.argwhere(np.ones((32, 32, 32))), 8), minlength=8)
     assert counts.min() > 0.9 * counts.mean()
+
+
+def test_bench_gpus_n_starts_its_own_ranks_or_says_why_not():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself - before the parent touches
+    a GPU - and, on a machine with fewer GPUs, exit 2 with a clear message instead of running one rank."""
+    import subprocess
+    import sys
+
+    import bench
+
+    have = bench.visible_gpus()
+    if have >= 2:
+        pytest.skip("this machine could really run two ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 2
+    assert "needs 2 GPUs" in out.stderr and out.stdout.strip() == ""
