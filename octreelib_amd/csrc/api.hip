@@ -379,7 +379,7 @@ int octl_forest_clear(octl_forest* f) {
   f->vkeys.clear();
   f->vkeys_stale = false;
   f->n_voxels = 0;
-  f->level_first.clear();
+  f->level_segs.clear();
   f->n_internal = 0;
   f->max_depth_reached = 0;
   f->n_ord = 0;

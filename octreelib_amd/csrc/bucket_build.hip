@@ -52,9 +52,7 @@ enum { BK_NVOX = 0, BK_NINT = 1 /* .. 7 */, BK_NBLK = 8, BK_ROWS = 9 };
 constexpr uint32_t LI_VHEAD = 1u << 24;   // first point of its top-level voxel
 constexpr uint32_t LI_BHEAD = 1u << 25;   // first point of its (leaf, pose) block
 // bucket flags
-constexpr uint32_t BF_OVERFLOW = 1u;      // more than BB_CAP points
-constexpr uint32_t BF_DEEP = 2u;          // a node at level 6 still exceeds K
-constexpr uint32_t BF_BAD = 4u;           // a point outside its cube (exact slow path needed)
+constexpr uint32_t BF_OVERFLOW = 1u;      // a bucket beyond what the oversize launch handles: whole build -> general path
 
 struct LinParams {
   int mode;          // 0 grid, 1 single cube
@@ -435,9 +433,15 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     const uint32_t vox_stage, const uint32_t lin0, const BkParams& P, const int64_t* __restrict__ pose_off,
     uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord, uint32_t* __restrict__ leafinfo,
     uint32_t* __restrict__ bk_vox, uint32_t* s_bins, uint16_t (*s_slot)[BB_CAP], uint32_t (*s_cnt)[256],
-    uint32_t* s_scr, uint32_t* s_tot) {
+    uint32_t* s_scr, uint32_t* s_tot, uint32_t* s_todo, uint32_t* __restrict__ small) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s = P.lp.shift;
+  // s_todo: one bit per voxel of the bucket - the voxel cannot be finished here (a point outside its
+  // cube, a tree deeper than the digits the records carry, more nodes per level than the histogram
+  // holds).  Such a voxel stays ONE leaf (its root, points in insertion order) and is flagged in its
+  // staging record; the host lets the level loop of build.hip subdivide exactly those voxels.
+  // (the bitmap is zero on entry: cleared by the kernel's prologue and again at the end of every chunk)
+  const uint32_t snap = tid < BK_ROWS ? s_tot[tid] : 0u;  // totals before this chunk (for the second attempt)
   // wave w owns items [w * per_wave, (w+1) * per_wave) in `rounds` rounds of 64 consecutive items:
   // item order == (wave, round, lane) order, which the stable ranks below rely on
   const int rounds = (n + BB_THREADS - 1) / BB_THREADS;  // <= 16
@@ -468,6 +472,18 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       }
     }
   }
+  // (after the loop: a conditional LDS access between the loads serialises them)
+  if (__any(bad_any)) {
+#pragma unroll
+    for (int r = 0; r < BB_IPT; ++r)
+      if (pth[r] & 0x40000000u) atomicOr(&s_todo[vlv[r] >> 5], 1u << (vlv[r] & 31u));
+  }
+  int dmax = 0;
+  bool again = false;   // some voxel turned out to be unfinishable here: second attempt without it
+  // (a lambda instantiated twice rather than a loop: the second attempt is rare and a loop back-edge
+  //  over the per-item register arrays cost 20 % of the kernel)
+  auto run_levels = [&]() {
+  again = false;
 
   // ---- 2. level 0: the voxels ------------------------------------------------------------------------------------
   // bin = voxel inside the bucket; low half: scheme-pose points, high half: all points
@@ -481,12 +497,15 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   uint32_t n_over;
   {
     const int per = (nbins0 + BB_THREADS - 1) / BB_THREADS;
+    auto is_over = [&](int d, uint32_t c) {
+      return P.K >= 0 && (int64_t)(c & 0xFFFFu) > P.K && !((s_todo[d >> 5] >> (d & 31)) & 1u);
+    };
     uint32_t mine = 0;  // low half: voxels, high half: overfull voxels
     for (int q = 0; q < per; ++q) {
       const int d = tid * per + q;
       if (d < nbins0) {
         const uint32_t c = s_bins[d];
-        mine += ((c >> 16) ? 1u : 0u) + ((P.K >= 0 && (int64_t)(c & 0xFFFFu) > P.K) ? 0x10000u : 0u);
+        mine += ((c >> 16) ? 1u : 0u) + (is_over(d, c) ? 0x10000u : 0u);
       }
     }
     uint32_t tot;
@@ -495,12 +514,15 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       const int d = tid * per + q;
       if (d < nbins0) {
         const uint32_t c = s_bins[d];
-        if (c >> 16) {  // staging of the j-th voxel of this bucket: linear key and point count
-          bk_vox[2 * ((size_t)vox_stage + (run & 0xFFFFu))] = lin0 + (uint32_t)d;
-          bk_vox[2 * ((size_t)vox_stage + (run & 0xFFFFu)) + 1] = c >> 16;
+        if (c >> 16) {  // staging of the j-th voxel of this chunk: linear key, points (| todo), scheme points
+          const size_t at = 3 * ((size_t)vox_stage + (run & 0xFFFFu));
+          const bool todo = (s_todo[d >> 5] >> (d & 31)) & 1u;
+          bk_vox[at] = lin0 + (uint32_t)d;
+          bk_vox[at + 1] = (c >> 16) | (todo ? 0x80000000u : 0u);
+          bk_vox[at + 2] = c & 0xFFFFu;
           run += 1u;
         }
-        const bool over = P.K >= 0 && (int64_t)(c & 0xFFFFu) > P.K;
+        const bool over = is_over(d, c);
         s_bins[d] = over ? (run >> 16) : NOT_OVER;
         if (over) run += 0x10000u;
       }
@@ -522,17 +544,18 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   __syncthreads();
 
   // ---- 3. deeper levels: bins = (overfull node of the level above, child digit) -----------------------------
-  int dmax = 0;
-  uint32_t flags = __any(bad_any) ? BF_BAD : 0u;
+  dmax = 0;
 #pragma unroll 1
   for (int l = 1; n_over > 0; ++l) {
-    if (l > PATH_EAGER) {  // a node of level 6 still exceeds K: deeper than the digits the records carry
-      flags |= BF_DEEP;    // (the general path of build.hip has no depth limit)
-      break;
-    }
     const int nbl = 8 * (int)n_over;
-    if (nbl > BB_BINS) {  // tiny K with many points: more nodes per level than the histogram holds
-      flags |= BF_OVERFLOW;
+    // a node of level 6 still exceeds K (deeper than the digits the records carry), or more nodes on
+    // this level than the histogram holds (tiny K, many points): the voxels of the still undecided
+    // points are left to the level loop of build.hip, which has neither limit
+    if (l > PATH_EAGER || nbl > BB_BINS) {
+#pragma unroll
+      for (int r = 0; r < BB_IPT; ++r)
+        if (stt[r] >> 31) atomicOr(&s_todo[vlv[r] >> 5], 1u << (vlv[r] & 31u));
+      again = true;
       break;
     }
     dmax = l;
@@ -574,11 +597,29 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     }
     __syncthreads();
   }
+  if (again) __syncthreads();  // (uniform) the flagged voxels are read below
+  };  // run_levels
+  run_levels();
+  if (again) {
+    if (tid < BK_ROWS) s_tot[tid] = snap;
+#pragma unroll
+    for (int r = 0; r < BB_IPT; ++r) stt[r] = (r < rounds && wave * per_wave + r * 64 + lane < n) ? 0x80000000u : 0u;
+    __syncthreads();
+    run_levels();
+    if (again) return BF_OVERFLOW;  // (cannot happen: the second attempt runs without the flagged voxels)
+  }
+  // voxels left to the general path (counted once, by the owners of their bins)
+  {
+    uint32_t c = 0;
+    for (int d = tid; d < (1 << s); d += BB_THREADS) c += (s_todo[d >> 5] >> (d & 31)) & 1u;
+    // (a flagged voxel of ANOTHER chunk of this bucket cannot be set here: the bitmap is per chunk)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0 && c) atomicAdd(&small[SM_BK_TODO], c);
+  }
   const int kshift = 3 * dmax;          // key = voxel << kshift | first d digits, left aligned in dmax digits
   const int kbits = s + kshift;
-  if (kbits > 32) flags |= BF_OVERFLOW;
-  if (flags & (BF_OVERFLOW | BF_DEEP | BF_BAD)) return flags;  // the host runs the general path instead
-
+  if (kbits > 32) return BF_OVERFLOW;   // (s = 12 and 7 levels: cannot happen with 6)
   // ---- 4. sort keys ------------------------------------------------------------------------------------------------
   uint32_t* KEY = s_bins;
   uint32_t* INFO = s_bins + BB_CAP;
@@ -685,6 +726,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) nblk += __shfl_xor(nblk, off);
   if (lane == 0 && nblk) atomicAdd(&s_tot[BK_NBLK], nblk);
+  if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
   __syncthreads();  // the LDS arrays are free for the next chunk
   return 0u;
 }
@@ -705,11 +747,14 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
   __shared__ uint32_t s_cnt[BB_THREADS / 64][256];
   __shared__ uint32_t s_scr[8];
   __shared__ uint32_t s_tot[BK_ROWS];
+  __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
   // buckets with more than BB_CAP points are cut into chunks of whole voxels
   __shared__ uint16_t s_src[OVERSIZE ? BB_CAP : 1];          // chunk item -> record of the bucket
   __shared__ uint8_t s_chunk[OVERSIZE ? (1 << PT_BITS) : 1]; // voxel inside the bucket -> chunk
-  __shared__ uint32_t s_cofs[BB_MAX_CHUNKS];                 // first output position of the chunk
-  __shared__ uint16_t s_csize[BB_MAX_CHUNKS], s_cvox[BB_MAX_CHUNKS];
+  constexpr int NCH = OVERSIZE ? BB_MAX_CHUNKS : 1;
+  __shared__ uint32_t s_cofs[NCH];                           // first output position of the chunk
+  __shared__ uint16_t s_csize[NCH], s_cvox[NCH];
+  __shared__ uint16_t s_cbig[NCH];                           // voxel + 1 of a single-voxel chunk beyond BB_CAP
   __shared__ int s_nchunks;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t b = blockIdx.x;
@@ -718,6 +763,7 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
   const int n = (int)(end - start);
   if (OVERSIZE ? n <= BB_CAP : n > BB_CAP) return;  // the other launch's bucket
   if (tid < BK_ROWS) s_tot[tid] = 0;
+  if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
   if (n == 0 || n > 65535) {
     if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
     if (tid == 0 && n > 0) atomicOr(&small[SM_BK_FLAGS], BF_OVERFLOW);
@@ -730,7 +776,7 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
   uint32_t fl = 0;
   if (!OVERSIZE) {
     fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
-                             bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot);
+                             bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot, s_todo, small);
   } else {
     // ---- plan: points per voxel, then greedy runs of voxels with at most BB_CAP points ------------------
     const int nbins0 = 1 << s;
@@ -746,33 +792,116 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
       bool fits = true;
       s_cofs[0] = 0;
       s_cvox[0] = 0;
+      s_cbig[0] = 0;
+      auto close_chunk = [&]() {
+        s_csize[c] = (uint16_t)size;
+        if (++c >= BB_MAX_CHUNKS) {
+          fits = false;
+          c = BB_MAX_CHUNKS - 1;
+        }
+        size = 0;
+        s_cofs[c] = cum;
+        s_cvox[c] = (uint16_t)vox;
+        s_cbig[c] = 0;
+      };
       for (int d = 0; d < nbins0; ++d) {
         const int cnt = (int)s_bins[d];
-        if (cnt > BB_CAP) fits = false;  // a single voxel beyond the LDS capacity: general path
-        if (cnt > 0 && size + cnt > BB_CAP) {
-          s_csize[c] = (uint16_t)size;
-          if (++c >= BB_MAX_CHUNKS) {
-            fits = false;
-            c = BB_MAX_CHUNKS - 1;
-          }
-          size = 0;
-          s_cofs[c] = cum;
-          s_cvox[c] = (uint16_t)vox;
+        if (cnt == 0) {
+          s_chunk[d] = (uint8_t)c;
+          continue;
         }
+        const bool big = cnt > BB_CAP;  // a single voxel beyond the LDS capacity: copied through as one leaf
+        if (size > 0 && (big || size + cnt > BB_CAP)) close_chunk();
         s_chunk[d] = (uint8_t)c;
-        if (cnt > 0) {
-          size += cnt;
-          cum += (uint32_t)cnt;
-          ++vox;
+        size += cnt;
+        cum += (uint32_t)cnt;
+        ++vox;
+        if (big) {
+          s_cbig[c] = (uint16_t)(d + 1);
+          close_chunk();
         }
       }
-      s_csize[c] = (uint16_t)size;
-      s_nchunks = fits ? c + 1 : 0;
+      if (size > 0) {
+        s_csize[c] = (uint16_t)size;
+        ++c;
+      }
+      s_nchunks = fits ? c : 0;
     }
     __syncthreads();
     const int nchunks = s_nchunks;
     if (nchunks == 0) fl = BF_OVERFLOW;
     for (int c = 0; c < nchunks && fl == 0; ++c) {
+      if (s_cbig[c]) {
+        // ---- one voxel with more than BB_CAP points: copied through in insertion order as ONE leaf (its
+        //      root), flagged for the level loop of build.hip --------------------------------------------------
+        const uint32_t vl = (uint32_t)s_cbig[c] - 1u;
+        const uint32_t out_base = start + s_cofs[c];
+        uint32_t* tmp = s_bins;  // [BB_THREADS] indices of the selected records of one pass
+        uint32_t basec = 0, last_idx = 0, nblk = 0, nsch = 0;
+        for (int i0 = 0; i0 < n; i0 += BB_THREADS) {
+          const int i = i0 + tid;
+          uint4 a = uint4{0, 0, 0, 0}, bq = uint4{0, 0, 0, 0};
+          if (i < n) {
+            a = reinterpret_cast<const uint4*>(recs + i)[0];
+            bq = reinterpret_cast<const uint4*>(recs + i)[1];
+          }
+          const bool sel = i < n && (bq.z >> 19) == vl;
+          const uint64_t m = __ballot(sel);
+          if (lane == 0) s_scr[wave] = (uint32_t)__popcll(m);
+          __syncthreads();
+          uint32_t off = 0, tot = 0;
+#pragma unroll
+          for (int w = 0; w < BB_THREADS / 64; ++w) {
+            if (w < wave) off += s_scr[w];
+            tot += s_scr[w];
+          }
+          off += (uint32_t)__popcll(m & lanemask_lt());
+          if (sel) tmp[off] = bq.w;
+          __syncthreads();
+          if (sel) {
+            const uint32_t idx = bq.w & IDX_MASK;
+            const bool first = basec + off == 0;
+            bool bhead = first;
+            if (!first && P.n_poses > 1) {
+              const uint32_t pidx = (off > 0 ? tmp[off - 1] : last_idx) & IDX_MASK;
+              bhead = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, pidx);
+            }
+            const size_t o = (size_t)out_base + basec + off;
+            leafinfo[o] = (first ? LI_VHEAD : 0u) | (bhead ? LI_BHEAD : 0u);
+            ord_idx[o] = idx;
+            reinterpret_cast<uint2*>(xyz_ord + 3 * o)[0] = uint2{a.x, a.y};
+            reinterpret_cast<uint2*>(xyz_ord + 3 * o)[1] = uint2{a.z, a.w};
+            reinterpret_cast<uint2*>(xyz_ord + 3 * o)[2] = uint2{bq.x, bq.y};
+            nblk += bhead ? 1u : 0u;
+            nsch += bq.w >> 31;
+          }
+          if (tot > 0) last_idx = tmp[tot - 1];
+          basec += tot;
+          __syncthreads();
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          nblk += __shfl_xor(nblk, off);
+          nsch += __shfl_xor(nsch, off);
+        }
+        if (lane == 0) {
+          atomicAdd(&s_tot[BK_NBLK], nblk);
+          atomicAdd(&s_scr[4], nsch);
+        }
+        if (tid == 0) s_scr[5] = 0;
+        __syncthreads();
+        if (tid == 0) {
+          const size_t at = 3 * ((size_t)start + s_cvox[c]);
+          bk_vox[at] = lin0 + vl;
+          bk_vox[at + 1] = basec | 0x80000000u;
+          bk_vox[at + 2] = s_scr[4];
+          s_scr[4] = 0;
+          s_tot[BK_NVOX] += 1;
+          atomicAdd(&small[SM_BK_TODO], 1u);
+        }
+        __syncthreads();
+        continue;
+      }
       // stable compaction of the chunk's records: SRC[k] = k-th record of the bucket whose voxel is in the chunk
       uint32_t basec = 0;
       for (int i0 = 0; i0 < n; i0 += BB_THREADS) {
@@ -792,7 +921,8 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
         __syncthreads();
       }
       fl = bucket_chunk<true>(recs, s_src, (int)s_csize[c], start + s_cofs[c], start + s_cvox[c], lin0, P,
-                              pose_off, ord_idx, xyz_ord, leafinfo, bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot);
+                              pose_off, ord_idx, xyz_ord, leafinfo, bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot,
+                              s_todo, small);
     }
   }
   if (fl) {  // the host runs the general path instead
@@ -950,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
       double c0x = P.lp.c0x, c0y = P.lp.c0y, c0z = P.lp.c0z;
       uint32_t lin = 0;
       if (P.lp.mode == 0 && ((any_heads >> lane) & 1ull)) {
-        lin = bk_vox[2 * ((size_t)start + vo)];
+        lin = bk_vox[3 * ((size_t)start + vo)];
         const uint32_t qz = lin % P.lp.nz, qy = (lin / P.lp.nz) % P.lp.ny, qx = lin / (P.lp.nz * P.lp.ny);
         // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
         c0x = (double)(long long)((double)((int)qx + P.lp.minx) * P.lp.L);
@@ -958,10 +1088,12 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
         c0z = (double)(long long)((double)((int)qz + P.lp.minz) * P.lp.L);
       }
       if (vhead) {
-        const uint32_t cntv = bk_vox[2 * ((size_t)start + vo) + 1];
+        // (bit 31 of the count: the voxel is left to the level loop of build.hip, which then splits
+        //  every root with more than K scheme points that is still a leaf)
+        const uint32_t cntv = bk_vox[3 * ((size_t)start + vo) + 1] & 0x7FFFFFFFu;
         nd.start[v] = start + (uint32_t)f;
         nd.count[v] = cntv;
-        nd.scount[v] = P.all_scheme ? cntv : 0u;
+        nd.scount[v] = bk_vox[3 * ((size_t)start + vo) + 2];
         nd.depth[v] = 0;
         nd.voxel[v] = v;
         nd.parent[v] = -1;
@@ -1052,8 +1184,8 @@ int ceil_log2_u64(uint64_t v) {
 // arrays, pos_node and the block table are complete; *done = 0 when this path does not apply (the
 // caller then runs the general path; nothing it relies on has been modified).
 int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,
-                        std::vector<int64_t>* level_first, int64_t* n_internal, int* levels,
-                        int64_t* n_voxels, int64_t* n_blocks, BucketBuildGeom* geom) {
+                        std::vector<octl_forest::LevelSeg>* segs, int64_t* n_internal, int* levels,
+                        int64_t* n_voxels, int64_t* n_blocks, int64_t* pending, BucketBuildGeom* geom) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
   *done = 0;
@@ -1121,7 +1253,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   OCTL_TRY(devbuf_reserve(ctx, f->bk_table,
                           (std::max((size_t)nd_a * nst_a, (size_t)nd_b * nst_b) + (two_pass ? nb + 1 : 0) + 16) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, ((size_t)BK_ROWS * nb + 8) * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 8));
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 12));
   OCTL_TRY(devbuf_reserve(ctx, f->leafinfo, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, (size_t)n_alive * 24));
@@ -1131,7 +1263,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n_alive * 4));
   uint32_t* table = f->bk_table.as<uint32_t>();
-  HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_FLAGS, 0, 4, st));
+  HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_FLAGS, 0, 12, st));  // flags, grand total, pending voxels
   // ---- partition ----------------------------------------------------------------------------------------------
   lp.dshift = s;
   lp.dmask = two_pass ? (uint32_t)(PT_BINS - 1) : 0xFFFFFFFFu;
@@ -1232,12 +1364,12 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   const int64_t V = sm[SM_NVOX];
   int64_t n_int = 0;
   int depth = 0;
-  level_first->assign({0, V});
+  segs->assign(1, octl_forest::LevelSeg{0, V, 0});
   for (int l = 0; l < BB_LEVELS; ++l) {
     if (sm[SM_BK_LEVEL + l] == 0) break;
     n_int += sm[SM_BK_LEVEL + l];
     depth = l + 1;
-    level_first->push_back(V + 8 * n_int);
+    segs->push_back(octl_forest::LevelSeg{V + 8 * (n_int - (int64_t)sm[SM_BK_LEVEL + l]), V + 8 * n_int, l + 1});
   }
   if (depth > a.max_depth) return octl_set_error(ctx, OCTL_E_DEPTH, "maximum depth %d exceeded", a.max_depth);
   const int64_t total = V + 8 * n_int;
@@ -1277,6 +1409,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   *levels = depth;
   *n_voxels = V;
   *n_blocks = sm[SM_NBLOCKS];
+  *pending = sm[SM_BK_TODO];
   geom->min[0] = bb[0];
   geom->min[1] = bb[1];
   geom->min[2] = bb[2];

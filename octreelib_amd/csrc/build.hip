@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_make_roots(const uint64_t* __restrict__
 //   keep mode: the node is internal in the previous scheme (octree.py:39-47, subdivide_as)
 __global__ __launch_bounds__(256) void k_split_flags(NodePtrs nd, int64_t first, int64_t n_new,
                                                      int keep_mode, int64_t K,
-                                                     const int32_t* __restrict__ old_fc,
+                                                     const int32_t* __restrict__ old_fc, int leaves_only,
                                                      uint32_t* __restrict__ flags) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_new) return;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_split_flags(NodePtrs nd, int64_t first,
     const int32_t o = nd.old_id[c];
     split = (o >= 0) && (old_fc[o] >= 0);
   } else {
-    split = (K >= 0) && ((int64_t)nd.scount[c] > K);
+    split = (K >= 0) && ((int64_t)nd.scount[c] > K) && !(leaves_only && nd.first_child[c] >= 0);
   }
   flags[j] = split ? 1u : 0u;
 }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_split_flags(NodePtrs nd, int64_t first,
 __global__ __launch_bounds__(256) void k_compact_split(NodePtrs nd, int64_t first, int64_t n_new,
                                                        const uint32_t* __restrict__ flags_scanned,
                                                        int keep_mode, int64_t K,
-                                                       const int32_t* __restrict__ old_fc,
+                                                       const int32_t* __restrict__ old_fc, int leaves_only,
                                                        int32_t* __restrict__ split_nodes,
                                                        uint32_t* __restrict__ split_tiles) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_compact_split(NodePtrs nd, int64_t firs
     const int32_t o = nd.old_id[c];
     split = (o >= 0) && (old_fc[o] >= 0);
   } else {
-    split = (K >= 0) && ((int64_t)nd.scount[c] > K);
+    split = (K >= 0) && ((int64_t)nd.scount[c] > K) && !(leaves_only && nd.first_child[c] >= 0);
   }
   if (split) {
     const uint32_t pos = flags_scanned[j];
@@ -420,6 +420,32 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_rekey(
       path_io[i] = compute_path(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2], cx, cy, cz, e);
     }
   }
+}
+
+// level-0 buffer of the roots a resumed build subdivides: store index | scheme bit of the points in
+// the root's range of the leaf-ordered permutation
+__global__ __launch_bounds__(LV_THREADS) void k_lv_init_idx(
+    const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
+    uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ ord_idx,
+    const int64_t* __restrict__ pose_off, int n_poses, const uint8_t* __restrict__ scheme,
+    uint32_t* __restrict__ idx_out) {
+  const TileRef tr = locate_tile(tile_base, ns, n_tiles, blockIdx.x);
+  const int32_t node = split_nodes[tr.s];
+  const uint32_t nstart = nd.start[node], nend = nstart + nd.count[node];
+  for (int r = 0; r < LV_IPT; ++r) {
+    const uint32_t i = nstart + tr.tl * LV_TILE + r * LV_THREADS + threadIdx.x;
+    if (i < nend) {
+      uint32_t v = ord_idx[i];
+      if (!scheme || scheme[find_slot(pose_off, n_poses, (int64_t)v)]) v |= 0x80000000u;
+      idx_out[i] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mark_nodes(const int32_t* __restrict__ nodes, int n,
+                                                    uint8_t* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[nodes[i]] = 1;
 }
 
 template <bool SCHEME_SUBSET>
@@ -603,6 +629,29 @@ __global__ __launch_bounds__(256) void k_finalize(const int32_t* __restrict__ po
   xyz_ord[3 * i + 2] = z;
 }
 
+// the same for the points of the roots a resumed build has subdivided (root_flag), everything else
+// was written by the bucket build
+__global__ __launch_bounds__(256) void k_finalize_marked(const int32_t* __restrict__ pos_node,
+                                                         const int32_t* __restrict__ depth,
+                                                         const int32_t* __restrict__ voxel,
+                                                         const uint8_t* __restrict__ root_flag,
+                                                         const uint32_t* __restrict__ idx_a,
+                                                         const uint32_t* __restrict__ idx_b,
+                                                         const double* __restrict__ xyz, int64_t n_alive,
+                                                         uint32_t* __restrict__ ord_idx,
+                                                         double* __restrict__ xyz_ord) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  const int32_t node = pos_node[i];
+  if (!root_flag[voxel[node]]) return;
+  const int d = depth[node];
+  const uint32_t v = ((d & 1) ? idx_b[i] : idx_a[i]) & IDX_MASK;
+  ord_idx[i] = v;
+  xyz_ord[3 * i] = xyz[3 * (int64_t)v];
+  xyz_ord[3 * i + 1] = xyz[3 * (int64_t)v + 1];
+  xyz_ord[3 * i + 2] = xyz[3 * (int64_t)v + 2];
+}
+
 __device__ __forceinline__ bool block_head(const int32_t* __restrict__ pos_node,
                                            const uint32_t* __restrict__ ord_idx,
                                            const int64_t* __restrict__ pose_off, int n_poses,
@@ -762,6 +811,168 @@ int forest_sync_vkeys(octl_forest* f) {
   return OCTL_OK;
 }
 
+// The level loop: level-synchronous recursive subdivide of the nodes [first_new, first_new + n_new) and
+// of everything they spawn.  resume = true: the bucket build has already produced the node table and
+// the leaf-ordered arrays; only roots that are still leaves with more than K scheme points split (the
+// voxels it left behind), and the level buffers are set up for them here.
+struct LevelLoop {
+  octl_forest* f;
+  NodeTable* nt;
+  int64_t K;
+  int keep_scheme;
+  bool all_scheme;
+  const uint8_t* scheme_dev;
+  const int32_t *old_fc, *old_epoch;
+  int cur_epoch, max_depth;
+  int64_t n_alive;
+  bool resume;
+  int64_t first_new, n_new;
+  int64_t n_internal;
+  int level;
+  std::vector<octl_forest::LevelSeg>* segs;
+};
+
+static int run_level_loop(LevelLoop& L) {
+  octl_forest* f = L.f;
+  octl_ctx* ctx = f->ctx;
+  hipStream_t st = ctx->stream;
+  NodeTable& nt = *L.nt;
+  NodePtrs nd = node_ptrs(nt);
+  uint32_t* small = ctx->small.as<uint32_t>();
+  uint32_t* flags = nullptr;
+  int32_t* pos_node = f->pos_node.as<int32_t>();
+  while (L.n_new > 0) {
+    // split list of the freshly created nodes
+    OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(L.n_new, L.n_alive) + 8) * 4));
+    flags = f->flags.as<uint32_t>();
+    for (int b = 0; b < 2; ++b) {
+      OCTL_TRY(devbuf_reserve(ctx, f->split[b], (size_t)(L.n_new + 8) * 4));
+      OCTL_TRY(devbuf_reserve(ctx, f->split_tiles[b], (size_t)(L.n_new + 8) * 4));
+    }
+    int32_t* split_nodes = f->split[0].as<int32_t>();
+    uint32_t* tile_base = f->split_tiles[0].as<uint32_t>();
+    {
+      KTimer t(ctx, "level_prepare");
+      const int leaves_only = (L.resume && L.level == 0) ? 1 : 0;
+      hipLaunchKernelGGL(k_split_flags, dim3(grid_for(L.n_new)), dim3(256), 0, st, nd, L.first_new,
+                         L.n_new, L.keep_scheme, L.K, L.old_fc, leaves_only, flags);
+      HIP_TRY(ctx, hipGetLastError());
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, L.n_new, small + SM_NSPLIT));
+      // tiles of the nodes that split: scanned over L.n_new entries (zeros beyond the ns that are
+      // filled) so that ns and the tile count come back in ONE readback
+      HIP_TRY(ctx, hipMemsetAsync(tile_base, 0, (size_t)(L.n_new + 8) * 4, st));
+      hipLaunchKernelGGL(k_compact_split, dim3(grid_for(L.n_new)), dim3(256), 0, st, nd, L.first_new,
+                         L.n_new, (const uint32_t*)flags, L.keep_scheme, L.K, L.old_fc, leaves_only,
+                         split_nodes, tile_base);
+      HIP_TRY(ctx, hipGetLastError());
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_base, tile_base, L.n_new, small + SM_NTILES));
+    }
+    uint32_t lv[2];
+    OCTL_TRY(read_small(ctx, SM_NSPLIT, 2, lv));
+    const int ns = (int)lv[0];
+    const uint32_t n_tiles = lv[1];
+    if (ns == 0) break;
+    if (L.level >= L.max_depth)
+      return octl_set_error(ctx, OCTL_E_DEPTH,
+                            "maximum depth %d exceeded (duplicate points with a count criterion "
+                            "never stop subdividing)", L.max_depth);
+
+    if (L.resume && L.level == 0) {
+      // the roots that are subdivided here: their points are (re)written by k_finalize_marked
+      OCTL_TRY(devbuf_reserve(ctx, f->root_up, (size_t)L.n_new));
+      HIP_TRY(ctx, hipMemsetAsync(f->root_up.p, 0, (size_t)L.n_new, st));
+      hipLaunchKernelGGL(k_mark_nodes, dim3(grid_for(ns)), dim3(256), 0, st, (const int32_t*)split_nodes, ns,
+                         f->root_up.as<uint8_t>());
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    const int64_t child_base = nt.n;
+    if (child_base + 8 * (int64_t)ns >= ((int64_t)1 << 31))
+      return octl_set_error(ctx, OCTL_E_NOMEM, "more than 2^31 scheme nodes");
+    OCTL_TRY(nodes_reserve(ctx, nt, child_base + 8 * (int64_t)ns));
+    nd = node_ptrs(nt);
+    if (!L.all_scheme && !L.keep_scheme) {
+      OCTL_TRY(devbuf_reserve(ctx, f->child_sc, (size_t)8 * ns * 4));
+      HIP_TRY(ctx, hipMemsetAsync(f->child_sc.p, 0, (size_t)8 * ns * 4, st));
+    }
+    const int src = L.level & 1;
+    const int shift = 61 - 3 * (L.level % PATH_LEVELS);
+    uint32_t* entries = nullptr;
+    if (n_tiles > 0) {
+      OCTL_TRY(devbuf_reserve(ctx, f->entries, ((size_t)8 * n_tiles + 8) * 4));
+      entries = f->entries.as<uint32_t>();
+      if (L.resume && L.level == 0) {
+        // resuming after the bucket build: the level buffers only exist for the voxels it left behind -
+        // store index | scheme bit from the leaf-ordered permutation (insertion order inside a root)
+        hipLaunchKernelGGL(k_lv_init_idx, dim3(n_tiles), dim3(LV_THREADS), 0, st, (const int32_t*)split_nodes,
+                           (const uint32_t*)tile_base, ns, n_tiles, nd,
+                           (const uint32_t*)f->ord_idx.as<uint32_t>(),
+                           (const int64_t*)f->pose_off_dev.as<int64_t>(), (int)f->pose_off.size() - 1,
+                           L.scheme_dev, f->idxbuf[src].as<uint32_t>());
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      if ((L.level > 0 || L.resume) && L.level % PATH_LEVELS == 0) {
+        KTimer t(ctx, "level_rekey");
+        hipLaunchKernelGGL(k_lv_rekey, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                           (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
+                           (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                           f->pathbuf[src].as<uint64_t>(), (const double*)f->xyz.as<double>());
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      {
+        KTimer t(ctx, "level_hist");
+        if (!L.all_scheme && !L.keep_scheme)
+          hipLaunchKernelGGL(k_lv_hist<true>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                             (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
+                             nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                             (const double*)f->xyz.as<double>(), shift, entries,
+                             f->child_sc.as<uint32_t>(), small);
+        else
+          hipLaunchKernelGGL(k_lv_hist<false>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                             (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
+                             nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                             (const double*)f->xyz.as<double>(), shift, entries,
+                             (uint32_t*)nullptr, small);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      {
+        KTimer t(ctx, "level_scan");
+        OCTL_TRY(octl_exclusive_scan_u32(ctx, entries, entries, (int64_t)8 * n_tiles,
+                                         small + SM_ETOTAL));
+      }
+      {
+        KTimer t(ctx, "level_scatter");
+        hipLaunchKernelGGL(k_lv_scatter, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+                           (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
+                           (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
+                           (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                           (const double*)f->xyz.as<double>(), shift, (const uint32_t*)entries,
+                           (int32_t)child_base, f->idxbuf[src ^ 1].as<uint32_t>(),
+                           f->pathbuf[src ^ 1].as<uint64_t>(), pos_node, small);
+        HIP_TRY(ctx, hipGetLastError());
+      }
+    }
+    {
+      KTimer t(ctx, "level_children");
+      hipLaunchKernelGGL(k_make_children, dim3(grid_for((int64_t)8 * ns)), dim3(256), 0, st,
+                         (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
+                         (const uint32_t*)entries, (const uint32_t*)small,
+                         (const uint32_t*)f->child_sc.as<uint32_t>(),
+                         (int)(L.all_scheme || L.keep_scheme), (int32_t)child_base, L.keep_scheme,
+                         L.cur_epoch, L.old_fc, L.old_epoch);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    nt.n = child_base + 8 * (int64_t)ns;
+    L.segs->push_back({child_base, nt.n, L.level + 1});
+    L.first_new = child_base;
+    L.n_new = 8 * (int64_t)ns;
+    L.n_internal += ns;
+    ++L.level;
+  }
+  return OCTL_OK;
+}
+
 int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
                  int32_t keep_scheme, int32_t max_depth, octl_build_info* info) {
   octl_ctx* ctx = f->ctx;
@@ -829,13 +1040,53 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   // ---- 0. fresh forest: the bucket build does insert + subdivide in one go (bucket_build.hip) -----------
   if (!keep_scheme && !f->built && f->vkeys.empty() && n_alive > 0) {
     NodeTable& bt = f->nodes[f->cur ^ 1];
-    BucketBuildArgs ba{K, scheme_dev, f->epoch + 1, max_depth};
+    const int cur_epoch = f->epoch + 1;
+    BucketBuildArgs ba{K, scheme_dev, cur_epoch, max_depth};
     BucketBuildGeom geom;
     int done = 0, lv = 0;
-    int64_t ni = 0, nv = 0, nblk = 0;
-    std::vector<int64_t> lf;
-    OCTL_TRY(forest_bucket_build(f, ba, bt, &done, &lf, &ni, &lv, &nv, &nblk, &geom));
+    int64_t ni = 0, nv = 0, nblk = 0, pending = 0;
+    std::vector<octl_forest::LevelSeg> segs;
+    OCTL_TRY(forest_bucket_build(f, ba, bt, &done, &segs, &ni, &lv, &nv, &nblk, &pending, &geom));
     trace.mark("bucket build");
+    if (done && pending > 0) {
+      // some voxels were left as single leaves (more than 4096 points, deeper than 6 levels, a point
+      // outside its cube): the level loop subdivides exactly those roots, the rest of the build stands
+      for (int b = 0; b < 2; ++b) {
+        OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)n_alive * 4));
+        OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)n_alive * 8));
+      }
+      LevelLoop L{f, &bt, K, 0, all_scheme, scheme_dev, nullptr, nullptr, cur_epoch, max_depth, n_alive,
+                  true, 0, nv, 0, 0, &segs};
+      OCTL_TRY(run_level_loop(L));
+      trace.mark("level loop (pending voxels)");
+      if (L.n_internal > 0) {
+        NodePtrs nd = node_ptrs(bt);
+        KTimer t(ctx, "finalize");
+        hipLaunchKernelGGL(k_finalize_marked, dim3(grid_for(n_alive)), dim3(256), 0, st,
+                           (const int32_t*)f->pos_node.as<int32_t>(), (const int32_t*)nd.depth,
+                           (const int32_t*)nd.voxel, (const uint8_t*)f->root_up.as<uint8_t>(),
+                           (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
+                           (const uint32_t*)f->idxbuf[1].as<uint32_t>(), (const double*)f->xyz.as<double>(),
+                           n_alive, f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>());
+        HIP_TRY(ctx, hipGetLastError());
+      }
+      ni += L.n_internal;
+      lv = std::max(lv, L.level);
+      const int64_t n_ord_before = f->n_ord;
+      f->n_ord = n_alive;
+      OCTL_TRY(forest_make_blocks(f));
+      uint32_t e = 0;
+      OCTL_TRY(forest_finish_blocks(f, &e));
+      nblk = f->n_blocks;
+      if (e) {
+        f->n_ord = n_ord_before;
+        f->n_blocks = 0;
+        f->built = false;
+        return octl_set_error(ctx, OCTL_E_DOMAIN,
+                              "a point lies outside the cube of a node that is being subdivided "
+                              "(the reference raises IndexError or picks a wrong child here)");
+      }
+    }
     if (done) {
       f->cur ^= 1;
       f->n_voxels = nv;
@@ -844,9 +1095,9 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       f->vl_min[0] = geom.min[0]; f->vl_min[1] = geom.min[1]; f->vl_min[2] = geom.min[2];
       f->vl_ny = geom.ny;
       f->vl_nz = geom.nz;
-      f->level_first.swap(lf);
+      f->level_segs.swap(segs);
       f->built = true;
-      f->epoch = f->epoch + 1;
+      f->epoch = cur_epoch;
       f->n_ord = n_alive;
       f->n_blocks = nblk;
       f->n_internal = ni;
@@ -1075,7 +1326,6 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   const int64_t old_internal = have_old ? f->n_internal : 0;
   int64_t first_new = 0, n_new = V, n_internal = 0;
   int level = 0;
-  std::vector<int64_t> level_first{0, V};
 
   int32_t* pos_node = nullptr;
   // ---- 4. level-0 buffers ---------------------------------------------------------------------------
@@ -1110,116 +1360,13 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
 
   trace.mark("level-0 buffers");
   // ---- 5. level loop ----------------------------------------------------------------------------------
-  while (n_new > 0) {
-    // split list of the freshly created nodes
-    OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_new, n_alive) + 8) * 4));
-    flags = f->flags.as<uint32_t>();
-    for (int b = 0; b < 2; ++b) {
-      OCTL_TRY(devbuf_reserve(ctx, f->split[b], (size_t)(n_new + 8) * 4));
-      OCTL_TRY(devbuf_reserve(ctx, f->split_tiles[b], (size_t)(n_new + 8) * 4));
-    }
-    int32_t* split_nodes = f->split[0].as<int32_t>();
-    uint32_t* tile_base = f->split_tiles[0].as<uint32_t>();
-    {
-      KTimer t(ctx, "level_prepare");
-      hipLaunchKernelGGL(k_split_flags, dim3(grid_for(n_new)), dim3(256), 0, st, nd, first_new,
-                         n_new, (int)keep_scheme, K, old_fc, flags);
-      HIP_TRY(ctx, hipGetLastError());
-      OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_new, small + SM_NSPLIT));
-      // tiles of the nodes that split: scanned over n_new entries (zeros beyond the ns that are
-      // filled) so that ns and the tile count come back in ONE readback
-      HIP_TRY(ctx, hipMemsetAsync(tile_base, 0, (size_t)(n_new + 8) * 4, st));
-      hipLaunchKernelGGL(k_compact_split, dim3(grid_for(n_new)), dim3(256), 0, st, nd, first_new,
-                         n_new, (const uint32_t*)flags, (int)keep_scheme, K, old_fc, split_nodes,
-                         tile_base);
-      HIP_TRY(ctx, hipGetLastError());
-      OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_base, tile_base, n_new, small + SM_NTILES));
-    }
-    uint32_t lv[2];
-    OCTL_TRY(read_small(ctx, SM_NSPLIT, 2, lv));
-    const int ns = (int)lv[0];
-    const uint32_t n_tiles = lv[1];
-    if (ns == 0) break;
-    if (level >= max_depth)
-      return octl_set_error(ctx, OCTL_E_DEPTH,
-                            "maximum depth %d exceeded (duplicate points with a count criterion "
-                            "never stop subdividing)", max_depth);
-
-    const int64_t child_base = nt.n;
-    if (child_base + 8 * (int64_t)ns >= ((int64_t)1 << 31))
-      return octl_set_error(ctx, OCTL_E_NOMEM, "more than 2^31 scheme nodes");
-    OCTL_TRY(nodes_reserve(ctx, nt, child_base + 8 * (int64_t)ns));
-    nd = node_ptrs(nt);
-    if (!all_scheme && !keep_scheme) {
-      OCTL_TRY(devbuf_reserve(ctx, f->child_sc, (size_t)8 * ns * 4));
-      HIP_TRY(ctx, hipMemsetAsync(f->child_sc.p, 0, (size_t)8 * ns * 4, st));
-    }
-    const int src = level & 1;
-    const int shift = 61 - 3 * (level % PATH_LEVELS);
-    uint32_t* entries = nullptr;
-    if (n_tiles > 0) {
-      OCTL_TRY(devbuf_reserve(ctx, f->entries, ((size_t)8 * n_tiles + 8) * 4));
-      entries = f->entries.as<uint32_t>();
-      if (level > 0 && level % PATH_LEVELS == 0) {
-        KTimer t(ctx, "level_rekey");
-        hipLaunchKernelGGL(k_lv_rekey, dim3(n_tiles), dim3(LV_THREADS), 0, st,
-                           (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
-                           (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                           f->pathbuf[src].as<uint64_t>(), (const double*)f->xyz.as<double>());
-        HIP_TRY(ctx, hipGetLastError());
-      }
-      {
-        KTimer t(ctx, "level_hist");
-        if (!all_scheme && !keep_scheme)
-          hipLaunchKernelGGL(k_lv_hist<true>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
-                             (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
-                             nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
-                             (const double*)f->xyz.as<double>(), shift, entries,
-                             f->child_sc.as<uint32_t>(), small);
-        else
-          hipLaunchKernelGGL(k_lv_hist<false>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
-                             (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
-                             nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
-                             (const double*)f->xyz.as<double>(), shift, entries,
-                             (uint32_t*)nullptr, small);
-        HIP_TRY(ctx, hipGetLastError());
-      }
-      {
-        KTimer t(ctx, "level_scan");
-        OCTL_TRY(octl_exclusive_scan_u32(ctx, entries, entries, (int64_t)8 * n_tiles,
-                                         small + SM_ETOTAL));
-      }
-      {
-        KTimer t(ctx, "level_scatter");
-        hipLaunchKernelGGL(k_lv_scatter, dim3(n_tiles), dim3(LV_THREADS), 0, st,
-                           (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
-                           (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                           (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
-                           (const double*)f->xyz.as<double>(), shift, (const uint32_t*)entries,
-                           (int32_t)child_base, f->idxbuf[src ^ 1].as<uint32_t>(),
-                           f->pathbuf[src ^ 1].as<uint64_t>(), pos_node, small);
-        HIP_TRY(ctx, hipGetLastError());
-      }
-    }
-    {
-      KTimer t(ctx, "level_children");
-      hipLaunchKernelGGL(k_make_children, dim3(grid_for((int64_t)8 * ns)), dim3(256), 0, st,
-                         (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
-                         (const uint32_t*)entries, (const uint32_t*)small,
-                         (const uint32_t*)f->child_sc.as<uint32_t>(),
-                         (int)(all_scheme || keep_scheme), (int32_t)child_base, (int)keep_scheme,
-                         cur_epoch, old_fc, old_epoch);
-      HIP_TRY(ctx, hipGetLastError());
-    }
-    nt.n = child_base + 8 * (int64_t)ns;
-    level_first.push_back(nt.n);
-    first_new = child_base;
-    n_new = 8 * (int64_t)ns;
-    n_internal += ns;
-    ++level;
-  }
+  std::vector<octl_forest::LevelSeg> segs{{0, V, 0}};
+  LevelLoop L{f, &nt, K, (int)keep_scheme, all_scheme, scheme_dev, old_fc, old_epoch, cur_epoch, max_depth,
+              n_alive, false, first_new, n_new, 0, 0, &segs};
+  OCTL_TRY(run_level_loop(L));
+  nd = node_ptrs(nt);
+  n_internal = L.n_internal;
+  level = L.level;
   trace.mark("level loop");
   // ---- 6. leaf-ordered arrays and the block table ------------------------------------------------------
   if (n_alive > 0) {
@@ -1269,7 +1416,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     f->vkeys.swap(new_vkeys);
     f->vkeys_stale = false;
   }
-  f->level_first.swap(level_first);
+  f->level_segs.swap(segs);
   f->built = true;
   f->epoch = cur_epoch;
   f->n_ord = n_alive;

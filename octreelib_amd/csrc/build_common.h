@@ -17,6 +17,7 @@ enum {
   // 20: kept count of apply_mask, 21: slot-voxel count, 24: debug scan total
   SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
   SM_BK_TOTAL = 26,     // bucket build: grand total of the scanned bucket table
+  SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
   // 64..: slot histogram, 512..: allreduce
 };
@@ -56,6 +57,7 @@ struct BucketBuildGeom {  // decoding of the linear voxel keys: lin = ((qx-min0)
   int min[3];
   uint64_t ny, nz;
 };
+// *pending = number of voxels left as single leaves for the level loop of build.hip (flagged roots).
 int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,
-                        std::vector<int64_t>* level_first, int64_t* n_internal, int* levels,
-                        int64_t* n_voxels, int64_t* n_blocks, BucketBuildGeom* geom);
+                        std::vector<octl_forest::LevelSeg>* segs, int64_t* n_internal, int* levels,
+                        int64_t* n_voxels, int64_t* n_blocks, int64_t* pending, BucketBuildGeom* geom);

@@ -60,7 +60,6 @@ struct octl_forest {
 
   DevBuf rs_scratch, rs_order, rs_hyp, rs_plane, rs_count, rs_index;  // ransac staging
   DevBuf ord_idx2, xyz_ord2, pos_node2;  // compaction targets (swapped with the live arrays)
-  std::vector<int64_t> level_first;      // node id of the first node of every level (+ end)
 
   // bucket build (bucket_build.hip): the cloud partitioned into buckets of consecutive voxels
   DevBuf part_lin[2], part_idx[2], part_xyz[2];  // u32 linear voxel key, u32 store index | scheme bit, f64 x3
@@ -68,8 +67,9 @@ struct octl_forest {
   DevBuf bk_tot;       // u32 [BK_ROWS][n_buckets] per-bucket totals (scanned in place)
   DevBuf bk_vox;       // u32 [n_alive] staging: linear key of the j-th voxel of bucket b at [bucket start + j]
   DevBuf leafinfo;     // u32 [n_alive] per leaf-ordered point: path21 | depth << 21 | flags
-  // levels of the current node table as (first, end, depth) segments, ordered by depth (parents
-  // before children); one segment per level when a single build path numbered the nodes
+  // levels of the current node table as (first, end, depth) ranges of node ids: one per level when a
+  // single build path numbered the nodes, two where the level loop has subdivided voxels the bucket
+  // build left behind (order.hip sweeps them by depth)
   struct LevelSeg { int64_t a, b; int depth; };
   std::vector<LevelSeg> level_segs;
   // build scratch (kept between builds to avoid re-allocation)

@@ -11,6 +11,8 @@
 // max(epoch(parent), e0).  Everything is computed from the scheme node table:
 //   1. bottom-up: internal nodes per subtree; 2. top-down: global preorder rank of every
 //   internal node (voxel-major); 3. one key per (leaf, pose) block; 4. two stable radix sorts.
+#include <algorithm>
+
 #include "forest.h"
 
 namespace {
@@ -178,20 +180,21 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   uint32_t* nint = f->entries.as<uint32_t>();
   uint32_t* rank = reinterpret_cast<uint32_t*>(static_cast<char*>(f->entries.p) + off_rank);
   const int32_t* fc = t.first_child.as<int32_t>();
-  const int n_levels = (int)f->level_first.size() - 1;  // level L = [level_first[L], level_first[L+1])
-  for (int L = n_levels - 1; L >= 0; --L) {
-    const int64_t a = f->level_first[L], b = f->level_first[L + 1];
-    if (b > a) {
-      hipLaunchKernelGGL(k_sub_up, dim3(grid_for(b - a)), dim3(256), 0, st, fc, a, b, nint);
+  // bottom-up over the level ranges, deepest first; then top-down (ranges of equal depth are independent)
+  std::vector<octl_forest::LevelSeg> segs = f->level_segs;
+  std::stable_sort(segs.begin(), segs.end(),
+                   [](const octl_forest::LevelSeg& x, const octl_forest::LevelSeg& y) { return x.depth > y.depth; });
+  for (const auto& sg : segs) {
+    if (sg.b > sg.a) {
+      hipLaunchKernelGGL(k_sub_up, dim3(grid_for(sg.b - sg.a)), dim3(256), 0, st, fc, sg.a, sg.b, nint);
       HIP_TRY(ctx, hipGetLastError());
     }
   }
   // roots: global rank base = exclusive scan of the per-voxel internal-node counts
   OCTL_TRY(octl_exclusive_scan_u32(ctx, nint, rank, V, nullptr));
-  for (int L = 0; L < n_levels - 1; ++L) {
-    const int64_t a = f->level_first[L], b = f->level_first[L + 1];
-    if (b > a) {
-      hipLaunchKernelGGL(k_rank_down, dim3(grid_for(b - a)), dim3(256), 0, st, fc, a, b,
+  for (auto it = segs.rbegin(); it != segs.rend(); ++it) {
+    if (it->b > it->a) {
+      hipLaunchKernelGGL(k_rank_down, dim3(grid_for(it->b - it->a)), dim3(256), 0, st, fc, it->a, it->b,
                          (const uint32_t*)nint, rank);
       HIP_TRY(ctx, hipGetLastError());
     }

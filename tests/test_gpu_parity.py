@@ -946,6 +946,35 @@ def test_manager_insert_points_into_any_existing_pose_vs_oracle():
 # ------------------------------------------------------------------------------------------------
 # the two build paths (bucket build / level-synchronous) must produce identical tables
 # ------------------------------------------------------------------------------------------------
+def _canon_build(out):
+    """A build result independent of the node numbering (the bucket build numbers level-major; where the
+    level loop subdivides voxels it left behind, those nodes are appended): nodes keyed by (voxel, child
+    digit path), blocks as (leaf key, slot, size) in storage order."""
+    nd, blk = out[0], out[1]
+    n = len(nd["parent"])
+    keys = [None] * n
+    order = np.argsort(nd["depth"], kind="stable")
+    par, fc = nd["parent"], nd["first_child"]
+    for i in order.tolist():
+        p = par[i]
+        keys[i] = (int(nd["voxel"][i]), ()) if p < 0 else (keys[p][0], keys[p][1] + (int(i - fc[p]),))
+    nodes = {keys[i]: (int(nd["depth"][i]), nd["corner"][i].tobytes(), nd["edge"][i].tobytes(), int(nd["epoch"][i]),
+                       bool(fc[i] >= 0)) for i in range(n)}
+    assert len(nodes) == n
+    blocks = [(keys[b], int(sl), int(st), int(sz)) for b, sl, st, sz in
+              zip(blk["node"].tolist(), blk["slot"].tolist(), blk["start"].tolist(), blk["size"].tolist())]
+    return nodes, blocks
+
+
+def _assert_same_build(a, b):
+    assert a[5] == b[5]
+    na, ba = _canon_build(a)
+    nb, bb = _canon_build(b)
+    assert na == nb
+    assert ba == bb
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
 @pytest.mark.parametrize("scheme", [None, [0]])
 def test_voxel_local_build_equals_level_synchronous_build(monkeypatch, scheme):
     from octreelib_amd import synthetic
@@ -1026,12 +1055,9 @@ def test_voxel_local_build_random_voxels_vs_level_synchronous_build(monkeypatch,
     assert "bucket_build" in names_a and "bucket_build" not in names_b
     if not deep and K >= 8:
         assert "level_hist" not in names_a    # the bucket path did the whole build
-    assert a[5] == b[5]
-    for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
-        assert np.array_equal(a[0][k], b[0][k]), k
-    for k in a[1]:
-        assert np.array_equal(a[1][k], b[1][k]), k
-    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+        for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
+            assert np.array_equal(a[0][k], b[0][k]), k     # ... with the numbering of the general path
+    _assert_same_build(a, b)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -1136,6 +1162,63 @@ def test_bucket_build_two_pass_partition_vs_level_synchronous_build(monkeypatch,
     for k in a[1]:
         assert np.array_equal(a[1][k], b[1][k]), k
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_bucket_build_leaves_huge_and_deep_voxels_to_the_level_loop(monkeypatch, seed):
+    """A few voxels hold more points than a workgroup sorts in LDS (5000 .. 9000) or clusters that need
+    more than 6 levels: the bucket build finishes every other voxel and the level loop subdivides exactly
+    those (it must NOT redo the whole build).  Same tables as the level-synchronous path."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    rng = np.random.default_rng(1500 + seed)
+    dims = rng.integers(4, 8, 3)
+    K = int(rng.choice([24, 64, 200]))
+    parts, special = [], 0
+    for c in np.argwhere(np.ones(dims)):
+        r = rng.random()
+        if r < 0.03:
+            m = int(rng.integers(5000, 9001))         # beyond the 4096 points of one workgroup
+            pts = rng.random((m, 3))
+            special += 1
+        elif r < 0.06:
+            m = int(rng.integers(200, 600))
+            pts = rng.random((m, 3))
+            pts[: m // 2] = rng.random(3) * 0.9 + rng.random((m // 2, 3)) * 2.0 ** -9   # needs > 6 levels
+            special += 1
+        else:
+            m = int(rng.integers(0, 500))
+            pts = rng.random((m, 3))
+        parts.append(pts + c)
+    assert special >= 2
+    cloud = np.unique(np.vstack(parts), axis=0)
+    rng.shuffle(cloud)
+    cut = int(len(cloud) * 0.6)
+    poses = [cloud[:cut], cloud[cut:]]
+    scheme = [1] if seed == 2 else None
+    ctx = nat.get_context()
+
+    def build():
+        f = Forest(0, np.zeros(3), 1.0)
+        for c in poses:
+            f.add_pose(c)
+        ctx.set_profiling(True)
+        f.subdivide(K, scheme)
+        t = ctx.timings()
+        ctx.set_profiling(False)
+        out = ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()},
+               f.perm.copy(), f.xyz.copy(), f.order.copy(), int(f.info.n_levels))
+        f.close()
+        return out, t
+
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    a, ta = build()
+    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    b, tb = build()
+    assert "bucket_build" in ta and "level_hist" in ta and "keygen" not in ta    # resumed, not redone
+    assert "bucket_build" not in tb and "keygen" in tb
+    _assert_same_build(a, b)
 
 
 def test_grid_get_points_follows_voxel_creation_order():
