@@ -487,6 +487,34 @@ def main():
                 "note": "BASELINE C2-U / C3-U: np.random.default_rng(0).random((10 M, 3)) * 32, same step",
             }
             uw.close()
+            # two independent step sequences (two contexts = two streams, two forests, two host threads): what
+            # a pipeline over consecutive scans gains from overlapping the memory-bound build of one scan with
+            # the VALU-bound RANSAC of another.  NOT the headline: a step there is strictly sequential.
+            import threading
+
+            ctx2 = nat.Context(local_rank)
+            w2 = Workload(ctx2, ctx2, 0, 1, n_local, dims, args.cloud, args.k_split, False, False)
+            w2.step()
+            ctx2.sync()
+            reps = 10
+
+            def seq(w, c):
+                for _ in range(reps):
+                    w.step()
+                c.sync()
+
+            barrier()
+            t1 = time.perf_counter()
+            ths = [threading.Thread(target=seq, args=(wl, ctx)), threading.Thread(target=seq, args=(w2, ctx2))]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            d2 = time.perf_counter() - t1
+            secondary["two_streams"] = {
+                "ms_per_step": d2 / (2 * reps) * 1e3, "Mpoints_per_s": 2 * reps * n_local / d2 / 1e6,
+                "note": "aggregate of two independent step sequences on two contexts of the same GPU",
+            }
+            w2.close()
+            ctx2.close()
         if world == 8 and n_local != 10_000_000 and not args.scene:
             # the 10 M points per rank point of the weak-scaling series (the N = 1 line's per-rank load)
             w10 = Workload(ctx, rctx, rank, world, 10_000_000, scene_dims(world, False), args.cloud,

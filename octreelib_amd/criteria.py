@@ -11,6 +11,7 @@ run there); the bucketing / partition / ordering stays on the device.
 """
 
 import dis
+import warnings
 from typing import Callable, Optional, Sequence
 
 import numpy as np
@@ -167,13 +168,49 @@ def _probe(fn, k: int) -> bool:
     return True
 
 
+_warned = False
+
+
+def _mentions_len(fn) -> bool:
+    code = getattr(fn, "__code__", None)
+    return code is not None and "len" in code.co_names
+
+
 def try_count_threshold(criteria: Sequence[Callable]):
     """K for a pure point-count criterion (runs entirely on the device), or None when the
-    criteria are arbitrary callables (the host then evaluates them level by level)."""
+    criteria are arbitrary callables (the host then evaluates them level by level).  A criterion that
+    mentions len() but is not recognised gets ONE warning per process: it takes the slow host path
+    (e.g. a CPython whose bytecode this matcher does not know) - MaxPoints(K) is the explicit form."""
+    global _warned
     try:
         return count_threshold(criteria)
     except UnsupportedCriterion:
+        if not _warned and any(_mentions_len(c) for c in criteria):
+            _warned = True
+            warnings.warn("octreelib_amd: a subdivision criterion that uses len(points) was not recognised as "
+                          "`len(points) > K`; it is evaluated on the host level by level. Use "
+                          "octreelib_amd.MaxPoints(K) for the device path.", RuntimeWarning, stacklevel=3)
         return None
+
+
+_match_cache = {}
+
+
+def _cached_threshold(c):
+    """(k or None) for a callable, cached per code object + closure / global constant it compares with
+    (the probe calls the user's function on zero arrays: once per distinct criterion, not per call)."""
+    code = getattr(c, "__code__", None)
+    if code is None:
+        k = _match_len_compare(c)
+        return k if k is not None and _probe(c, k) else None
+    k = _match_len_compare(c)
+    key = (code, k)
+    if key not in _match_cache:
+        if len(_match_cache) > 4096:
+            _match_cache.clear()
+        _match_cache[key] = k if (k is not None and k <= (1 << 20) and _probe(c, k)) else (
+            k if (k is not None and k > (1 << 20)) else None)
+    return _match_cache[key]
 
 
 def count_threshold(criteria: Sequence[Callable]) -> int:
@@ -186,8 +223,8 @@ def count_threshold(criteria: Sequence[Callable]) -> int:
         if isinstance(c, MaxPoints):
             ks.append(c.k)
             continue
-        k = _match_len_compare(c)
-        if k is None or not _probe(c, k):
+        k = _cached_threshold(c)
+        if k is None:
             raise UnsupportedCriterion(
                 "only point-count criteria (octreelib_amd.MaxPoints(K) or `lambda points: "
                 "len(points) > K`) run on the device; arbitrary Python callables cannot be "

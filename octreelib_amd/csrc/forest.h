@@ -62,10 +62,11 @@ struct octl_forest {
   DevBuf ord_idx2, xyz_ord2, pos_node2;  // compaction targets (swapped with the live arrays)
 
   // bucket build (bucket_build.hip): the cloud partitioned into buckets of consecutive voxels
-  DevBuf part_lin[2], part_idx[2], part_xyz[2];  // u32 linear voxel key, u32 store index | scheme bit, f64 x3
+  DevBuf part_xyz[2];  // 32-byte records {x, y, z, voxel | child digits, store index | scheme bit}, two passes
   DevBuf bk_table;     // u32 [digit][supertile] partition histogram (scanned in place)
   DevBuf bk_tot;       // u32 [BK_ROWS][n_buckets] per-bucket totals (scanned in place)
-  DevBuf bk_vox;       // u32 [n_alive] staging: linear key of the j-th voxel of bucket b at [bucket start + j]
+  DevBuf bk_vox;       // u32 x3 staging {linear key, points | todo, scheme points} of the j-th voxel of bucket b
+                       // at [bucket start + j]
   DevBuf leafinfo;     // u32 [n_alive] per leaf-ordered point: path21 | depth << 21 | flags
   // levels of the current node table as (first, end, depth) ranges of node ids: one per level when a
   // single build path numbered the nodes, two where the level loop has subdivided voxels the bucket
