@@ -815,6 +815,163 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   }
 }
 
+#if RS_SCREEN
+// A block with more than THREADS-1 points (unsplit voxels - what Grid.map_leaf_points_cuda_ransac sees
+// when nobody called subdivide, as in the reference's own test - poses outside the scheme, large K):
+// the same screened scoring as k_ransac, the block taken in TILES of THREADS points staged in LDS as
+// block-local f32 coordinates.  The bound of the screen needs the extent of the whole block first (one
+// extra pass over its points); a hypothesis the screen cannot decide is recounted exactly by its whole
+// wavefront over all n points (the per-hypothesis recount is what makes the screen pay here: per group it
+// was slower than the plain f64 loop, 4.9 vs 3.0 ms per 10 M points of unsplit voxels).
+template <int THREADS, int HPL, int KT>
+__device__ __forceinline__ void ransac_block_tiled(const BlockDesc& d, int be,
+                                                   const double* __restrict__ xyz,
+                                                   const double* __restrict__ hyp, int H, int k_rt,
+                                                   double thr, const RansacOut& out, f4* s_loc,
+                                                   float* s_wext, unsigned long long* s_best,
+                                                   float* s_plane) {
+  constexpr int KS = KT > 0 ? KT : RS_KMAX;
+  constexpr int W = THREADS / 64;
+  const int k = KT > 0 ? KT : k_rt;
+  const int n = d.n;
+  const int64_t pstart = d.pstart;
+  const double* __restrict__ pts = xyz + 3 * pstart;
+  const double ox = pts[0], oy = pts[1], oz = pts[2];
+  // ---- extent of the block in local coordinates ----------------------------------------------------------
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += THREADS) {
+    const float u = (float)(pts[3 * (int64_t)i] - ox), v = (float)(pts[3 * (int64_t)i + 1] - oy),
+                w = (float)(pts[3 * (int64_t)i + 2] - oz);
+    float mm = fmaxf(fabsf(u), fmaxf(fabsf(v), fabsf(w)));
+    if (!(mm == mm) || u != u || v != v || w != w) mm = __int_as_float(0x7f800000);  // NaN: all ambiguous
+    m = fmaxf(m, mm);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) s_wext[threadIdx.x >> 6] = m;
+  __syncthreads();
+  float extent = s_wext[0];
+#pragma unroll
+  for (int w = 1; w < W; ++w) extent = fmaxf(extent, s_wext[w]);
+  const double delta_blk = fma(0x1p-23 * 9.0, (double)extent,
+                               0x1p-49 * (fabs(ox) + fabs(oy) + fabs(oz) + (double)extent + 1.0));
+  const double dprime_thr = 0x1p-21 * (thr * thr);
+  const bool blk_sane = thr >= 0x1p-40 && thr <= 0x1p40 && extent < 0x1p60f;
+  const float nthr2 = -(float)(thr * thr);
+  // ---- the hypotheses' planes (samples gathered from global memory) + screening constants -----------------
+  float fa[HPL], fb[HPL], fc[HPL], fd[HPL], sto[HPL], sdl[HPL], margin[HPL];
+  int cnt[HPL];
+#pragma unroll
+  for (int q = 0; q < HPL; ++q) {
+    const int t = threadIdx.x + q * THREADS;
+    cnt[q] = 0;
+    fa[q] = fb[q] = fc[q] = fd[q] = sto[q] = 0.f;
+    sdl[q] = 0.f;
+    margin[q] = __int_as_float(0x7f800000);
+    if (t < H) {
+      double sx[KS], sy[KS], sz[KS];
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        sx[i] = sy[i] = sz[i] = 0.0;
+        if (i < k) {
+          const int g = sample_index_exact(hyp[(int64_t)t * k + i], n, d.vstart);
+          const int64_t p = (g < n) ? pstart + g : (int64_t)d.pspill;
+          sx[i] = xyz[3 * p];
+          sy[i] = xyz[3 * p + 1];
+          sz[i] = xyz[3 * p + 2];
+        }
+      }
+      float pf[4];
+      plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
+      // (explicit fma: error BOUNDS and the screen's own inputs, not parity arithmetic; see k_ransac)
+      const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
+      const double to = fma(A, ox, fma(B, oy, fma(Cc, oz, D)));
+      const double delta = fma(0x1p-21, fabs(to), fma(0x1p-49, fabs(D), delta_blk));
+      const double dprime = fma(delta, thr + thr + delta, dprime_thr) * 1.000001;
+      const bool sane = blk_sane && (fabs(to) < 0x1p60);
+      fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
+      sto[q] = (float)to;
+      sdl[q] = sane ? (float)dprime : __int_as_float(0x7f800000);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- screened scoring, tile by tile -----------------------------------------------------------------------
+  for (int t0 = 0; t0 < n; t0 += THREADS) {
+    const int nt = min(THREADS, n - t0);
+    if ((int)threadIdx.x < nt) {
+      const int64_t i = t0 + threadIdx.x;
+      s_loc[threadIdx.x] = f4{(float)(pts[3 * i] - ox), (float)(pts[3 * i + 1] - oy), (float)(pts[3 * i + 2] - oz), 0.f};
+    }
+    __syncthreads();
+    float mt[HPL];
+    screen_group<HPL>(s_loc, nt, fa, fb, fc, sto, nthr2, cnt, mt);
+#pragma unroll
+    for (int q = 0; q < HPL; ++q) margin[q] = fminf(margin[q], mt[q]);
+    __syncthreads();
+  }
+  // ---- exact recount of the hypotheses the screen could not decide (whole wave, one point per lane) -------
+#pragma unroll
+  for (int q = 0; q < HPL; ++q) {
+    const bool redo = (int)threadIdx.x + q * THREADS < H && !(margin[q] > sdl[q]);  // (NaN: recount)
+    unsigned long long todo = __ballot(redo);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const double A = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fa[q]), src));
+      const double B = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fb[q]), src));
+      const double Cc = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fc[q]), src));
+      const double D = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fd[q]), src));
+      int c = 0;
+      for (int base = 0; base < n; base += 64) {
+        const int ii = base + (int)(threadIdx.x & 63u);
+        const int64_t jj = ii < n ? ii : 0;
+        const bool in = ii < n && plane_distance(A, B, Cc, D, pts[3 * jj], pts[3 * jj + 1], pts[3 * jj + 2]) < thr;
+        c += __popcll(__ballot(in));
+      }
+      if ((int)(threadIdx.x & 63u) == src) cnt[q] = c;
+    }
+  }
+  // ---- maximum, lowest index among the tied (cuda_ransac.py:125-146), final mask -------------------------------
+  unsigned long long best = 0;
+#pragma unroll
+  for (int q = 0; q < HPL; ++q) {
+    const int t = threadIdx.x + q * THREADS;
+    if (t < H) {
+      const unsigned long long key = ((unsigned long long)(unsigned)cnt[q] << 32) | (unsigned)(0x7FFFFFFF - t);
+      best = key > best ? key : best;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(best, off);
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+  __syncthreads();
+  best = s_best[0];
+#pragma unroll
+  for (int w = 1; w < W; ++w) best = s_best[w] > best ? s_best[w] : best;
+  const int win = 0x7FFFFFFF - (int)(unsigned)(best & 0xFFFFFFFFu);
+#pragma unroll
+  for (int q = 0; q < HPL; ++q) {
+    if ((int)threadIdx.x + q * THREADS == win) {
+      s_plane[0] = fa[q]; s_plane[1] = fb[q]; s_plane[2] = fc[q]; s_plane[3] = fd[q];
+      if (out.plane) {
+        out.plane[4 * (int64_t)be + 0] = fa[q]; out.plane[4 * (int64_t)be + 1] = fb[q];
+        out.plane[4 * (int64_t)be + 2] = fc[q]; out.plane[4 * (int64_t)be + 3] = fd[q];
+      }
+      if (out.count) out.count[be] = cnt[q];
+      if (out.index) out.index[be] = win;
+    }
+  }
+  __syncthreads();
+  const double a = (double)s_plane[0], bb = (double)s_plane[1], c = (double)s_plane[2], dd = (double)s_plane[3];
+  for (int i = threadIdx.x; i < n; i += THREADS)
+    out.mask[pstart + i] = (plane_distance(a, bb, c, dd, pts[3 * (int64_t)i], pts[3 * (int64_t)i + 1],
+                                           pts[3 * (int64_t)i + 2]) < thr) ? 1 : 0;
+}
+#endif
+
 // Blocks with more than THREADS-1 points (unsplit voxels, poses outside the scheme, large K):
 // points stay in global memory (wave-uniform scalar loads in the scoring loop).  The list of such
 // batch entries is appended by k_block_desc; its length lives in device memory, so the grid is
@@ -828,11 +985,19 @@ __global__ __launch_bounds__(THREADS) void k_ransac_big(const double* __restrict
                                                         int k, double thr, RansacOut out) {
   __shared__ unsigned long long s_best[THREADS / 64];
   __shared__ float s_plane[4];
+#if RS_SCREEN
+  __shared__ f4 s_loc[THREADS];
+  __shared__ float s_wext[THREADS / 64];
+#endif
   const uint32_t count = *big_count;
   for (uint32_t j = blockIdx.x; j < count; j += gridDim.x) {
     const int be = (int)big_list[j];
     const BlockDesc d = desc[be];
+#if RS_SCREEN
+    ransac_block_tiled<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_loc, s_wext, s_best, s_plane);
+#else
     ransac_block_global<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_best, s_plane);
+#endif
     __syncthreads();
   }
 }
