@@ -62,7 +62,7 @@ struct octl_ctx {
   int n_ranks = 1, rank = 0;
   // routed cloud of the last octl_route_points + its scratch (kept: hipMalloc per step costs ms)
   DevBuf routed_xyz, routed_gidx;
-  DevBuf rt_keys[2], rt_vals[2], rt_hist, rt_counts, rt_matrix, rt_send_xyz, rt_send_gidx;
+  DevBuf rt_hist, rt_counts, rt_matrix, rt_send_xyz, rt_send_gidx;
   int64_t routed_n = 0;
 };
 

@@ -188,8 +188,7 @@ void octl_ctx_destroy(octl_ctx* ctx) {
   devbuf_free(ctx->small);
   devbuf_free(ctx->routed_xyz);
   devbuf_free(ctx->routed_gidx);
-  for (DevBuf* b : {&ctx->rt_keys[0], &ctx->rt_keys[1], &ctx->rt_vals[0], &ctx->rt_vals[1],
-                    &ctx->rt_hist, &ctx->rt_counts, &ctx->rt_matrix, &ctx->rt_send_xyz,
+  for (DevBuf* b : {&ctx->rt_hist, &ctx->rt_counts, &ctx->rt_matrix, &ctx->rt_send_xyz,
                     &ctx->rt_send_gidx})
     devbuf_free(*b);
   if (ctx->small_host) (void)hipHostFree(ctx->small_host);
