@@ -276,7 +276,8 @@ class Workload:
                     raise failed[0]
                 ctx.check(lib.octl_forest_clear(self.fh))
                 ctx.check(lib.octl_forest_add_pose_routed_from(self.fh, rctx.handle, C.byref(self.slot)))
-                ctx.sync()   # the routed buffer has been copied into the forest: free for the next cloud
+                # (the forest took the routed buffer over, or the library waited for its copy: the
+                #  router is free for the next cloud)
                 free.set()
                 self.compute()
         finally:

@@ -242,15 +242,19 @@ int octl_comm_destroy(octl_ctx* ctx);
  * then index_base + i) to the ranks that own the points' top-level voxels (edge L, grid
  * corner c): key + count per destination, 8x8 count exchange, one grouped ncclSend/ncclRecv
  * all-to-all over xGMI.  The received cloud stays on the device inside ctx; its size is
- * returned through *n_recv and it is handed to a forest with octl_forest_add_pose_routed.   */
+ * returned through *n_recv and it is handed to a forest with octl_forest_add_pose_routed:
+ * an empty forest takes the receive buffer over (its own store buffer goes to the router in
+ * exchange, no copy), a forest that holds poses already copies the cloud behind them.  Either
+ * way the routed cloud is consumed: route again before the next add_pose_routed.             */
 int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_dev,
                       int64_t n, int64_t index_base, const double corner[3], double L,
                       int64_t* n_recv, int64_t* send_counts /* [n_ranks], nullable */);
 int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot);
 /* The same with the routed cloud of ANOTHER context on the same device: routing (its kernels, the
  * RCCL communicator and its stream) can then run in a second context - from a second host thread -
- * while this forest's context builds and fits the previous cloud.  The cloud is copied into the
- * forest on the forest's stream; route_ctx may be re-used once that stream has been synchronised. */
+ * while this forest's context builds and fits the previous cloud.  route_ctx may route the next
+ * cloud as soon as this call has returned (a buffer swap in the common case; when the cloud has to
+ * be copied the call waits for the copy).                                                        */
 int octl_forest_add_pose_routed_from(octl_forest* f, octl_ctx* route_ctx, int32_t* slot);
 /* global indices of the routed cloud of the last octl_route_points call (n_recv) i64        */
 int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n);

@@ -237,7 +237,11 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
     // (an odd store offset would misalign the 16-byte accesses of the pair-wise kernel: such a pose
     //  goes through the plain copy + the in-place form on its own, 8-byte aligned, pointer)
     const bool aligned = (f->n_store % 2) == 0 && (reinterpret_cast<uintptr_t>(xyz) % 16) == 0;
-    if (from_device && aligned) {
+    if (from_device && xyz == dst) {
+      // an adopted buffer (store_adopt): the points are in place already
+      hipLaunchKernelGGL(k_ingest<false>, dim3(grid), dim3(256), 0, st, (const double*)dst, dst, alive, n,
+                         f->mode, f->edge, f->bbox_dev.as<int32_t>());
+    } else if (from_device && aligned) {
       hipLaunchKernelGGL(k_ingest<true>, dim3(grid), dim3(256), 0, st, xyz, dst, alive, n, f->mode,
                          f->edge, f->bbox_dev.as<int32_t>());
     } else {
@@ -316,6 +320,16 @@ int ensure_mask(octl_forest* f) {
 }
 
 }  // namespace
+
+// An empty store takes over a library-owned device buffer that holds the cloud (and hands its own
+// buffer back in exchange) instead of copying it: the routed cloud of the multi-GPU path.
+int store_adopt(octl_forest* f, DevBuf& src, int64_t n, bool* adopted) {
+  *adopted = !(f->n_store != 0 || n <= 0 || src.cap < (size_t)n * 24 + 16);
+  if (!*adopted) return store_append(f, src.as<double>(), n, true);
+  std::swap(f->xyz, src);
+  return store_append(f, f->xyz.as<double>(), n, true);
+}
+
 
 extern "C" {
 

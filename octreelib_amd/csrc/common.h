@@ -53,6 +53,7 @@ struct octl_ctx {
   // one event per staging region ([0,128K) build, [128K,192K) hypothesis table, [192K,256K) pose
   // epochs): recorded after the region's H2D copy, waited for before the region is written again
   hipEvent_t pin_event[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t handoff_event = nullptr;  // orders a buffer handed to another context behind this stream
   // device blocks handed back by destroyed forests, kept for the next one: a fresh Grid per scan
   // otherwise pays ~10 ms of hipMalloc / hipFree per build for its dozen large buffers
   std::vector<DevBuf> pool;
@@ -62,6 +63,7 @@ struct octl_ctx {
   int n_ranks = 1, rank = 0;
   // routed cloud of the last octl_route_points + its scratch (kept: hipMalloc per step costs ms)
   DevBuf routed_xyz, routed_gidx;
+  bool routed_taken = false;  // a forest took routed_xyz over: nothing to hand out until the next route
   DevBuf rt_hist, rt_counts, rt_matrix, rt_send_xyz, rt_send_gidx;
   int64_t routed_n = 0;
 };

@@ -179,6 +179,7 @@ void octl_ctx_destroy(octl_ctx* ctx) {
     (void)hipEventDestroy(pe.stop);
   }
   for (auto ev : ctx->event_pool) (void)hipEventDestroy(ev);
+  if (ctx->handoff_event) (void)hipEventDestroy(ctx->handoff_event);
   for (auto ev : ctx->pin_event)
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pb : ctx->pool) (void)hipFree(pb.p);

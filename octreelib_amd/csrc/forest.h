@@ -102,6 +102,8 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                   uint8_t* evaluated_dev, DevBuf& scratch);
 // the hypothesis table must hold draws from [0, 1) (np.random.random, cuda_ransac.py:39-41): anything
 // else would index outside the block in the sampling arithmetic (cuda_ransac.py:103-107)
+// api.hip: an empty store takes over a library-owned device buffer (swap) instead of copying it
+int store_adopt(octl_forest* f, DevBuf& src, int64_t n, bool* adopted);
 int ransac_check_table(octl_ctx* ctx, const double* hyp, int32_t H, int32_t k);
 // build.hip: (re)build the (leaf, pose) block table from pos_node / ord_idx
 int forest_make_blocks(octl_forest* f);

@@ -308,7 +308,8 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   // COLLECTIVE: each row of the exchange carries the rank's domain-error flag and the capacity of its
   // receive buffers next to its R counts; what can only fail locally (growing those buffers) is
   // agreed on with one more all-reduce, and only in the steps in which some rank has to grow.
-  const int64_t cap_pts = (int64_t)std::min(ctx->routed_xyz.cap / 24, ctx->routed_gidx.cap / 8);
+  const int64_t cap_pts =
+      (int64_t)std::min((ctx->routed_xyz.cap > 16 ? ctx->routed_xyz.cap - 16 : 0) / 24, ctx->routed_gidx.cap / 8);
   const int W = R + 2;  // words per row
   std::vector<int64_t> matrix((size_t)R * W, 0);
   if (use_rccl) {
@@ -362,7 +363,7 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   }
   const int64_t nr = roff[R];
   {
-    int rc_a = devbuf_reserve(ctx, ctx->routed_xyz, (size_t)std::max<int64_t>(nr, 1) * 24);
+    int rc_a = devbuf_reserve(ctx, ctx->routed_xyz, (size_t)std::max<int64_t>(nr, 1) * 24 + 16);
     if (rc_a == OCTL_OK) rc_a = devbuf_reserve(ctx, ctx->routed_gidx, (size_t)std::max<int64_t>(nr, 1) * 8);
     if (use_rccl && grow_any) {
       int64_t* flag_d = reinterpret_cast<int64_t*>(ctx->small.as<uint32_t>() + 512);
@@ -431,24 +432,52 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
     return octl_set_error(ctx, OCTL_E_HIP, "route: all-to-all stream failed");
   }
   ctx->routed_n = nr;
+  ctx->routed_taken = false;
   *n_recv = nr;
   cleanup();
 #undef RT_TRY
   return OCTL_OK;
 }
 
+// The routed cloud becomes the pose: an empty forest takes the receive buffer over (and gives its own
+// store buffer to the router for the next cloud), any other forest copies it behind its store.
+static int add_routed(octl_forest* f, octl_ctx* rctx, int32_t* slot) {
+  const int64_t n = rctx->routed_n;
+  bool adopted = false;
+  if (rctx->routed_taken)
+    return octl_set_error(f->ctx, OCTL_E_INVALID, "the routed cloud has been handed to a forest already");
+  OCTL_TRY(store_adopt(f, rctx->routed_xyz, n, &adopted));
+  // a copy out of another context's buffer has to be over before that context routes again
+  if (!adopted && rctx != f->ctx) HIP_TRY(f->ctx, hipStreamSynchronize(f->ctx->stream));
+  rctx->routed_taken = adopted;
+  if (adopted && rctx != f->ctx) {
+    // the buffer handed back was the forest's store: the router's stream waits for whatever the
+    // forest's stream still has queued on it
+    octl_ctx* c = f->ctx;
+    if (!c->handoff_event) HIP_TRY(c, hipEventCreateWithFlags(&c->handoff_event, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->handoff_event, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(rctx->stream, c->handoff_event, 0));
+  }
+  if (slot) *slot = (int32_t)f->pose_off.size() - 1;
+  f->n_store += n;
+  f->n_alive += n;
+  f->pose_off.push_back(f->n_store);
+  f->store_dirty = true;
+  return OCTL_OK;
+}
+
 int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot) {
   if (!f) return OCTL_E_INVALID;
-  return octl_forest_add_pose_device(f, f->ctx->routed_xyz.as<double>(), f->ctx->routed_n, slot);
+  return add_routed(f, f->ctx, slot);
 }
 
 int octl_forest_add_pose_routed_from(octl_forest* f, octl_ctx* route_ctx, int32_t* slot) {
   if (!f || !route_ctx) return OCTL_E_INVALID;
   if (route_ctx->device != f->ctx->device)
     return octl_set_error(f->ctx, OCTL_E_INVALID, "the routing context lives on another device");
-  // octl_route_points returns after its stream has drained: the routed cloud is complete, and the
-  // copy below runs on the forest's stream
-  return octl_forest_add_pose_device(f, route_ctx->routed_xyz.as<double>(), route_ctx->routed_n, slot);
+  // octl_route_points returns after its stream has drained: the routed cloud is complete; what
+  // follows runs on the forest's stream
+  return add_routed(f, route_ctx, slot);
 }
 
 int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n) {

@@ -88,8 +88,7 @@ def test_route_ahead_on_a_second_context(monkeypatch):
             assert n_recv.value == len(c)
             ctx.check(lib.octl_forest_clear(fh))
             ctx.check(lib.octl_forest_add_pose_routed_from(fh, rctx.handle, C.byref(slot)))
-            ctx.sync()
-            free.set()
+            free.set()  # (no wait: the call has swapped buffers with the router, or waited for its copy)
             ctx.check(lib.octl_forest_build(fh, 32, None, 0, 0, 0, C.byref(info)))
             ctx.check(lib.octl_forest_clear(fref))
             ctx.check(lib.octl_forest_add_pose_device(fref, p, len(c), C.byref(slot)))
@@ -109,6 +108,63 @@ def test_route_ahead_on_a_second_context(monkeypatch):
             lib.octl_dev_free(ctx.handle, p)
         lib.octl_comm_destroy(rctx.handle)
         rctx.close()
+
+
+def test_routed_cloud_is_handed_over_once(monkeypatch):
+    """An empty forest takes the router's receive buffer over (no copy): the routed cloud is then
+    gone and a second hand-over is refused; a forest that already holds a pose copies the cloud
+    behind it, and the two poses read back as inserted."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+
+    monkeypatch.setenv("OCTL_ROUTE_SELF_SENDRECV", "1")
+    ctx = nat.Context(0)
+    lib = ctx.lib
+    uid = (C.c_uint8 * nat.UNIQUE_ID_BYTES)()
+    ctx.check(lib.octl_comm_unique_id(C.cast(uid, C.c_void_p)))
+    ctx.check(lib.octl_comm_init(ctx.handle, 1, 0, C.cast(uid, C.c_void_p)))
+    corner = np.zeros(3)
+    clouds = [np.ascontiguousarray(synthetic.planar_cloud(n, (3, 3, 3), seed=6, stream=s)) for s, n in ((0, 20_001), (1, 9_999))]
+    fh, slot, n_recv = C.c_void_p(), C.c_int32(0), C.c_int64(0)
+    ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(corner), 1.0, C.byref(fh)))
+    dev = []
+    try:
+        for k, c in enumerate(clouds):
+            p = C.c_void_p()
+            ctx.check(lib.octl_dev_alloc(ctx.handle, c.nbytes, C.byref(p)))
+            ctx.check(lib.octl_dev_upload(ctx.handle, p, nat.ptr(c), c.nbytes))
+            dev.append(p)
+            ctx.check(lib.octl_route_points(ctx.handle, p, None, len(c), 0, nat.ptr(corner), 1.0,
+                                            C.byref(n_recv), None))
+            ctx.check(lib.octl_forest_add_pose_routed(fh, C.byref(slot)))
+            assert slot.value == k
+            if k == 0:   # taken over: nothing left to hand out
+                with pytest.raises(ValueError, match="handed to a forest already"):
+                    ctx.check(lib.octl_forest_add_pose_routed(fh, C.byref(slot)))
+        info, iref, fref = nat.BuildInfo(), nat.BuildInfo(), C.c_void_p()
+        ctx.check(lib.octl_forest_build(fh, 32, None, 0, 0, 0, C.byref(info)))
+        ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(corner), 1.0, C.byref(fref)))
+        try:
+            for c in clouds:
+                ctx.check(lib.octl_forest_add_pose(fref, nat.ptr(c), len(c), C.byref(slot)))
+            ctx.check(lib.octl_forest_build(fref, 32, None, 0, 0, 0, C.byref(iref)))
+            n = sum(len(c) for c in clouds)
+            assert (info.n_points, info.n_voxels, info.n_nodes, info.n_blocks) == (
+                n, iref.n_voxels, iref.n_nodes, iref.n_blocks)
+            a, b = np.empty((n, 3)), np.empty((n, 3))
+            ctx.check(lib.octl_forest_get_points(fh, 0, n, nat.ptr(a)))
+            ctx.check(lib.octl_forest_get_points(fref, 0, n, nat.ptr(b)))
+            assert np.array_equal(a, b)
+        finally:
+            lib.octl_forest_destroy(fref)
+    finally:
+        lib.octl_forest_destroy(fh)
+        for p in dev:
+            lib.octl_dev_free(ctx.handle, p)
+        lib.octl_comm_destroy(ctx.handle)
+        ctx.close()
 
 
 @pytest.mark.parametrize("n_ranks", [2, 3, 8])
