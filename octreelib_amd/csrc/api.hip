@@ -375,7 +375,8 @@ void octl_forest_destroy(octl_forest* f) {
         &f->pos_node2, &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
         &f->hist, &f->idxbuf[0], &f->idxbuf[1], &f->pathbuf[0], &f->pathbuf[1], &f->flags,
         &f->entries, &f->split[0], &f->split[1], &f->split_tiles[0], &f->split_tiles[1],
-        &f->child_sc, &f->pose_off_dev, &f->scheme_dev, &f->root_up, &f->vlin_dev})
+        &f->child_sc, &f->pose_off_dev, &f->scheme_dev, &f->root_up, &f->vlin_dev, &f->vcode_dev[0],
+        &f->vcode_dev[1]})
     devbuf_release(f->ctx, *b);
   delete f;
 }
@@ -392,6 +393,10 @@ int octl_forest_clear(octl_forest* f) {
   f->built = false;
   f->vkeys.clear();
   f->vkeys_stale = false;
+  f->vcode_valid = false;
+  f->built_store = 0;
+  f->built_poses = 0;
+  f->append_only = true;
   f->n_voxels = 0;
   f->level_segs.clear();
   f->n_internal = 0;
@@ -452,6 +457,7 @@ int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int
   f->n_alive += n;
   for (int p = slot + 1; p <= n_poses; ++p) f->pose_off[p] += n;
   f->store_dirty = true;
+  f->append_only = false;  // the store was rotated: the next build re-places everything
   return OCTL_OK;
 }
 

@@ -793,6 +793,16 @@ int forest_finish_blocks(octl_forest* f, uint32_t* err_out) {
 int forest_sync_vkeys(octl_forest* f) {
   if (!f->vkeys_stale) return OCTL_OK;
   octl_ctx* ctx = f->ctx;
+  if (f->vcode_valid) {  // the packed keys are on the device already (incremental.hip)
+    f->vkeys.resize((size_t)f->n_voxels);
+    if (f->n_voxels > 0) {
+      HIP_TRY(ctx, hipMemcpyAsync(f->vkeys.data(), f->vcode_dev[0].p, (size_t)f->n_voxels * 8,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    f->vkeys_stale = false;
+    return OCTL_OK;
+  }
   std::vector<uint64_t> lin((size_t)f->n_voxels);
   if (f->n_voxels > 0) {
     HIP_TRY(ctx, hipMemcpyAsync(lin.data(), f->vlin_dev.p, (size_t)f->n_voxels * 8,
@@ -989,8 +999,6 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
                           n_poses);
   if (max_depth <= 0) max_depth = 63;
   BuildTrace trace;
-  OCTL_TRY(forest_sync_vkeys(f));  // the previous scheme's voxels persist (no-op when fresh)
-  trace.mark("sync_vkeys");
   uint32_t* small = ctx->small.as<uint32_t>();
 
   bool all_scheme = true;
@@ -1035,6 +1043,16 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
     if (!fits) HIP_TRY(ctx, hipStreamSynchronize(st));  // pageable sources must not change in flight
   }
+
+  // ---- poses appended to a built forest inherit its scheme: only the new points are placed -----------
+  if (keep_scheme) {
+    int done = 0;
+    OCTL_TRY(forest_insert_incremental(f, &done, info));
+    trace.mark("incremental insertion");
+    if (done) return OCTL_OK;
+  }
+  OCTL_TRY(forest_sync_vkeys(f));  // the previous scheme's voxels persist (no-op when fresh)
+  trace.mark("sync_vkeys");
 
   const int64_t n_alive = f->n_alive;
   // ---- 0. fresh forest: the bucket build does insert + subdivide in one go (bucket_build.hip) -----------
@@ -1105,6 +1123,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       f->max_depth_reached = lv;
       f->mask_valid = false;
       f->store_dirty = false;
+      f->vcode_valid = false;
+      f->built_store = f->n_store;
+      f->built_poses = n_poses;
+      f->append_only = true;
       if (info) {
         info->n_points = n_alive;
         info->n_voxels = nv;
@@ -1427,6 +1449,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   f->max_depth_reached = level;
   f->mask_valid = false;
   f->store_dirty = false;
+  f->vcode_valid = false;
+  f->built_store = f->n_store;
+  f->built_poses = n_poses;
+  f->append_only = true;
   if (info) {
     info->n_points = n_alive;
     info->n_voxels = V;

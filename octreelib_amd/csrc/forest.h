@@ -22,6 +22,11 @@ struct octl_forest {
   std::vector<int64_t> pose_off{0};  // [P+1] offsets into the store
   int64_t n_store = 0, n_alive = 0;
   bool store_dirty = true;  // points were added/removed since the last build
+  // what the last build covered, for the incremental insertion of incremental.hip: the store prefix
+  // and the poses the tables describe, and whether every change since was a pose appended behind them
+  int64_t built_store = 0;
+  int built_poses = 0;
+  bool append_only = true;
   // voxel bounding box of every point added since the last clear, kept by the ingest kernel
   // (api.hip): int32 x 8 = {min x,y,z, max x,y,z, domain-error flag, unused}; bbox_host is a pinned
   // mirror refreshed asynchronously after every ingest (bbox_event marks the copy)
@@ -38,6 +43,8 @@ struct octl_forest {
                                 // (filled lazily from vlin_dev: forest_sync_vkeys)
   bool vkeys_stale = false;
   int64_t n_voxels = 0;
+  DevBuf vcode_dev[2];          // u64 [n_voxels] sorted packed voxel keys on the device (forest_sync_vcodes); [1] = scratch
+  bool vcode_valid = false;
   DevBuf vlin_dev;              // u64 [n_voxels] compact linear voxel keys of the last build
   int vl_min[3] = {0, 0, 0};    // decoding of vlin_dev: lin = ((qx-min0)*ny + (qy-min1))*nz + (qz-min2)
   uint64_t vl_ny = 1, vl_nz = 1;
@@ -111,3 +118,7 @@ int forest_make_blocks(octl_forest* f);
 int forest_finish_blocks(octl_forest* f, uint32_t* err_out);
 // host copy of the voxel keys (synchronises when stale)
 int forest_sync_vkeys(octl_forest* f);
+// incremental.hip: device copy of the packed voxel keys; poses appended to a built forest placed into
+// its scheme in O(new points).  *done = 0: not applicable, nothing was changed
+int forest_sync_vcodes(octl_forest* f);
+int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info);

@@ -1337,3 +1337,106 @@ def test_integration_md_binding_stub_runs():
     mask = op.evaluate(cloud, sizes)
     assert mask.dtype == np.bool_ and mask.shape == (len(cloud),)
     assert np.array_equal(mask, rnp.evaluate(cloud, sizes, op._table, 0.01))
+
+
+def _incremental_poses():
+    rng = np.random.default_rng(23)
+    poses = [rng.random((20_000, 3)) * 6.0,                                  # the scheme's pose
+             rng.random((6_000, 3)) * 6.0,                                   # known voxels only
+             rng.random((7_000, 3)) * 6.0 + np.array([4.0, 0.0, -3.0]),      # new voxels in front of and behind the old
+             rng.random((3_000, 3)) * 2.0 + np.array([-5.0, 9.0, 1.0]),      # new voxels only
+             rng.random((5_000, 3)) * 8.0 - 1.0]
+    return poses
+
+
+def test_incremental_insertion_vs_oracle():
+    """Poses appended to a subdivided grid are placed into the existing scheme point by point
+    (incremental.hip) - known voxels, new voxels on both sides of the old ones, two poses between two
+    queries - then RANSAC-free refinement: leaf tables and counters against the oracle at every step."""
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    poses = _incremental_poses()
+    idx = [index_map(p) for p in poses]
+    grid, og = Grid(GridConfig(voxel_edge_length=2)), onp.OGrid(2)
+
+    def check(n):
+        for p in range(n):
+            assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), _oracle_pose_table(og, p))
+            assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+
+    grid.insert_points(0, poses[0])
+    og.insert_points(0, poses[0])
+    grid.subdivide(crit(100))
+    og.subdivide(100)
+    check(1)
+    for p in (1, 2):
+        grid.insert_points(p, poses[p])
+        og.insert_points(p, poses[p])
+        check(p + 1)
+    for p in (3, 4):   # two poses before the next query
+        grid.insert_points(p, poses[p])
+        og.insert_points(p, poses[p])
+    check(5)
+    grid.subdivide(crit(40))
+    og.subdivide(40)
+    check(5)
+
+
+def test_incremental_insertion_equals_replacement(monkeypatch):
+    """The same sequence through the incremental path and through the re-placement of every stored point
+    (keep_scheme build of build.hip): same scheme, and per (leaf, pose) block the same points in the same
+    order, listed in the same reference order; only the storage order of the blocks differs."""
+    from octreelib_amd._engine import Forest
+
+    poses = _incremental_poses()
+
+    def run():
+        f = Forest(0, np.zeros(3), 2.0)
+        f.add_pose(poses[0])
+        f.subdivide(100)
+        f.ctx.sync()
+        f.ctx.set_profiling(True)
+        snaps = []
+        for group in ((1,), (2,), (3, 4)):
+            for p in group:
+                f.add_pose(poses[p])
+            f.ensure_built()
+            f.ctx.sync()
+            nd = {k: v.copy() for k, v in f.nodes.items()}
+            blk = {k: v.copy() for k, v in f.blocks.items()}
+            nodes, blocks = _canon_build((nd, blk))
+            xyz, perm, order = f.xyz, f.perm, f.order
+            listing = [(blocks[b][0], blocks[b][1], xyz[blocks[b][2]:blocks[b][2] + blocks[b][3]].tobytes(),
+                        perm[blocks[b][2]:blocks[b][2] + blocks[b][3]].tobytes()) for b in order.tolist()]
+            snaps.append((nodes, listing, f.voxels.copy(), [f.n_leaves(s) for s in range(f.n_slots)],
+                          [f.n_nodes(s) for s in range(f.n_slots)]))
+        timers = f.ctx.timings()
+        f.ctx.set_profiling(False)
+        # RANSAC over everything, then removal of the outliers: the compaction keeps the storage order
+        np.random.seed(4)
+        table = np.random.random((256, 6))
+        f.ransac_all(10, table, 0.05)
+        f.apply_device_mask()
+        blk = {k: v.copy() for k, v in f.blocks.items()}
+        nodes, blocks = _canon_build(({k: v.copy() for k, v in f.nodes.items()}, blk))
+        xyz, order = f.xyz, f.order
+        after = [(blocks[b][0], blocks[b][1], xyz[blocks[b][2]:blocks[b][2] + blocks[b][3]].tobytes())
+                 for b in order.tolist()]
+        f.close()
+        return snaps, after, timers
+
+    monkeypatch.delenv("OCTL_NO_INCREMENTAL", raising=False)
+    a, a_after, ta = run()
+    monkeypatch.setenv("OCTL_NO_INCREMENTAL", "1")
+    b, b_after, tb = run()
+    # the first run placed only the new points (three insertions, two of them with new voxels), the
+    # second re-placed everything
+    assert ta["inc_place"][1] == 3 and ta["inc_new_voxels"][1] == 2 and "keygen" not in ta
+    assert "inc_place" not in tb and tb["keygen"][1] == 3
+    for (na, la, va, leaves_a, nodes_a), (nb, lb, vb, leaves_b, nodes_b) in zip(a, b):
+        assert na == nb
+        assert la == lb
+        assert np.array_equal(va, vb)
+        assert leaves_a == leaves_b and nodes_a == nodes_b
+    assert a_after == b_after
