@@ -14,9 +14,15 @@ g0 = Grid(GridConfig(voxel_edge_length=1)); g0.insert_points(0, clouds[0][:1000]
 grid = Grid(GridConfig(voxel_edge_length=1))
 t0 = time.perf_counter(); grid.insert_points(0, clouds[0]); grid.subdivide([lambda p: len(p) > 64]); c = grid.n_leaves(0)
 print("pose 0 insert + subdivide: %.1f ms (%d leaves)" % ((time.perf_counter() - t0) * 1e3, c))
+from octreelib_amd import _native as _nat
+_ctx = _nat.get_context()
 for p in range(1, P):
+    _ctx.sync(); _ctx.set_profiling(True)
     t0 = time.perf_counter(); grid.insert_points(p, clouds[p]); c = grid.n_leaves(p)
-    print("pose %d insert (inherits the scheme) + n_leaves: %.1f ms (%d leaves)" % (p, (time.perf_counter() - t0) * 1e3, c))
+    dt = (time.perf_counter() - t0) * 1e3
+    _ctx.sync(); tm = _ctx.timings(); _ctx.set_profiling(False)
+    dev = " ".join("%s %.3f" % (k, v[0]) for k, v in sorted(tm.items()))
+    print("pose %d insert (inherits the scheme) + n_leaves: %.1f ms (%d leaves)   device ms: %s" % (p, dt, c, dev))
 t0 = time.perf_counter(); grid.subdivide([lambda p: len(p) > 64]); c = grid.n_leaves(0)
 print("subdivide over all poses: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 np.random.seed(0)
