@@ -119,9 +119,11 @@ typedef struct octl_build_info {
 
 /* Build the scheme for the count criterion len(points) > K over the union of the poses
  * whose scheme_mask[slot] != 0 (NULL = all poses), then place every alive point of every
- * pose in its scheme leaf.  keep_scheme != 0 re-places the points in the EXISTING scheme
+ * pose in its scheme leaf.  keep_scheme != 0 places the points in the EXISTING scheme
  * (a pose inserted after a subdivide inherits it, octree_manager.py:161-171) and ignores
- * K / scheme_mask.  K < 0 means "never split" (the state right after insert_points).
+ * K / scheme_mask: when whole poses were appended since the last build only their points are
+ * placed and appended behind the leaf-ordered arrays (cost independent of what is stored);
+ * after octl_forest_extend_pose / octl_forest_set_scheme every point is placed again.  K < 0 means "never split" (the state right after insert_points).
  * max_depth guards the recursion the reference does not bound (<= 0: default 63).
  * On OCTL_E_DOMAIN / OCTL_E_DEPTH / OCTL_E_NOMEM / OCTL_E_HIP the forest keeps its points and
  * voxels but is left without a scheme (the next build starts from the top-level voxels).     */

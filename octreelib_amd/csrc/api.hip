@@ -510,7 +510,9 @@ int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int
   f->n_internal = n_internal;
   f->uniform_epoch = false;
   if (new_epoch > f->epoch) f->epoch = new_epoch;
-  // only first_child / epoch of this table are meaningful until the next (keep_scheme) build
+  // only first_child / epoch of this table are meaningful until the next (keep_scheme) build,
+  // which has to place every point again
+  f->append_only = false;
   f->n_ord = 0;
   f->n_blocks = 0;
   f->mask_valid = false;
