@@ -157,6 +157,44 @@ def gen_grid():
 
 
 # --------------------------------------------------------------------------------------
+# G2c': Grid, poses inserted AFTER a subdivide: known voxels, new voxels on both sides of the old
+#       ones (negative indices), two late poses in a row; then a refinement over all poses
+# --------------------------------------------------------------------------------------
+def gen_grid_late_poses():
+    rng = np.random.default_rng(41)
+    poses = [rng.random((5000, 3)) * 6.0,
+             rng.random((1500, 3)) * 6.0,
+             rng.random((2000, 3)) * 6.0 + np.array([4.0, 0.0, -3.0]),
+             rng.random((800, 3)) * 2.0 + np.array([-5.0, 9.0, 1.0]),
+             rng.random((1200, 3)) * 8.0 - 1.0]
+    g = Grid(GridConfig(voxel_edge_length=2))
+    out = {"L": np.float64(2), "n_poses": np.int64(len(poses))}
+    for p, pts in enumerate(poses):
+        out[f"points{p}"] = pts
+    index = [_index_of(pts) for pts in poses]
+
+    def snap(tag, n):
+        for p in range(n):
+            c, e, s, i = _leaf_table(g.get_leaf_points(p), index[p])
+            out[f"{tag}_p{p}_corners"], out[f"{tag}_p{p}_edges"] = c, e
+            out[f"{tag}_p{p}_sizes"], out[f"{tag}_p{p}_idx"] = s, i
+            out[f"{tag}_p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+
+    g.insert_points(0, poses[0])
+    g.subdivide(crit(60))
+    g.insert_points(1, poses[1])
+    snap("a", 2)
+    g.insert_points(2, poses[2])
+    snap("b", 3)
+    g.insert_points(3, poses[3])
+    g.insert_points(4, poses[4])
+    snap("c", 5)
+    g.subdivide(crit(25))
+    snap("d", 5)
+    _save("grid_late_poses.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # G2d: OctreeManager, 4 poses: subdivide on a pose subset, then a late-inserted pose
 # --------------------------------------------------------------------------------------
 def gen_manager():
@@ -344,6 +382,7 @@ GENERATORS = {
     "octree": gen_octree,
     "grid": gen_grid,
     "manager": gen_manager,
+    "grid_late_poses": gen_grid_late_poses,
     "ransac": gen_ransac,
     "grid_ransac": gen_grid_ransac,
     "ransac_thick": gen_ransac_thick,   # ~10 minutes: 380 blocks x up to 1024 simulated threads

@@ -94,6 +94,38 @@ def test_grid_L5_two_poses_golden():
         assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"r_p{p}_counts"])
 
 
+@pytest.mark.parametrize("incremental", [True, False])
+def test_grid_late_poses_golden(monkeypatch, incremental):
+    """The reference's own leaf tables for poses inserted after a subdivide - through the incremental
+    insertion (incremental.hip) and through the re-placement of every stored point."""
+    from octreelib_amd.grid import Grid, GridConfig
+
+    if incremental:
+        monkeypatch.delenv("OCTL_NO_INCREMENTAL", raising=False)
+    else:
+        monkeypatch.setenv("OCTL_NO_INCREMENTAL", "1")
+    g = load_golden("grid_late_poses.npz")
+    grid = Grid(GridConfig(voxel_edge_length=2))
+    idx = [index_map(g[f"points{p}"]) for p in range(5)]
+
+    def check(tag, n):
+        for p in range(n):
+            assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"{tag}_p{p}"))
+            assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    grid.insert_points(0, g["points0"])
+    grid.subdivide(crit(60))
+    grid.insert_points(1, g["points1"])
+    check("a", 2)
+    grid.insert_points(2, g["points2"])
+    check("b", 3)
+    grid.insert_points(3, g["points3"])
+    grid.insert_points(4, g["points4"])
+    check("c", 5)
+    grid.subdivide(crit(25))
+    check("d", 5)
+
+
 def test_manager_four_poses_golden():
     from octreelib_amd.octree import Octree, OctreeConfig
     from octreelib_amd.octree_manager import OctreeManager

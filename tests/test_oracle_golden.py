@@ -51,6 +51,30 @@ def test_grid_L5_two_poses():
         assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"r_p{p}_counts"])
 
 
+def test_grid_late_poses():
+    """Poses inserted after a subdivide (known voxels, new voxels on both sides of the old ones, two
+    late poses in a row), then a refinement: the reference's leaf tables at every stage."""
+    g = load_golden("grid_late_poses.npz")
+    og = onp.OGrid(2)
+
+    def check(tag, n):
+        for p in range(n):
+            assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"{tag}_p{p}"))
+            assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    og.insert_points(0, g["points0"])
+    og.subdivide(60)
+    og.insert_points(1, g["points1"])
+    check("a", 2)
+    og.insert_points(2, g["points2"])
+    check("b", 3)
+    og.insert_points(3, g["points3"])
+    og.insert_points(4, g["points4"])
+    check("c", 5)
+    og.subdivide(25)
+    check("d", 5)
+
+
 def test_manager_four_poses():
     g = load_golden("manager_four_poses.npz")
     m = onp.OManager(np.array([0.0, 0.0, 0.0]), 2.0)
