@@ -99,31 +99,124 @@ __global__ __launch_bounds__(256) void k_fill_u8(uint8_t* p, int64_t n, uint8_t 
   if (i < n) p[i] = v;
 }
 
-__global__ __launch_bounds__(256) void k_mask_to_flags(const uint8_t* __restrict__ mask, int64_t n,
-                                                       uint32_t* __restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) flags[i] = mask[i] ? 1u : 0u;
+// ---- apply_mask: stream compaction of the leaf-ordered arrays and of the block table ----------------------
+// kept points per 2048-point tile (the compaction's tile offsets) ...
+__global__ __launch_bounds__(256) void k_mask_tiles(const uint8_t* __restrict__ mask, int64_t n,
+                                                    uint32_t* __restrict__ tilecnt) {
+  __shared__ uint32_t s_w[4];
+  const int64_t i0 = (int64_t)blockIdx.x * 2048 + (int64_t)threadIdx.x * 8;
+  uint32_t c = 0;
+  if (i0 + 8 <= n) {
+    const uint64_t w = *reinterpret_cast<const uint64_t*>(mask + i0);  // (the mask buffer is 16-byte aligned)
+    // bytes that are not zero
+    const uint64_t nz = ((w & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | w;
+    c = (uint32_t)__popcll(nz & 0x8080808080808080ull);
+  } else {
+    for (int64_t i = i0; i < n; ++i) c += mask[i] ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tilecnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// stream compaction of the leaf-ordered arrays by the mask; dropped points die in the store
-__global__ __launch_bounds__(256) void k_compact_ord(
-    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ scanned, int64_t n,
+// ... and per (leaf, pose) block: the block table is compacted block-wise, not re-derived from the points
+__global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ mask,
+                                                  const uint32_t* __restrict__ blk_start,
+                                                  const int32_t* __restrict__ blk_size, int64_t nb,
+                                                  uint32_t* __restrict__ kept, uint32_t* __restrict__ nonempty) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t st = b < nb ? blk_start[b] : 0u;
+  const int sz = b < nb ? blk_size[b] : 0;
+  uint32_t c = 0;
+  if (sz <= 256)
+    for (int i = 0; i < sz; ++i) c += mask[(size_t)st + i] ? 1u : 0u;
+  // large blocks (unsplit voxels, big leaves of a bare octree): the whole wave, one block at a time
+  unsigned long long big = __ballot(sz > 256);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const uint32_t s0 = (uint32_t)__shfl((int)st, src);
+    const int z = __shfl(sz, src);
+    uint32_t cc = 0;
+    for (int i = lane; i < z; i += 64) cc += mask[(size_t)s0 + i] ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cc += __shfl_xor(cc, off);
+    if (lane == src) c = cc;
+  }
+  if (b < nb) {
+    kept[b] = c;
+    nonempty[b] = c ? 1u : 0u;
+  }
+}
+
+// tile-wise stable compaction (8 rows of 256 points per workgroup, ballot ranks); dropped points die in the store
+__global__ __launch_bounds__(256) void k_compact_tiles(
+    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ tile_off, int64_t n,
     const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
     const int32_t* __restrict__ pos_node, uint32_t* __restrict__ ord_idx2,
     double* __restrict__ xyz_ord2, int32_t* __restrict__ pos_node2, uint8_t* __restrict__ alive) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t v = ord_idx[i];
-  if (mask[i]) {
-    const uint32_t d = scanned[i];
-    ord_idx2[d] = v;
-    xyz_ord2[3 * (int64_t)d] = xyz_ord[3 * i];
-    xyz_ord2[3 * (int64_t)d + 1] = xyz_ord[3 * i + 1];
-    xyz_ord2[3 * (int64_t)d + 2] = xyz_ord[3 * i + 2];
-    pos_node2[d] = pos_node[i];
-  } else {
-    alive[v] = 0;
+  __shared__ uint32_t s_cnt[32];  // [row][wave] -> exclusive offsets
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t base = (int64_t)blockIdx.x * 2048;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  uint32_t rk[8];
+  uint32_t keepbits = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    const bool k = i < n && mask[i] != 0;
+    const unsigned long long bal = __ballot(k);
+    rk[r] = (uint32_t)__popcll(bal & lt);
+    keepbits |= (k ? 1u : 0u) << r;
+    if (lane == 0) s_cnt[r * 4 + wave] = (uint32_t)__popcll(bal);
   }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    uint32_t v = lane < 32 ? s_cnt[lane] : 0u, inc = v;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
+    }
+    if (lane < 32) s_cnt[lane] = inc - v;
+  }
+  __syncthreads();
+  const uint32_t toff = tile_off[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i >= n) continue;
+    const uint32_t v = ord_idx[i];
+    if ((keepbits >> r) & 1u) {
+      const int64_t d = (int64_t)toff + s_cnt[r * 4 + wave] + rk[r];
+      ord_idx2[d] = v;
+      xyz_ord2[3 * d] = xyz_ord[3 * i];
+      xyz_ord2[3 * d + 1] = xyz_ord[3 * i + 1];
+      xyz_ord2[3 * d + 2] = xyz_ord[3 * i + 2];
+      pos_node2[d] = pos_node[i];
+    } else {
+      alive[v] = 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_blk_compact(
+    const uint32_t* __restrict__ kept, const uint32_t* __restrict__ new_start,
+    const uint32_t* __restrict__ new_id, int64_t nb, const int32_t* __restrict__ blk_node,
+    const int32_t* __restrict__ blk_slot, int32_t* __restrict__ blk_node2, int32_t* __restrict__ blk_slot2,
+    uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t c = kept[b];
+  if (!c) return;
+  const uint32_t id = new_id[b];
+  blk_node2[id] = blk_node[b];
+  blk_slot2[id] = blk_slot[b];
+  blk_start2[id] = new_start[b];
+  blk_size2[id] = (int32_t)c;
 }
 
 // OctreeNode.filter for count predicates (octree.py:102-112): a leaf of a selected pose whose point
@@ -268,43 +361,70 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
   return OCTL_OK;
 }
 
+// The block table describes the leaf-ordered arrays exactly (every producer leaves it that way), so both
+// are compacted together: points tile-wise, blocks block-wise.  One synchronisation (kept points, blocks).
 int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
-  const int64_t n = f->n_ord;
-  if (n > 0) {
+  const int64_t n = f->n_ord, nb = f->n_blocks;
+  f->mask_valid = false;
+  if (n > 0 && nb > 0) {
     KTimer t(ctx, "apply_mask");
-    OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n + 8) * 4));
-    uint32_t* flags = f->flags.as<uint32_t>();
     uint32_t* small = ctx->small.as<uint32_t>();
-    hipLaunchKernelGGL(k_mask_to_flags, dim3(grid_for(n)), dim3(256), 0, st,
-                       (const uint8_t*)f->mask.as<uint8_t>(), n, flags);
+    const int64_t nt = ceil_div(n, 2048);
+    // scratch: [tile counts nt | kept nb | new start nb | new id nb], 16-byte aligned pieces
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_kept = al(((size_t)nt + 8) * 4), o_start = o_kept + al(((size_t)nb + 8) * 4),
+                 o_id = o_start + al(((size_t)nb + 8) * 4);
+    OCTL_TRY(devbuf_reserve(ctx, f->flags, o_id + al(((size_t)nb + 8) * 4)));
+    char* base = static_cast<char*>(f->flags.p);
+    uint32_t* tiles = reinterpret_cast<uint32_t*>(base);
+    uint32_t* kept = reinterpret_cast<uint32_t*>(base + o_kept);
+    uint32_t* nstart = reinterpret_cast<uint32_t*>(base + o_start);
+    uint32_t* nid = reinterpret_cast<uint32_t*>(base + o_id);
+    const uint8_t* mask = f->mask.as<uint8_t>();
+    hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, n, tiles);
     HIP_TRY(ctx, hipGetLastError());
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n, small + 20));
+    hipLaunchKernelGGL(k_blk_kept, dim3(grid_for(nb)), dim3(256), 0, st, mask,
+                       (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
+                       kept, nid);
+    HIP_TRY(ctx, hipGetLastError());
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, tiles, tiles, nt, small + 20));
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, kept, nstart, nb, nullptr));
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, nid, nid, nb, small + 21));
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord2, (size_t)n * 24));
     OCTL_TRY(devbuf_reserve(ctx, f->pos_node2, (size_t)n * 4));
-    hipLaunchKernelGGL(k_compact_ord, dim3(grid_for(n)), dim3(256), 0, st,
-                       (const uint8_t*)f->mask.as<uint8_t>(), (const uint32_t*)flags, n,
-                       (const uint32_t*)f->ord_idx.as<uint32_t>(),
-                       (const double*)f->xyz_ord.as<double>(),
+    // (block buffers keep the capacity convention of forest_make_blocks: one block per point)
+    OCTL_TRY(devbuf_reserve(ctx, f->blk_node2, (size_t)n * 4));
+    OCTL_TRY(devbuf_reserve(ctx, f->blk_slot2, (size_t)n * 4));
+    OCTL_TRY(devbuf_reserve(ctx, f->blk_start2, (size_t)n * 4));
+    OCTL_TRY(devbuf_reserve(ctx, f->blk_size2, (size_t)n * 4));
+    hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)tiles, n,
+                       (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
                        (const int32_t*)f->pos_node.as<int32_t>(), f->ord_idx2.as<uint32_t>(),
-                       f->xyz_ord2.as<double>(), f->pos_node2.as<int32_t>(),
-                       f->alive.as<uint8_t>());
+                       f->xyz_ord2.as<double>(), f->pos_node2.as<int32_t>(), f->alive.as<uint8_t>());
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small + 20, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)kept,
+                       (const uint32_t*)nstart, (const uint32_t*)nid, nb, (const int32_t*)f->blk_node.as<int32_t>(),
+                       (const int32_t*)f->blk_slot.as<int32_t>(), f->blk_node2.as<int32_t>(),
+                       f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(), f->blk_size2.as<int32_t>());
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small + 20, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    uint32_t kept;
-    std::memcpy(&kept, ctx->small_host, 4);
+    uint32_t res[2];
+    std::memcpy(res, ctx->small_host, 8);
     std::swap(f->ord_idx, f->ord_idx2);
     std::swap(f->xyz_ord, f->xyz_ord2);
     std::swap(f->pos_node, f->pos_node2);
-    f->n_alive -= (n - (int64_t)kept);
-    f->n_ord = kept;
+    std::swap(f->blk_node, f->blk_node2);
+    std::swap(f->blk_slot, f->blk_slot2);
+    std::swap(f->blk_start, f->blk_start2);
+    std::swap(f->blk_size, f->blk_size2);
+    f->n_alive -= (n - (int64_t)res[0]);
+    f->n_ord = res[0];
+    f->n_blocks = res[1];
   }
-  f->mask_valid = false;
-  OCTL_TRY(forest_make_blocks(f));
-  OCTL_TRY(forest_finish_blocks(f, nullptr));
   if (n_alive_out) *n_alive_out = f->n_ord;
   return OCTL_OK;
 }
@@ -370,7 +490,7 @@ void octl_forest_destroy(octl_forest* f) {
   for (DevBuf* b :
        {&f->bbox_dev, &f->part_xyz[0], &f->part_xyz[1], &f->bk_table, &f->bk_tot, &f->bk_vox, &f->leafinfo,
         &f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
-        &f->blk_start, &f->blk_size, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order,
+        &f->blk_start, &f->blk_size, &f->blk_node2, &f->blk_slot2, &f->blk_start2, &f->blk_size2, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order,
         &f->rs_hyp, &f->rs_plane, &f->rs_count, &f->rs_index, &f->ord_idx2, &f->xyz_ord2,
         &f->pos_node2, &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
         &f->hist, &f->idxbuf[0], &f->idxbuf[1], &f->pathbuf[0], &f->pathbuf[1], &f->flags,

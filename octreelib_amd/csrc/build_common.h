@@ -14,7 +14,7 @@ enum {
   SM_NTILES = 14,   // tiles of the next level
   SM_ETOTAL = 15,   // total of the scanned tile histogram
   SM_NBLOCKS = 16,
-  // 20: kept count of apply_mask, 21: slot-voxel count, 24: debug scan total
+  // 20, 21: kept points / blocks of apply_mask (21 also: slot-voxel count), 24: debug scan total
   SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
   SM_BK_TOTAL = 26,     // bucket build: grand total of the scanned bucket table
   SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip

@@ -67,6 +67,7 @@ struct octl_forest {
 
   DevBuf rs_scratch, rs_order, rs_hyp, rs_plane, rs_count, rs_index;  // ransac staging
   DevBuf ord_idx2, xyz_ord2, pos_node2;  // compaction targets (swapped with the live arrays)
+  DevBuf blk_node2, blk_slot2, blk_start2, blk_size2;
 
   // bucket build (bucket_build.hip): the cloud partitioned into buckets of consecutive voxels
   DevBuf part_xyz[2];  // 32-byte records {x, y, z, voxel | child digits, store index | scheme bit}, two passes
