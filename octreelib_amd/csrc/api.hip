@@ -156,8 +156,7 @@ __global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ ma
 __global__ __launch_bounds__(256) void k_compact_tiles(
     const uint8_t* __restrict__ mask, const uint32_t* __restrict__ tile_off, int64_t n,
     const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
-    const int32_t* __restrict__ pos_node, uint32_t* __restrict__ ord_idx2,
-    double* __restrict__ xyz_ord2, int32_t* __restrict__ pos_node2, uint8_t* __restrict__ alive) {
+    uint32_t* __restrict__ ord_idx2, double* __restrict__ xyz_ord2, uint8_t* __restrict__ alive) {
   __shared__ uint32_t s_cnt[32];  // [row][wave] -> exclusive offsets
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t base = (int64_t)blockIdx.x * 2048;
@@ -196,7 +195,6 @@ __global__ __launch_bounds__(256) void k_compact_tiles(
       xyz_ord2[3 * d] = xyz_ord[3 * i];
       xyz_ord2[3 * d + 1] = xyz_ord[3 * i + 1];
       xyz_ord2[3 * d + 2] = xyz_ord[3 * i + 2];
-      pos_node2[d] = pos_node[i];
     } else {
       alive[v] = 0;
     }
@@ -394,7 +392,6 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     OCTL_TRY(octl_exclusive_scan_u32(ctx, nid, nid, nb, small + 21));
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord2, (size_t)n * 24));
-    OCTL_TRY(devbuf_reserve(ctx, f->pos_node2, (size_t)n * 4));
     // (block buffers keep the capacity convention of forest_make_blocks: one block per point)
     OCTL_TRY(devbuf_reserve(ctx, f->blk_node2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->blk_slot2, (size_t)n * 4));
@@ -402,8 +399,7 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     OCTL_TRY(devbuf_reserve(ctx, f->blk_size2, (size_t)n * 4));
     hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)tiles, n,
                        (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
-                       (const int32_t*)f->pos_node.as<int32_t>(), f->ord_idx2.as<uint32_t>(),
-                       f->xyz_ord2.as<double>(), f->pos_node2.as<int32_t>(), f->alive.as<uint8_t>());
+                       f->ord_idx2.as<uint32_t>(), f->xyz_ord2.as<double>(), f->alive.as<uint8_t>());
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)kept,
                        (const uint32_t*)nstart, (const uint32_t*)nid, nb, (const int32_t*)f->blk_node.as<int32_t>(),
@@ -416,7 +412,6 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     std::memcpy(res, ctx->small_host, 8);
     std::swap(f->ord_idx, f->ord_idx2);
     std::swap(f->xyz_ord, f->xyz_ord2);
-    std::swap(f->pos_node, f->pos_node2);
     std::swap(f->blk_node, f->blk_node2);
     std::swap(f->blk_slot, f->blk_slot2);
     std::swap(f->blk_start, f->blk_start2);
@@ -492,7 +487,7 @@ void octl_forest_destroy(octl_forest* f) {
         &f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
         &f->blk_start, &f->blk_size, &f->blk_node2, &f->blk_slot2, &f->blk_start2, &f->blk_size2, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order,
         &f->rs_hyp, &f->rs_plane, &f->rs_count, &f->rs_index, &f->ord_idx2, &f->xyz_ord2,
-        &f->pos_node2, &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
+        &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
         &f->hist, &f->idxbuf[0], &f->idxbuf[1], &f->pathbuf[0], &f->pathbuf[1], &f->flags,
         &f->entries, &f->split[0], &f->split[1], &f->split_tiles[0], &f->split_tiles[1],
         &f->child_sc, &f->pose_off_dev, &f->scheme_dev, &f->root_up, &f->vlin_dev, &f->vcode_dev[0],

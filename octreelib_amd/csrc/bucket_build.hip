@@ -969,6 +969,7 @@ struct NodeParams {
   uint32_t bstride, nb, n_alive;
   int n_poses, all_scheme, cur_epoch;
   int64_t node_cap;   // capacity of the node table (nodes); a larger table is needed -> overflow flag
+  int write_pos;      // position -> leaf is only read by the level loop that finishes the voxels left behind
 };
 
 __global__ __launch_bounds__(256) void k_bucket_nodes(
@@ -1146,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
         }
       }
     }
-    if (valid) pos_node[(size_t)start + f] = leaf;
+    if (valid && P.write_pos) pos_node[(size_t)start + f] = leaf;
     // (leaf, pose) blocks
     const uint64_t bbm = __ballot(bhead);
     if (bhead) {
@@ -1388,6 +1389,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   np.all_scheme = bp.all_scheme;
   np.cur_epoch = a.cur_epoch;
   np.node_cap = nt.cap;
+  np.write_pos = sm[SM_BK_TODO] > 0;
   {
     KTimer t(ctx, "bucket_nodes");
     hipLaunchKernelGGL(k_bucket_nodes, dim3((unsigned)ceil_div(nb, 4)), dim3(256), 0, st, nd, np,

@@ -55,7 +55,8 @@ struct octl_forest {
   // leaf-ordered arrays of the last build
   DevBuf ord_idx;    // u32 [n_ord] store index of the point at storage position i
   DevBuf xyz_ord;    // f64 [n_ord][3]
-  DevBuf pos_node;   // i32 [n_ord] scheme leaf of position i
+  DevBuf pos_node;   // i32 build scratch: scheme leaf of position i while a build runs (afterwards the block
+                     // table alone says which leaf a position belongs to)
   int64_t n_ord = 0;
   // non-empty (leaf, pose) blocks in storage order
   DevBuf blk_node, blk_slot, blk_start, blk_size;  // i32, i32, u32, i32
@@ -66,7 +67,7 @@ struct octl_forest {
   bool mask_valid = false;
 
   DevBuf rs_scratch, rs_order, rs_hyp, rs_plane, rs_count, rs_index;  // ransac staging
-  DevBuf ord_idx2, xyz_ord2, pos_node2;  // compaction targets (swapped with the live arrays)
+  DevBuf ord_idx2, xyz_ord2;  // compaction targets (swapped with the live arrays)
   DevBuf blk_node2, blk_slot2, blk_start2, blk_size2;
 
   // bucket build (bucket_build.hip): the cloud partitioned into buckets of consecutive voxels

@@ -12,9 +12,8 @@
 // runs in storage order.
 //
 // Voxels the scheme has not seen get new roots.  Roots stay the nodes [0, V) in voxel order (the
-// invariant the rest of the library is written against), so this case renumbers the node table -
-// O(nodes) - and shifts the leaf ids of the stored points and blocks: one streaming pass over 4 bytes
-// per stored point, the only work here that grows with the number of stored poses.
+// invariant the rest of the library is written against), so this case renumbers the node table and
+// shifts the leaf ids in the block table - O(nodes + blocks), nothing per stored point.
 //
 // Anything unusual (a point outside the voxel domain or outside a cube that is split, a store that
 // was changed other than by appending poses) makes forest_insert_incremental return *done = 0 with
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(256) void k_inc_gather(
     int64_t n_ord, const double* __restrict__ xyz, const int64_t* __restrict__ pose_off, int n_poses,
     int64_t V, int32_t U, const int32_t* __restrict__ shift, int64_t first_miss,
     const uint32_t* __restrict__ miss_rank, const int32_t* __restrict__ new_root,
-    uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord, int32_t* __restrict__ pos_node,
+    uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord, int32_t* __restrict__ new_node,
     uint32_t* __restrict__ heads) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_live) return;
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256) void k_inc_gather(
   xyz_ord[3 * o + 0] = xyz[3 * i + 0];
   xyz_ord[3 * o + 1] = xyz[3 * i + 1];
   xyz_ord[3 * o + 2] = xyz[3 * i + 2];
-  pos_node[o] = node;
+  new_node[j] = node;
   bool h = (j == 0) || key[j - 1] != k;
   if (!h) {
     const int64_t ip = first + (int64_t)val[j - 1];
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(256) void k_inc_blocks(const uint32_t* __restrict__
                                                     const uint64_t* __restrict__ key, const uint32_t* __restrict__ val,
                                                     int64_t n_live, int64_t first, int64_t n_ord,
                                                     int64_t n_blocks, const int64_t* __restrict__ pose_off,
-                                                    int n_poses, const int32_t* __restrict__ pos_node,
+                                                    int n_poses, const int32_t* __restrict__ new_node,
                                                     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot,
                                                     uint32_t* __restrict__ blk_start) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(256) void k_inc_blocks(const uint32_t* __restrict__
   if (!h) h = slot_of(pose_off, n_poses, first + (int64_t)val[j - 1]) != slot;
   if (h) {
     const int64_t b = n_blocks + heads_scanned[j];
-    blk_node[b] = pos_node[n_ord + j];
+    blk_node[b] = new_node[j];
     blk_slot[b] = slot;
     blk_start[b] = (uint32_t)(n_ord + j);
   }
@@ -434,11 +433,6 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
     hipLaunchKernelGGL(k_inc_new_roots, dim3(grid_for(U)), dim3(256), 0, st, (const uint64_t*)ucode,
                        (const int32_t*)root_w, U, f->mode, f->edge, f->corner[0], f->corner[1], f->corner[2], dst);
     HIP_TRY(ctx, hipGetLastError());
-    if (n_ord > 0) {
-      hipLaunchKernelGGL(k_inc_remap, dim3(grid_for(n_ord)), dim3(256), 0, st, f->pos_node.as<int32_t>(), n_ord,
-                         V, (int32_t)U, (const int32_t*)shift_w);
-      HIP_TRY(ctx, hipGetLastError());
-    }
     if (n_blocks > 0) {
       hipLaunchKernelGGL(k_inc_remap, dim3(grid_for(n_blocks)), dim3(256), 0, st, f->blk_node.as<int32_t>(),
                          n_blocks, V, (int32_t)U, (const int32_t*)shift_w);
@@ -455,7 +449,7 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
     KTimer t(ctx, "inc_append");
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_total * 4, 1));
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, (size_t)n_total * 24, 1));
-    OCTL_TRY(devbuf_reserve(ctx, f->pos_node, (size_t)n_total * 4, 1));
+    OCTL_TRY(devbuf_reserve(ctx, f->pos_node, (size_t)n_live * 4));  // scratch: leaf of every sorted new point
     // (capacity as in forest_make_blocks: one block per point)
     OCTL_TRY(devbuf_reserve(ctx, f->blk_node, (size_t)n_total * 4, 1));
     OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n_total * 4, 1));
