@@ -48,7 +48,9 @@ constexpr uint32_t PATH_MASK = 0x1FFFFFu;
 
 // rows of the per-bucket totals table bk_tot[row][bucket]
 enum { BK_NVOX = 0, BK_NINT = 1 /* .. 7 */, BK_NBLK = 8, BK_ROWS = 9 };
-// leafinfo word of a leaf-ordered point
+// leafinfo word of a leaf-ordered point: bits 0..15 ordinal (inside the bucket) of the leaf's parent among
+// the internal nodes of its level - or of the voxel when the root is the leaf -, child digit, leaf depth
+constexpr int LC_DIGIT = 16, LC_DEPTH = 19;
 constexpr uint32_t LI_VHEAD = 1u << 24;   // first point of its top-level voxel
 constexpr uint32_t LI_BHEAD = 1u << 25;   // first point of its (leaf, pose) block
 // bucket flags
@@ -432,10 +434,24 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     const PartRec* __restrict__ part, const uint16_t* __restrict__ SRC, const int n, const uint32_t out_base,
     const uint32_t vox_stage, const uint32_t lin0, const BkParams& P, const int64_t* __restrict__ pose_off,
     uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord, uint32_t* __restrict__ leafinfo,
-    uint32_t* __restrict__ bk_vox, uint32_t* s_bins, uint16_t (*s_slot)[BB_CAP], uint32_t (*s_cnt)[256],
-    uint32_t* s_scr, uint32_t* s_tot, uint32_t* s_todo, uint32_t* __restrict__ small) {
+    uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_node, const uint32_t node_stage, const uint32_t node_room,
+    uint32_t* s_bins, uint16_t (*s_slot)[BB_CAP], uint32_t (*s_cnt)[256],
+    uint32_t* s_scr, uint32_t* s_tot, uint32_t* s_base, uint32_t* s_todo, uint32_t* __restrict__ small) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s = P.lp.shift;
+  // ordinals are counted per chunk; the bucket-wide ones add what the earlier chunks of the bucket hold
+  // (s_tot is stable here: the previous chunk ended with a barrier, this one updates it behind barriers)
+  if (tid < BK_ROWS) s_base[tid] = s_tot[tid];
+  __syncthreads();
+  const uint32_t basev = s_base[BK_NVOX];
+  uint32_t rec_base = 0;
+#pragma unroll
+  for (int l = 0; l < BB_LEVELS; ++l) rec_base += s_base[BK_NINT + l];
+  const uint32_t* basel = s_base + BK_NINT;
+  // vord << 18 | path prefix of the overfull nodes of the previous / the current level, kept by the owners
+  // of the histogram bins (the sort buffers are free while the levels run)
+  uint32_t* s_ninfo = reinterpret_cast<uint32_t*>(&s_slot[0][0]);   // [2][1024]
+  bool rec_overflow = false;
   // s_todo: one bit per voxel of the bucket - the voxel cannot be finished here (a point outside its
   // cube, a tree deeper than the digits the records carry, more nodes per level than the histogram
   // holds).  Such a voxel stays ONE leaf (its root, points in insertion order) and is flagged in its
@@ -449,8 +465,10 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 
   // ---- 1. points -> (voxel inside the bucket, child digits) ----------------------------------------------
   // pth: bits 0..20 child digits (level j at bits 20-3j..18-3j), bit 30 bad point, bit 31 scheme pose
-  // stt: bit 31 undecided; undecided: bits 0..15 ordinal of the point's node among the overfull nodes of
-  //      the current level; decided: bits 16..19 leaf depth
+  // stt: bit 31 undecided, bits 16..27 ordinal of the point's voxel among the voxels of the chunk;
+  //      undecided: bits 0..15 ordinal of the point's node among the overfull nodes of the current level;
+  //      decided: bits 28..30 leaf depth d, bits 0..15 ordinal of the leaf's PARENT among the overfull nodes
+  //      of level d - 1 (d = 0: the voxel ordinal again)
   uint32_t pth[BB_IPT], vlv[BB_IPT], stt[BB_IPT];
   bool bad_any = false;
 #pragma unroll
@@ -484,6 +502,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   //  over the per-item register arrays cost 20 % of the kernel)
   auto run_levels = [&]() {
   again = false;
+  rec_overflow = false;
 
   // ---- 2. level 0: the voxels ------------------------------------------------------------------------------------
   // bin = voxel inside the bucket; low half: scheme-pose points, high half: all points
@@ -523,8 +542,22 @@ __device__ __forceinline__ uint32_t bucket_chunk(
           run += 1u;
         }
         const bool over = is_over(d, c);
-        s_bins[d] = over ? (run >> 16) : NOT_OVER;
-        if (over) run += 0x10000u;
+        // (run & 0xFFFF counts this voxel already when it has points)
+        const uint32_t vord = (run & 0xFFFFu) - ((c >> 16) ? 1u : 0u);
+        s_bins[d] = (vord << 16) | (over ? (run >> 16) : 0xFFFFu);
+        if (over) {
+          const uint32_t q = run >> 16;
+          if (q < 1024u) s_ninfo[q] = (basev + vord) << 18;
+          if (rec_base + q < node_room) {
+            const size_t at = 3 * ((size_t)node_stage + rec_base + q);
+            bk_node[at] = (basev + vord) << 18;
+            bk_node[at + 1] = basel[0] + q;          // level 0 | ordinal inside the bucket
+            bk_node[at + 2] = 0u;
+          } else {
+            rec_overflow = true;
+          }
+          run += 0x10000u;
+        }
       }
     }
     n_over = tot >> 16;
@@ -538,13 +571,15 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   for (int r = 0; r < BB_IPT; ++r) {
     if (stt[r] >> 31) {
       const uint32_t v = s_bins[vlv[r]];
-      stt[r] = v == NOT_OVER ? 0u : (0x80000000u | v);
+      const uint32_t vo = (v >> 16) << 16;
+      stt[r] = (v & 0xFFFFu) == 0xFFFFu ? (vo | (v >> 16)) : (0x80000000u | vo | (v & 0xFFFFu));
     }
   }
   __syncthreads();
 
   // ---- 3. deeper levels: bins = (overfull node of the level above, child digit) -----------------------------
   dmax = 0;
+  uint32_t nrec = n_over;  // node records of this chunk so far
 #pragma unroll 1
   for (int l = 1; n_over > 0; ++l) {
     const int nbl = 8 * (int)n_over;
@@ -576,15 +611,32 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       }
       uint32_t tot;
       uint32_t run = block_excl_add(mine, &tot, s_scr);
+      const uint32_t* ninfo_up = s_ninfo + 1024 * ((l - 1) & 1);
+      uint32_t* ninfo_me = s_ninfo + 1024 * (l & 1);
       for (int q = 0; q < per; ++q) {
         const int d = tid * per + q;
         if (d < nbl) {
           const bool over = (int64_t)s_bins[d] > P.K;
           s_bins[d] = over ? run : NOT_OVER;
-          if (over) ++run;
+          if (over) {
+            // the node's voxel and path: its parent's (nodes of the level above: <= 1024) + its own digit
+            const uint32_t up = ninfo_up[d >> 3];
+            const uint32_t info = (up & 0xFFFC0000u) | (((up & 0x3FFFFu) << 3) | (uint32_t)(d & 7));
+            if (run < 1024u) ninfo_me[run] = info;
+            if (l < BB_LEVELS && rec_base + nrec + run < node_room) {
+              const size_t at = 3 * ((size_t)node_stage + rec_base + nrec + run);
+              bk_node[at] = info;
+              bk_node[at + 1] = ((uint32_t)l << 28) | (basel[l] + run);
+              bk_node[at + 2] = basel[l - 1] + (uint32_t)(d >> 3);
+            } else {
+              rec_overflow = true;
+            }
+            ++run;
+          }
         }
       }
       n_over = tot;
+      nrec += tot;
       if (tid == 0 && l < BB_LEVELS) s_tot[BK_NINT + l] += tot;
     }
     __syncthreads();
@@ -592,7 +644,8 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     for (int r = 0; r < BB_IPT; ++r) {
       if (stt[r] >> 31) {
         const uint32_t v = s_bins[(stt[r] & 0xFFFFu) * 8u + ((pth[r] >> dsh) & 7u)];
-        stt[r] = v == NOT_OVER ? ((uint32_t)l << 16) : (0x80000000u | v);
+        stt[r] = v == NOT_OVER ? (((uint32_t)l << 28) | (stt[r] & 0x0FFFFFFFu))
+                               : (0x80000000u | (stt[r] & 0x0FFF0000u) | v);
       }
     }
     __syncthreads();
@@ -608,6 +661,9 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     run_levels();
     if (again) return BF_OVERFLOW;  // (cannot happen: the second attempt runs without the flagged voxels)
   }
+  // more internal nodes than points in the bucket (K of one or two and trees six levels deep): the staging
+  // area of the node records is sized by the points
+  if (__syncthreads_or(rec_overflow ? 1 : 0)) return BF_OVERFLOW;
   // voxels left to the general path (counted once, by the owners of their bins)
   {
     uint32_t c = 0;
@@ -628,11 +684,14 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     if (r < rounds) {
       const int i = wave * per_wave + r * 64 + lane;
       if (i < n) {
-        const uint32_t d = (stt[r] >> 16) & 15u;
+        const uint32_t d = (stt[r] >> 28) & 7u;
         const uint32_t path = pth[r] & PATH_MASK;
         const uint32_t trunc = d == 0 ? 0u : ((path >> (21 - 3 * d)) << (3 * (dmax - (int)d)));
         KEY[i] = (kshift ? (vlv[r] << kshift) : vlv[r]) | trunc;
-        INFO[i] = path | (d << 21);
+        // the leaf in bucket terms: depth, ordinal of its parent among the internal nodes of level d - 1 of
+        // the bucket (d = 0: ordinal of the voxel) and its child digit - k_bucket_finish adds the bases
+        const uint32_t ob = (stt[r] & 0xFFFFu) + (d == 0 ? basev : basel[d - 1]);
+        INFO[i] = ob | (d == 0 ? 0u : (((path >> (21 - 3 * d)) & 7u) << LC_DIGIT)) | (d << LC_DEPTH);
       }
     }
   }
@@ -740,9 +799,10 @@ template <bool OVERSIZE>
 __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
     const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
-    uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_tot,
-    uint32_t* __restrict__ small) {
+    uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_node,
+    uint32_t* __restrict__ bk_tot, uint32_t* __restrict__ small) {
   __shared__ uint32_t s_bins[BB_BINS];            // pyramid bins; afterwards KEY[BB_CAP] | INFO[BB_CAP]
+  __shared__ uint32_t s_base[BK_ROWS];            // totals of the bucket before the current chunk
   __shared__ uint16_t s_slot[2][BB_CAP];          // sort buffers: positions -> item
   __shared__ uint32_t s_cnt[BB_THREADS / 64][256];
   __shared__ uint32_t s_scr[8];
@@ -776,7 +836,8 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
   uint32_t fl = 0;
   if (!OVERSIZE) {
     fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
-                             bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot, s_todo, small);
+                             bk_vox, bk_node, start, (uint32_t)n, s_bins, s_slot, s_cnt, s_scr, s_tot, s_base,
+                             s_todo, small);
   } else {
     // ---- plan: points per voxel, then greedy runs of voxels with at most BB_CAP points ------------------
     const int nbins0 = 1 << s;
@@ -867,7 +928,7 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
               bhead = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, pidx);
             }
             const size_t o = (size_t)out_base + basec + off;
-            leafinfo[o] = (first ? LI_VHEAD : 0u) | (bhead ? LI_BHEAD : 0u);
+            leafinfo[o] = (uint32_t)s_cvox[c] | (first ? LI_VHEAD : 0u) | (bhead ? LI_BHEAD : 0u);  // depth 0
             ord_idx[o] = idx;
             reinterpret_cast<uint2*>(xyz_ord + 3 * o)[0] = uint2{a.x, a.y};
             reinterpret_cast<uint2*>(xyz_ord + 3 * o)[1] = uint2{a.z, a.w};
@@ -921,8 +982,8 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
         __syncthreads();
       }
       fl = bucket_chunk<true>(recs, s_src, (int)s_csize[c], start + s_cofs[c], start + s_cvox[c], lin0, P,
-                              pose_off, ord_idx, xyz_ord, leafinfo, bk_vox, s_bins, s_slot, s_cnt, s_scr, s_tot,
-                              s_todo, small);
+                              pose_off, ord_idx, xyz_ord, leafinfo, bk_vox, bk_node, start, (uint32_t)n, s_bins,
+                              s_slot, s_cnt, s_scr, s_tot, s_base, s_todo, small);
     }
   }
   if (fl) {  // the host runs the general path instead
@@ -972,17 +1033,25 @@ struct NodeParams {
   int write_pos;      // position -> leaf is only read by the level loop that finishes the voxels left behind
 };
 
-__global__ __launch_bounds__(256) void k_bucket_nodes(
+// One workgroup per bucket, three independent sweeps (nothing is a serial chain any more: the bucket
+// kernel has already numbered voxels, internal nodes and leaves INSIDE the bucket, this kernel adds the
+// bases that the scan over all buckets produced):
+//   roots    one thread per voxel (staging record: linear key, points, scheme points)
+//   nodes    eight lanes per internal node (record: voxel, path, level, own / parent ordinal): the node's
+//            first_child / epoch and its eight children (octree.py:177-191)
+//   blocks   the leafinfo words in storage order: (leaf, pose) block table, and position -> leaf when
+//            the level loop of build.hip is going to resume
+__global__ __launch_bounds__(256) void k_bucket_finish(
     NodePtrs nd, NodeParams P, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bk_base,
-    const uint32_t* __restrict__ leafinfo,
-    const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
-    const uint32_t* __restrict__ bk_vox, const int64_t* __restrict__ pose_off,
+    const uint32_t* __restrict__ grand_total, const uint32_t* __restrict__ leafinfo,
+    const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bk_vox,
+    const uint32_t* __restrict__ bk_node, const int64_t* __restrict__ pose_off,
     int32_t* __restrict__ pos_node, uint64_t* __restrict__ vlin,
     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot, uint32_t* __restrict__ blk_start,
     uint32_t* small) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t b = blockIdx.x * 4 + wave;
-  if (b >= P.nb) return;  // no workgroup barrier below: waves are independent
+  __shared__ uint32_t s_scr[8];
+  const int tid = threadIdx.x;
+  const uint32_t b = blockIdx.x;
   const uint32_t start = bstart[(size_t)b * P.bstride];
   const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   const int n = (int)(end - start);
@@ -991,174 +1060,131 @@ __global__ __launch_bounds__(256) void k_bucket_nodes(
   const int64_t V = (int64_t)head_int;                     // total of row BK_NVOX
   const int64_t n_int = (int64_t)(head_blk - head_int);    // total of the level rows
   if (V + 8 * n_int > P.node_cap) {
-    if (lane == 0) atomicOr(&small[SM_BK_FLAGS], 0x100u);  // the host grows the table and launches again
+    if (tid == 0) atomicOr(&small[SM_BK_FLAGS], 0x100u);  // the host grows the table and launches again
     return;
   }
-  const uint32_t vbase = bk_base[(size_t)BK_NVOX * P.nb + b];
-  uint32_t lbase[BB_LEVELS];
-#pragma unroll
-  for (int l = 0; l < BB_LEVELS; ++l) lbase[l] = bk_base[(size_t)(BK_NINT + l) * P.nb + b] - head_int;
-  const uint32_t bbase = bk_base[(size_t)BK_NBLK * P.nb + b] - head_blk;
-
-  uint32_t vcarry = 0, bcarry = 0;
-  uint32_t carry[BB_LEVELS], tail_pref[BB_LEVELS];
-  bool tail_act[BB_LEVELS];
-#pragma unroll
-  for (int l = 0; l < BB_LEVELS; ++l) {
-    carry[l] = 0;
-    tail_pref[l] = 0;
-    tail_act[l] = false;
-  }
-  // The chunks of a bucket are a serial chain (the running ordinals): the leafinfo words are loaded two
-  // chunks ahead so that the chain does not wait for them.
-  auto load_li = [&](int f0) {
-    const int f = f0 + lane;
-    return f < n ? leafinfo[(size_t)start + f] : 0u;
+  // entries of the scanned table: row r, bucket b; the entry behind the last one of the table is the total
+  auto at = [&](int r, uint32_t q) {
+    const size_t i = (size_t)r * P.nb + q;
+    return i < (size_t)BK_ROWS * P.nb ? bk_base[i] : *grand_total;
   };
-  uint32_t li_cur = load_li(0), li_nxt = load_li(64);
-  for (int f0 = 0; f0 < n; f0 += 64) {
-    const int f = f0 + lane;
-    const bool valid = f < n;
-    const uint32_t li = li_cur;
-    const uint32_t li_nx2 = load_li(f0 + 128);
-    const uint32_t pw = li & PATH_MASK;
-    const uint32_t dep = (li >> 21) & 7u;
-    const bool vhead = valid && (li & LI_VHEAD);
-    const bool bhead = valid && (li & LI_BHEAD);
-    // voxel of every lane
-    const uint64_t vb = __ballot(vhead);
-    const uint32_t vo = vcarry + (uint32_t)__popcll(vb & lanemask_le64()) - 1u;  // ordinal inside the bucket
-    vcarry += (uint32_t)__popcll(vb);
-    const int32_t v = (int32_t)(vbase + vo);
-    int32_t leaf = v;  // dep == 0: the root is the leaf
-    int32_t cb_prev = 0;
-    // pass 1: ordinals of the nodes of every level, position -> leaf; the nodes that START in this
-    // chunk are remembered per level (head lanes, their child group and their own id)
-    uint64_t hmask[BB_LEVELS];
-    int32_t h_cb[BB_LEVELS], h_xid[BB_LEVELS];
-    uint64_t any_heads = vb;
-#pragma unroll
-    for (int l = 0; l < BB_LEVELS; ++l) {
-      hmask[l] = 0;
-      h_cb[l] = 0;
-      h_xid[l] = 0;
-      const bool actl = valid && dep > (uint32_t)l;  // inside an internal node of level l
-      if (!__any(actl)) {  // (wave uniform) nobody of this chunk is that deep
-        tail_act[l] = false;
-        continue;
-      }
-      const uint32_t pref = l == 0 ? 0u : (pw >> (21 - 3 * l));
-      uint32_t pp = __shfl_up(pref, 1);
-      bool pa = __shfl_up(actl ? 1 : 0, 1) != 0;
-      if (lane == 0) {
-        pp = tail_pref[l];
-        pa = tail_act[l];
-      }
-      const bool head = actl && (vhead || !pa || pp != pref);
-      const uint64_t hb = __ballot(head);
-      const uint32_t ord = carry[l] + (uint32_t)__popcll(hb & lanemask_le64()) - 1u;
-      carry[l] += (uint32_t)__popcll(hb);
-      tail_pref[l] = __shfl(pref, 63);
-      tail_act[l] = __shfl(actl ? 1 : 0, 63) != 0;
-      if (actl) {
-        const int32_t cb = (int32_t)(V + 8 * (int64_t)(lbase[l] + ord));  // its 8 children
-        const int32_t xid = l == 0 ? v : cb_prev + (int32_t)digit_at(pw, l - 1);
-        if (head) {
-          nd.first_child[xid] = cb;
-          nd.epoch[xid] = P.cur_epoch;
-          h_cb[l] = cb;
-          h_xid[l] = xid;
-        }
-        if (dep == (uint32_t)l + 1u) leaf = cb + (int32_t)digit_at(pw, l);
-        cb_prev = cb;
-      }
-      hmask[l] = hb;
-      any_heads |= hb;
+  const uint32_t vbase = at(BK_NVOX, b);
+  const uint32_t nvox = at(BK_NVOX, b + 1) - vbase;
+  uint32_t nrec = 0;
+  for (int l = 0; l < BB_LEVELS; ++l) nrec += at(BK_NINT + l, b + 1) - at(BK_NINT + l, b);
+  const uint32_t bbase = at(BK_NBLK, b) - head_blk;
+
+  // ---- roots --------------------------------------------------------------------------------------------------
+  // (first position of a voxel = bucket start + points of the voxels in front of it)
+  uint32_t run = 0;
+  for (uint32_t j0 = 0; j0 < nvox; j0 += 256) {
+    const uint32_t j = j0 + tid;
+    uint32_t lin = 0, cntw = 0, sc = 0;
+    if (j < nvox) {
+      lin = bk_vox[3 * ((size_t)start + j)];
+      cntw = bk_vox[3 * ((size_t)start + j) + 1];
+      sc = bk_vox[3 * ((size_t)start + j) + 2];
     }
-    // pass 2, only in chunks where a voxel or a node starts: root geometry from the staging record of
-    // the lane's voxel (a dependent load - kept off the chain of the other chunks), then the nodes
-    if (any_heads) {
+    const uint32_t cntv = cntw & 0x7FFFFFFFu;  // (bit 31: the voxel is left to the level loop of build.hip)
+    uint32_t tot;
+    const uint32_t pre = block_excl_add(cntv, &tot, s_scr);
+    if (j < nvox) {
+      const int32_t v = (int32_t)(vbase + j);
       double c0x = P.lp.c0x, c0y = P.lp.c0y, c0z = P.lp.c0z;
-      uint32_t lin = 0;
-      if (P.lp.mode == 0 && ((any_heads >> lane) & 1ull)) {
-        lin = bk_vox[3 * ((size_t)start + vo)];
+      if (P.lp.mode == 0) {
         const uint32_t qz = lin % P.lp.nz, qy = (lin / P.lp.nz) % P.lp.ny, qx = lin / (P.lp.nz * P.lp.ny);
         // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
         c0x = (double)(long long)((double)((int)qx + P.lp.minx) * P.lp.L);
         c0y = (double)(long long)((double)((int)qy + P.lp.miny) * P.lp.L);
         c0z = (double)(long long)((double)((int)qz + P.lp.minz) * P.lp.L);
       }
-      if (vhead) {
-        // (bit 31 of the count: the voxel is left to the level loop of build.hip, which then splits
-        //  every root with more than K scheme points that is still a leaf)
-        const uint32_t cntv = bk_vox[3 * ((size_t)start + vo) + 1] & 0x7FFFFFFFu;
-        nd.start[v] = start + (uint32_t)f;
-        nd.count[v] = cntv;
-        nd.scount[v] = bk_vox[3 * ((size_t)start + vo) + 2];
-        nd.depth[v] = 0;
-        nd.voxel[v] = v;
-        nd.parent[v] = -1;
-        nd.old_id[v] = -1;
-        nd.edge[v] = P.lp.L;
-        nd.corner[3 * (int64_t)v] = c0x;
-        nd.corner[3 * (int64_t)v + 1] = c0y;
-        nd.corner[3 * (int64_t)v + 2] = c0z;
-        vlin[v] = (uint64_t)lin;
-      }
-      // the 8 children of every node that starts in this chunk, written by the WHOLE wave, one node at
-      // a time: lane j < 8 writes child j (one store instruction per field and node)
-#pragma unroll
-      for (int l = 0; l < BB_LEVELS; ++l) {
-        uint64_t todo = hmask[l];
-        while (todo) {
-          const int src = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          const int32_t cbh = __shfl(h_cb[l], src);
-          const int32_t xidh = __shfl(h_xid[l], src);
-          const uint32_t pwh = (uint32_t)__shfl((int)pw, src);
-          const int32_t vh = __shfl(v, src);
-          double cx = __shfl(c0x, src), cy = __shfl(c0y, src), cz = __shfl(c0z, src), e = P.lp.L;
-          // corner / edge: descend from the root with the reference's arithmetic
-          // (corner + offset, edge / 2: octree.py:181-191)
-          for (int t = 0; t < l; ++t) {
-            const uint32_t d = digit_at(pwh, t);
-            const double h = e / 2.0;
-            cx = cx + ((d & 4u) ? h : 0.0);
-            cy = cy + ((d & 2u) ? h : 0.0);
-            cz = cz + ((d & 1u) ? h : 0.0);
-            e = h;
-          }
-          const double h = e / 2.0;
-          if (lane < 8) {
-            const int j = lane;
-            const int64_t c = (int64_t)cbh + j;
-            nd.start[c] = 0;  // ranges are only meaningful inside the level-synchronous path
-            nd.count[c] = 0;
-            nd.scount[c] = 0;
-            nd.depth[c] = l + 1;
-            nd.voxel[c] = vh;
-            nd.parent[c] = xidh;
-            nd.old_id[c] = -1;
-            nd.edge[c] = h;
-            nd.corner[3 * c + 0] = cx + ((j & 4) ? h : 0.0);
-            nd.corner[3 * c + 1] = cy + ((j & 2) ? h : 0.0);
-            nd.corner[3 * c + 2] = cz + ((j & 1) ? h : 0.0);
-          }
-        }
+      nd.start[v] = start + run + pre;
+      nd.count[v] = cntv;
+      nd.scount[v] = sc;
+      nd.depth[v] = 0;
+      nd.voxel[v] = v;
+      nd.parent[v] = -1;
+      nd.old_id[v] = -1;
+      nd.edge[v] = P.lp.L;
+      nd.corner[3 * (int64_t)v] = c0x;
+      nd.corner[3 * (int64_t)v + 1] = c0y;
+      nd.corner[3 * (int64_t)v + 2] = c0z;
+      vlin[v] = (uint64_t)lin;
+    }
+    run += tot;
+  }
+
+  // ---- internal nodes and their children -----------------------------------------------------------------
+  for (uint32_t j = (uint32_t)tid >> 3; j < nrec; j += 32) {
+    const int c = tid & 7;
+    const size_t r = 3 * ((size_t)start + j);
+    const uint32_t info = bk_node[r], w1 = bk_node[r + 1], up = bk_node[r + 2];
+    const int l = (int)(w1 >> 28);
+    const uint32_t own = w1 & 0xFFFFu, vord = info >> 18, prefix = info & 0x3FFFFu;  // l digits
+    const int32_t v = (int32_t)(vbase + vord);
+    const int32_t cb = (int32_t)(V + 8 * (int64_t)(at(BK_NINT + l, b) - head_int + own));
+    const int32_t xid =
+        l == 0 ? v : (int32_t)(V + 8 * (int64_t)(at(BK_NINT + l - 1, b) - head_int + up)) + (int32_t)(prefix & 7u);
+    double cx = P.lp.c0x, cy = P.lp.c0y, cz = P.lp.c0z, e = P.lp.L;
+    if (P.lp.mode == 0) {
+      const uint32_t lin = bk_vox[3 * ((size_t)start + vord)];
+      const uint32_t qz = lin % P.lp.nz, qy = (lin / P.lp.nz) % P.lp.ny, qx = lin / (P.lp.nz * P.lp.ny);
+      cx = (double)(long long)((double)((int)qx + P.lp.minx) * P.lp.L);
+      cy = (double)(long long)((double)((int)qy + P.lp.miny) * P.lp.L);
+      cz = (double)(long long)((double)((int)qz + P.lp.minz) * P.lp.L);
+    }
+    // corner / edge: descend from the root with the reference's arithmetic
+    // (corner + offset, edge / 2: octree.py:181-191)
+    for (int t = 0; t < l; ++t) {
+      const uint32_t d = (prefix >> (3 * (l - 1 - t))) & 7u;
+      const double h = e / 2.0;
+      cx = cx + ((d & 4u) ? h : 0.0);
+      cy = cy + ((d & 2u) ? h : 0.0);
+      cz = cz + ((d & 1u) ? h : 0.0);
+      e = h;
+    }
+    const double h = e / 2.0;
+    if (c == 0) {
+      nd.first_child[xid] = cb;
+      nd.epoch[xid] = P.cur_epoch;
+    }
+    const int64_t ch = (int64_t)cb + c;
+    nd.start[ch] = 0;  // ranges are only meaningful inside the level-synchronous path
+    nd.count[ch] = 0;
+    nd.scount[ch] = 0;
+    nd.depth[ch] = l + 1;
+    nd.voxel[ch] = v;
+    nd.parent[ch] = xid;
+    nd.old_id[ch] = -1;
+    nd.edge[ch] = h;
+    nd.corner[3 * ch + 0] = cx + ((c & 4) ? h : 0.0);
+    nd.corner[3 * ch + 1] = cy + ((c & 2) ? h : 0.0);
+    nd.corner[3 * ch + 2] = cz + ((c & 1) ? h : 0.0);
+  }
+
+  // ---- (leaf, pose) blocks, position -> leaf ------------------------------------------------------------------
+  uint32_t brun = 0;
+  for (int f0 = 0; f0 < n; f0 += 256) {
+    const int f = f0 + tid;
+    const uint32_t li = f < n ? leafinfo[(size_t)start + f] : 0u;
+    const bool bhead = f < n && (li & LI_BHEAD);
+    uint32_t tot;
+    const uint32_t pre = block_excl_add(bhead ? 1u : 0u, &tot, s_scr);
+    if (f < n && (bhead || P.write_pos)) {
+      const uint32_t dep = (li >> LC_DEPTH) & 7u, ob = li & 0xFFFFu;
+      const int32_t leaf =
+          dep == 0 ? (int32_t)(vbase + ob)
+                   : (int32_t)(V + 8 * (int64_t)(at(BK_NINT + (int)dep - 1, b) - head_int + ob)) +
+                         (int32_t)((li >> LC_DIGIT) & 7u);
+      if (P.write_pos) pos_node[(size_t)start + f] = leaf;
+      if (bhead) {
+        const uint32_t bo = bbase + brun + pre;
+        blk_node[bo] = leaf;
+        blk_slot[bo] = P.n_poses > 1 ? find_slot_dev(pose_off, P.n_poses, ord_idx[(size_t)start + f]) : 0;
+        blk_start[bo] = start + (uint32_t)f;
       }
     }
-    if (valid && P.write_pos) pos_node[(size_t)start + f] = leaf;
-    // (leaf, pose) blocks
-    const uint64_t bbm = __ballot(bhead);
-    if (bhead) {
-      const uint32_t bo = bbase + bcarry + (uint32_t)__popcll(bbm & lanemask_le64()) - 1u;
-      blk_node[bo] = leaf;
-      blk_slot[bo] = P.n_poses > 1 ? find_slot_dev(pose_off, P.n_poses, ord_idx[(size_t)start + f]) : 0;
-      blk_start[bo] = start + (uint32_t)f;
-    }
-    bcarry += (uint32_t)__popcll(bbm);
-    li_cur = li_nxt;
-    li_nxt = li_nx2;
+    brun += tot;
   }
 }
 
@@ -1255,6 +1281,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
                           (std::max((size_t)nd_a * nst_a, (size_t)nd_b * nst_b) + (two_pass ? nb + 1 : 0) + 16) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, ((size_t)BK_ROWS * nb + 8) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 12));
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_node, (size_t)n_alive * 12));
   OCTL_TRY(devbuf_reserve(ctx, f->leafinfo, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, (size_t)n_alive * 24));
@@ -1341,12 +1368,12 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
     KTimer t(ctx, "bucket_build");
     hipLaunchKernelGGL(k_bucket_build<false>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
-                       f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(),
+                       f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
                        bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_bucket_build<true>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
-                       f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(),
+                       f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
                        bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1392,11 +1419,10 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   np.write_pos = sm[SM_BK_TODO] > 0;
   {
     KTimer t(ctx, "bucket_nodes");
-    hipLaunchKernelGGL(k_bucket_nodes, dim3((unsigned)ceil_div(nb, 4)), dim3(256), 0, st, nd, np,
-                       bstart, (const uint32_t*)f->bk_tot.as<uint32_t>(),
-                       (const uint32_t*)f->leafinfo.as<uint32_t>(),
-                       (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
-                       (const uint32_t*)f->bk_vox.as<uint32_t>(),
+    hipLaunchKernelGGL(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd, np, bstart,
+                       (const uint32_t*)f->bk_tot.as<uint32_t>(), (const uint32_t*)(small + SM_BK_TOTAL),
+                       (const uint32_t*)f->leafinfo.as<uint32_t>(), (const uint32_t*)f->ord_idx.as<uint32_t>(),
+                       (const uint32_t*)f->bk_vox.as<uint32_t>(), (const uint32_t*)f->bk_node.as<uint32_t>(),
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->pos_node.as<int32_t>(),
                        f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
                        f->blk_start.as<uint32_t>(), small);

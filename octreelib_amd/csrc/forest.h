@@ -76,6 +76,8 @@ struct octl_forest {
   DevBuf bk_tot;       // u32 [BK_ROWS][n_buckets] per-bucket totals (scanned in place)
   DevBuf bk_vox;       // u32 x3 staging {linear key, points | todo, scheme points} of the j-th voxel of bucket b
                        // at [bucket start + j]
+  DevBuf bk_node;      // u32 x3 staging {voxel << 18 | path, level << 28 | ordinal, parent ordinal} of the j-th internal
+                       // node of bucket b at [bucket start + j]
   DevBuf leafinfo;     // u32 [n_alive] per leaf-ordered point: path21 | depth << 21 | flags
   // levels of the current node table as (first, end, depth) ranges of node ids: one per level when a
   // single build path numbered the nodes, two where the level loop has subdivided voxels the bucket
