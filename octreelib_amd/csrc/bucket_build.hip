@@ -16,15 +16,19 @@
 //                                  histograms, wave64 ballot ranks) for up to 4096 buckets - the only
 //                                  scatter of coordinates - and a second one on the next 12 bits for
 //                                  clouds that need more buckets (> 10 M points);
-//   k_bucket_build                 one workgroup per bucket (<= 4096 points, a few voxels): the bucket
-//                                  is sorted in LDS by (voxel, 21-bit child-digit path), the leaf of
-//                                  every point follows from segment scans over the sorted keys (a node
-//                                  splits while its scheme-pose count exceeds K), a second LDS sort
-//                                  restores insertion order inside the leaves, and the leaf-ordered
-//                                  permutation + coordinates are written with coalesced stores;
+//   k_bucket_build                 one workgroup per bucket (<= 4096 points, a few voxels; larger buckets in
+//                                  chunks of whole voxels): level by level the undecided points add
+//                                  themselves to an LDS histogram over (node ordinal, child digit), bins
+//                                  above K become the nodes of the next level (a node splits while its
+//                                  scheme-pose count exceeds K) - no point moves until every point knows
+//                                  its leaf; then ONE stable LDS radix sort by (voxel, leaf path) and
+//                                  coalesced stores of permutation, coordinates and a leaf word per
+//                                  point; voxels, internal nodes and leaves are numbered INSIDE the
+//                                  bucket (staging records per voxel and per internal node);
 //   one exclusive scan             bucket totals -> voxel / node / block numbering bases;
-//   k_bucket_nodes                 one wavefront per bucket: scheme nodes in the level-major numbering
-//                                  of the level-synchronous path, position -> leaf map, block table.
+//   k_bucket_finish                one workgroup per bucket, parallel sweeps: roots, internal nodes and
+//                                  their children in the level-major numbering of the level-synchronous
+//                                  path, (leaf, pose) block table, position -> leaf map when needed.
 // Everything is HBM-bound integer / compare work; the f64 arithmetic is the reference's own
 // (exact comparisons on the rounded differences it forms).  Results are bit-identical to the
 // level-synchronous path of build.hip.
