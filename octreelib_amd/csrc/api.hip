@@ -10,52 +10,83 @@ namespace {
 // One pass over the new points of a pose: copies them into the forest's store (device sources),
 // marks them alive and folds their top-level voxel indices - floor((p - corner) / L), grid.py:72-76 -
 // into the forest's voxel bounding box, so that the build can form compact linear voxel keys without
-// a pass of its own.  Two points per thread, 16-byte accesses.
+// a pass of its own.
+// The cloud is read as a FLAT array of doubles, 16 bytes per lane and instruction (a lane reading its
+// own 48-byte pair of points touches every cache line three times): the bounding box needs the minimum
+// and maximum per AXIS, and the axis of flat element i is i mod 3, whichever point it belongs to.
+constexpr int ING_UNITS = 12;  // 16-byte units per thread
 template <bool COPY>
 __global__ __launch_bounds__(256) void k_ingest(const double* __restrict__ src, double* __restrict__ dst,
                                                 uint8_t* __restrict__ alive, int64_t n, int mode,
                                                 double L, int32_t* __restrict__ bbox) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p0 = 2 * t;
   const int big = 1 << 30;
   int mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
   bool bad = false;
-  if (p0 < n) {
-    double v[6];
-    const int m = (p0 + 1 < n) ? 6 : 3;
-    if (m == 6) {
-      const double2* s2 = reinterpret_cast<const double2*>(src + 3 * p0);
-      const double2 a = s2[0], b = s2[1], c = s2[2];
-      v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
-      if (COPY) {
-        double2* d2 = reinterpret_cast<double2*>(dst + 3 * p0);
-        d2[0] = a; d2[1] = b; d2[2] = c;
-      }
-      *reinterpret_cast<uint16_t*>(alive + p0) = 0x0101;
-    } else {
-      for (int j = 0; j < 3; ++j) {
-        v[j] = src[3 * p0 + j];
-        if (COPY) dst[3 * p0 + j] = v[j];
-      }
-      alive[p0] = 1;
-    }
-    if (mode == 0) {
-      const double lim = (double)OCTL_VOX_BIAS;
+  const int64_t n_flat = 3 * n, n_units = n_flat / 2;
+  const int64_t u0 = (int64_t)blockIdx.x * (256 * ING_UNITS) + threadIdx.x;
+  const double lim = (double)OCTL_VOX_BIAS;
+  auto fold = [&](double v, int axis) {
+    const double f = L == 1.0 ? floor(v) : floor_div_exact(v, L);  // (floor_div_exact(v, 1) == floor(v))
+    if (fabs(f) < lim) {  // false for NaN / inf
+      const int q = (int)f;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if (j < m) {
-          const double f = floor_div_exact(v[j], L);
-          if (fabs(f) < lim) {  // false for NaN / inf
-            const int q = (int)f;
-            mn[j % 3] = min(mn[j % 3], q);
-            mx[j % 3] = max(mx[j % 3], q);
-          } else {
-            bad = true;
-          }
+      for (int a = 0; a < 3; ++a) {
+        if (a == axis) {
+          mn[a] = min(mn[a], q);
+          mx[a] = max(mx[a], q);
         }
       }
     } else {
-      mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0;
+      bad = true;
+    }
+  };
+  // (a pose behind an odd number of stored points starts 8 bytes off: scalar accesses then)
+  const bool al16 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  double2 v[ING_UNITS];
+#pragma unroll
+  for (int k = 0; k < ING_UNITS; ++k) {
+    const int64_t u = u0 + k * 256;
+    if (u < n_units) {
+      if (al16) {
+        v[k] = reinterpret_cast<const double2*>(src)[u];
+      } else {
+        v[k].x = src[2 * u];
+        v[k].y = src[2 * u + 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ING_UNITS; ++k) {
+    const int64_t u = u0 + k * 256;
+    if (u < n_units) {
+      if (COPY) {
+        if (al16) {
+          reinterpret_cast<double2*>(dst)[u] = v[k];
+        } else {
+          dst[2 * u] = v[k].x;
+          dst[2 * u + 1] = v[k].y;
+        }
+      }
+      if (mode == 0) {
+        const int ax = (int)((2 * u) % 3);
+        fold(v[k].x, ax);
+        fold(v[k].y, ax == 2 ? 0 : ax + 1);
+      }
+    }
+  }
+  if ((n_flat & 1) && u0 == 0) {  // the last double of an odd number of points
+    const double t = src[n_flat - 1];
+    if (COPY) dst[n_flat - 1] = t;
+    if (mode == 0) fold(t, 2);
+  }
+  if (mode != 0 && u0 < n_units) mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0;
+  // alive flags: 16 per thread
+  {
+    const int64_t a0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (a0 + 16 <= n && (reinterpret_cast<uintptr_t>(alive) & 15) == 0) {
+      *reinterpret_cast<uint4*>(alive + a0) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+    } else {
+      for (int64_t i = a0; i < n && i < a0 + 16; ++i) alive[i] = 1;
     }
   }
   // wave + block reduction, then at most six atomics per block and only when the block widens the
@@ -323,7 +354,7 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
     hipStream_t st = ctx->stream;
     double* dst = f->xyz.as<double>() + 3 * f->n_store;
     uint8_t* alive = f->alive.as<uint8_t>() + f->n_store;
-    const unsigned grid = (unsigned)ceil_div(ceil_div(n, 2), 256);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(3 * n / 2, 256 * ING_UNITS));
     KTimer t(ctx, "ingest");
     // (an odd store offset would misalign the 16-byte accesses of the pair-wise kernel: such a pose
     //  goes through the plain copy + the in-place form on its own, 8-byte aligned, pointer)
@@ -346,7 +377,7 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
         hipLaunchKernelGGL(k_ingest<false>, dim3(1), dim3(256), 0, st, (const double*)dst, dst, alive,
                            (int64_t)1, f->mode, f->edge, f->bbox_dev.as<int32_t>());
         if (n > 1)
-          hipLaunchKernelGGL(k_ingest<false>, dim3((unsigned)ceil_div(ceil_div(n - 1, 2), 256)), dim3(256),
+          hipLaunchKernelGGL(k_ingest<false>, dim3((unsigned)std::max<int64_t>(1, ceil_div(3 * (n - 1) / 2, 256 * ING_UNITS))), dim3(256),
                              0, st, (const double*)(dst + 3), dst + 3, alive + 1, n - 1, f->mode, f->edge,
                              f->bbox_dev.as<int32_t>());
       }
