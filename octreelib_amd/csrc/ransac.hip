@@ -113,6 +113,47 @@ __device__ __forceinline__ void div3_by_norm(double& ax, double& ay, double& az,
   az = copysign(fma(fma(-norm, qz, az), r, qz), az);
 }
 
+// util.py:59-84: the plane of the centroid and the six covariance sums
+__device__ __forceinline__ void plane_from_moments(double cx, double cy, double cz, double xx, double xy,
+                                                   double xz, double yy, double yz, double zz,
+                                                   float (&plane)[4]) {
+  const double det_x = yy * zz - yz * yz;  // util.py:59-61
+  const double det_y = xx * zz - xz * xz;
+  const double det_z = xx * yy - xy * xy;
+  // util.py:63-74: the three cofactors that the branches share, then selects instead of a three-way
+  // branch (lanes of a wave take all three, so every branch body was executed anyway):
+  //   x: (det_x, A, B)   y: (A, det_y, C)   z: (B, C, det_z)
+  const double cA = xz * yz - xy * zz;
+  const double cB = xy * yz - xz * yy;
+  const double cC = xy * xz - yz * xx;
+  const bool is_x = det_x > det_y && det_x > det_z;
+  const bool is_y = !is_x && det_y > det_z;
+  double ax = is_x ? det_x : (is_y ? cA : cB);
+  double ay = is_x ? cA : (is_y ? det_y : cC);
+  double az = is_x ? cB : (is_y ? cC : det_z);
+#if RS_FAST_DIV
+  const double norm = sqrt_rn_guarded(ax * ax + ay * ay + az * az);  // util.py:76
+#else
+  const double norm = __dsqrt_rn(ax * ax + ay * ay + az * az);  // util.py:76
+#endif
+  if (norm == 0.0) {                                            // util.py:77-78
+    plane[0] = plane[1] = plane[2] = plane[3] = 0.0f;
+    return;
+  }
+#if RS_FAST_DIV
+  div3_by_norm(ax, ay, az, norm);
+#else
+  ax /= norm;
+  ay /= norm;
+  az /= norm;
+#endif
+  const double d = -(ax * cx + ay * cy + az * cz);  // util.py:83
+  plane[0] = (float)ax;
+  plane[1] = (float)ay;
+  plane[2] = (float)az;
+  plane[3] = (float)d;
+}
+
 // util.py:27-84 on k sampled points; returns the plane already rounded to f32
 // (cuda_ransac.py:110-113).  KT > 0: compile-time k (arrays stay in registers).
 template <int KT, int KMAX>
@@ -159,41 +200,7 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
       yz += ry * rz;
     }
   }
-  const double det_x = yy * zz - yz * yz;  // util.py:59-61
-  const double det_y = xx * zz - xz * xz;
-  const double det_z = xx * yy - xy * xy;
-  // util.py:63-74: the three cofactors that the branches share, then selects instead of a three-way
-  // branch (lanes of a wave take all three, so every branch body was executed anyway):
-  //   x: (det_x, A, B)   y: (A, det_y, C)   z: (B, C, det_z)
-  const double cA = xz * yz - xy * zz;
-  const double cB = xy * yz - xz * yy;
-  const double cC = xy * xz - yz * xx;
-  const bool is_x = det_x > det_y && det_x > det_z;
-  const bool is_y = !is_x && det_y > det_z;
-  double ax = is_x ? det_x : (is_y ? cA : cB);
-  double ay = is_x ? cA : (is_y ? det_y : cC);
-  double az = is_x ? cB : (is_y ? cC : det_z);
-#if RS_FAST_DIV
-  const double norm = sqrt_rn_guarded(ax * ax + ay * ay + az * az);  // util.py:76
-#else
-  const double norm = __dsqrt_rn(ax * ax + ay * ay + az * az);  // util.py:76
-#endif
-  if (norm == 0.0) {                                            // util.py:77-78
-    plane[0] = plane[1] = plane[2] = plane[3] = 0.0f;
-    return;
-  }
-#if RS_FAST_DIV
-  div3_by_norm(ax, ay, az, norm);
-#else
-  ax /= norm;
-  ay /= norm;
-  az /= norm;
-#endif
-  const double d = -(ax * cx + ay * cy + az * cz);  // util.py:83
-  plane[0] = (float)ax;
-  plane[1] = (float)ay;
-  plane[2] = (float)az;
-  plane[3] = (float)d;
+  plane_from_moments(cx, cy, cz, xx, xy, xz, yy, yz, zz, plane);
 }
 
 // util.py:22-24 with the f32 plane promoted to f64: ((a*x + b*y) + c*z) + d
@@ -271,6 +278,40 @@ __device__ __forceinline__ int sample_index_cached(double r, int n, bool* risky)
   return g0 < n ? g0 : n;
 }
 
+// The same fit for ANY k (the reference puts no bound on initial_points_number): the k sampled points
+// are streamed from global memory twice instead of being held in registers, and the centroid is
+// divided by k with the true division (div_by_small_int is only proven for k <= 16).
+__device__ __forceinline__ void plane_streamed(const double* __restrict__ hyp_row, int k, const BlockDesc& d,
+                                               const double* __restrict__ xyz, float (&plane)[4]) {
+  auto point = [&](int i) {
+    const int g = sample_index_exact(hyp_row[i], d.n, d.vstart);
+    return (g < d.n) ? (int64_t)d.pstart + g : (int64_t)d.pspill;
+  };
+  double cx = 0.0, cy = 0.0, cz = 0.0;
+  for (int i = 0; i < k; ++i) {  // util.py:37-40
+    const int64_t p = point(i);
+    cx += xyz[3 * p];
+    cy += xyz[3 * p + 1];
+    cz += xyz[3 * p + 2];
+  }
+  const double kd = (double)k;
+  cx = cx / kd;  // util.py:42-44
+  cy = cy / kd;
+  cz = cz / kd;
+  double xx = 0.0, xy = 0.0, xz = 0.0, yy = 0.0, yz = 0.0, zz = 0.0;
+  for (int i = 0; i < k; ++i) {  // util.py:48-57
+    const int64_t p = point(i);
+    const double rx = xyz[3 * p] - cx, ry = xyz[3 * p + 1] - cy, rz = xyz[3 * p + 2] - cz;
+    xx += rx * rx;
+    xy += rx * ry;
+    xz += rx * rz;
+    yy += ry * ry;
+    yz += ry * rz;
+    zz += rz * rz;
+  }
+  plane_from_moments(cx, cy, cz, xx, xy, xz, yy, yz, zz, plane);
+}
+
 // The exact (reference order) evaluation of one block whose points are in global memory.
 // THREADS lanes, HPL hypotheses per lane (lane t owns hypotheses t, t+THREADS, ...).
 template <int THREADS, int HPL, int KT>
@@ -292,20 +333,24 @@ __device__ __forceinline__ void ransac_block_global(const BlockDesc& d, int be,
     cnt[q] = -1;
     pa[q] = pb[q] = pc[q] = pd[q] = 0.0;
     if (t < H) {
-      double sx[KS], sy[KS], sz[KS];
-#pragma unroll
-      for (int i = 0; i < KS; ++i) {
-        sx[i] = sy[i] = sz[i] = 0.0;
-        if (i < k) {
-          const int g = sample_index_exact(hyp[(int64_t)t * k + i], n, d.vstart);
-          const int64_t p = (g < n) ? pstart + g : (int64_t)d.pspill;
-          sx[i] = xyz[3 * p];
-          sy[i] = xyz[3 * p + 1];
-          sz[i] = xyz[3 * p + 2];
-        }
-      }
       float pf[4];
-      plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
+      if constexpr (KT < 0) {
+        plane_streamed(hyp + (int64_t)t * k, k, d, xyz, pf);
+      } else {
+        double sx[KS], sy[KS], sz[KS];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          sx[i] = sy[i] = sz[i] = 0.0;
+          if (i < k) {
+            const int g = sample_index_exact(hyp[(int64_t)t * k + i], n, d.vstart);
+            const int64_t p = (g < n) ? pstart + g : (int64_t)d.pspill;
+            sx[i] = xyz[3 * p];
+            sy[i] = xyz[3 * p + 1];
+            sz[i] = xyz[3 * p + 2];
+          }
+        }
+        plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
+      }
       pa[q] = (double)pf[0];
       pb[q] = (double)pf[1];
       pc[q] = (double)pf[2];
@@ -869,20 +914,24 @@ __device__ __forceinline__ void ransac_block_tiled(const BlockDesc& d, int be,
     sdl[q] = 0.f;
     margin[q] = __int_as_float(0x7f800000);
     if (t < H) {
-      double sx[KS], sy[KS], sz[KS];
-#pragma unroll
-      for (int i = 0; i < KS; ++i) {
-        sx[i] = sy[i] = sz[i] = 0.0;
-        if (i < k) {
-          const int g = sample_index_exact(hyp[(int64_t)t * k + i], n, d.vstart);
-          const int64_t p = (g < n) ? pstart + g : (int64_t)d.pspill;
-          sx[i] = xyz[3 * p];
-          sy[i] = xyz[3 * p + 1];
-          sz[i] = xyz[3 * p + 2];
-        }
-      }
       float pf[4];
-      plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
+      if constexpr (KT < 0) {
+        plane_streamed(hyp + (int64_t)t * k, k, d, xyz, pf);
+      } else {
+        double sx[KS], sy[KS], sz[KS];
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          sx[i] = sy[i] = sz[i] = 0.0;
+          if (i < k) {
+            const int g = sample_index_exact(hyp[(int64_t)t * k + i], n, d.vstart);
+            const int64_t p = (g < n) ? pstart + g : (int64_t)d.pspill;
+            sx[i] = xyz[3 * p];
+            sy[i] = xyz[3 * p + 1];
+            sz[i] = xyz[3 * p + 2];
+          }
+        }
+        plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
+      }
       // (explicit fma: error BOUNDS and the screen's own inputs, not parity arithmetic; see k_ransac)
       const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
       const double to = fma(A, ox, fma(B, oy, fma(Cc, oz, D)));
@@ -994,7 +1043,10 @@ __global__ __launch_bounds__(THREADS) void k_ransac_big(const double* __restrict
     const int be = (int)big_list[j];
     const BlockDesc d = desc[be];
 #if RS_SCREEN
-    ransac_block_tiled<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_loc, s_wext, s_best, s_plane);
+    if constexpr (KT < 0)
+      ransac_block_global<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_best, s_plane);
+    else
+      ransac_block_tiled<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_loc, s_wext, s_best, s_plane);
 #else
     ransac_block_global<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_best, s_plane);
 #endif
@@ -1146,8 +1198,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   (void)evaluated_dev;
   if (nb <= 0) return OCTL_OK;
   if (H < 1 || H > 1024) return octl_set_error(ctx, OCTL_E_INVALID, "H must be in [1, 1024]");
-  if (k < 1 || k > RS_KMAX)
-    return octl_set_error(ctx, OCTL_E_INVALID, "initial_points_number must be in [1, %d]", RS_KMAX);
+  if (k < 1) return octl_set_error(ctx, OCTL_E_INVALID, "initial_points_number must be positive");
+  // more sample points than the register path holds: every block takes the exact path with a streamed fit
+  const bool any_k = k > RS_KMAX;
   if (nb >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "too many blocks");
   hipStream_t st = ctx->stream;
   // scratch: [sizes/scanned u32 nb+8 | desc 32 B x nb | sorted desc 32 B x nb | big list u32 nb |
@@ -1173,13 +1226,13 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     OCTL_TRY(octl_exclusive_scan_u32(ctx, tmp, tmp, nb, nullptr));
     HIP_TRY(ctx, hipMemsetAsync(counters, 0, RC_WORDS * 4, st));
     hipLaunchKernelGGL(k_block_desc, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size,
-                       (const uint32_t*)tmp, nb, n_points, threads - 1, (int)k, desc, big_list,
+                       (const uint32_t*)tmp, nb, n_points, any_k ? 0 : threads - 1, (int)k, desc, big_list,
                        counters, out);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(256), 0, st, counters);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_block_scatter, dim3((unsigned)ceil_div(nb, 1024)), dim3(256), 0, st,
-                       (const BlockDesc*)desc, nb, threads - 1, (int)k, counters, sdesc);
+                       (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc);
     HIP_TRY(ctx, hipGetLastError());
   }
   int cus = 256;
@@ -1196,7 +1249,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                        xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(counters + RC_SORTED), \
                        hyp_dev, H, k, thr, out);                                                  \
   } while (0)
-  if (H <= 64) {
+  if (any_k) {
+    // (nothing was put on the sorted list)
+  } else if (H <= 64) {
     if (k == 6) OCTL_RANSAC_LAUNCH(64, 1, 6, 0, 16); else OCTL_RANSAC_LAUNCH(64, 1, 0, 0, 8);
   } else if (H <= 256) {
     if (k == 6) OCTL_RANSAC_LAUNCH(256, 1, 6, 0, 8); else OCTL_RANSAC_LAUNCH(256, 1, 0, 0, 4);
@@ -1220,7 +1275,11 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                      dim3(THREADS), 0, st, xyz_dev, (const BlockDesc*)desc,                     \
                      (const uint32_t*)big_list, (const uint32_t*)(counters + RC_BIG), hyp_dev,  \
                      H, k, thr, out)
-  if (H <= 64) {
+  if (any_k) {
+    if (H <= 64) OCTL_RANSAC_BIG(64, 1, -1);
+    else if (H <= 256) OCTL_RANSAC_BIG(256, 1, -1);
+    else OCTL_RANSAC_BIG(RS_BIG_THREADS, RS_BIG_HPL, -1);
+  } else if (H <= 64) {
     if (k == 6) OCTL_RANSAC_BIG(64, 1, 6); else OCTL_RANSAC_BIG(64, 1, 0);
   } else if (H <= 256) {
     if (k == 6) OCTL_RANSAC_BIG(256, 1, 6); else OCTL_RANSAC_BIG(256, 1, 0);

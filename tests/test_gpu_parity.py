@@ -539,10 +539,12 @@ def test_ransac_operator_random_blocks_vs_oracle():
         assert np.array_equal(mask, o_mask)
 
 
-@pytest.mark.parametrize("H,k", [(1, 6), (2, 3), (65, 6), (255, 2), (257, 1), (1000, 16), (1024, 7), (64, 16), (1024, 3), (513, 4), (1024, 5)])
+@pytest.mark.parametrize("H,k", [(1, 6), (2, 3), (65, 6), (255, 2), (257, 1), (1000, 16), (1024, 7), (64, 16), (1024, 3), (513, 4), (1024, 5),
+                                 (1024, 17), (200, 33), (64, 100)])
 def test_ransac_operator_boundary_shapes_vs_oracle(H, k):
     """Block sizes around the LDS-staged / global-memory split (255 | 256 points), around k, empty
-    blocks; hypothesis counts around the 64 / 256 / 1024 lane mappings; every supported k."""
+    blocks; hypothesis counts around the 64 / 256 / 1024 lane mappings; k in registers (<= 16) and
+    streamed (any k, as the reference allows)."""
     from octreelib_amd.ransac import CudaRansac
     from oracle import ransac_np as rnp
 
