@@ -3,8 +3,9 @@
 import collections, csv, glob, re, sys
 
 def short(k):
-    m = re.search(r"(k_[a-z0-9_]+|__amd_rocclr_[A-Za-z]+)", k)
-    return m.group(1) if m else k[:40]
+    # (template arguments kept: k_bucket_build<false> / <true> and k_ingest<true> / <false> are different launches)
+    m = re.search(r"(k_[a-z0-9_]+(?:<[^>(]*>)?|__amd_rocclr_[A-Za-z]+)", k)
+    return m.group(1).replace(" ", "") if m else k[:40]
 
 tab = collections.defaultdict(dict)
 dur = {}

@@ -13,8 +13,9 @@ import sys
 
 
 def short(k):
-    m = re.search(r"(k_[a-z0-9_]+|__amd_rocclr_[A-Za-z]+)", k)
-    return m.group(1) if m else k[:40]
+    # (template arguments kept: k_bucket_build<false> / <true> and k_ingest<true> / <false> are different launches)
+    m = re.search(r"(k_[a-z0-9_]+(?:<[^>(]*>)?|__amd_rocclr_[A-Za-z]+)", k)
+    return m.group(1).replace(" ", "") if m else k[:40]
 
 
 def counters(d):
@@ -73,7 +74,9 @@ def main():
     json.dump({"_note": "SQ counters per launch (sum over XCDs); SQ_* cycle counters are quad-cycles; "
                         "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8)",
                "kernels": rows}, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
-    for k in ("k_ransac", "k_ingest", "k_part_hist", "k_part_scatter", "k_bucket_build", "k_bucket_nodes", "k_compact_ord"):
+    for k in sorted(set(rows) | set(out["kernels"])):
+        if not re.match(r"k_(ransac<|ingest|part_|bucket_|compact_tiles)", k):
+            continue
         if k in rows:
             print(k, json.dumps(rows[k]))
         if k in out["kernels"]:
