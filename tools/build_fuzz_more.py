@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""More seeds for the tests that build the same forest through the bucket path and through the
+level-synchronous path and compare everything bit for bit (run on the GPU box)."""
+import sys, traceback
+sys.path.insert(0, '.')
+from _pytest.monkeypatch import MonkeyPatch
+import tests.test_gpu_parity as T
+
+cases = [(T.test_voxel_local_build_random_voxels_vs_level_synchronous_build, range(10, 70)),
+         (T.test_bucket_build_mixed_voxel_populations_vs_level_synchronous_build, range(6, 30)),
+         (T.test_bucket_build_two_pass_partition_vs_level_synchronous_build, range(3, 12))]
+bad = 0
+for fn, seeds in cases:
+    for seed in seeds:
+        mp = MonkeyPatch()
+        try:
+            fn(mp, seed)
+        except Exception:
+            bad += 1
+            print("FAILED", fn.__name__, seed); traceback.print_exc()
+        finally:
+            mp.undo()
+    print(fn.__name__, "done", flush=True)
+print("failures:", bad)
