@@ -77,6 +77,61 @@ __device__ __forceinline__ uint32_t digit_of(const LinParams& lp, uint32_t lin) 
   return (lin >> lp.dshift) & lp.dmask;
 }
 
+// The geometry of the linear voxel keys, formed ON THE DEVICE from the bounding box the ingest kernel
+// keeps: clouds that need one partition pass (up to 4096 buckets - ~10 M points) are partitioned and
+// built without the host ever waiting for the box; it reads this record together with the bucket totals.
+struct GeomDev {
+  LinParams lp;
+  int32_t bb[6];
+  uint32_t valid;   // 1: the kernels run; 0: they return at once, and the host acts on `reason`
+  uint32_t reason;  // 1 a point outside the voxel domain, 2 nothing alive, 3 not a single-pass case
+};
+enum { GEOM_DOMAIN = 1, GEOM_EMPTY = 2, GEOM_RETRY = 3 };
+static_assert(sizeof(GeomDev) <= 192, "GeomDev lives in the scalar block");
+
+__global__ void k_bucket_geom(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+                              GeomDev* __restrict__ g) {
+  if (threadIdx.x != 0) return;
+  GeomDev o;
+  o.lp = base;
+  for (int a = 0; a < 6; ++a) o.bb[a] = bbox[a];
+  o.valid = 0;
+  o.reason = 0;
+  if (bbox[6]) {
+    o.reason = GEOM_DOMAIN;
+  } else if (o.bb[0] > o.bb[3]) {
+    o.reason = GEOM_EMPTY;
+  } else {
+    const uint64_t nx = (uint64_t)(o.bb[3] - o.bb[0] + 1), ny = (uint64_t)(o.bb[4] - o.bb[1] + 1),
+                   nz = (uint64_t)(o.bb[5] - o.bb[2] + 1);
+    if (nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32)) {
+      o.reason = GEOM_RETRY;  // (the host path decides: keys would not fit 32 bits)
+    } else {
+      const uint64_t R = nx * ny * nz;
+      int lr = 0, lw = 0;
+      while (lr < 64 && (1ull << lr) < R) ++lr;
+      while (lw < 64 && (1ull << lw) < want) ++lw;
+      int s = lr - lw;
+      s = s < 0 ? 0 : (s > 12 ? 12 : s);
+      if (((R - 1) >> s) + 1 > (uint64_t)(1u << 12)) {
+        o.reason = GEOM_RETRY;  // a sparse scene: more than 4096 buckets, two passes
+      } else {
+        o.lp.minx = o.bb[0];
+        o.lp.miny = o.bb[1];
+        o.lp.minz = o.bb[2];
+        o.lp.ny = (uint32_t)ny;
+        o.lp.nz = (uint32_t)nz;
+        o.lp.shift = s;
+        o.lp.dshift = s;
+        o.lp.dmask = 0xFFFFFFFFu;
+        o.lp.raw_vp = 0;
+        o.valid = 1;
+      }
+    }
+  }
+  *g = o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // partition
 // ---------------------------------------------------------------------------------------------
@@ -154,9 +209,14 @@ __device__ __forceinline__ uint32_t lin_corner_of(const LinParams& lp, double x,
 constexpr int PH_THREADS = 1024;
 __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restrict__ xyz,
                                                           const uint8_t* __restrict__ alive, int64_t N,
-                                                          LinParams lp, uint32_t nst, uint32_t nd,
+                                                          LinParams lp, const GeomDev* __restrict__ G,
+                                                          uint32_t nst, uint32_t nd,
                                                           int64_t st_items, uint32_t* __restrict__ table) {
   __shared__ uint32_t hist[PT_BINS];
+  if (G) {  // geometry formed on the device (k_bucket_geom)
+    if (!G->valid) return;
+    lp = G->lp;
+  }
   for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) hist[d] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * st_items;
@@ -215,11 +275,16 @@ __device__ __forceinline__ uint32_t wave_rank_u16(uint32_t digit, bool valid, ui
 template <int PT_IPT, bool FROM_REC>
 __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     const double* __restrict__ xyz, const uint8_t* __restrict__ alive, int64_t N, LinParams lp,
-    uint32_t nst, uint32_t nd, int st_tiles, const uint32_t* __restrict__ table_scanned,
+    const GeomDev* __restrict__ G, uint32_t nst, uint32_t nd, int st_tiles,
+    const uint32_t* __restrict__ table_scanned,
     const int64_t* __restrict__ pose_off, int n_poses, const uint8_t* __restrict__ scheme,
     PartRec* __restrict__ out) {
   __shared__ uint32_t base[PT_BINS];                 // running destination of every bucket
   __shared__ uint16_t cnt[PT_THREADS / 64][PT_BINS]; // per wave, per tile
+  if (G) {
+    if (!G->valid) return;
+    lp = G->lp;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
     base[d] = table_scanned[(size_t)d * nst + blockIdx.x];
@@ -802,9 +867,14 @@ constexpr int BB_MAX_CHUNKS = 64;
 template <bool OVERSIZE>
 __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
     const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
+    const GeomDev* __restrict__ G,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
     uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_node,
     uint32_t* __restrict__ bk_tot, uint32_t* __restrict__ small) {
+  if (G) {
+    if (!G->valid) return;
+    P.lp = G->lp;
+  }
   __shared__ uint32_t s_bins[BB_BINS];            // pyramid bins; afterwards KEY[BB_CAP] | INFO[BB_CAP]
   __shared__ uint32_t s_base[BK_ROWS];            // totals of the bucket before the current chunk
   __shared__ uint16_t s_slot[2][BB_CAP];          // sort buffers: positions -> item
@@ -1214,9 +1284,21 @@ int ceil_log2_u64(uint64_t v) {
 // Complete build of a fresh forest (no previous scheme): *done = 1 when the scheme, the leaf-ordered
 // arrays, pos_node and the block table are complete; *done = 0 when this path does not apply (the
 // caller then runs the general path; nothing it relies on has been modified).
+static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,
+                             std::vector<octl_forest::LevelSeg>* segs, int64_t* n_internal, int* levels,
+                             int64_t* n_voxels, int64_t* n_blocks, int64_t* pending, BucketBuildGeom* geom,
+                             bool force_sync);
+
 int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,
                         std::vector<octl_forest::LevelSeg>* segs, int64_t* n_internal, int* levels,
                         int64_t* n_voxels, int64_t* n_blocks, int64_t* pending, BucketBuildGeom* geom) {
+  return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, false);
+}
+
+static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,
+                             std::vector<octl_forest::LevelSeg>* segs, int64_t* n_internal, int* levels,
+                             int64_t* n_voxels, int64_t* n_blocks, int64_t* pending, BucketBuildGeom* geom,
+                             bool force_sync) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
   *done = 0;
@@ -1224,28 +1306,39 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   // (OCTL_NO_BUCKET_BUILD: tests compare this path with the level-synchronous one)
   if (n_alive <= 0 || !f->bbox_dev.p || getenv("OCTL_NO_BUCKET_BUILD")) return OCTL_OK;
   const int n_poses = (int)f->pose_off.size() - 1;
-  // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
-  HIP_TRY(ctx, hipEventSynchronize(f->bbox_event));
-  int bb[6];
-  std::memcpy(bb, f->bbox_host, sizeof(bb));
-  if (f->bbox_host[6])
-    return octl_set_error(ctx, OCTL_E_DOMAIN,
-                          "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
-                          OCTL_VOX_BIAS);
-  if (bb[0] > bb[3]) return OCTL_OK;
-  const uint64_t nx = (uint64_t)(bb[3] - bb[0] + 1), ny = (uint64_t)(bb[4] - bb[1] + 1),
-                 nz = (uint64_t)(bb[5] - bb[2] + 1);
-  if (nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32)) return OCTL_OK;  // keys would not fit 32 bits
-  const uint64_t R = nx * ny * nz;
   // buckets: runs of 2^s consecutive voxel keys, sized for ~2500 points on average (at most 2^24)
   // (OCTL_BUCKET_POINTS: tests force many small buckets - and with them the two-pass partition - on small clouds)
   const uint64_t target = getenv("OCTL_BUCKET_POINTS") ? std::max(1, atoi(getenv("OCTL_BUCKET_POINTS"))) : 2560;
   uint64_t want = 1;
   while (want < ((uint64_t)PT_BINS << PT_BITS) && want * target < (uint64_t)n_alive) want <<= 1;
-  const int s = std::min(12, std::max(0, ceil_log2_u64(R) - ceil_log2_u64(want)));
-  if (((R - 1) >> s) + 1 > ((uint64_t)PT_BINS << PT_BITS)) return OCTL_OK;  // a sparse scene: too many keys
-  const uint32_t nb = (uint32_t)(((R - 1) >> s) + 1);
-  const bool two_pass = nb > (uint32_t)PT_BINS;
+  // One partition pass (want <= 4096 buckets): the key geometry is formed on the device (k_bucket_geom) and
+  // the host does not wait for the bounding box; all 4096 buckets exist then, the ones behind the last
+  // voxel key are empty.  (OCTL_SYNC_GEOM: tests run the host-side form on small clouds too.)
+  const bool async_geom = !force_sync && want <= (uint64_t)PT_BINS && !getenv("OCTL_SYNC_GEOM");
+  int bb[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t ny = 1, nz = 1;
+  int s = 0;
+  uint32_t nb = (uint32_t)PT_BINS;
+  bool two_pass = false;
+  if (!async_geom) {
+    // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
+    HIP_TRY(ctx, hipEventSynchronize(f->bbox_event));
+    std::memcpy(bb, f->bbox_host, sizeof(bb));
+    if (f->bbox_host[6])
+      return octl_set_error(ctx, OCTL_E_DOMAIN,
+                            "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
+                            OCTL_VOX_BIAS);
+    if (bb[0] > bb[3]) return OCTL_OK;
+    const uint64_t nx = (uint64_t)(bb[3] - bb[0] + 1);
+    ny = (uint64_t)(bb[4] - bb[1] + 1);
+    nz = (uint64_t)(bb[5] - bb[2] + 1);
+    if (nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32)) return OCTL_OK;  // keys would not fit 32 bits
+    const uint64_t R = nx * ny * nz;
+    s = std::min(12, std::max(0, ceil_log2_u64(R) - ceil_log2_u64(want)));
+    if (((R - 1) >> s) + 1 > ((uint64_t)PT_BINS << PT_BITS)) return OCTL_OK;  // a sparse scene: too many keys
+    nb = (uint32_t)(((R - 1) >> s) + 1);
+    two_pass = nb > (uint32_t)PT_BINS;
+  }
 
   LinParams lp;
   lp.mode = f->mode;
@@ -1259,6 +1352,9 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   lp.ny = (uint32_t)ny;
   lp.nz = (uint32_t)nz;
   lp.shift = s;
+  lp.dshift = s;
+  lp.dmask = 0xFFFFFFFFu;
+  lp.raw_vp = 0;
   uint32_t* small = ctx->small.as<uint32_t>();
   // supertiles: one round of workgroups (2 per CU) over the cloud, at most 16 tiles each
   int cus = 256;
@@ -1296,6 +1392,12 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n_alive * 4));
   uint32_t* table = f->bk_table.as<uint32_t>();
   HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_FLAGS, 0, 12, st));  // flags, grand total, pending voxels
+  GeomDev* gdev = nullptr;
+  if (async_geom) {
+    gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
+    hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want, lp, gdev);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   // ---- partition ----------------------------------------------------------------------------------------------
   lp.dshift = s;
   lp.dmask = two_pass ? (uint32_t)(PT_BINS - 1) : 0xFFFFFFFFu;
@@ -1303,7 +1405,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   {
     KTimer t(ctx, "part_hist");
     hipLaunchKernelGGL(k_part_hist, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
-                       (const uint8_t*)f->alive.as<uint8_t>(), N, lp, nst_a, nd_a,
+                       (const uint8_t*)f->alive.as<uint8_t>(), N, lp, (const GeomDev*)gdev, nst_a, nd_a,
                        (int64_t)st_tiles_a * tile, table);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1315,7 +1417,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
     KTimer t(ctx, "part_scatter");
     hipLaunchKernelGGL((k_part_scatter<PT_IPT, false>), dim3(nst_a), dim3(PT_THREADS), 0, st,
                        (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
-                       nst_a, nd_a, st_tiles_a, (const uint32_t*)table,
+                       (const GeomDev*)gdev, nst_a, nd_a, st_tiles_a, (const uint32_t*)table,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
                        f->part_xyz[0].as<PartRec>());
     HIP_TRY(ctx, hipGetLastError());
@@ -1343,7 +1445,7 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
       KTimer t(ctx, "part_scatter");
       hipLaunchKernelGGL((k_part_scatter<PT_IPT, true>), dim3(nst_b), dim3(PT_THREADS), 0, st,
                          (const double*)f->part_xyz[0].as<double>(), (const uint8_t*)nullptr, n_alive, lp,
-                         nst_b, nd_b, st_tiles_b, (const uint32_t*)table, (const int64_t*)nullptr, 0,
+                         (const GeomDev*)nullptr, nst_b, nd_b, st_tiles_b, (const uint32_t*)table, (const int64_t*)nullptr, 0,
                          (const uint8_t*)nullptr, f->part_xyz[1].as<PartRec>());
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -1371,12 +1473,12 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   {
     KTimer t(ctx, "bucket_build");
     hipLaunchKernelGGL(k_bucket_build<false>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
-                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
+                       (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
                        bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_bucket_build<true>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
-                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
+                       (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
                        bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
@@ -1390,8 +1492,28 @@ int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt,
   }
   uint32_t sm[64];
   HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small, sizeof(sm), hipMemcpyDeviceToHost, st));
+  if (async_geom)
+    HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ctx->small_host) + SM_GEOM * 4, small + SM_GEOM, sizeof(GeomDev),
+                                hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   std::memcpy(sm, ctx->small_host, sizeof(sm));
+  if (async_geom) {
+    GeomDev g;
+    std::memcpy(&g, static_cast<char*>(ctx->small_host) + SM_GEOM * 4, sizeof(g));
+    if (!g.valid) {
+      if (g.reason == GEOM_DOMAIN)
+        return octl_set_error(ctx, OCTL_E_DOMAIN,
+                              "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
+                              OCTL_VOX_BIAS);
+      if (g.reason == GEOM_EMPTY) return OCTL_OK;
+      // not a single-pass case after all (a sparse scene): the host-side form decides
+      return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
+    }
+    lp = g.lp;
+    std::memcpy(bb, g.bb, sizeof(bb));
+    ny = lp.ny;
+    nz = lp.nz;
+  }
   if (sm[SM_BK_FLAGS]) return OCTL_OK;  // some bucket / voxel does not fit: the caller runs the general path
   const int64_t V = sm[SM_NVOX];
   int64_t n_int = 0;

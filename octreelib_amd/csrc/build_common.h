@@ -20,6 +20,7 @@ enum {
   SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
   // 64..: slot histogram, 512..: allreduce
+  SM_GEOM = 768,        // bucket build: key geometry formed on the device (GeomDev, <= 192 bytes)
 };
 
 struct NodePtrs {
