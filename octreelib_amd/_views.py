@@ -183,15 +183,18 @@ def map_slots(forest, slots: Iterable[int], function: Callable):
             pts = xyz[s : s + z]
             res = np.asarray(function(pts.copy()), dtype=float).reshape(-1, 3)
             sel = np.zeros(z, dtype=np.uint8)
-            used = np.zeros(z, dtype=bool)
-            for row in res:
-                hit = np.nonzero((pts == row).all(axis=1) & ~used)[0]
-                if len(hit) == 0:
+            # the returned rows are matched against the leaf's own rows by value (bytes of the three f64;
+            # equal rows are handed out in storage order), one dictionary per leaf
+            where = {}
+            for i in range(z - 1, -1, -1):
+                where.setdefault(pts[i].tobytes(), []).append(i)
+            for row in np.ascontiguousarray(res, dtype=np.float64):
+                hit = where.get(row.tobytes())
+                if not hit:
                     raise NotImplementedError(
                         "map_leaf_points: the function returned a point that is not one of the "
                         "leaf's points; only selections of the leaf's own points are supported"
                     )
-                used[hit[0]] = True
-                sel[hit[0]] = 1
+                sel[hit.pop()] = 1
             keep[s : s + z] = sel
     forest.apply_host_mask(keep)
