@@ -115,7 +115,13 @@ __global__ __launch_bounds__(256) void k_inc_place(const double* __restrict__ xy
   }
   int32_t node = (int32_t)r;
   int32_t fc = first_child[node];
-  while (fc >= 0) {
+  // (children are numbered behind their parents, so the walk ends; the bound only guards against a
+  //  damaged table - the general path then reports it)
+  for (int depth = 0; fc >= 0; ++depth) {
+    if (depth >= 64) {
+      atomicAdd(&small[SM_INC_BAD], 1u);
+      break;
+    }
     const double cx = corner[3 * (int64_t)node + 0], cy = corner[3 * (int64_t)node + 1],
                  cz = corner[3 * (int64_t)node + 2], e = edge[node];
     const double h = e / 2.0;
