@@ -428,6 +428,16 @@ def main():
     info, n_alive_after = wl.info, int(wl.n_alive.value)
     leaves, nodes, levels = int(info.n_blocks), int(info.n_nodes), int(info.n_levels)
 
+    # host <-> device round trips of one step (library-internal synchronisations, counted by the library;
+    # a few extra steps outside the timed region, profiling off)
+    host_syncs = None
+    if world == 1 and not route:
+        c0, c1 = C.c_uint64(0), C.c_uint64(0)
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
+        wl.run(4)
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
+        host_syncs = (c1.value - c0.value) / 4.0
+
     # ---- secondary figures (outside the timed region) --------------------------------------------
     secondary = {}
     flops = None
@@ -588,6 +598,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "host_syncs_per_step": host_syncs,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -260,6 +260,10 @@ int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot);
 int octl_forest_add_pose_routed_from(octl_forest* f, octl_ctx* route_ctx, int32_t* slot);
 /* global indices of the routed cloud of the last octl_route_points call (n_recv) i64        */
 int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n);
+/* Number of times the library has made the host wait for the device (stream / event synchronisations)
+ * since it was loaded: bench.py reports the round trips per step from it.                        */
+int octl_debug_host_syncs(uint64_t* count);
+
 /* Test hook: the communicator-independent half of octl_route_points for ANY number of ranks -
  * destination of every point (host cloud in), per-destination counts [n_ranks], and the packed
  * send buffers (points and global indices stably partitioned by destination).                */

@@ -13,6 +13,21 @@
 
 #include "../../include/octreelib_hip.h"
 
+// Every place where the host waits for the device is counted (octl_debug_host_syncs): the number of
+// round trips per step is part of what bench.py reports.
+#include <atomic>
+extern std::atomic<uint64_t> g_octl_host_syncs;
+static inline hipError_t octl_counted_stream_sync(hipStream_t s) {
+  g_octl_host_syncs.fetch_add(1, std::memory_order_relaxed);
+  return hipStreamSynchronize(s);
+}
+static inline hipError_t octl_counted_event_sync(hipEvent_t e) {
+  g_octl_host_syncs.fetch_add(1, std::memory_order_relaxed);
+  return hipEventSynchronize(e);
+}
+#define hipStreamSynchronize(s) octl_counted_stream_sync(s)
+#define hipEventSynchronize(e) octl_counted_event_sync(e)
+
 #define OCTL_WAVE 64
 #define OCTL_PINNED_BYTES (256 * 1024)
 

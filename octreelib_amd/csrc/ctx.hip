@@ -13,6 +13,14 @@ int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...) {
   return code;
 }
 
+std::atomic<uint64_t> g_octl_host_syncs{0};
+
+extern "C" int octl_debug_host_syncs(uint64_t* count) {
+  if (!count) return OCTL_E_INVALID;
+  *count = g_octl_host_syncs.load(std::memory_order_relaxed);
+  return OCTL_OK;
+}
+
 int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
   if (bytes <= b.cap) return OCTL_OK;
   size_t want = bytes + bytes / 4 + 256;  // grow with slack so level loops rarely realloc
@@ -72,7 +80,11 @@ void devbuf_release(octl_ctx* ctx, DevBuf& b) {
 }
 
 int pin_region_wait(octl_ctx* ctx, int r) {
-  if (ctx->pin_event[r]) HIP_TRY(ctx, hipEventSynchronize(ctx->pin_event[r]));
+  // (a copy out of the region that finished long ago - the usual case - costs no wait)
+  if (ctx->pin_event[r] && hipEventQuery(ctx->pin_event[r]) != hipSuccess) {
+    (void)hipGetLastError();  // (hipErrorNotReady is not an error here; keep it out of the launch checks)
+    HIP_TRY(ctx, hipEventSynchronize(ctx->pin_event[r]));
+  }
   return OCTL_OK;
 }
 
