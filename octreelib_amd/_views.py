@@ -21,14 +21,16 @@ class LeafView(Voxel):
     __slots__ = ("_xyz", "_start", "_size", "node")
 
     def __init__(self, corner_min, edge_length, xyz, start, size, node):
+        # (start, size, node: Python ints - the callers hand over .tolist() values; this constructor runs
+        #  once per leaf, 4 * 10^5 times for a 10 M point grid)
         self._corner_min = corner_min
         self._edge_length = edge_length
         self._id = None  # resolved on first access (internal/voxel.py)
         self._points = None
         self._xyz = xyz
-        self._start = int(start)
-        self._size = int(size)
-        self.node = int(node)
+        self._start = start
+        self._size = size
+        self.node = node
 
     def get_points(self):
         if self._size == 0:
@@ -53,6 +55,19 @@ def _node_corner(forest, node):
     return c.copy()
 
 
+def _node_corners(forest, nodes: np.ndarray):
+    """_node_corner for many nodes at once: a list of per-leaf corner arrays (each its own copy)."""
+    nd = forest.nodes
+    corners = list(nd["corner"][nodes])          # rows of a fresh (m, 3) array
+    if forest.mode == 0:
+        roots = np.nonzero(nd["depth"][nodes] == 0)[0]
+        if len(roots):
+            vox = forest.voxels[nd["voxel"][nodes[roots]]]   # int64 corners of the root leaves
+            for i, row in zip(roots.tolist(), vox):
+                corners[i] = row
+    return corners
+
+
 def leaf_views(forest, slot: int, non_empty: bool = True) -> List[LeafView]:
     """Leaves of one pose in the reference's order (voxel lexicographic, cached-leaf order)."""
     nd = forest.nodes
@@ -62,9 +77,11 @@ def leaf_views(forest, slot: int, non_empty: bool = True) -> List[LeafView]:
         if len(ids) == 0:
             return []
         xyz = forest.xyz
+        nodes = blk["node"][ids]
         return [
-            LeafView(_node_corner(forest, n), nd["edge"][n], xyz, s, z, n)
-            for n, s, z in zip(blk["node"][ids].tolist(), blk["start"][ids].tolist(), blk["size"][ids].tolist())
+            LeafView(c, e, xyz, s, z, n)
+            for c, e, s, z, n in zip(_node_corners(forest, nodes), nd["edge"][nodes], blk["start"][ids].tolist(),
+                                     blk["size"][ids].tolist(), nodes.tolist())
         ]
     # all leaves, empty ones included: host-side ordering from the node table
     order = all_leaves_order(forest, slot)
