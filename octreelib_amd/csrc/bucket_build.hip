@@ -1105,6 +1105,11 @@ struct NodeParams {
   int n_poses, all_scheme, cur_epoch;
   int64_t node_cap;   // capacity of the node table (nodes); a larger table is needed -> overflow flag
   int write_pos;      // position -> leaf is only read by the level loop that finishes the voxels left behind
+  // previous scheme (nullptr: none): epochs of the nodes that were internal before, roots' old ids
+  const int32_t* old_fc;
+  const int32_t* old_epoch;
+  const uint64_t* old_vcode;
+  int64_t old_voxels;
 };
 
 // One workgroup per bucket, three independent sweeps (nothing is a serial chain any more: the bucket
@@ -1115,6 +1120,52 @@ struct NodeParams {
 //            first_child / epoch and its eight children (octree.py:177-191)
 //   blocks   the leafinfo words in storage order: (leaf, pose) block table, and position -> leaf when
 //            the level loop of build.hip is going to resume
+// packed key (forest.h) of the voxel with linear key lin; root of that voxel in the previous scheme or -1
+__device__ __forceinline__ int32_t old_root_of(const NodeParams& P, uint32_t lin) {
+  int64_t qx = 0, qy = 0, qz = 0;
+  if (P.lp.mode == 0) {
+    qz = (int64_t)(lin % P.lp.nz) + P.lp.minz;
+    qy = (int64_t)((lin / P.lp.nz) % P.lp.ny) + P.lp.miny;
+    qx = (int64_t)(lin / (P.lp.nz * P.lp.ny)) + P.lp.minx;
+  }
+  const uint64_t code = ((uint64_t)(qx + OCTL_VOX_BIAS) << 42) | ((uint64_t)(qy + OCTL_VOX_BIAS) << 21) |
+                        (uint64_t)(qz + OCTL_VOX_BIAS);
+  int64_t lo = 0, hi = P.old_voxels;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (P.old_vcode[mid] < code) lo = mid + 1; else hi = mid;
+  }
+  return (lo < P.old_voxels && P.old_vcode[lo] == code) ? (int32_t)lo : -1;
+}
+
+// every voxel of the previous scheme must be a voxel again (they persist even without points, which this
+// path cannot express): counts the ones that are not
+__global__ __launch_bounds__(256) void k_old_voxels_missing(const uint64_t* __restrict__ old_vcode, int64_t old_V,
+                                                            const uint64_t* __restrict__ new_vlin, int64_t new_V,
+                                                            LinParams lp, int nx, uint32_t* __restrict__ missing) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= old_V) return;
+  const uint64_t k = old_vcode[r];
+  const int64_t qx = (int64_t)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS, qy = (int64_t)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS,
+                qz = (int64_t)(k & 0x1FFFFF) - OCTL_VOX_BIAS;
+  bool found = false;
+  if (lp.mode != 0) {
+    found = new_V > 0;
+  } else {
+    const int64_t ax = qx - lp.minx, ay = qy - lp.miny, az = qz - lp.minz;
+    if (ax >= 0 && ax < nx && ay >= 0 && ay < (int64_t)lp.ny && az >= 0 && az < (int64_t)lp.nz) {
+      const uint64_t lin = ((uint64_t)ax * lp.ny + (uint64_t)ay) * lp.nz + (uint64_t)az;
+      int64_t lo = 0, hi = new_V;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (new_vlin[mid] < lin) lo = mid + 1; else hi = mid;
+      }
+      found = lo < new_V && new_vlin[lo] == lin;
+    }
+  }
+  if (!found) atomicAdd(missing, 1u);
+}
+
 __global__ __launch_bounds__(256) void k_bucket_finish(
     NodePtrs nd, NodeParams P, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bk_base,
     const uint32_t* __restrict__ grand_total, const uint32_t* __restrict__ leafinfo,
@@ -1178,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       nd.depth[v] = 0;
       nd.voxel[v] = v;
       nd.parent[v] = -1;
-      nd.old_id[v] = -1;
+      nd.old_id[v] = P.old_fc ? old_root_of(P, lin) : -1;
       nd.edge[v] = P.lp.L;
       nd.corner[3 * (int64_t)v] = c0x;
       nd.corner[3 * (int64_t)v + 1] = c0y;
@@ -1220,7 +1271,18 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     const double h = e / 2.0;
     if (c == 0) {
       nd.first_child[xid] = cb;
-      nd.epoch[xid] = P.cur_epoch;
+      int32_t ep = P.cur_epoch;
+      if (P.old_fc) {
+        // the same node (voxel, path) of the previous scheme: internal there -> it keeps its epoch
+        // (k_make_children of build.hip: epoch = old_epoch[old id] when the old node had children)
+        int32_t o = old_root_of(P, bk_vox[3 * ((size_t)start + vord)]);
+        for (int t = 0; t < l && o >= 0; ++t) {
+          const int32_t ofc = P.old_fc[o];
+          o = ofc >= 0 ? ofc + (int32_t)((prefix >> (3 * (l - 1 - t))) & 7u) : -1;
+        }
+        if (o >= 0 && P.old_fc[o] >= 0) ep = P.old_epoch[o];
+      }
+      nd.epoch[xid] = ep;
     }
     const int64_t ch = (int64_t)cb + c;
     nd.start[ch] = 0;  // ranges are only meaningful inside the level-synchronous path
@@ -1543,6 +1605,10 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   np.cur_epoch = a.cur_epoch;
   np.node_cap = nt.cap;
   np.write_pos = sm[SM_BK_TODO] > 0;
+  np.old_fc = a.old_fc;
+  np.old_epoch = a.old_epoch;
+  np.old_vcode = a.old_vcode;
+  np.old_voxels = a.old_voxels;
   {
     KTimer t(ctx, "bucket_nodes");
     hipLaunchKernelGGL(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd, np, bstart,
@@ -1557,6 +1623,20 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                        (const uint32_t*)f->blk_start.as<uint32_t>(), (const uint32_t*)(small + SM_NBLOCKS),
                        (uint32_t)n_alive, f->blk_size.as<int32_t>());
     HIP_TRY(ctx, hipGetLastError());
+  }
+  if (a.old_vcode && a.old_voxels > 0) {
+    // a voxel of the previous scheme that has lost all its points keeps its (empty) octree in the reference:
+    // roots this path cannot make - the general path takes the build then (nothing is committed yet)
+    HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_MISSING, 0, 4, st));
+    hipLaunchKernelGGL(k_old_voxels_missing, dim3((unsigned)ceil_div(a.old_voxels, 256)), dim3(256), 0, st,
+                       a.old_vcode, a.old_voxels, (const uint64_t*)f->vlin_dev.as<uint64_t>(), V, lp,
+                       bb[3] - bb[0] + 1, small + SM_BK_MISSING);
+    HIP_TRY(ctx, hipGetLastError());
+    uint32_t missing = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small + SM_BK_MISSING, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::memcpy(&missing, ctx->small_host, 4);
+    if (missing) return OCTL_OK;
   }
   nt.n = total;
   *n_internal = n_int;

@@ -1051,15 +1051,25 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     trace.mark("incremental insertion");
     if (done) return OCTL_OK;
   }
-  OCTL_TRY(forest_sync_vkeys(f));  // the previous scheme's voxels persist (no-op when fresh)
-  trace.mark("sync_vkeys");
-
   const int64_t n_alive = f->n_alive;
-  // ---- 0. fresh forest: the bucket build does insert + subdivide in one go (bucket_build.hip) -----------
-  if (!keep_scheme && !f->built && f->vkeys.empty() && n_alive > 0) {
+  // ---- 0. the bucket build does insert + subdivide in one go (bucket_build.hip): a fresh forest, or a
+  //         count-driven subdivide over a previous scheme (its internal nodes keep their epochs, its voxels
+  //         must all be there again) ----------------------------------------------------------------------------
+  const bool fresh0 = !f->built && f->vkeys.empty() && !f->vkeys_stale;
+  const bool over_old = f->built && !getenv("OCTL_NO_BUCKET_HISTORY");
+  if (!keep_scheme && (fresh0 || over_old) && n_alive > 0) {
     NodeTable& bt = f->nodes[f->cur ^ 1];
     const int cur_epoch = f->epoch + 1;
     BucketBuildArgs ba{K, scheme_dev, cur_epoch, max_depth};
+    const int64_t old_internal0 = f->built ? f->n_internal : 0;
+    if (over_old) {
+      OCTL_TRY(forest_sync_vcodes(f));
+      NodeTable& old0 = f->nodes[f->cur];
+      ba.old_fc = old0.first_child.as<int32_t>();
+      ba.old_epoch = old0.epoch.as<int32_t>();
+      ba.old_vcode = f->vcode_dev[0].as<uint64_t>();
+      ba.old_voxels = f->n_voxels;
+    }
     BucketBuildGeom geom;
     int done = 0, lv = 0;
     int64_t ni = 0, nv = 0, nblk = 0, pending = 0;
@@ -1073,7 +1083,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
         OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)n_alive * 4));
         OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)n_alive * 8));
       }
-      LevelLoop L{f, &bt, K, 0, all_scheme, scheme_dev, nullptr, nullptr, cur_epoch, max_depth, n_alive,
+      LevelLoop L{f, &bt, K, 0, all_scheme, scheme_dev, ba.old_fc, ba.old_epoch, cur_epoch, max_depth, n_alive,
                   true, 0, nv, 0, 0, &segs};
       OCTL_TRY(run_level_loop(L));
       trace.mark("level loop (pending voxels)");
@@ -1119,7 +1129,8 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       f->n_ord = n_alive;
       f->n_blocks = nblk;
       f->n_internal = ni;
-      f->uniform_epoch = true;
+      // nodes inherit an older epoch only from a previous scheme that had internal nodes
+      f->uniform_epoch = !(over_old && old_internal0 > 0);
       f->max_depth_reached = lv;
       f->mask_valid = false;
       f->store_dirty = false;
@@ -1139,6 +1150,8 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       return OCTL_OK;
     }
   }
+  OCTL_TRY(forest_sync_vkeys(f));  // the previous scheme's voxels persist (no-op when fresh)
+  trace.mark("sync_vkeys");
   // ---- 1. keys -----------------------------------------------------------------------------------
   if (N > 0) {
     OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));

@@ -18,6 +18,7 @@ enum {
   SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
   SM_BK_TOTAL = 26,     // bucket build: grand total of the scanned bucket table
   SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip
+  SM_BK_MISSING = 28,   // bucket build over a previous scheme: voxels of that scheme without points now
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
   // 64..: slot histogram, 512..: allreduce
   SM_GEOM = 768,        // bucket build: key geometry formed on the device (GeomDev, <= 192 bytes)
@@ -53,6 +54,12 @@ struct BucketBuildArgs {
   const uint8_t* scheme_dev;  // per pose slot: 1 = the pose drives the scheme; nullptr = all poses
   int cur_epoch;
   int max_depth;
+  // the previous scheme (subdivide on an already subdivided forest): nodes that were internal before keep
+  // their epoch, and every voxel of the previous scheme has to be there again.  nullptr / 0 when fresh.
+  const int32_t* old_fc = nullptr;
+  const int32_t* old_epoch = nullptr;
+  const uint64_t* old_vcode = nullptr;  // sorted packed voxel keys; old root r = voxel r
+  int64_t old_voxels = 0;
 };
 struct BucketBuildGeom {  // decoding of the linear voxel keys: lin = ((qx-min0)*ny + (qy-min1))*nz + (qz-min2)
   int min[3];

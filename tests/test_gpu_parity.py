@@ -1474,3 +1474,58 @@ def test_incremental_insertion_equals_replacement(monkeypatch):
         assert np.array_equal(va, vb)
         assert leaves_a == leaves_b and nodes_a == nodes_b
     assert a_after == b_after
+
+
+@pytest.mark.parametrize("empty_voxel", [False, True])
+def test_bucket_build_over_a_previous_scheme_equals_level_synchronous_build(monkeypatch, empty_voxel):
+    """subdivide on an already subdivided forest: the bucket path takes it too - nodes that were internal
+    before keep their epochs (they decide the cached-leaf order), every voxel of the previous scheme has to
+    be there again.  Same scheme (epochs included), same blocks in the same reference order as the
+    level-synchronous path; a voxel that has lost all its points sends the build down that path."""
+    from octreelib_amd._engine import Forest
+
+    rng = np.random.default_rng(77)
+    poses = [rng.random((30_000, 3)) * 5.0 - 1.0, rng.random((20_000, 3)) * 5.0 - 1.0, rng.random((25_000, 3)) * 6.0 - 1.5]
+
+    def run():
+        f = Forest(0, np.zeros(3), 1.0)
+        f.add_pose(poses[0])
+        f.add_pose(poses[1])
+        f.subdivide(120, [0])
+        f.add_pose(poses[2])                 # inherits the scheme (incremental placement)
+        np.random.seed(3)
+        f.ransac_all(10, np.random.random((256, 6)), 0.05)
+        f.apply_device_mask()                # points leave the tree
+        if empty_voxel:                      # ... and one voxel loses all of them
+            v0 = int(f.nodes["voxel"][f.blocks["node"][0]])
+            keep = np.ones(f.n_ord, dtype=np.uint8)
+            for b in np.nonzero(f.nodes["voxel"][f.blocks["node"]] == v0)[0]:
+                s0, z = int(f.blocks["start"][b]), int(f.blocks["size"][b])
+                keep[s0:s0 + z] = 0
+            f.apply_host_mask(keep)
+        f.ctx.sync()
+        f.ctx.set_profiling(True)
+        f.subdivide(40)                      # all poses, finer: a build over the previous scheme
+        f.ctx.sync()
+        names = set(f.ctx.timings())
+        f.ctx.set_profiling(False)
+        nodes, blocks = _canon_build(({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()}))
+        xyz, perm = f.xyz, f.perm
+        listing = [(blocks[b][0], blocks[b][1], xyz[blocks[b][2]:blocks[b][2] + blocks[b][3]].tobytes(),
+                    perm[blocks[b][2]:blocks[b][2] + blocks[b][3]].tobytes()) for b in f.order.tolist()]
+        counts = [(f.n_nodes(s), f.n_leaves(s), f.n_points(s)) for s in range(f.n_slots)]
+        vox = f.voxels.copy()
+        f.close()
+        return nodes, listing, counts, vox, names
+
+    monkeypatch.delenv("OCTL_NO_BUCKET_HISTORY", raising=False)
+    a = run()
+    monkeypatch.setenv("OCTL_NO_BUCKET_HISTORY", "1")
+    b = run()
+    assert "bucket_build" in a[4] and "bucket_build" not in b[4] and "keygen" in b[4]
+    assert ("keygen" in a[4]) == empty_voxel    # the empty voxel: back to the level-synchronous path
+    assert a[0] == b[0]
+    assert a[1] == b[1]
+    assert a[2] == b[2]
+    assert np.array_equal(a[3], b[3])
+    assert len({e for (_d, _c, _e, e, _i) in a[0].values()}) > 1    # epochs of two builds in the scheme
