@@ -1045,11 +1045,18 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   }
 
   // ---- poses appended to a built forest inherit its scheme: only the new points are placed -----------
-  if (keep_scheme) {
+  // (K < 0, "never split", over a scheme that has no internal nodes - the state between insert_points calls
+  //  before the first subdivide - is the same thing: new points into the existing roots, new voxels as
+  //  new roots; only the build counter advances)
+  const bool unsplit_again = !keep_scheme && K < 0 && f->built && f->n_internal == 0;
+  if (keep_scheme || unsplit_again) {
     int done = 0;
     OCTL_TRY(forest_insert_incremental(f, &done, info));
     trace.mark("incremental insertion");
-    if (done) return OCTL_OK;
+    if (done) {
+      if (unsplit_again) f->epoch += 1;
+      return OCTL_OK;
+    }
   }
   const int64_t n_alive = f->n_alive;
   // ---- 0. the bucket build does insert + subdivide in one go (bucket_build.hip): a fresh forest, or a
