@@ -1419,12 +1419,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   lp.raw_vp = 0;
   uint32_t* small = ctx->small.as<uint32_t>();
   // supertiles: one round of workgroups (2 per CU) over the cloud, at most 16 tiles each
-  int cus = 256;
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-  }
+  const int cus = octl_ctx_cus(ctx);
   constexpr int PT_IPT = 16;
   constexpr int tile = PT_THREADS * PT_IPT;
   auto supertiles = [&](int64_t items, int* st_tiles) {

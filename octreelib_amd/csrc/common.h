@@ -62,6 +62,7 @@ struct octl_ctx {
   DevBuf scan_tmp[3];
   DevBuf scan_status;            // single-pass scan: per-tile status words
   uint32_t scan_epoch = 0;
+  int cus = 0;      // compute units of the device (queried once: hipGetDeviceProperties is not free)
   DevBuf small;     // 4 KiB of device scalars (counters, flags)
   void* small_host = nullptr;  // pinned mirror
   void* pinned = nullptr;      // pinned staging for small uploads (OCTL_PINNED_BYTES)
@@ -125,6 +126,8 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- device-wide primitives (scan.hip, radix_sort.hip) ------------------------------------
 // exclusive prefix sum of n uint32 (in may equal out); if total_dev != nullptr the grand total
 // (uint32) is written there.  n up to 2^31.
+// compute units of the context's device (cached)
+int octl_ctx_cus(octl_ctx* ctx);
 int octl_exclusive_scan_u32(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n,
                             uint32_t* total_dev);
 // stable LSD radix sort of (key u64, value u32) pairs on bits [0, key_bits).  keys[0]/vals[0]

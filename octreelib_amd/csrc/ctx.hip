@@ -21,6 +21,16 @@ extern "C" int octl_debug_host_syncs(uint64_t* count) {
   return OCTL_OK;
 }
 
+int octl_ctx_cus(octl_ctx* ctx) {
+  if (ctx->cus <= 0) {
+    hipDeviceProp_t prop;
+    ctx->cus = (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount
+                   : 256;
+  }
+  return ctx->cus;
+}
+
 int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
   if (bytes <= b.cap) return OCTL_OK;
   size_t want = bytes + bytes / 4 + 256;  // grow with slack so level loops rarely realloc

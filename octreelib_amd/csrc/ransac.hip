@@ -1235,12 +1235,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                        (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc);
     HIP_TRY(ctx, hipGetLastError());
   }
-  int cus = 256;
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-  }
+  const int cus = octl_ctx_cus(ctx);
   KTimer t(ctx, "ransac");
 #define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU)                                        \
   do {                                                                                           \
