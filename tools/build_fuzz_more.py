@@ -6,9 +6,10 @@ sys.path.insert(0, '.')
 from _pytest.monkeypatch import MonkeyPatch
 import tests.test_gpu_parity as T
 
-cases = [(T.test_voxel_local_build_random_voxels_vs_level_synchronous_build, range(10, 70)),
-         (T.test_bucket_build_mixed_voxel_populations_vs_level_synchronous_build, range(6, 30)),
-         (T.test_bucket_build_two_pass_partition_vs_level_synchronous_build, range(3, 12))]
+scale = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = [(T.test_voxel_local_build_random_voxels_vs_level_synchronous_build, range(10, 10 + 60 * scale)),
+         (T.test_bucket_build_mixed_voxel_populations_vs_level_synchronous_build, range(6, 6 + 24 * scale)),
+         (T.test_bucket_build_two_pass_partition_vs_level_synchronous_build, range(3, 3 + 9 * scale))]
 bad = 0
 for fn, seeds in cases:
     for seed in seeds:
