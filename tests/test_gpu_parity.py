@@ -1579,3 +1579,43 @@ def test_bucket_build_integer_edges_vs_level_synchronous_build_and_oracle(monkey
     for p, c in enumerate(small):
         assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index_map(c))), _oracle_pose_table(og, p))
         assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+
+
+def test_bucket_build_far_from_the_origin_vs_level_synchronous_build_and_oracle(monkeypatch):
+    """Voxel indices near the limit of the domain (+-2^20): the differences p - corner are formed at
+    magnitudes where an ulp is 1e-10 of a voxel - both build paths and the oracle must still agree."""
+    from octreelib_amd._engine import Forest
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(5150)
+    off = np.array([1_000_000.0, -1_040_000.0, 524_287.0])
+    cloud = rng.random((150_000, 3)) * np.array([6.0, 5.0, 4.0]) + off
+    cloud[:40_000] = off + rng.random(3) * 3 + rng.random((40_000, 3)) * 0.02    # a dense cluster: deep trees
+    cloud = np.unique(cloud, axis=0)
+    rng.shuffle(cloud)
+
+    def build():
+        f = Forest(0, np.zeros(3), 1.0)
+        f.add_pose(cloud)
+        f.subdivide(24)
+        out = ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()},
+               f.perm.copy(), f.xyz.copy(), f.order.copy(), int(f.info.n_levels))
+        f.close()
+        return out
+
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    a = build()
+    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    b = build()
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    _assert_same_build(a, b)
+    assert a[5] >= 5
+    small = cloud[:8000]
+    grid, og = Grid(GridConfig(voxel_edge_length=1)), onp.OGrid(1)
+    grid.insert_points(0, small)
+    og.insert_points(0, small)
+    grid.subdivide(crit(10))
+    og.subdivide(10)
+    assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(0), index_map(small))), _oracle_pose_table(og, 0))
+    assert [grid.n_nodes(0), grid.n_leaves(0), grid.n_points(0)] == [og.n_nodes(0), og.n_leaves(0), og.n_points(0)]
