@@ -78,7 +78,7 @@ struct octl_forest {
                        // at [bucket start + j]
   DevBuf bk_node;      // u32 x3 staging {voxel << 18 | path, level << 28 | ordinal, parent ordinal} of the j-th internal
                        // node of bucket b at [bucket start + j]
-  DevBuf leafinfo;     // u32 [n_alive] per leaf-ordered point: path21 | depth << 21 | flags
+  DevBuf leafinfo;     // u32 [n_alive] per leaf-ordered point: leaf in bucket terms (parent ordinal, child digit, depth) | head flags
   // levels of the current node table as (first, end, depth) ranges of node ids: one per level when a
   // single build path numbered the nodes, two where the level loop has subdivided voxels the bucket
   // build left behind (order.hip sweeps them by depth)
