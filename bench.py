@@ -485,6 +485,34 @@ def main():
                 "note": "Grid(GridConfig(1)).insert_points(host cloud) + subdivide([MaxPoints(64)]) + "
                         "map_leaf_points_cuda_ransac() + n_points(), a fresh Grid per step",
             }
+            # poses that arrive one at a time: 12 poses x 0.5 M points into a 16^3-voxel scheme
+            # fixed by the first pose - the cost of a late pose must not grow with what is stored
+            from octreelib_amd import synthetic as _syn
+
+            lp_clouds = [_syn.planar_cloud(500_000, (16, 16, 16), seed=1, stream=p) for p in range(12)]
+            lg = Grid(GridConfig(voxel_edge_length=1))
+            lg.insert_points(0, lp_clouds[0])
+            lg.subdivide([MaxPoints(args.k_split)])
+            lg.n_leaves(0)
+            lp_ms = []
+            for p in range(1, 12):
+                t1 = time.perf_counter()
+                lg.insert_points(p, lp_clouds[p])
+                lg.n_leaves(p)   # forces the placement
+                lp_ms.append((time.perf_counter() - t1) * 1e3)
+            t1 = time.perf_counter()
+            lg.subdivide([MaxPoints(args.k_split)])
+            lg.n_leaves(0)
+            resub_ms = (time.perf_counter() - t1) * 1e3
+            secondary["late_poses"] = {
+                "insert_ms_pose_2_to_4": [round(x, 3) for x in lp_ms[1:4]],
+                "insert_ms_pose_9_to_11": [round(x, 3) for x in lp_ms[8:11]],
+                "resubdivide_all_12_poses_ms": resub_ms,
+                "note": "Grid.insert_points(pose, 0.5 M host points) + n_leaves(pose) on a subdivided grid "
+                        "(incremental placement, H2D copy included); then subdivide over the 6 M stored points",
+            }
+            lg._forest.close()
+            del lp_clouds
             # BASELINE C2-U / C3-U: uniform cloud default_rng(0).random((10 M, 3)) * 32
             uw = Workload(ctx, ctx, 0, 1, n_local, (32, 32, 32), "uniform32", args.k_split, False, False)
             uw.step()
