@@ -1367,6 +1367,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   const int64_t N = f->n_store, n_alive = f->n_alive;
   // (OCTL_NO_BUCKET_BUILD: tests compare this path with the level-synchronous one)
   if (n_alive <= 0 || !f->bbox_dev.p || getenv("OCTL_NO_BUCKET_BUILD")) return OCTL_OK;
+  // a single cube (bare Octree / OctreeManager) is ONE bucket: beyond what the oversize launch takes it is the
+  // level loop's job from the start
+  if (f->mode == 1 && n_alive > 65535) return OCTL_OK;
   const int n_poses = (int)f->pose_off.size() - 1;
   // buckets: runs of 2^s consecutive voxel keys, sized for ~2500 points on average (at most 2^24)
   // (OCTL_BUCKET_POINTS: tests force many small buckets - and with them the two-pass partition - on small clouds)
