@@ -306,6 +306,56 @@ def gen_grid_ransac():
 
 
 # --------------------------------------------------------------------------------------
+# G4b: end to end over BATCHES: three poses, subdivided first, poses_per_batch 1 and 2 (the cloud of a
+#      batch is the concatenation of its poses' leaves, block starts count from the batch's first leaf:
+#      grid.py:149-194).  Inliers lie exactly on their voxel's plane, so every hypothesis that attains
+#      the maximum yields the same mask and the reference's racy choice among them does not matter.
+# --------------------------------------------------------------------------------------
+def gen_grid_ransac_batches():
+    rng = np.random.default_rng(61)
+    planes = {}
+    poses = []
+    for p in range(3):
+        parts = []
+        for corner in ([0, 0, 0], [4, 0, 4], [4, 4, 0], [0, 4, 4]):
+            key = tuple(corner)
+            if key not in planes:
+                planes[key] = rng.uniform(-0.3, 0.3, 2)
+            a, b = planes[key]
+            corner = np.array(corner, dtype=float)
+            # (one outlier per voxel and pose: a block that is evaluated holds at least five inliers, no other
+            #  plane reaches their count, so the result does not depend on the order of the points inside a leaf)
+            n_in, n_out = int(rng.integers(30, 60)), 1
+            xy = rng.random((n_in, 2)) * 3.6 + 0.2
+            z = 2.0 + a * (xy[:, 0] - 2.0) + b * (xy[:, 1] - 2.0)
+            inl = np.column_stack([xy, z]) + corner
+            outl = rng.random((n_out, 3)) * np.array([3.6, 3.6, 0.5]) + corner + np.array([0.2, 0.2, 3.4])
+            parts.append(np.vstack([inl, outl]))
+        pts = np.vstack(parts)
+        rng.shuffle(pts)
+        poses.append(pts)
+    out = {"L": np.float64(4), "n_poses": np.int64(3), "seed": np.int64(11), "K": np.int64(30)}
+    for p, pts in enumerate(poses):
+        out[f"points{p}"] = pts
+    for ppb in (1, 2):
+        g = Grid(GridConfig(voxel_edge_length=4))
+        for p, pts in enumerate(poses):
+            g.insert_points(p, pts)
+        g.subdivide(crit(30))
+        np.random.seed(11)
+        g.map_leaf_points_cuda_ransac(
+            poses_per_batch=ppb, threshold=0.01, hypotheses_number=128, initial_points_number=6
+        )
+        for p, pts in enumerate(poses):
+            index = _index_of(pts)
+            c, e, s, i = _leaf_table(g.get_leaf_points(p), index)
+            out[f"b{ppb}_p{p}_corners"], out[f"b{ppb}_p{p}_edges"] = c, e
+            out[f"b{ppb}_p{p}_sizes"], out[f"b{ppb}_p{p}_idx"] = s, i
+            out[f"b{ppb}_p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+    _save("grid_ransac_batches.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # G3b: RANSAC operator on blocks cut from the BENCHMARK scene's own leaves, with the kernel's
 #      shared best_plane / max_inliers_number (cuda_ransac.py:125-146) recorded per block -
 #      observables the upstream API never returns (evaluate() hands back the mask only).
@@ -385,6 +435,7 @@ GENERATORS = {
     "grid_late_poses": gen_grid_late_poses,
     "ransac": gen_ransac,
     "grid_ransac": gen_grid_ransac,
+    "grid_ransac_batches": gen_grid_ransac_batches,
     "ransac_thick": gen_ransac_thick,   # ~10 minutes: 380 blocks x up to 1024 simulated threads
 }
 

@@ -1619,3 +1619,25 @@ def test_bucket_build_far_from_the_origin_vs_level_synchronous_build_and_oracle(
     og.subdivide(10)
     assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(0), index_map(small))), _oracle_pose_table(og, 0))
     assert [grid.n_nodes(0), grid.n_leaves(0), grid.n_points(0)] == [og.n_nodes(0), og.n_leaves(0), og.n_points(0)]
+
+
+@pytest.mark.parametrize("poses_per_batch", [1, 2])
+def test_grid_ransac_batches_golden(poses_per_batch):
+    """map_leaf_points_cuda_ransac over batches of poses on a subdivided grid, against the reference's own
+    result (tests/golden/grid_ransac_batches.npz: three poses, K = 30, H = 128)."""
+    from octreelib_amd.grid import Grid, GridConfig
+
+    g = load_golden("grid_ransac_batches.npz")
+    grid = Grid(GridConfig(voxel_edge_length=int(g["L"])))
+    idx = []
+    for p in range(3):
+        grid.insert_points(p, g[f"points{p}"])
+        idx.append(index_map(g[f"points{p}"]))
+    grid.subdivide(crit(int(g["K"])))
+    np.random.seed(int(g["seed"]))
+    grid.map_leaf_points_cuda_ransac(poses_per_batch=poses_per_batch, threshold=0.01, hypotheses_number=128,
+                                     initial_points_number=6)
+    tag = f"b{poses_per_batch}"
+    for p in range(3):
+        assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"{tag}_p{p}"))
+        assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"{tag}_p{p}_counts"])

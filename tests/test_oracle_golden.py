@@ -228,3 +228,35 @@ def test_reference_known_answers_grid():
     assert [g.n_leaves(0), g.n_leaves(1)] == [3, 5]
     with pytest.raises(ValueError, match="Cannot insert points to existing pose 0"):
         g.insert_points(0, np.zeros((1, 3)))
+
+
+@pytest.mark.parametrize("poses_per_batch", [1, 2])
+def test_grid_ransac_batches(poses_per_batch):
+    """Grid.map_leaf_points_cuda_ransac over batches of poses (grid.py:149-215) restated on the oracle:
+    batches of consecutive poses, one evaluate() per batch, masks applied per pose - against the reference's
+    own result for three poses on a subdivided grid."""
+    g = load_golden("grid_ransac_batches.npz")
+    og = onp.OGrid(int(g["L"]))
+    poses = [g[f"points{p}"] for p in range(3)]
+    for p in range(3):
+        og.insert_points(p, poses[p])
+    og.subdivide(int(g["K"]))
+    np.random.seed(int(g["seed"]))
+    table = np.random.random((128, 6))          # CudaRansac.__init__ (cuda_ransac.py:39-41)
+    for i in range(0, 3, poses_per_batch):
+        batch = list(range(i, min(i + poses_per_batch, 3)))
+        clouds, sizes = [], []
+        for p in batch:
+            for _, _, idx in og.leaf_table(p):
+                clouds.append(poses[p][idx])
+                sizes.append(len(idx))
+        mask = rnp.evaluate(np.vstack(clouds), np.array(sizes, dtype=np.int32), table, 0.01)
+        off = 0
+        for p in batch:
+            m = og.n_points(p)
+            og.apply_mask(p, mask[off:off + m])
+            off += m
+    tag = f"b{poses_per_batch}"
+    for p in range(3):
+        assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"{tag}_p{p}"))
+        assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
