@@ -173,6 +173,13 @@ class OTree:
             leaf.idx = leaf.idx[mask[start : start + n]]
             start += n
 
+    # octree.py:102-112, 222-228: a leaf whose points fail any criterion is emptied (all(...) over the
+    # criteria; the criterion sees the leaf's point array)
+    def filter(self, criteria):
+        for leaf in self.cached.values():
+            if not all([c(self.points[leaf.idx]) for c in criteria]):
+                leaf.idx = np.empty(0, dtype=np.int64)
+
     @property
     def n_points(self):
         return sum(len(v.idx) for v in self.cached.values())
@@ -217,6 +224,14 @@ class OManager:
             v.idx = np.empty(0, dtype=np.int64)
         for p in self.octrees:
             self.octrees[p].subdivide_as(self.scheme)
+
+    # octree_manager.py:85-99
+    def filter(self, criteria, pose_numbers=None):
+        if pose_numbers is None:
+            pose_numbers = list(self.octrees.keys())
+        for p in pose_numbers:
+            if p in self.octrees:
+                self.octrees[p].filter(criteria)
 
     def n_nodes(self, pose):
         return self.octrees[pose].n_nodes if pose in self.octrees else 0
@@ -289,6 +304,11 @@ class OGrid:
 
     def n_points(self, pose):
         return sum(m.n_points(pose) for m in self.managers.values())
+
+    # grid.py:260-267: every voxel's manager, all poses
+    def filter(self, criteria):
+        for m in self.managers.values():
+            m.filter(criteria)
 
     # grid.py:203-215: mask is consumed per top voxel (per-pose voxel order), then per
     # non-empty cached leaf

@@ -195,6 +195,34 @@ def gen_grid_late_poses():
 
 
 # --------------------------------------------------------------------------------------
+# G2c'': Grid.filter with point-count criteria (octree.py:102-112) on a subdivided two-pose grid, twice
+# --------------------------------------------------------------------------------------
+def gen_grid_filter():
+    rng = np.random.default_rng(71)
+    poses = [rng.random((3000, 3)) * 3.0, rng.random((2000, 3)) * 3.0 - 1.0]
+    g = Grid(GridConfig(voxel_edge_length=1))
+    out = {"L": np.float64(1), "n_poses": np.int64(2), "K": np.int64(20)}
+    for p, pts in enumerate(poses):
+        g.insert_points(p, pts)
+        out[f"points{p}"] = pts
+    g.subdivide(crit(20))
+    index = [_index_of(pts) for pts in poses]
+
+    def snap(tag):
+        for p in range(2):
+            c, e, s, i = _leaf_table(g.get_leaf_points(p), index[p])
+            out[f"{tag}_p{p}_corners"], out[f"{tag}_p{p}_edges"] = c, e
+            out[f"{tag}_p{p}_sizes"], out[f"{tag}_p{p}_idx"] = s, i
+            out[f"{tag}_p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+
+    g.filter([lambda pts: len(pts) >= 5])
+    snap("ge5")
+    g.filter([lambda pts: len(pts) > 2, lambda pts: 12 >= len(pts)])
+    snap("in3to12")
+    _save("grid_filter.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # G2d: OctreeManager, 4 poses: subdivide on a pose subset, then a late-inserted pose
 # --------------------------------------------------------------------------------------
 def gen_manager():
@@ -433,6 +461,7 @@ GENERATORS = {
     "grid": gen_grid,
     "manager": gen_manager,
     "grid_late_poses": gen_grid_late_poses,
+    "grid_filter": gen_grid_filter,
     "ransac": gen_ransac,
     "grid_ransac": gen_grid_ransac,
     "grid_ransac_batches": gen_grid_ransac_batches,

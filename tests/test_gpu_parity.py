@@ -1641,3 +1641,29 @@ def test_grid_ransac_batches_golden(poses_per_batch):
     for p in range(3):
         assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"{tag}_p{p}"))
         assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+
+def test_grid_filter_golden():
+    """Grid.filter with point-count criteria (the device kernel over the block table) against the
+    reference's own leaf tables, two filters in a row."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd.grid import Grid, GridConfig
+
+    g = load_golden("grid_filter.npz")
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    idx = []
+    for p in range(2):
+        grid.insert_points(p, g[f"points{p}"])
+        idx.append(index_map(g[f"points{p}"]))
+    grid.subdivide(crit(int(g["K"])))
+    ctx = nat.get_context()
+    for tag, criteria in (("ge5", [lambda pts: len(pts) >= 5]),
+                          ("in3to12", [lambda pts: len(pts) > 2, lambda pts: 12 >= len(pts)])):
+        ctx.set_profiling(True)
+        grid.filter(criteria)
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        assert "filter" in names    # the device path
+        for p in range(2):
+            assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"{tag}_p{p}"))
+            assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"{tag}_p{p}_counts"])

@@ -260,3 +260,19 @@ def test_grid_ransac_batches(poses_per_batch):
     for p in range(3):
         assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"{tag}_p{p}"))
         assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+
+def test_grid_filter():
+    """Grid.filter with point-count criteria on a subdivided two-pose grid, twice in a row: the reference's
+    leaf tables after each filter."""
+    g = load_golden("grid_filter.npz")
+    og = onp.OGrid(1)
+    for p in range(2):
+        og.insert_points(p, g[f"points{p}"])
+    og.subdivide(int(g["K"]))
+    for tag, criteria in (("ge5", [lambda pts: len(pts) >= 5]),
+                          ("in3to12", [lambda pts: len(pts) > 2, lambda pts: 12 >= len(pts)])):
+        og.filter(criteria)
+        for p in range(2):
+            assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"{tag}_p{p}"))
+            assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
