@@ -253,6 +253,40 @@ def gen_manager():
 
 
 # --------------------------------------------------------------------------------------
+# G2e: OctreeManager.insert_points into poses that already exist (octree_manager.py:161-171): the points
+#      are appended to the pose's octree and descend the current scheme; then a finer subdivide
+# --------------------------------------------------------------------------------------
+def gen_manager_extend():
+    rng = np.random.default_rng(81)
+    poses = [rng.random((500, 3)), rng.random((400, 3)), rng.random((300, 3))]
+    extra = {0: rng.random((151, 3)), 1: rng.random((80, 3))}
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 1.0)
+    out = {"edge": np.float64(1.0), "n_poses": np.int64(3)}
+    for p in range(3):
+        m.insert_points(p, poses[p])
+        out[f"points{p}"] = poses[p]
+    for p in extra:
+        out[f"extra{p}"] = extra[p]
+    m.subdivide(crit(25))
+    for p in (0, 1):
+        m.insert_points(p, extra[p])
+    allp = [np.vstack([poses[0], extra[0]]), np.vstack([poses[1], extra[1]]), poses[2]]
+    index = [_index_of(a) for a in allp]
+
+    def snap(tag):
+        for p in range(3):
+            c, e, s, i = _leaf_table(m.get_leaf_points(True, p), index[p])
+            out[f"{tag}_p{p}_corners"], out[f"{tag}_p{p}_edges"] = c, e
+            out[f"{tag}_p{p}_sizes"], out[f"{tag}_p{p}_idx"] = s, i
+            out[f"{tag}_p{p}_counts"] = np.array([m.n_nodes(p), m.n_leaves(p), m.n_points(p)])
+
+    snap("a")
+    m.subdivide(crit(10))
+    snap("b")
+    _save("manager_extend.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # G3: RANSAC operator, CudaRansac.evaluate on explicit inputs (reference kernel source run
 #     under the simulator stand-in)
 # --------------------------------------------------------------------------------------
@@ -460,6 +494,7 @@ GENERATORS = {
     "octree": gen_octree,
     "grid": gen_grid,
     "manager": gen_manager,
+    "manager_extend": gen_manager_extend,
     "grid_late_poses": gen_grid_late_poses,
     "grid_filter": gen_grid_filter,
     "ransac": gen_ransac,

@@ -1667,3 +1667,30 @@ def test_grid_filter_golden():
         for p in range(2):
             assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"{tag}_p{p}"))
             assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+
+def test_manager_extend_golden():
+    """OctreeManager.insert_points into poses that already exist (neither the last one), then a finer
+    subdivide: the reference's own leaf tables."""
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+
+    g = load_golden("manager_extend.npz")
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(3):
+        m.insert_points(p, g[f"points{p}"])
+    m.subdivide(crit(25))
+    for p in (0, 1):
+        m.insert_points(p, g[f"extra{p}"])
+    allp = [np.vstack([g["points0"], g["extra0"]]), np.vstack([g["points1"], g["extra1"]]), g["points2"]]
+    idx = [index_map(a) for a in allp]
+
+    def check(tag):
+        for p in range(3):
+            got = canon_from_list(views_table(m.get_leaf_points(True, p), idx[p]))
+            assert_same_leaves(got, golden_canon(g, f"{tag}_p{p}"))
+            assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    check("a")
+    m.subdivide(crit(10))
+    check("b")

@@ -276,3 +276,23 @@ def test_grid_filter():
         for p in range(2):
             assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"{tag}_p{p}"))
             assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+
+def test_manager_extend():
+    """OctreeManager.insert_points into poses that already exist, then a finer subdivide."""
+    g = load_golden("manager_extend.npz")
+    m = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(3):
+        m.insert_points(p, g[f"points{p}"])
+    m.subdivide(25)
+    for p in (0, 1):
+        m.insert_points(p, g[f"extra{p}"])
+
+    def check(tag):
+        for p in range(3):
+            assert_same_leaves(canon_from_list(onp.tree_leaf_table(m.octrees[p])), golden_canon(g, f"{tag}_p{p}"))
+            assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    check("a")
+    m.subdivide(10)
+    check("b")
