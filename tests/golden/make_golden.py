@@ -253,6 +253,38 @@ def gen_manager():
 
 
 # --------------------------------------------------------------------------------------
+# G2f: Octree.subdivide_as between stand-alone octrees (octree.py:34-53, 222-227): a coarser history of
+#      its own first, then the structure of another octree, then of a finer one (equal-or-finer: the
+#      reference's merge branch is outside the domain)
+# --------------------------------------------------------------------------------------
+def gen_octree_subdivide_as():
+    rng = np.random.default_rng(12)
+    corner, edge = np.array([0.0, 0.0, 0.0]), np.float64(2)
+    pa = rng.random((3000, 3)) * 2.0
+    pb = np.vstack([rng.random((1500, 3)) * 2.0, 0.3 + rng.random((2500, 3)) * 0.2])
+    a, b, b2 = (Octree(OctreeConfig(), corner, edge) for _ in range(3))
+    a.insert_points(pa)
+    b.insert_points(pb)
+    b2.insert_points(pb)
+    b.subdivide(crit(100))
+    b2.subdivide(crit(30))
+    a.subdivide(crit(900))
+    out = {"pa": pa, "pb": pb, "edge": edge}
+    index = _index_of(pa)
+
+    def snap(tag):
+        c, e, s, i = _leaf_table(a.get_leaf_points(), index)
+        out[f"{tag}_corners"], out[f"{tag}_edges"], out[f"{tag}_sizes"], out[f"{tag}_idx"] = c, e, s, i
+        out[f"{tag}_counts"] = np.array([a.n_nodes, a.n_leaves, a.n_points])
+
+    a.subdivide_as(b)
+    snap("as100")
+    a.subdivide_as(b2)
+    snap("as30")
+    _save("octree_subdivide_as.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # G2e: OctreeManager.insert_points into poses that already exist (octree_manager.py:161-171): the points
 #      are appended to the pose's octree and descend the current scheme; then a finer subdivide
 # --------------------------------------------------------------------------------------
@@ -495,6 +527,7 @@ GENERATORS = {
     "grid": gen_grid,
     "manager": gen_manager,
     "manager_extend": gen_manager_extend,
+    "octree_subdivide_as": gen_octree_subdivide_as,
     "grid_late_poses": gen_grid_late_poses,
     "grid_filter": gen_grid_filter,
     "ransac": gen_ransac,

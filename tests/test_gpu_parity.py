@@ -1694,3 +1694,24 @@ def test_manager_extend_golden():
     check("a")
     m.subdivide(crit(10))
     check("b")
+
+
+def test_octree_subdivide_as_golden():
+    """Octree.subdivide_as between stand-alone octrees against the reference's own leaf tables (structure,
+    history-dependent leaf order, counters)."""
+    from octreelib_amd.octree import Octree, OctreeConfig
+
+    g = load_golden("octree_subdivide_as.npz")
+    corner, edge = np.array([0.0, 0.0, 0.0]), np.float64(g["edge"])
+    a, b, b2 = (Octree(OctreeConfig(), corner, edge) for _ in range(3))
+    a.insert_points(g["pa"])
+    b.insert_points(g["pb"])
+    b2.insert_points(g["pb"])
+    b.subdivide(crit(100))
+    b2.subdivide(crit(30))
+    a.subdivide(crit(900))
+    ia = index_map(g["pa"])
+    for tag, other in (("as100", b), ("as30", b2)):
+        a.subdivide_as(other)
+        assert_same_leaves(canon_from_list(views_table(a.get_leaf_points(), ia)), golden_canon(g, tag))
+        assert [a.n_nodes, a.n_leaves, a.n_points] == list(g[f"{tag}_counts"])

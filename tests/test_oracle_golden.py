@@ -296,3 +296,21 @@ def test_manager_extend():
     check("a")
     m.subdivide(10)
     check("b")
+
+
+def test_octree_subdivide_as():
+    """Octree.subdivide_as between stand-alone octrees: after a coarser history of its own, the structure of
+    another octree, then of a finer one."""
+    g = load_golden("octree_subdivide_as.npz")
+    corner, edge = np.array([0.0, 0.0, 0.0]), np.float64(g["edge"])
+    a, b, b2 = onp.OTree(corner, edge), onp.OTree(corner, edge), onp.OTree(corner, edge)
+    a.insert_points(g["pa"])
+    b.insert_points(g["pb"])
+    b2.insert_points(g["pb"])
+    b.subdivide(100)
+    b2.subdivide(30)
+    a.subdivide(900)
+    for tag, other in (("as100", b), ("as30", b2)):
+        a.subdivide_as(other)
+        assert_same_leaves(canon_from_list(onp.tree_leaf_table(a)), golden_canon(g, tag))
+        assert [a.n_nodes, a.n_leaves, a.n_points] == list(g[f"{tag}_counts"])
