@@ -223,6 +223,39 @@ def gen_grid_filter():
 
 
 # --------------------------------------------------------------------------------------
+# G2g: an arbitrary callable as subdivision criterion (octree.py:26), scheme from pose 0 only; then a
+#      count criterion over both poses on top of it
+# --------------------------------------------------------------------------------------
+def spread_criterion(points):
+    """split while the cloud is both large and wide (not a count criterion)"""
+    return len(points) > 40 and float(points.max(axis=0).max() - points.min(axis=0).min()) > 0.3
+
+
+def gen_grid_callable():
+    rng = np.random.default_rng(77)
+    poses = [rng.random((4000, 3)) * 3.0, rng.random((3000, 3)) * 3.0]
+    g = Grid(GridConfig(voxel_edge_length=1))
+    out = {"L": np.float64(1), "n_poses": np.int64(2)}
+    for p, pts in enumerate(poses):
+        g.insert_points(p, pts)
+        out[f"points{p}"] = pts
+    index = [_index_of(pts) for pts in poses]
+
+    def snap(tag):
+        for p in range(2):
+            c, e, s, i = _leaf_table(g.get_leaf_points(p), index[p])
+            out[f"{tag}_p{p}_corners"], out[f"{tag}_p{p}_edges"] = c, e
+            out[f"{tag}_p{p}_sizes"], out[f"{tag}_p{p}_idx"] = s, i
+            out[f"{tag}_p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+
+    g.subdivide([spread_criterion], [0])
+    snap("spread")
+    g.subdivide(crit(15))
+    snap("k15")
+    _save("grid_callable.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # G2d: OctreeManager, 4 poses: subdivide on a pose subset, then a late-inserted pose
 # --------------------------------------------------------------------------------------
 def gen_manager():
@@ -530,6 +563,7 @@ GENERATORS = {
     "octree_subdivide_as": gen_octree_subdivide_as,
     "grid_late_poses": gen_grid_late_poses,
     "grid_filter": gen_grid_filter,
+    "grid_callable": gen_grid_callable,
     "ransac": gen_ransac,
     "grid_ransac": gen_grid_ransac,
     "grid_ransac_batches": gen_grid_ransac_batches,

@@ -1715,3 +1715,29 @@ def test_octree_subdivide_as_golden():
         a.subdivide_as(other)
         assert_same_leaves(canon_from_list(views_table(a.get_leaf_points(), ia)), golden_canon(g, tag))
         assert [a.n_nodes, a.n_leaves, a.n_points] == list(g[f"{tag}_counts"])
+
+
+def test_grid_callable_criterion_golden():
+    """An arbitrary host callable as subdivision criterion (evaluated by the host level by level, placement
+    on the device), then a count criterion on top: the reference's own leaf tables."""
+    from octreelib_amd.grid import Grid, GridConfig
+
+    def spread(points):
+        return len(points) > 40 and float(points.max(axis=0).max() - points.min(axis=0).min()) > 0.3
+
+    g = load_golden("grid_callable.npz")
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    idx = []
+    for p in range(2):
+        grid.insert_points(p, g[f"points{p}"])
+        idx.append(index_map(g[f"points{p}"]))
+
+    def check(tag):
+        for p in range(2):
+            assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), idx[p])), golden_canon(g, f"{tag}_p{p}"))
+            assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    grid.subdivide([spread], [0])
+    check("spread")
+    grid.subdivide(crit(15))
+    check("k15")

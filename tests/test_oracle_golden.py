@@ -314,3 +314,25 @@ def test_octree_subdivide_as():
         a.subdivide_as(other)
         assert_same_leaves(canon_from_list(onp.tree_leaf_table(a)), golden_canon(g, tag))
         assert [a.n_nodes, a.n_leaves, a.n_points] == list(g[f"{tag}_counts"])
+
+
+def _spread(points):
+    return len(points) > 40 and float(points.max(axis=0).max() - points.min(axis=0).min()) > 0.3
+
+
+def test_grid_callable_criterion():
+    """An arbitrary callable as criterion (scheme from pose 0), then a count criterion over both poses."""
+    g = load_golden("grid_callable.npz")
+    og = onp.OGrid(1)
+    for p in range(2):
+        og.insert_points(p, g[f"points{p}"])
+
+    def check(tag):
+        for p in range(2):
+            assert_same_leaves(canon_from_list(og.leaf_table(p)), golden_canon(g, f"{tag}_p{p}"))
+            assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    og.subdivide([_spread], [0])
+    check("spread")
+    og.subdivide(15)
+    check("k15")
