@@ -1741,3 +1741,46 @@ def test_grid_callable_criterion_golden():
     check("spread")
     grid.subdivide(crit(15))
     check("k15")
+
+
+def test_two_host_synchronisations_per_step():
+    """clear + add_pose_device + build + ransac_all + apply_mask on a device-resident cloud: the host waits
+    for the device twice (bucket totals; kept points and blocks), counted by the library itself."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+
+    ctx = nat.get_context()
+    lib = ctx.lib
+    pts = np.ascontiguousarray(synthetic.planar_cloud(400_000, (12, 12, 12), seed=2))
+    d = C.c_void_p()
+    ctx.check(lib.octl_dev_alloc(ctx.handle, pts.nbytes, C.byref(d)))
+    ctx.check(lib.octl_dev_upload(ctx.handle, d, nat.ptr(pts), pts.nbytes))
+    fh = C.c_void_p()
+    corner = np.zeros(3)
+    ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(corner), 1.0, C.byref(fh)))
+    np.random.seed(0)
+    table = np.ascontiguousarray(np.random.random((1024, 6)))
+    info, slot, n_alive = nat.BuildInfo(), C.c_int32(0), C.c_int64(0)
+
+    def step():
+        ctx.check(lib.octl_forest_clear(fh))
+        ctx.check(lib.octl_forest_add_pose_device(fh, d, len(pts), C.byref(slot)))
+        ctx.check(lib.octl_forest_build(fh, 64, None, 0, 0, 0, C.byref(info)))
+        ctx.check(lib.octl_forest_ransac_all(fh, 10, None, 0, nat.ptr(table), 1024, 6, 0.01))
+        ctx.check(lib.octl_forest_apply_mask(fh, C.byref(n_alive)))
+
+    try:
+        step()
+        step()   # (the first steps allocate: growing a buffer waits for the stream)
+        c0, c1 = C.c_uint64(0), C.c_uint64(0)
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
+        for _ in range(3):
+            step()
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
+        assert c1.value - c0.value == 6
+        assert 0 < n_alive.value < len(pts)
+    finally:
+        lib.octl_forest_destroy(fh)
+        lib.octl_dev_free(ctx.handle, d)
