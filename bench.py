@@ -410,21 +410,34 @@ def main():
                   shard_of=args.shard_of if world == 1 else 0)
 
     # ---- the timed region: W warm-up steps, then exactly K steps between barriers ----------------
+    # Inside the timed region only the DOMINANT kernel (RANSAC scoring) is timed with hipEvents on its own
+    # stream, as the roofline needs it; every event pair drains the pipeline for ~10 us, so the other
+    # kernels' durations come from a second, fully instrumented pass of a few steps behind the timed region.
     wl.run(args.warmup)
-    ctx.set_profiling(True)
-    if rctx is not ctx:
-        rctx.set_profiling(True)
+    ctx.set_profiling(2)
     barrier()
     t0 = time.perf_counter()
     wl.run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    live = ctx.timings()
+    ctx.set_profiling(False)
+    dt = max_over_ranks(dt)
+    prof_steps = max(2, min(args.steps, 5))
+    ctx.set_profiling(True)
+    if rctx is not ctx:
+        rctx.set_profiling(True)
+    wl.run(prof_steps)
+    barrier()
     timings = ctx.timings()
     ctx.set_profiling(False)
     if rctx is not ctx:
         timings.update(rctx.timings())
         rctx.set_profiling(False)
-    dt = max_over_ranks(dt)
+    # per-step scale of the instrumented pass -> the timed region's step count (the table below divides by it)
+    timings = {k: (v[0] * args.steps / prof_steps, v[1] * args.steps / prof_steps) for k, v in timings.items()}
+    if "ransac" in live:
+        timings["ransac"] = live["ransac"]   # the live measurement of the timed region
     info, n_alive_after = wl.info, int(wl.n_alive.value)
     leaves, nodes, levels = int(info.n_blocks), int(info.n_nodes), int(info.n_levels)
 
@@ -686,6 +699,9 @@ def main():
                 "measured_copy_GBs": bw.value / 1e9,
             },
             "kernels": kern,
+            "kernels_note": "ransac: hipEvents inside the timed region (live); the others: the same step "
+                            "fully instrumented for a few steps behind the timed region (an event pair costs "
+                            "~10 us of pipeline, a dozen per step would be 2 % of the step)",
         }
         if secondary:
             out["secondary"] = secondary

@@ -74,7 +74,9 @@ const char* octl_last_error(const octl_ctx* ctx);
 int octl_ctx_sync(octl_ctx* ctx);
 /* timing of the kernels launched by the last build / ransac call, by name; fills up to cap
  * entries, returns the number available through *n.  Milliseconds from hipEvents on the
- * context's stream; only recorded when profiling was enabled with octl_ctx_set_profiling */
+ * context's stream; only recorded when profiling was enabled with octl_ctx_set_profiling:
+ * 1 = every timed region, 2 = the RANSAC scoring kernel only (every hipEvent pair drains the
+ * pipeline for ~10 us: a dozen of them are 2 % of a 10 M-point step), 0 = off.               */
 int octl_ctx_set_profiling(octl_ctx* ctx, int enabled);
 int octl_ctx_get_timings(octl_ctx* ctx, char* names, int name_stride, float* ms,
                          int64_t* launches, int cap, int* n);

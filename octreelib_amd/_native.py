@@ -184,7 +184,8 @@ class Context:
         self.check(self.lib.octl_ctx_sync(self.handle))
 
     def set_profiling(self, enabled: bool):
-        self.check(self.lib.octl_ctx_set_profiling(self.handle, 1 if enabled else 0))
+        # (True / 1: every timed region; 2: the RANSAC kernel only; False / 0: off)
+        self.check(self.lib.octl_ctx_set_profiling(self.handle, int(enabled)))
 
     def timings(self):
         """{kernel name: (total ms, launches)} since profiling was enabled."""

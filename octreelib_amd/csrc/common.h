@@ -54,7 +54,7 @@ struct octl_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every timed region, 2 the RANSAC kernel only (an event pair costs ~10 us of pipeline)
   std::map<std::string, KernelTiming> timings;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;

@@ -113,6 +113,7 @@ void devbuf_free(DevBuf& b) {
 
 KTimer::KTimer(octl_ctx* c, const char* name) : ctx(c) {
   if (!ctx->profiling) return;
+  if (ctx->profiling == 2 && std::strcmp(name, "ransac") != 0) return;
   PendingEvent pe;
   pe.name = name;
   for (hipEvent_t* ev : {&pe.start, &pe.stop}) {
@@ -231,7 +232,7 @@ int octl_ctx_sync(octl_ctx* ctx) {
 int octl_ctx_set_profiling(octl_ctx* ctx, int enabled) {
   if (!ctx) return OCTL_E_INVALID;
   OCTL_TRY(octl_collect_timings(ctx));
-  ctx->profiling = enabled != 0;
+  ctx->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
   ctx->timings.clear();
   return OCTL_OK;
 }
