@@ -383,8 +383,7 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
       }
     }
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(f->bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipEventRecord(f->bbox_event, st));
+    // (the box stays on the device: the build forms the key geometry there, or fetches it when it has to)
     if (!from_device) HIP_TRY(ctx, hipStreamSynchronize(st));  // the host buffer is the caller's again
   }
   return OCTL_OK;
@@ -867,6 +866,7 @@ int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
   OCTL_TRY(devbuf_reserve(ctx, f->rs_order, (size_t)nb * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
   HIP_TRY(ctx, hipMemcpyAsync(f->rs_order.p, block_order, (size_t)nb * 4, hipMemcpyHostToDevice, st));
+  f->rs_hyp_host.clear();  // (octl_forest_ransac_all keeps a host copy of what rs_hyp holds)
   HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   float* plane_d = nullptr;

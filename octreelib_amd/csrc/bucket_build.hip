@@ -1387,7 +1387,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   bool two_pass = false;
   if (!async_geom) {
     // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
-    HIP_TRY(ctx, hipEventSynchronize(f->bbox_event));
+    HIP_TRY(ctx, hipMemcpyAsync(f->bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
     std::memcpy(bb, f->bbox_host, sizeof(bb));
     if (f->bbox_host[6])
       return octl_set_error(ctx, OCTL_E_DOMAIN,

@@ -1017,7 +1017,11 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   }
 
   // ---- pose offsets / scheme mask on the device ----------------------------------------------
-  OCTL_TRY(devbuf_reserve(ctx, f->pose_off_dev, (size_t)(n_poses + 1) * 8));
+  {
+    const void* before = f->pose_off_dev.p;
+    OCTL_TRY(devbuf_reserve(ctx, f->pose_off_dev, (size_t)(n_poses + 1) * 8));
+    if (f->pose_off_dev.p != before) f->pose_off_uploaded.clear();  // a new buffer holds nothing yet
+  }
   const uint8_t* scheme_dev = nullptr;
   {
     // small uploads go through pinned staging so that no synchronisation is needed; the region
@@ -1030,7 +1034,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       std::memcpy(pin, f->pose_off.data(), off_bytes);
       src_off = pin;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(f->pose_off_dev.p, src_off, off_bytes, hipMemcpyHostToDevice, st));
+    if (f->pose_off_uploaded != f->pose_off) {  // (the same offsets step after step: nothing to upload)
+      HIP_TRY(ctx, hipMemcpyAsync(f->pose_off_dev.p, src_off, off_bytes, hipMemcpyHostToDevice, st));
+      f->pose_off_uploaded = f->pose_off;
+    }
     if (!all_scheme) {
       OCTL_TRY(devbuf_reserve(ctx, f->scheme_dev, (size_t)n_poses));
       const void* src_m = scheme_mask;

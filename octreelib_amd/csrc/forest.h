@@ -67,6 +67,9 @@ struct octl_forest {
   bool mask_valid = false;
 
   DevBuf rs_scratch, rs_order, rs_hyp, rs_plane, rs_count, rs_index;  // ransac staging
+  // what rs_hyp / pose_off_dev hold (a table or offsets that have not changed are not uploaded again)
+  std::vector<double> rs_hyp_host;
+  std::vector<int64_t> pose_off_uploaded;
   DevBuf ord_idx2, xyz_ord2;  // compaction targets (swapped with the live arrays)
   DevBuf blk_node2, blk_slot2, blk_start2, blk_size2;
 

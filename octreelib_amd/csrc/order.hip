@@ -359,8 +359,15 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
     f->mask_valid = true;
   }
   if (f->n_blocks == 0) return OCTL_OK;
+  const size_t hyp_cap_before = f->rs_hyp.cap;
   OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
-  if ((size_t)H * k * 8 <= 64 * 1024) {  // pinned staging: [128 KiB, 192 KiB) of ctx->pinned
+  // the table of the previous call (CudaRansac draws it once per object, cuda_ransac.py:39-41; a SLAM loop
+  // hands the same one over for every batch): already on the device
+  const bool same_table = hyp_cap_before == f->rs_hyp.cap && f->rs_hyp_host.size() == (size_t)H * k &&
+                          std::memcmp(f->rs_hyp_host.data(), hypotheses, (size_t)H * k * 8) == 0;
+  if (same_table) {
+    // nothing to upload
+  } else if ((size_t)H * k * 8 <= 64 * 1024) {  // pinned staging: [128 KiB, 192 KiB) of ctx->pinned
     // the launches below are not synchronised: a later call must not overwrite the staging area
     // while this copy is still pending
     char* pin = static_cast<char*>(ctx->pinned) + 128 * 1024;
@@ -372,6 +379,7 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
     HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
   }
+  if (!same_table) f->rs_hyp_host.assign(hypotheses, hypotheses + (size_t)H * k);
   const bool one_batch = n_poses <= poses_per_batch;
   std::vector<uint32_t> slot_counts;
   OCTL_TRY(forest_reference_order(f, e0, slot_counts, !one_batch));
