@@ -1120,6 +1120,22 @@ struct NodeParams {
 //            first_child / epoch and its eight children (octree.py:177-191)
 //   blocks   the leafinfo words in storage order: (leaf, pose) block table, and position -> leaf when
 //            the level loop of build.hip is going to resume
+// first_child = -1 (leaf), epoch = 0 for every node of the table (four per thread)
+__global__ __launch_bounds__(256) void k_node_init(int32_t* __restrict__ first_child, int32_t* __restrict__ epoch,
+                                                   int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  // (the node arrays are 16-byte aligned and have room for whole groups of four: nodes_reserve rounds up)
+  if (i + 4 <= n) {
+    *reinterpret_cast<int4*>(first_child + i) = make_int4(-1, -1, -1, -1);
+    *reinterpret_cast<int4*>(epoch + i) = make_int4(0, 0, 0, 0);
+  } else {
+    for (int64_t j = i; j < n; ++j) {
+      first_child[j] = -1;
+      epoch[j] = 0;
+    }
+  }
+}
+
 // packed key (forest.h) of the voxel with linear key lin; root of that voxel in the previous scheme or -1
 __device__ __forceinline__ int32_t old_root_of(const NodeParams& P, uint32_t lin) {
   int64_t qx = 0, qy = 0, qz = 0;
@@ -1452,7 +1468,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n_alive * 4));
   uint32_t* table = f->bk_table.as<uint32_t>();
-  HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_FLAGS, 0, 12, st));  // flags, grand total, pending voxels
+  // (SM_BK_FLAGS / SM_BK_TOTAL / SM_BK_TODO are zero: forest_build has reset the scalar block)
   GeomDev* gdev = nullptr;
   if (async_geom) {
     gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
@@ -1552,10 +1568,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t sm[64];
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small, sizeof(sm), hipMemcpyDeviceToHost, st));
-  if (async_geom)
-    HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(ctx->small_host) + SM_GEOM * 4, small + SM_GEOM, sizeof(GeomDev),
-                                hipMemcpyDeviceToHost, st));
+  static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small, sizeof(sm) + (async_geom ? sizeof(GeomDev) : 0),
+                              hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   std::memcpy(sm, ctx->small_host, sizeof(sm));
   if (async_geom) {
@@ -1592,8 +1607,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   OCTL_TRY(nodes_reserve(ctx, nt, total));
   OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
   NodePtrs nd = node_ptrs(nt);
-  HIP_TRY(ctx, hipMemsetAsync(nd.first_child, 0xFF, (size_t)total * 4, st));
-  HIP_TRY(ctx, hipMemsetAsync(nd.epoch, 0, (size_t)total * 4, st));
+  hipLaunchKernelGGL(k_node_init, dim3((unsigned)ceil_div(ceil_div(total, 4), 256)), dim3(256), 0, st,
+                     nd.first_child, nd.epoch, total);
+  HIP_TRY(ctx, hipGetLastError());
   NodeParams np;
   np.lp = lp;
   np.bstride = bstride;

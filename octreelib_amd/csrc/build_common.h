@@ -20,8 +20,9 @@ enum {
   SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip
   SM_BK_MISSING = 28,   // bucket build over a previous scheme: voxels of that scheme without points now
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
-  // 64..: slot histogram, 512..: allreduce
-  SM_GEOM = 768,        // bucket build: key geometry formed on the device (GeomDev, <= 192 bytes)
+  // 64..: slot histogram (RANSAC batches), 512..: allreduce
+  SM_GEOM = 64,         // bucket build: key geometry formed on the device (GeomDev, <= 192 bytes; the region is
+                        // the slot histogram's during RANSAC - never at the same time)
 };
 
 struct NodePtrs {

@@ -1055,20 +1055,25 @@ __global__ __launch_bounds__(THREADS) void k_ransac_big(const double* __restrict
 }
 
 // ---- batch preparation ------------------------------------------------------------------------
+// scratch counters of one launch (device): [0] big blocks, [1] sorted small blocks,
+// [8..8+256) blocks per size, [264..264+256) start of every size in the sorted list,
+// [520..520+256) fill cursor per size
+enum { RC_BIG = 0, RC_SORTED = 1, RC_BINS = 8, RC_START = 264, RC_FILL = 520, RC_WORDS = 776 };
+
 // sizes in batch order (scanned into virtual starts, cuda_ransac.py:64-66)
 __global__ __launch_bounds__(256) void k_block_sizes_in_order(const int32_t* __restrict__ order,
                                                               const int32_t* __restrict__ size,
                                                               int64_t nb,
-                                                              uint32_t* __restrict__ tmp_sizes) {
+                                                              uint32_t* __restrict__ tmp_sizes,
+                                                              uint32_t* __restrict__ counters) {
+  // (the launch counters are first touched by the NEXT kernel: this one clears them on the way)
+  if (blockIdx.x == 0)
+    for (int w = threadIdx.x; w < RC_WORDS; w += blockDim.x) counters[w] = 0;
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   tmp_sizes[b] = (uint32_t)size[order ? order[b] : b];
 }
 
-// scratch counters of one launch (device): [0] big blocks, [1] sorted small blocks,
-// [8..8+256) blocks per size, [264..264+256) start of every size in the sorted list,
-// [520..520+256) fill cursor per size
-enum { RC_BIG = 0, RC_SORTED = 1, RC_BINS = 8, RC_START = 264, RC_FILL = 520, RC_WORDS = 776 };
 
 // batch entry -> descriptor; blocks with n < k are finished right here (the reference's kernel
 // returns at once and their mask stays False, cuda_ransac.py:96-97)
@@ -1221,10 +1226,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   {
     KTimer t(ctx, "ransac_prepare");
     const unsigned g = (unsigned)ceil_div(nb, 256);
-    hipLaunchKernelGGL(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp);
+    hipLaunchKernelGGL(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp, counters);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, tmp, tmp, nb, nullptr));
-    HIP_TRY(ctx, hipMemsetAsync(counters, 0, RC_WORDS * 4, st));
     hipLaunchKernelGGL(k_block_desc, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size,
                        (const uint32_t*)tmp, nb, n_points, any_k ? 0 : threads - 1, (int)k, desc, big_list,
                        counters, out);
