@@ -1077,6 +1077,7 @@ __global__ __launch_bounds__(256) void k_block_sizes_in_order(const int32_t* __r
 
 // batch entry -> descriptor; blocks with n < k are finished right here (the reference's kernel
 // returns at once and their mask stays False, cuda_ransac.py:96-97)
+constexpr int BD_PER_THREAD = 8;
 __global__ __launch_bounds__(256) void k_block_desc(const int32_t* __restrict__ order,
                                                     const uint32_t* __restrict__ start,
                                                     const int32_t* __restrict__ size,
@@ -1088,8 +1089,12 @@ __global__ __launch_bounds__(256) void k_block_desc(const int32_t* __restrict__ 
   __shared__ uint32_t bins[256];
   bins[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) {
+  // (BD_PER_THREAD entries per thread: the per-size counts leave the workgroup as ONE global atomic per
+  //  non-empty size, and same-address atomics serialise - with one entry per thread they were half the kernel)
+#pragma unroll 1
+  for (int r = 0; r < BD_PER_THREAD; ++r) {
+    const int64_t b = ((int64_t)blockIdx.x * BD_PER_THREAD + r) * blockDim.x + threadIdx.x;
+    if (b >= nb) break;
     const int32_t phys = order ? order[b] : (int32_t)b;
     BlockDesc d;
     d.pstart = start[phys];
@@ -1229,7 +1234,8 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     hipLaunchKernelGGL(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp, counters);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, tmp, tmp, nb, nullptr));
-    hipLaunchKernelGGL(k_block_desc, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size,
+    hipLaunchKernelGGL(k_block_desc, dim3((unsigned)ceil_div(nb, 256 * BD_PER_THREAD)), dim3(256), 0, st, order_dev,
+                       blk_start, blk_size,
                        (const uint32_t*)tmp, nb, n_points, any_k ? 0 : threads - 1, (int)k, desc, big_list,
                        counters, out);
     HIP_TRY(ctx, hipGetLastError());
