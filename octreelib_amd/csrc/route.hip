@@ -83,12 +83,12 @@ __device__ __forceinline__ int route_dest_of(double x, double y, double z, doubl
   return 0;
 }
 
-// Pass 1: points per (destination, tile) + per-destination totals.  LDS histogram over 2048 points,
-// then one global atomic per (workgroup, destination) - same-address atomics serialise.
+// Pass 1: points per (destination, tile): LDS histogram over 2048 points.  (The per-destination totals
+// come out of the scanned table, k_route_counts: as one global atomic per (workgroup, destination) - 4883
+// same-address atomics per destination for 10 M points - they were half of this kernel's time.)
 __global__ __launch_bounds__(RT_THREADS) void k_route_hist(const double* __restrict__ xyz, int64_t n,
                                                            double L, int n_ranks, uint32_t ntiles,
                                                            uint32_t* __restrict__ hist,
-                                                           unsigned long long* __restrict__ counts,
                                                            uint32_t* __restrict__ err) {
   __shared__ uint32_t h[256];
   h[threadIdx.x] = 0;
@@ -102,10 +102,17 @@ __global__ __launch_bounds__(RT_THREADS) void k_route_hist(const double* __restr
   }
   if (bad) atomicExch(err, 1u);
   __syncthreads();
-  if ((int)threadIdx.x < n_ranks) {
-    hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
-    if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
-  }
+  if ((int)threadIdx.x < n_ranks) hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// points per destination = differences of the row heads of the scanned (destination-major) table
+__global__ void k_route_counts(const uint32_t* __restrict__ hist_scanned, uint32_t ntiles, int n_ranks,
+                               const uint32_t* __restrict__ total, unsigned long long* __restrict__ counts) {
+  const int d = threadIdx.x;
+  if (d >= n_ranks) return;
+  const uint32_t a = hist_scanned[(size_t)d * ntiles];
+  const uint32_t b = d + 1 < n_ranks ? hist_scanned[(size_t)(d + 1) * ntiles] : *total;
+  counts[d] = (unsigned long long)(b - a);
 }
 
 // Pass 2: the stable partition by destination WITH its payload - every point is read once and its
@@ -206,9 +213,13 @@ static int route_partition(octl_ctx* ctx, const double* xyz_dev, const int64_t* 
     {
       KTimer t(ctx, "route_hist");
       hipLaunchKernelGGL(k_route_hist, dim3(ntiles), dim3(RT_THREADS), 0, st, xyz_dev, n, L, R, ntiles,
-                         hist.as<uint32_t>(), counts_d.as<unsigned long long>(), err);
+                         hist.as<uint32_t>(), err);
       HIP_TRY(ctx, hipGetLastError());
-      OCTL_TRY(octl_exclusive_scan_u32(ctx, hist.as<uint32_t>(), hist.as<uint32_t>(), (int64_t)R * ntiles, nullptr));
+      uint32_t* total = err + 1;
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, hist.as<uint32_t>(), hist.as<uint32_t>(), (int64_t)R * ntiles, total));
+      hipLaunchKernelGGL(k_route_counts, dim3(1), dim3(256), 0, st, (const uint32_t*)hist.as<uint32_t>(), ntiles, R,
+                         (const uint32_t*)total, counts_d.as<unsigned long long>());
+      HIP_TRY(ctx, hipGetLastError());
     }
     KTimer t(ctx, "route_scatter");
     hipLaunchKernelGGL(k_route_scatter, dim3(ntiles), dim3(RT_THREADS), 0, st, xyz_dev, gidx_dev, index_base,
