@@ -1078,6 +1078,7 @@ __global__ __launch_bounds__(256) void k_block_sizes_in_order(const int32_t* __r
 // batch entry -> descriptor; blocks with n < k are finished right here (the reference's kernel
 // returns at once and their mask stays False, cuda_ransac.py:96-97)
 constexpr int BD_PER_THREAD = 8;
+constexpr int BS_PER_THREAD = 16;  // k_block_scatter: entries per thread (same reason)
 __global__ __launch_bounds__(256) void k_block_desc(const int32_t* __restrict__ order,
                                                     const uint32_t* __restrict__ start,
                                                     const int32_t* __restrict__ size,
@@ -1154,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_block_scatter(const BlockDesc* __restri
   __shared__ uint32_t base[256];
   cnt[threadIdx.x] = 0;
   __syncthreads();
-  constexpr int PER_THREAD = 4;
+  constexpr int PER_THREAD = BS_PER_THREAD;
   const int64_t b0 = (int64_t)blockIdx.x * (256 * PER_THREAD);
   int nn[PER_THREAD];
   uint32_t rank[PER_THREAD];
@@ -1241,7 +1242,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(256), 0, st, counters);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_block_scatter, dim3((unsigned)ceil_div(nb, 1024)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_block_scatter, dim3((unsigned)ceil_div(nb, 256 * BS_PER_THREAD)), dim3(256), 0, st,
                        (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc);
     HIP_TRY(ctx, hipGetLastError());
   }
