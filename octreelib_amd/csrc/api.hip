@@ -232,19 +232,27 @@ __global__ __launch_bounds__(256) void k_compact_tiles(
   }
 }
 
+// The three prefix sums of apply_mask come out of ONE scan over [tile counts | kept per block | block
+// non-empty]: the second and third segment carry the totals of the segments in front of them, which are
+// read from their first entries.
 __global__ __launch_bounds__(256) void k_blk_compact(
-    const uint32_t* __restrict__ kept, const uint32_t* __restrict__ new_start,
-    const uint32_t* __restrict__ new_id, int64_t nb, const int32_t* __restrict__ blk_node,
+    const uint32_t* __restrict__ raw, const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ grand_total,
+    int64_t nt, int64_t nb, const int32_t* __restrict__ blk_node,
     const int32_t* __restrict__ blk_slot, int32_t* __restrict__ blk_node2, int32_t* __restrict__ blk_slot2,
-    uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2) {
+    uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2, uint32_t* __restrict__ totals) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t base_kept = scanned[nt], base_id = scanned[nt + nb];
+  if (b == 0) {
+    totals[0] = base_id - base_kept;      // kept points
+    totals[1] = *grand_total - base_id;   // non-empty blocks
+  }
   if (b >= nb) return;
-  const uint32_t c = kept[b];
+  const uint32_t c = raw[nt + b];
   if (!c) return;
-  const uint32_t id = new_id[b];
+  const uint32_t id = scanned[nt + nb + b] - base_id;
   blk_node2[id] = blk_node[b];
   blk_slot2[id] = blk_slot[b];
-  blk_start2[id] = new_start[b];
+  blk_start2[id] = scanned[nt + b] - base_kept;
   blk_size2[id] = (int32_t)c;
 }
 
@@ -400,26 +408,20 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     KTimer t(ctx, "apply_mask");
     uint32_t* small = ctx->small.as<uint32_t>();
     const int64_t nt = ceil_div(n, 2048);
-    // scratch: [tile counts nt | kept nb | new start nb | new id nb], 16-byte aligned pieces
-    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_kept = al(((size_t)nt + 8) * 4), o_start = o_kept + al(((size_t)nb + 8) * 4),
-                 o_id = o_start + al(((size_t)nb + 8) * 4);
-    OCTL_TRY(devbuf_reserve(ctx, f->flags, o_id + al(((size_t)nb + 8) * 4)));
-    char* base = static_cast<char*>(f->flags.p);
-    uint32_t* tiles = reinterpret_cast<uint32_t*>(base);
-    uint32_t* kept = reinterpret_cast<uint32_t*>(base + o_kept);
-    uint32_t* nstart = reinterpret_cast<uint32_t*>(base + o_start);
-    uint32_t* nid = reinterpret_cast<uint32_t*>(base + o_id);
+    // scratch: in [tile counts nt | kept nb | non-empty nb], out (scanned) the same layout
+    const int64_t n_all = nt + 2 * nb;
+    const size_t o_out = (((size_t)n_all + 8) * 4 + 15) & ~(size_t)15;
+    OCTL_TRY(devbuf_reserve(ctx, f->flags, 2 * o_out));
+    uint32_t* raw = f->flags.as<uint32_t>();
+    uint32_t* scanned = reinterpret_cast<uint32_t*>(static_cast<char*>(f->flags.p) + o_out);
     const uint8_t* mask = f->mask.as<uint8_t>();
-    hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, n, tiles);
+    hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, n, raw);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_blk_kept, dim3(grid_for(nb)), dim3(256), 0, st, mask,
                        (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
-                       kept, nid);
+                       raw + nt, raw + nt + nb);
     HIP_TRY(ctx, hipGetLastError());
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, tiles, tiles, nt, small + 20));
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, kept, nstart, nb, nullptr));
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, nid, nid, nb, small + 21));
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, raw, scanned, n_all, small + 22));
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord2, (size_t)n * 24));
     // (block buffers keep the capacity convention of forest_make_blocks: one block per point)
@@ -427,14 +429,15 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     OCTL_TRY(devbuf_reserve(ctx, f->blk_slot2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->blk_start2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->blk_size2, (size_t)n * 4));
-    hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)tiles, n,
+    hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)scanned, n,
                        (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
                        f->ord_idx2.as<uint32_t>(), f->xyz_ord2.as<double>(), f->alive.as<uint8_t>());
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)kept,
-                       (const uint32_t*)nstart, (const uint32_t*)nid, nb, (const int32_t*)f->blk_node.as<int32_t>(),
-                       (const int32_t*)f->blk_slot.as<int32_t>(), f->blk_node2.as<int32_t>(),
-                       f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(), f->blk_size2.as<int32_t>());
+    hipLaunchKernelGGL(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)raw,
+                       (const uint32_t*)scanned, (const uint32_t*)(small + 22), nt, nb,
+                       (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
+                       f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
+                       f->blk_size2.as<int32_t>(), small + 20);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small + 20, 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
