@@ -404,6 +404,7 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
   hipStream_t st = ctx->stream;
   const int64_t n = f->n_ord, nb = f->n_blocks;
   f->mask_valid = false;
+  f->fast_order_valid = false;  // block ids change
   if (n > 0 && nb > 0) {
     KTimer t(ctx, "apply_mask");
     uint32_t* small = ctx->small.as<uint32_t>();
@@ -518,7 +519,7 @@ void octl_forest_destroy(octl_forest* f) {
   for (DevBuf* b :
        {&f->bbox_dev, &f->part_xyz[0], &f->part_xyz[1], &f->bk_table, &f->bk_tot, &f->bk_vox, &f->bk_node, &f->leafinfo,
         &f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
-        &f->blk_start, &f->blk_size, &f->blk_node2, &f->blk_slot2, &f->blk_start2, &f->blk_size2, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order,
+        &f->blk_start, &f->blk_size, &f->blk_node2, &f->blk_slot2, &f->blk_start2, &f->blk_size2, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order, &f->fast_order,
         &f->rs_hyp, &f->rs_plane, &f->rs_count, &f->rs_index, &f->ord_idx2, &f->xyz_ord2,
         &f->vkey, &f->path, &f->lin[0], &f->lin[1], &f->val[0], &f->val[1],
         &f->hist, &f->idxbuf[0], &f->idxbuf[1], &f->pathbuf[0], &f->pathbuf[1], &f->flags,
@@ -542,6 +543,7 @@ int octl_forest_clear(octl_forest* f) {
   f->vkeys.clear();
   f->vkeys_stale = false;
   f->vcode_valid = false;
+  f->fast_order_valid = false;
   f->built_store = 0;
   f->built_poses = 0;
   f->append_only = true;
@@ -661,6 +663,7 @@ int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int
   // only first_child / epoch of this table are meaningful until the next (keep_scheme) build,
   // which has to place every point again
   f->append_only = false;
+  f->fast_order_valid = false;
   f->n_ord = 0;
   f->n_blocks = 0;
   f->mask_valid = false;

@@ -58,6 +58,7 @@ constexpr int LC_DIGIT = 16, LC_DEPTH = 19;
 constexpr uint32_t LI_VHEAD = 1u << 24;   // first point of its top-level voxel
 constexpr uint32_t LI_BHEAD = 1u << 25;   // first point of its (leaf, pose) block
 // bucket flags
+constexpr uint32_t FO_MAX = 1024;       // internal nodes / blocks per bucket k_bucket_finish can order itself
 constexpr uint32_t BF_OVERFLOW = 1u;      // a bucket beyond what the oversize launch handles: whole build -> general path
 
 struct LinParams {
@@ -1067,6 +1068,12 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
   }
   __syncthreads();
   if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = s_tot[tid];
+  if (tid == 0) {
+    uint32_t nrec = 0;
+    for (int l = 0; l < BB_LEVELS; ++l) nrec += s_tot[BK_NINT + l];
+    // (k_bucket_finish ranks the internal nodes and the blocks of a bucket among themselves in LDS)
+    if (nrec > FO_MAX || s_tot[BK_NBLK] > FO_MAX) atomicOr(&small[SM_BK_NOORDER], 1u);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1105,6 +1112,7 @@ struct NodeParams {
   int n_poses, all_scheme, cur_epoch;
   int64_t node_cap;   // capacity of the node table (nodes); a larger table is needed -> overflow flag
   int write_pos;      // position -> leaf is only read by the level loop that finishes the voxels left behind
+  int32_t* order_out;  // nullable: the blocks in the reference's listing order (single pose, one epoch)
   // previous scheme (nullptr: none): epochs of the nodes that were internal before, roots' old ids
   const int32_t* old_fc;
   const int32_t* old_epoch;
@@ -1191,6 +1199,11 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot, uint32_t* __restrict__ blk_start,
     uint32_t* small) {
   __shared__ uint32_t s_scr[8];
+  // the reference's listing order of the bucket's blocks (P.order_out): preorder keys of its internal nodes,
+  // (level, ordinal) -> voxel << 16 | preorder rank, block keys
+  __shared__ unsigned long long s_rk[FO_MAX];
+  __shared__ uint32_t s_map[FO_MAX];
+  __shared__ uint32_t s_bkey[FO_MAX];
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
   const uint32_t start = bstart[(size_t)b * P.bstride];
@@ -1314,6 +1327,43 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     nd.corner[3 * ch + 2] = cz + ((c & 1) ? h : 0.0);
   }
 
+  // ---- preorder ranks of the internal nodes (for the block order) -------------------------------------------
+  // Octree.get_leaf_points lists the cached leaves: a leaf sorts by (preorder rank of its parent among the
+  // internal nodes of its voxel, child index) - octree_base.py:152-158, octree.py:183-191 (see order.hip) -
+  // voxels in lexicographic order.  All blocks of a voxel are in this bucket, and with ONE pose and ONE epoch
+  // the order of the whole forest is the buckets' orders one after the other.
+  const bool want_order = P.order_out != nullptr;
+  __shared__ uint32_t lvl_off[BB_LEVELS];  // first slot of every level in s_map
+  if (want_order) {
+    if (tid == 0) {
+      uint32_t o = 0;
+      for (int l = 0; l < BB_LEVELS; ++l) {
+        lvl_off[l] = o;
+        o += at(BK_NINT + l, b + 1) - at(BK_NINT + l, b);
+      }
+    }
+    for (uint32_t j = tid; j < nrec; j += 256) {
+      const size_t r = 3 * ((size_t)start + j);
+      const uint32_t info = bk_node[r], w1 = bk_node[r + 1];
+      const int l = (int)(w1 >> 28);
+      const uint32_t prefix = info & 0x3FFFFu;
+      // voxel, then the path as (digit + 1) nibbles, left aligned: an ancestor sorts in front of its descendants
+      unsigned long long key = (unsigned long long)(info >> 18) << 28;
+      for (int t = 0; t < l; ++t) key |= (unsigned long long)(((prefix >> (3 * (l - 1 - t))) & 7u) + 1u) << (4 * (6 - t));
+      s_rk[j] = key;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < nrec; j += 256) {
+      const unsigned long long key = s_rk[j];
+      uint32_t rk = 0;
+      for (uint32_t i = 0; i < nrec; ++i) rk += s_rk[i] < key ? 1u : 0u;
+      const size_t r = 3 * ((size_t)start + j);
+      const uint32_t w1 = bk_node[r + 1];
+      s_map[lvl_off[w1 >> 28] + (w1 & 0xFFFFu)] = ((bk_node[r] >> 18) << 16) | rk;
+    }
+    __syncthreads();
+  }
+
   // ---- (leaf, pose) blocks, position -> leaf ------------------------------------------------------------------
   uint32_t brun = 0;
   for (int f0 = 0; f0 < n; f0 += 256) {
@@ -1331,12 +1381,32 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       if (P.write_pos) pos_node[(size_t)start + f] = leaf;
       if (bhead) {
         const uint32_t bo = bbase + brun + pre;
+        if (want_order) {
+          // key: voxel, preorder rank of the parent, child digit (a root that is a leaf: the voxel alone)
+          uint32_t key;
+          if (dep == 0) {
+            key = ob << 13;
+          } else {
+            const uint32_t m = s_map[lvl_off[dep - 1] + ob];
+            key = ((m >> 16) << 13) | ((m & 0xFFFFu) << 3) | ((li >> LC_DIGIT) & 7u);
+          }
+          s_bkey[brun + pre] = key;
+        }
         blk_node[bo] = leaf;
         blk_slot[bo] = P.n_poses > 1 ? find_slot_dev(pose_off, P.n_poses, ord_idx[(size_t)start + f]) : 0;
         blk_start[bo] = start + (uint32_t)f;
       }
     }
     brun += tot;
+  }
+  if (want_order) {
+    __syncthreads();
+    for (uint32_t j = tid; j < brun; j += 256) {
+      const uint32_t key = s_bkey[j];
+      uint32_t rk = 0;
+      for (uint32_t i = 0; i < brun; ++i) rk += s_bkey[i] < key ? 1u : 0u;
+      P.order_out[bbase + rk] = (int32_t)(bbase + j);
+    }
   }
 }
 
@@ -1624,6 +1694,15 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   np.old_epoch = a.old_epoch;
   np.old_vcode = a.old_vcode;
   np.old_voxels = a.old_voxels;
+  // the listing order of the blocks falls out of the same kernel for the common case: one pose, a fresh
+  // scheme (one epoch), nothing left to the level loop, no bucket beyond what the kernel ranks in LDS
+  const bool fast_order = n_poses == 1 && !a.old_fc && sm[SM_BK_TODO] == 0 && sm[SM_BK_NOORDER] == 0 &&
+                          !getenv("OCTL_NO_FAST_ORDER");
+  np.order_out = nullptr;
+  if (fast_order) {
+    OCTL_TRY(devbuf_reserve(ctx, f->fast_order, (size_t)std::max<uint32_t>(sm[SM_NBLOCKS], 1) * 4));
+    np.order_out = f->fast_order.as<int32_t>();
+  }
   {
     KTimer t(ctx, "bucket_nodes");
     hipLaunchKernelGGL(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd, np, bstart,
@@ -1664,6 +1743,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   geom->min[2] = bb[2];
   geom->ny = ny;
   geom->nz = nz;
+  geom->order_done = fast_order;
   *done = 1;
   return OCTL_OK;
 }

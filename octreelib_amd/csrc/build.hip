@@ -998,6 +998,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     return octl_set_error(ctx, OCTL_E_INVALID, "scheme mask has %d entries for %d poses", n_mask,
                           n_poses);
   if (max_depth <= 0) max_depth = 63;
+  f->fast_order_valid = false;  // (the block table is about to change)
   BuildTrace trace;
   uint32_t* small = ctx->small.as<uint32_t>();
 
@@ -1149,6 +1150,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       f->mask_valid = false;
       f->store_dirty = false;
       f->vcode_valid = false;
+      f->fast_order_valid = geom.order_done && pending == 0;
       f->built_store = f->n_store;
       f->built_poses = n_poses;
       f->append_only = true;

@@ -15,6 +15,7 @@ enum {
   SM_ETOTAL = 15,   // total of the scanned tile histogram
   SM_NBLOCKS = 16,
   // 20, 21: kept points / blocks of apply_mask (21 also: slot-voxel count), 24: debug scan total
+  SM_BK_NOORDER = 23,   // bucket build: some bucket has too many nodes / blocks for k_bucket_finish's own block order
   SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
   SM_BK_TOTAL = 26,     // bucket build: grand total of the scanned bucket table
   SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip
@@ -65,6 +66,7 @@ struct BucketBuildArgs {
 struct BucketBuildGeom {  // decoding of the linear voxel keys: lin = ((qx-min0)*ny + (qy-min1))*nz + (qz-min2)
   int min[3];
   uint64_t ny, nz;
+  bool order_done = false;  // f->fast_order holds the blocks in the reference's listing order
 };
 // *pending = number of voxels left as single leaves for the level loop of build.hip (flagged roots).
 int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,

@@ -67,6 +67,10 @@ struct octl_forest {
   bool mask_valid = false;
 
   DevBuf rs_scratch, rs_order, rs_hyp, rs_plane, rs_count, rs_index;  // ransac staging
+  // the blocks in the reference's listing order as the bucket build left them (one pose, one epoch):
+  // forest_reference_order takes this instead of computing it; any change of the blocks invalidates it
+  DevBuf fast_order;
+  bool fast_order_valid = false;
   // what rs_hyp / pose_off_dev hold (a table or offsets that have not changed are not uploaded again)
   std::vector<double> rs_hyp_host;
   std::vector<int64_t> pose_off_uploaded;

@@ -502,6 +502,7 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
       }
     }
   }
+  f->fast_order_valid = false;
   f->n_ord = n_total;
   f->n_blocks = n_blocks + nb_new;
   f->mask_valid = false;

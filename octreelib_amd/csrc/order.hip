@@ -170,6 +170,13 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   const int n_poses = (int)f->pose_off.size() - 1;
   slot_counts.assign((size_t)std::max(n_poses, 1), 0);
   if (nb <= 0) return OCTL_OK;
+  if (f->fast_order_valid && n_poses == 1) {
+    // the bucket build has left the order behind (k_bucket_finish): one pose, one epoch - e0 cannot matter
+    std::swap(f->rs_order, f->fast_order);
+    f->fast_order_valid = false;
+    slot_counts[0] = (uint32_t)nb;
+    return OCTL_OK;
+  }
   NodeTable& t = f->nodes[f->cur];
   const int64_t V = f->n_voxels;
   KTimer timer(ctx, "ransac_order");

@@ -1784,3 +1784,55 @@ def test_two_host_synchronisations_per_step():
     finally:
         lib.octl_forest_destroy(fh)
         lib.octl_dev_free(ctx.handle, d)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_block_order_left_by_the_bucket_build_equals_order_hip(monkeypatch, seed):
+    """One pose, a fresh scheme: k_bucket_finish leaves the blocks' listing order behind (preorder ranks and
+    block keys ranked inside each bucket); it must be the order order.hip computes from the node table -
+    shallow and deep trees, skewed voxels, K from 1."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    rng = np.random.default_rng(4200 + seed)
+    dims = rng.integers(2, 9, 3)
+    K = int(rng.choice([1, 3, 8, 40, 64, 200]))
+    parts = []
+    for c in np.argwhere(np.ones(dims)):
+        m = int(rng.choice([0, 3, 40, 170, 600]))
+        pts = rng.random((m, 3))
+        if m and rng.random() < 0.4:
+            w = 2.0 ** -int(rng.integers(2, 6))
+            pts[: m // 2] = rng.random(3) * (1 - w) + rng.random((m // 2, 3)) * w
+        parts.append(pts + c - 2.0)
+    cloud = np.unique(np.vstack(parts), axis=0)
+    rng.shuffle(cloud)
+    ctx = nat.get_context()
+
+    def run():
+        f = Forest(0, np.zeros(3), 1.0)
+        f.add_pose(cloud)
+        f.subdivide(K)
+        ctx.sync()
+        ctx.set_profiling(True)
+        order = f.order.copy()
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        blocks = {k: v.copy() for k, v in f.blocks.items()}
+        depth = int(f.info.max_depth)
+        f.close()
+        return order, blocks, names, depth
+
+    monkeypatch.delenv("OCTL_NO_FAST_ORDER", raising=False)
+    a, ba, na, depth = run()
+    monkeypatch.setenv("OCTL_NO_FAST_ORDER", "1")
+    b, bb, nb_, _ = run()
+    for k in ba:
+        assert np.array_equal(ba[k], bb[k]), k
+    assert np.array_equal(a, b)
+    assert sorted(a.tolist()) == list(range(len(a)))
+    assert "ransac_order" in nb_                 # order.hip ran for the second forest ...
+    if K >= 40 and depth <= 6:
+        # ... and not for the first (a small K may exceed what a bucket ranks in LDS, a tree deeper than the
+        # bucket kernel's six levels is finished by the level loop: both leave the order to order.hip)
+        assert "ransac_order" not in na
