@@ -359,10 +359,11 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
   if (e0 && n_e0 != n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "e0 size mismatch");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  // the mask of unevaluated positions is "keep"
+  // (no "keep" fill here: the batches below cover every block of every pose, the blocks tile the
+  //  leaf-ordered arrays, and every block's mask bytes are written - by the scoring kernels, or as zeros for
+  //  the blocks with fewer than k points)
   if (!f->mask_valid) {
     OCTL_TRY(devbuf_reserve(ctx, f->mask, (size_t)std::max<int64_t>(f->n_ord, 1)));
-    if (f->n_ord > 0) HIP_TRY(ctx, hipMemsetAsync(f->mask.p, 1, (size_t)f->n_ord, st));
     f->mask_valid = true;
   }
   if (f->n_blocks == 0) return OCTL_OK;
