@@ -1401,10 +1401,14 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   }
   if (want_order) {
     __syncthreads();
+    // (the blocks of a voxel are neighbours in storage order, and the listing order only permutes them
+    //  inside their voxel: a block is ranked among those)
     for (uint32_t j = tid; j < brun; j += 256) {
-      const uint32_t key = s_bkey[j];
-      uint32_t rk = 0;
-      for (uint32_t i = 0; i < brun; ++i) rk += s_bkey[i] < key ? 1u : 0u;
+      const uint32_t key = s_bkey[j], vox = key >> 13;
+      uint32_t lo = j;
+      while (lo > 0 && (s_bkey[lo - 1] >> 13) == vox) --lo;
+      uint32_t rk = lo;
+      for (uint32_t i = lo; i < brun && (s_bkey[i] >> 13) == vox; ++i) rk += s_bkey[i] < key ? 1u : 0u;
       P.order_out[bbase + rk] = (int32_t)(bbase + j);
     }
   }
