@@ -92,6 +92,7 @@ def _match_len_compare(fn) -> Optional[int]:
 
 _FLIP = {"<": ">", "<=": ">=", ">": "<", ">=": "<=", "==": "==", "!=": "!="}
 _INT_MAX = (1 << 63) - 1
+_PROBE_MAX = 1 << 22  # largest cloud a criterion is probed with (zeros((n, 3)): 100 MB)
 
 
 def _match_len_interval(fn):
@@ -125,6 +126,8 @@ def _match_len_interval(fn):
         c = float(c)
     except Exception:
         return None
+    if not np.isfinite(c) or abs(c) >= 2.0 ** 62:
+        return None  # len(p) < inf, len(p) > nan ...: left to the host path
     if op == ">":
         return int(np.floor(c)) + 1, _INT_MAX
     if op == ">=":
@@ -148,7 +151,13 @@ def try_count_interval(criteria: Sequence[Callable]):
             return None
         # double-check by probing around the bounds
         try:
-            for n in {max(iv[0] - 1, 0), iv[0], min(iv[1], iv[0] + 3), min(iv[1] + 1, iv[0] + 4)}:
+            # both ends of the interval (an end beyond any allocatable cloud is taken as open)
+            probes = {max(iv[0] - 1, 0), iv[0], iv[0] + 1}
+            if iv[1] < _PROBE_MAX:
+                probes |= {max(iv[1] - 1, 0), iv[1], iv[1] + 1}
+            for n in probes:
+                if n < 0 or n > _PROBE_MAX:
+                    continue
                 if bool(c(np.zeros((n, 3)))) != (iv[0] <= n <= iv[1]):
                     return None
         except Exception:

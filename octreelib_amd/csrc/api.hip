@@ -588,20 +588,23 @@ int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int
   OCTL_TRY(store_append(f, xyz, n, false));  // lands behind everything (bounding box, alive flags)
   if (tail > 0 && n > 0) {
     // The store is pose-major: rotate the new points in front of the later poses' points (they were
-    // appended at the end).  Two device copies through the partition scratch; the next build
-    // re-derives every table from the store.
+    // appended at the end).  The whole range [tail | new] goes through the partition scratch and comes
+    // back as [new | tail]: with more new points than later points the two pieces overlap in the
+    // store, so nothing is copied store-to-store.  The next build re-derives every table from the store.
     hipStream_t st = ctx->stream;
     const int64_t at = f->pose_off[slot + 1];
-    OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)tail * 25));
+    const int64_t span = tail + n;
+    OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)span * 25));
     char* tmp = static_cast<char*>(f->part_xyz[0].p);
+    char* tmp_al = tmp + (size_t)span * 24;
     double* xs = f->xyz.as<double>();
     uint8_t* al = f->alive.as<uint8_t>();
-    HIP_TRY(ctx, hipMemcpyAsync(tmp, xs + 3 * at, (size_t)tail * 24, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(tmp + (size_t)tail * 24, al + at, (size_t)tail, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(xs + 3 * at, xs + 3 * f->n_store, (size_t)n * 24, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(al + at, al + f->n_store, (size_t)n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(tmp, xs + 3 * at, (size_t)span * 24, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(tmp_al, al + at, (size_t)span, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(xs + 3 * at, tmp + (size_t)tail * 24, (size_t)n * 24, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(al + at, tmp_al + tail, (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(xs + 3 * (at + n), tmp, (size_t)tail * 24, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(al + at + n, tmp + (size_t)tail * 24, (size_t)tail, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(al + at + n, tmp_al, (size_t)tail, hipMemcpyDeviceToDevice, st));
   }
   f->n_store += n;
   f->n_alive += n;

@@ -346,10 +346,26 @@ extern "C" int octl_forest_reference_order(octl_forest* f, const int32_t* e0, in
   return OCTL_OK;
 }
 
+static int ransac_all_impl(octl_forest* f, int32_t poses_per_batch, const int32_t* e0, int32_t n_e0,
+                           const double* hypotheses, int32_t H, int32_t k, double threshold,
+                           bool* mask_fresh);
+
 extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, const int32_t* e0,
                                       int32_t n_e0, const double* hypotheses, int32_t H, int32_t k,
                                       double threshold) {
   if (!f || !hypotheses) return OCTL_E_INVALID;
+  // A mask buffer that was NOT valid before this call only becomes valid when every batch has been
+  // enqueued: a failure half way (reference order, a scratch reservation, a later batch) must not leave
+  // uninitialised or partly written bytes marked valid for the next apply_mask / filter.
+  bool mask_fresh = false;
+  const int rc = ransac_all_impl(f, poses_per_batch, e0, n_e0, hypotheses, H, k, threshold, &mask_fresh);
+  if (mask_fresh) f->mask_valid = (rc == OCTL_OK);
+  return rc;
+}
+
+static int ransac_all_impl(octl_forest* f, int32_t poses_per_batch, const int32_t* e0, int32_t n_e0,
+                           const double* hypotheses, int32_t H, int32_t k, double threshold,
+                           bool* mask_fresh) {
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "ransac before build");
   if (poses_per_batch < 1) return octl_set_error(ctx, OCTL_E_INVALID, "poses_per_batch < 1");
@@ -364,7 +380,7 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
   //  the blocks with fewer than k points)
   if (!f->mask_valid) {
     OCTL_TRY(devbuf_reserve(ctx, f->mask, (size_t)std::max<int64_t>(f->n_ord, 1)));
-    f->mask_valid = true;
+    *mask_fresh = true;  // (the caller marks it valid once everything below has been enqueued)
   }
   if (f->n_blocks == 0) return OCTL_OK;
   const size_t hyp_cap_before = f->rs_hyp.cap;

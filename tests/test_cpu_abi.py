@@ -85,6 +85,36 @@ def test_count_criterion_recognition():
         count_threshold([lambda p: len(p) > -1])
 
 
+def test_filter_interval_recognition_handles_non_finite_constants_and_probes_both_ends():
+    from octreelib_amd.criteria import try_count_interval
+
+    assert try_count_interval([lambda p: len(p) < 100]) == (0, 99)
+    assert try_count_interval([lambda p: len(p) >= 2, lambda p: len(p) <= 50.5]) == (2, 50)
+    assert try_count_interval([lambda p: 5 <= len(p)])[0] == 5
+    assert try_count_interval([lambda p: len(p) == 3]) == (3, 3)
+    # non-finite constants: no crash, the host path takes them
+    assert try_count_interval([lambda p: len(p) < float("inf")]) is None
+    assert try_count_interval([lambda p: len(p) > np.nan]) is None
+    assert try_count_interval([lambda p: len(p) > -np.inf]) is None
+
+    # a function whose bytecode looks like `len(p) < c` but whose upper end behaves differently is
+    # caught by the probe at hi (c changes between recognition and the probe calls)
+    class Shifty:
+        def __init__(self):
+            self.calls = 0
+
+        def __float__(self):
+            return 100.0
+
+        def __gt__(self, n):  # len(p) < self  ->  self > len(p)
+            return n < 50
+
+        __rlt__ = __gt__
+
+    shifty = Shifty()
+    assert try_count_interval([lambda p: len(p) < shifty]) is None
+
+
 def test_voxel_value_type():
     # reference: internal/voxel.py - equal voxels share an id, hash/eq on (corner, edge)
     from octreelib_amd.internal import Voxel, VoxelBase

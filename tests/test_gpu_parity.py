@@ -977,6 +977,39 @@ def test_manager_insert_points_into_any_existing_pose_vs_oracle():
         assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(om.octrees[p])))
 
 
+@pytest.mark.parametrize("n_extra", [300, 301, 10, 11])
+def test_manager_extend_pose_with_more_points_than_the_later_poses_hold(n_extra):
+    """The store is pose-major: points appended to an EARLIER pose are rotated in front of the later
+    poses' points.  With more new points than later points (300 vs 10) the two pieces overlap in the
+    store - the rotation must not copy store-to-store (round-2 advisor finding)."""
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+    from oracle import octree_np as onp
+
+    rng = np.random.default_rng(1000 + n_extra)
+    poses = [rng.random((500, 3)), rng.random((10, 3))]
+    extra = rng.random((n_extra, 3))
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 1.0)
+    om = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(2):
+        m.insert_points(p, poses[p])
+        om.insert_points(p, poses[p])
+    m.subdivide(crit(20))
+    om.subdivide(20)
+    m.insert_points(0, extra)
+    om.insert_points(0, extra)
+    allp = [np.vstack([poses[0], extra]), poses[1]]
+    for rnd in range(2):
+        for p in range(2):
+            assert np.array_equal(np.sort(m.get_points(p), axis=0), np.sort(allp[p], axis=0))
+            index = index_map(allp[p])
+            got = canon_from_list(views_table(m.get_leaf_points(True, p), index))
+            assert_same_leaves(got, canon_from_list(onp.tree_leaf_table(om.octrees[p])))
+            assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == [om.n_nodes(p), om.n_leaves(p), om.n_points(p)]
+        m.subdivide(crit(7))
+        om.subdivide(7)
+
+
 # ------------------------------------------------------------------------------------------------
 # the two build paths (bucket build / level-synchronous) must produce identical tables
 # ------------------------------------------------------------------------------------------------
