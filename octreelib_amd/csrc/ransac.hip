@@ -44,11 +44,49 @@ __device__ __forceinline__ double div_by_small_int(double c, int k) {
   return copysign(fma(c, zh, c * zl), c);         // (the sign: zl may be negative, c may be -0)
 }
 
+// ---- wave-uniform range certificate (RS_BLKFAST) -----------------------------------------------------------
+// The three shortcuts below (division of the centroid by k, in-range square root, shared-reciprocal
+// division by the norm) are exact only while no operand or intermediate leaves the normal range, and each
+// used to test that per lane and per fit: ~20 f64 compares out of ~250 instructions.  Almost all of that
+// follows from ONE property of the block, tested once per point when the block is staged:
+//
+//   every coordinate of every point of the block (and of its spill point) is +0.0 or has 2^-30 <= |v| < 2^31
+//
+// With it (the "grid" argument: a value that is a multiple of g stays a multiple of g under +, - and
+// round-to-nearest, so a non-zero result is at least g in magnitude):
+//   * coordinates are multiples of 2^-82; a non-zero centroid sum is >= 2^-82 and < 2^35: in the range of
+//     div3_by_small_int, and never -0 (x + y is -0 only for x = y = -0), so its copysign is the identity;
+//     `0.0 + x` is x (util.py:35-40 starts the sums at 0.0);
+//   * the centroid (|c| >= 2^-86 or 0) is a multiple of 2^-138, so are the residuals; products and the six
+//     covariance sums are multiples of 2^-276 below 2^68; cofactors are multiples of 2^-552 below 2^137;
+//     s = |cofactor row|^2 < 2^276 is never NaN / inf;
+//   * per fit ONE test remains: s >= 2^-400 (an integer compare on the high word).  Then norm is in
+//     [2^-200, 2^138] - inside sqrt_rn_guarded's and div3_by_norm's ranges and non-zero (util.py:77-78 is the
+//     slow path's business) - and every numerator is 0 or >= 2^-552: quotients >= 2^-690 stay normal, and
+//     the residual fma(-norm, q0, a), a multiple of ulp(norm) ulp(q0) >= 2^-252 2^-743, is exact.
+// Blocks that fail the property (denormal-scale or astronomically large coordinates, -0.0, NaN, inf) keep the
+// per-lane guards.  tests/test_gpu_primitives.py checks the unguarded forms bit-for-bit against IEEE division
+// and square root over this wider domain.
+#ifndef RS_BLKFAST
+#define RS_BLKFAST 1
+#endif
+__device__ __forceinline__ bool coord_in_fast_range(double v) {
+  const uint32_t hi = (uint32_t)__double2hiint(v), lo = (uint32_t)__double2loint(v);
+  const uint32_t e = (hi >> 20) & 0x7FFu;
+  return (e - (1023u - 30u)) <= 60u || (hi | lo) == 0u;  // (-0.0: hi = 0x80000000 - not accepted)
+}
+
 // the three centroid coordinates at once: one flat predicate, one (never taken) slow branch
-__device__ __forceinline__ void div3_by_small_int(double& cx, double& cy, double& cz, int k) {
+__device__ __forceinline__ void div3_by_small_int(double& cx, double& cy, double& cz, int k, bool fast = false) {
   const double kd = (double)k;
   const double zh = 1.0 / kd;
   const double zl = fma(-kd, zh, 1.0) / kd;
+  if (fast) {  // wave-uniform: sums are 0 or in [2^-82, 2^35), never -0
+    cx = fma(cx, zh, cx * zl);
+    cy = fma(cy, zh, cy * zl);
+    cz = fma(cz, zh, cz * zl);
+    return;
+  }
   const double ax = fabs(cx), ay = fabs(cy), az = fabs(cz);
   // (ints on purpose: one flat predicate, no short-circuit branches)
   const int ok = (int(ax > 1e-290) | int(cx == 0.0)) & int(ax < 1e290) &
@@ -68,8 +106,7 @@ __device__ __forceinline__ void div3_by_small_int(double& cx, double& cy, double
 // sqrt(s), correctly rounded (util.py:76, `** 0.5`).  In range this IS the compiler's IEEE f64 square
 // root - v_rsq_f64, one coupled Goldschmidt step, two residual corrections - without the operand
 // rescaling it applies below 2^-767 and the patch for 0 / inf; everything else takes the full one.
-__device__ __forceinline__ double sqrt_rn_guarded(double s) {
-  if (!(int(s >= 0x1p-700) & int(s < 0x1p1000))) return __dsqrt_rn(s);  // also NaN, 0, inf, negative
+__device__ __forceinline__ double sqrt_rn_inrange(double s) {
   const double y = __builtin_amdgcn_rsq(s);
   double g = s * y;
   double h = y * 0.5;
@@ -81,6 +118,10 @@ __device__ __forceinline__ double sqrt_rn_guarded(double s) {
   d = fma(-g, g, s);
   return fma(d, h, g);
 }
+__device__ __forceinline__ double sqrt_rn_guarded(double s) {
+  if (!(int(s >= 0x1p-700) & int(s < 0x1p1000))) return __dsqrt_rn(s);  // also NaN, 0, inf, negative
+  return sqrt_rn_inrange(s);
+}
 
 // (ax, ay, az) / norm, correctly rounded (util.py:80-82), norm > 0.  In range this IS the
 // compiler's IEEE f64 division - v_rcp_f64, two Newton steps on the reciprocal, q0 = a*r,
@@ -90,6 +131,17 @@ __device__ __forceinline__ double sqrt_rn_guarded(double s) {
 // zeros / infinities / NaNs).  The sign is taken from the numerator: a (-0) numerator would
 // otherwise come out as +0 from the final fma.  Everything else takes the true division.
 // Domain of the shortcut: |a_i| <= 2^60 norm (in the plane fit |a_i| <= norm (1 + 2^-52) always).
+__device__ __forceinline__ void div3_by_norm_inrange(double& ax, double& ay, double& az, double norm) {
+  double r = __builtin_amdgcn_rcp(norm);
+  double e = fma(-norm, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-norm, r, 1.0);
+  r = fma(r, e, r);
+  const double qx = ax * r, qy = ay * r, qz = az * r;
+  ax = copysign(fma(fma(-norm, qx, ax), r, qx), ax);
+  ay = copysign(fma(fma(-norm, qy, ay), r, qy), ay);
+  az = copysign(fma(fma(-norm, qz, az), r, qz), az);
+}
 __device__ __forceinline__ void div3_by_norm(double& ax, double& ay, double& az, double norm) {
   const double lo = 0x1p-400, hi = 0x1p500;
   // (ints and bitwise on purpose: one flat predicate instead of a chain of short-circuit
@@ -102,21 +154,14 @@ __device__ __forceinline__ void div3_by_norm(double& ax, double& ay, double& az,
     az /= norm;
     return;
   }
-  double r = __builtin_amdgcn_rcp(norm);
-  double e = fma(-norm, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-norm, r, 1.0);
-  r = fma(r, e, r);
-  const double qx = ax * r, qy = ay * r, qz = az * r;
-  ax = copysign(fma(fma(-norm, qx, ax), r, qx), ax);
-  ay = copysign(fma(fma(-norm, qy, ay), r, qy), ay);
-  az = copysign(fma(fma(-norm, qz, az), r, qz), az);
+  div3_by_norm_inrange(ax, ay, az, norm);
 }
 
-// util.py:59-84: the plane of the centroid and the six covariance sums
+// util.py:59-84: the plane of the centroid and the six covariance sums.  `fast`: the block holds the range
+// certificate above (wave-uniform).
 __device__ __forceinline__ void plane_from_moments(double cx, double cy, double cz, double xx, double xy,
                                                    double xz, double yy, double yz, double zz,
-                                                   float (&plane)[4]) {
+                                                   float (&plane)[4], bool fast = false) {
   const double det_x = yy * zz - yz * yz;  // util.py:59-61
   const double det_y = xx * zz - xz * xz;
   const double det_z = xx * yy - xy * xy;
@@ -131,18 +176,26 @@ __device__ __forceinline__ void plane_from_moments(double cx, double cy, double 
   double ax = is_x ? det_x : (is_y ? cA : cB);
   double ay = is_x ? cA : (is_y ? det_y : cC);
   double az = is_x ? cB : (is_y ? cC : det_z);
+  const double s = ax * ax + ay * ay + az * az;  // util.py:76
 #if RS_FAST_DIV
-  const double norm = sqrt_rn_guarded(ax * ax + ay * ay + az * az);  // util.py:76
+  // one integer compare on the high word: s >= 2^-400 (s is finite and non-negative here)
+  if (RS_BLKFAST && fast && (uint32_t)__double2hiint(s) >= ((1023u - 400u) << 20)) {
+    const double norm = sqrt_rn_inrange(s);
+    div3_by_norm_inrange(ax, ay, az, norm);
+  } else {
+    const double norm = sqrt_rn_guarded(s);
+    if (norm == 0.0) {  // util.py:77-78
+      plane[0] = plane[1] = plane[2] = plane[3] = 0.0f;
+      return;
+    }
+    div3_by_norm(ax, ay, az, norm);
+  }
 #else
-  const double norm = __dsqrt_rn(ax * ax + ay * ay + az * az);  // util.py:76
-#endif
-  if (norm == 0.0) {                                            // util.py:77-78
+  const double norm = __dsqrt_rn(s);
+  if (norm == 0.0) {  // util.py:77-78
     plane[0] = plane[1] = plane[2] = plane[3] = 0.0f;
     return;
   }
-#if RS_FAST_DIV
-  div3_by_norm(ax, ay, az, norm);
-#else
   ax /= norm;
   ay /= norm;
   az /= norm;
@@ -160,11 +213,21 @@ template <int KT, int KMAX>
 __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
                                                    const double (&sy)[KMAX],
                                                    const double (&sz)[KMAX], int k_rt,
-                                                   float (&plane)[4]) {
+                                                   float (&plane)[4], bool fast = false) {
   const int k = KT > 0 ? KT : k_rt;
   double cx = 0.0, cy = 0.0, cz = 0.0;
+  if (RS_BLKFAST && fast) {  // (wave-uniform) no -0.0 among the coordinates: 0.0 + x == x
+    cx = sx[0];
+    cy = sy[0];
+    cz = sz[0];
+  } else {
+    asm volatile("" ::: "memory");  // (a real branch: if-converted this is three adds AND six selects)
+    cx += sx[0];
+    cy += sy[0];
+    cz += sz[0];
+  }
 #pragma unroll
-  for (int i = 0; i < (KT > 0 ? KT : KMAX); ++i) {  // util.py:37-40
+  for (int i = 1; i < (KT > 0 ? KT : KMAX); ++i) {  // util.py:37-40
     if (i < k) {
       cx += sx[i];
       cy += sy[i];
@@ -175,7 +238,7 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
   // divisor k <= 16 the quotient c/k is never closer than 1/(2k) ulp to a rounding midpoint, so
   // RN(c*zh + RN(c*zl)) with zh + zl = 1/k to ~2^-106 IS the correctly rounded quotient:
   // one multiply + one FMA instead of the 11-instruction IEEE division sequence.
-  div3_by_small_int(cx, cy, cz, k);
+  div3_by_small_int(cx, cy, cz, k, RS_BLKFAST && fast);
   // util.py:48-57.  The reference starts every sum at 0.0: for the squares 0.0 + r*r == r*r exactly
   // (a square is never -0), so their first add is dropped; a cross product CAN be -0 and 0.0 + (-0) is
   // +0, so the cross terms keep it (axis-aligned samples reach the sign of a zero plane coefficient).
@@ -200,7 +263,7 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
       yz += ry * rz;
     }
   }
-  plane_from_moments(cx, cy, cz, xx, xy, xz, yy, yz, zz, plane);
+  plane_from_moments(cx, cy, cz, xx, xy, xz, yy, yz, zz, plane, fast);
 }
 
 // util.py:22-24 with the f32 plane promoted to f64: ((a*x + b*y) + c*z) + d
@@ -226,6 +289,12 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #endif
 #ifndef RS_SCREEN
 #define RS_SCREEN 1  // f32 screening of the scoring loop (exact counts; see "Screening" in k_ransac)
+#endif
+#ifndef RS_ABLATE
+#define RS_ABLATE 0
+#endif
+#ifndef RS_F32_BOUND
+#define RS_F32_BOUND 1  // the screening bound of a hypothesis in f32 (rounded up) where the block is certified
 #endif
 #ifndef RS_BIG_THREADS
 #define RS_BIG_THREADS 256  // lanes per workgroup for H > 256 (x RS_BIG_HPL hypotheses per lane)
@@ -431,7 +500,7 @@ __device__ __forceinline__ float min3abs(float m, float a, float b) {
 template <int THREADS>
 __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, const BlockDesc& d,
                                             double px, double py, double pz, f4* loc,
-                                            float* wext) {
+                                            float* wext, uint32_t* wfast) {
   const double ox = xyz[3 * (int64_t)d.pstart], oy = xyz[3 * (int64_t)d.pstart + 1],
                oz = xyz[3 * (int64_t)d.pstart + 2];
   float m = 0.f;
@@ -444,7 +513,13 @@ __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, cons
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-  if ((threadIdx.x & 63) == 0) wext[threadIdx.x >> 6] = m;
+  // the range certificate of the plane fit's shortcuts (see RS_BLKFAST): lanes that stage nothing hold +0.0
+  const bool inr = coord_in_fast_range(px) && coord_in_fast_range(py) && coord_in_fast_range(pz);
+  const bool wave_fast = __all(inr);
+  if ((threadIdx.x & 63) == 0) {
+    wext[threadIdx.x >> 6] = m;
+    wfast[threadIdx.x >> 6] = wave_fast ? 1u : 0u;
+  }
 }
 
 // The screened scoring of the block's n staged points (block-local f32 coordinates in LDS, read
@@ -534,6 +609,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   // relative to the block's first point and, per wave, the largest |coordinate|
   __shared__ f4 s_loc[3][THREADS];
   __shared__ float s_wext[3][W];
+  __shared__ uint32_t s_wfast[3][W];
 #endif
   const int nbs = (int)*n_sorted_ptr;
   // workgroup w owns the CONTIGUOUS chunk [w*C, (w+1)*C) of the size-sorted list: its blocks have
@@ -558,7 +634,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       s_pts[0][2][threadIdx.x] = pz;
     }
 #if RS_SCREEN
-    stage_local<THREADS>(xyz, cur, px, py, pz, s_loc[0], s_wext[0]);
+    stage_local<THREADS>(xyz, cur, px, py, pz, s_loc[0], s_wext[0], s_wfast[0]);
 #endif
   }
   __syncthreads();
@@ -654,6 +730,12 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     float extent = s_wext[buf][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) extent = fmaxf(extent, s_wext[buf][w]);
+    // every staged coordinate (block + spill point) is +0.0 or in [2^-30, 2^31): the plane fits run without
+    // their per-lane range guards (RS_BLKFAST).  Wave-uniform, kept in an SGPR.
+    uint32_t fastw = s_wfast[buf][0];
+#pragma unroll
+    for (int w = 1; w < W; ++w) fastw &= s_wfast[buf][w];
+    const bool blk_fast = RS_BLKFAST && __builtin_amdgcn_readfirstlane((int)fastw) != 0;
     // block-uniform parts of the bound.  Thresholds or extents outside the sane range (nobody's
     // plane tolerance) are always recounted exactly.
     const double delta_blk = fma(0x1p-23 * 9.0, (double)extent,
@@ -662,6 +744,11 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const bool blk_sane = thr >= 0x1p-40 && thr <= 0x1p40 && extent < 0x1p60f;
     const float nthr2 = -(float)(thr * thr);
     const f4* __restrict__ loc = s_loc[buf];
+    // f32 forms of the bound's block-uniform parts, rounded up (RS_F32_BOUND)
+    const bool fast_screen = blk_fast && thr >= 0x1p-40 && thr <= 0x1p40;
+    const float delta_blk_f = (float)delta_blk * 0x1.0002p0f;
+    const float thr2_f = (float)(thr + thr) * 0x1.0002p0f;
+    const float dprime_thr_f = (float)dprime_thr * 0x1.0002p0f;
 
     float fa[HPL], fb[HPL], fc[HPL], fd[HPL], sto[HPL], sdl[HPL];
     int cnt[HPL];
@@ -700,17 +787,25 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         if (ABL == 2) {  // ablation: no plane fit (timing only, results meaningless)
           pf[0] = (float)sx[0]; pf[1] = (float)sy[1]; pf[2] = (float)sz[2]; pf[3] = (float)sx[3];
         } else {
-          plane_from_samples<KT, KS>(sx, sy, sz, k, pf);
+          plane_from_samples<KT, KS>(sx, sy, sz, k, pf, blk_fast);
         }
         // (explicit fma: error BOUNDS and the screen's own inputs, not parity arithmetic)
         const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
         const double to = fma(A, ox, fma(B, oy, fma(Cc, oz, D)));
-        const double delta = fma(0x1p-21, fabs(to), fma(0x1p-49, fabs(D), delta_blk));
-        const double dprime = fma(delta, thr + thr + delta, dprime_thr) * 1.000001;
-        const bool sane = blk_sane && (fabs(to) < 0x1p60);  // false for NaN
         fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
         sto[q] = (float)to;
-        sdl[q] = sane ? (float)dprime : __int_as_float(0x7f800000);
+        if (RS_F32_BOUND && fast_screen) {
+          // (wave-uniform) the same bound evaluated in f32, every constant rounded UP and the result
+          // inflated by 2^-15 - the f32 roundings and the rounding of `to` lose at most 2^-21 of it;
+          // |to| < 2^35 and no NaN under the block's range certificate, thr is in range: always "sane"
+          const float dl = fma32(fabsf(sto[q]), 0x1.0002p-21f, fma32(fabsf(pf[3]), 0x1.0002p-49f, delta_blk_f));
+          sdl[q] = fma32(dl, thr2_f + dl, dprime_thr_f) * 0x1.0002p0f;
+        } else {
+          const double delta = fma(0x1p-21, fabs(to), fma(0x1p-49, fabs(D), delta_blk));
+          const double dprime = fma(delta, thr + thr + delta, dprime_thr) * 1.000001;
+          const bool sane = blk_sane && (fabs(to) < 0x1p60);  // false for NaN
+          sdl[q] = sane ? (float)dprime : __int_as_float(0x7f800000);
+        }
       }
       // keep the plane fits of the lane's hypotheses apart: interleaved they need > 200 VGPRs
       __builtin_amdgcn_sched_barrier(0);
@@ -823,7 +918,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       s_pts[nbuf][2][tx] = rz;
     }
 #if RS_SCREEN
-    if (has_next) stage_local<THREADS>(xyz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf]);
+    if (has_next) stage_local<THREADS>(xyz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf], s_wfast[nbuf]);
 #endif
     __syncthreads();
     unsigned long long gbest = s_wbest[par][0];
@@ -1262,10 +1357,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   } else if (H <= 256) {
     if (k == 6) OCTL_RANSAC_LAUNCH(256, 1, 6, 0, 8); else OCTL_RANSAC_LAUNCH(256, 1, 0, 0, 4);
   } else {
-    const char* abl = getenv("OCTL_RANSAC_ABLATE");  // timing experiments only
-    if (k == 6 && abl && abl[0] == '1') OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 1, RS_PER_CU);
-    else if (k == 6 && abl && abl[0] == '2') OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 2, RS_PER_CU);
-    else if (k == 6) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, 0, RS_PER_CU);
+    // (timing experiments - no fit / no scoring, results meaningless - exist only in builds made with
+    //  -DRS_ABLATE=1|2, tools/build_variant.sh; the shipped library has no such switch)
+    if (k == 6) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, RS_ABLATE, RS_PER_CU);
     // the other small sample sizes also get compile-time k (sample arrays in registers; the generic
     // instantiation indexes them at run time and spills)
     else if (k == 5) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 5, 0, RS_PER_CU);

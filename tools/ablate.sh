@@ -1,11 +1,9 @@
 #!/bin/bash
-# RANSAC kernel time with parts removed (timing only, results meaningless): 0 = full, 1 = no scoring, 2 = no plane fit
-for a in 0 1 2; do
-  OCTL_RANSAC_ABLATE=$a python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/abl_$a.json 2> gpurun_out/abl_$a.err || echo FAILED $a
+# Ablation timings of k_ransac (no scoring / no plane fit).  The switches are COMPILE-TIME (-DRS_ABLATE=1|2):
+# the shipped library has none.  Builds two variants and runs the headline-only bench on each.
+set -e
+tools/build_variant.sh abl1 "-DRS_ABLATE=1"
+tools/build_variant.sh abl2 "-DRS_ABLATE=2"
+for a in abl1 abl2; do
+  OCTREELIB_AMD_LIB=$PWD/build/variants/$a.so python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary > gpurun_out/$a.json 2> gpurun_out/$a.err || echo FAILED $a
 done
-python - <<'PY'
-import json
-for a in (0, 1, 2):
-    d = json.load(open(f'gpurun_out/abl_{a}.json'))
-    print('ablate', a, 'ransac %.3f ms' % d['kernels']['ransac']['ms_per_step'], 'step %.2f' % d['ms_per_step'])
-PY
