@@ -106,6 +106,7 @@ SIGNATURES = {
     "octl_debug_exclusive_scan": (C.c_int, [_p, _p, _i64, _p, _p]),
     "octl_debug_radix_sort": (C.c_int, [_p, _p, _p, _i64, C.c_int]),
     "octl_debug_plane_arith": (C.c_int, [_p, _p, _p, _p, C.c_int32, _i64, _p, _p, _p]),
+    "octl_debug_plane_arith_certified": (C.c_int, [_p, _p, _p, _p, C.c_int32, _i64, _p, _p, _p]),
 }
 
 _lib = None

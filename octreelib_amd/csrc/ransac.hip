@@ -1398,28 +1398,51 @@ __global__ __launch_bounds__(256) void k_debug_plane_arith(const double* __restr
                                                             const double* __restrict__ c, int kdiv,
                                                             int64_t n, double* __restrict__ q3,
                                                             double* __restrict__ ck,
-                                                            double* __restrict__ sq) {
+                                                            double* __restrict__ sq, int certified) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double a = num3[3 * i], b = num3[3 * i + 1], cc = num3[3 * i + 2];
-  div3_by_norm(a, b, cc, den[i]);
+  double c0 = c[i], c1 = c[i + 1 < n ? i + 1 : 0], c2 = c[i + 2 < n ? i + 2 : 0];
+  if (certified) {
+    // the guard-free forms a block with the range certificate (RS_BLKFAST) runs
+    div3_by_norm_inrange(a, b, cc, den[i]);
+    div3_by_small_int(c0, c1, c2, kdiv, true);
+    ck[i] = c0;
+    sq[i] = sqrt_rn_inrange(c[i]);
+  } else {
+    div3_by_norm(a, b, cc, den[i]);
+    // the 3-wide form the plane fit uses, with neighbours as the other two lanes of the predicate
+    div3_by_small_int(c0, c1, c2, kdiv);
+    ck[i] = (i & 1) ? c0 : div_by_small_int(c[i], kdiv);
+    sq[i] = sqrt_rn_guarded(c[i]);
+  }
   q3[3 * i] = a;
   q3[3 * i + 1] = b;
   q3[3 * i + 2] = cc;
-  // the 3-wide form the plane fit uses, with neighbours as the other two lanes of the predicate
-  double c0 = c[i], c1 = c[i + 1 < n ? i + 1 : 0], c2 = c[i + 2 < n ? i + 2 : 0];
-  div3_by_small_int(c0, c1, c2, kdiv);
-  ck[i] = (i & 1) ? c0 : div_by_small_int(c[i], kdiv);
-  sq[i] = sqrt_rn_guarded(c[i]);
 }
 }  // namespace
 
 // q3[i] = num3[i] / den[i] (three numerators per divisor, den > 0), ck[i] = c[i] / kdiv and
 // sq[i] = sqrt(c[i]) as the plane fit computes them; host arrays in, host arrays out
 // (tests/test_gpu_primitives.py)
+static int debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den, const double* c,
+                             int32_t kdiv, int64_t n, double* q3, double* ck, double* sq, int certified);
 extern "C" int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den,
                                       const double* c, int32_t kdiv, int64_t n, double* q3,
                                       double* ck, double* sq) {
+  return debug_plane_arith(ctx, num3, den, c, kdiv, n, q3, ck, sq, 0);
+}
+// the same three operations WITHOUT their range guards, as the plane fit runs them on a block that holds the
+// range certificate (RS_BLKFAST): the caller keeps the operands inside the certified ranges
+// (den in [2^-200, 2^138], num3 zero or >= 2^-552 and <= den, c zero (+0.0) or in [2^-82, 2^35) for the
+// division by kdiv, c in [2^-400, 2^276] for the square root)
+extern "C" int octl_debug_plane_arith_certified(octl_ctx* ctx, const double* num3, const double* den,
+                                                const double* c, int32_t kdiv, int64_t n, double* q3,
+                                                double* ck, double* sq) {
+  return debug_plane_arith(ctx, num3, den, c, kdiv, n, q3, ck, sq, 1);
+}
+static int debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den, const double* c,
+                             int32_t kdiv, int64_t n, double* q3, double* ck, double* sq, int certified) {
   if (!ctx || n < 0 || kdiv < 1 || kdiv > 16 ||
       (n > 0 && (!num3 || !den || !c || !q3 || !ck || !sq)))
     return OCTL_E_INVALID;
@@ -1442,7 +1465,7 @@ extern "C" int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const d
   if (rc == OCTL_OK) {
     hipLaunchKernelGGL(k_debug_plane_arith, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                        (const double*)d_num, (const double*)d_den, (const double*)d_c, (int)kdiv, n,
-                       d_q, d_ck, d_sq);
+                       d_q, d_ck, d_sq, certified);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(q3, d_q, (size_t)n * 24, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(ck, d_ck, (size_t)n * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||

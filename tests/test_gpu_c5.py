@@ -71,7 +71,8 @@ def test_c5_one_rank_shard_125M_properties():
     inv[perm] = np.arange(n)
     assert np.array_equal(xyz_ord[inv[:chunk]], first)
     _check_points_in_leaf_cubes(f, xyz_ord)
-    del inv, xyz_head
+    inv_of = lambda c: inv[c * chunk : (c + 1) * chunk]
+    del xyz_head
     # ---- RANSAC on a sample of blocks with details, then on everything ---------------------------------------
     np.random.seed(0)
     table = np.random.random((1024, 6))
@@ -84,6 +85,31 @@ def test_c5_one_rank_shard_125M_properties():
     cs = np.concatenate(([0], np.cumsum(mask, dtype=np.int64)))
     assert np.array_equal(cs[starts + sizes] - cs[starts], count)
     assert (count[sizes < 6] == 0).all() and (count <= sizes).all()
+    # ---- the oracle at this size -------------------------------------------------------------------------------
+    from tests._fullsize import (oracle_check_every_leaf, oracle_check_ransac_blocks, oracle_check_voxels,
+                                 pick_blocks_of_every_size)
+
+    def chunks():
+        for c in range(n // chunk):
+            yield c * chunk, np.ascontiguousarray(synthetic.uniform_cloud(chunk, dims, seed=2000 + c, voxels=vox))
+
+    rng = np.random.default_rng(13)
+    # 200 whole voxels (their ~477 points collected from all ten uploaded chunks) rebuilt by the recursive oracle
+    nv, nl = oracle_check_voxels(f, chunks(), 200, K, rng)
+    assert nv == 200 and nl > 2000
+    # >= 2500 blocks of every size through the operator: count, winner, plane bits, mask
+    sel = pick_blocks_of_every_size(blk["size"], 40, rng, at_least=2500)
+    sz, _ = oracle_check_ransac_blocks(f, sel, table, 0.01, xyz_ord)
+    assert len(sz) >= 2500 and len(np.unique(sz)) >= K - 2
+    # every leaf and the leaf of every one of the 125 M points against the count-only oracle (the ten chunks
+    # as consecutive pieces of the one pose)
+    pieces = [p for _, p in chunks()]
+    for c, piece in enumerate(pieces):
+        assert np.array_equal(xyz_ord[inv_of(c)], piece)   # the stored cloud IS the uploaded one
+    del xyz_ord
+    f._xyz = None  # (3 GB: the forest's cached host copy is not needed any more)
+    oracle_check_every_leaf(f, pieces, K, grid=True, one_slot=True)
+    del pieces
     f.ransac_all(10, table, 0.01)
     mask = f.device_mask()
     kept = int(mask.sum())

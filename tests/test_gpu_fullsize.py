@@ -106,6 +106,37 @@ def test_c3_grid_10M_properties():
     zero = nrm == 0
     assert np.allclose(nrm[~zero], 1.0, atol=1e-6)
     assert (count[sizes >= 6][zero] == sizes[sizes >= 6][zero]).all()
+    # ---- the oracle at this size (round-2 review: "full size is property-checked only") ---------------------
+    from tests._fullsize import (oracle_check_every_leaf, oracle_check_ransac_blocks, oracle_check_voxels,
+                                 pick_blocks_of_every_size)
+
+    rng = np.random.default_rng(11)
+    # every leaf and every point against the count-only oracle
+    oracle_check_every_leaf(f, [pts], K, grid=True)
+    # 200 whole voxels rebuilt by the recursive oracle: leaf tables, index sets, listing order
+    nv, nl = oracle_check_voxels(f, [(0, pts)], 200, K, rng)
+    assert nv == 200 and nl > 2000
+    # >= 2500 RANSAC blocks of every size from 1 to K: count, winning hypothesis, f32 plane bits, mask
+    sel = pick_blocks_of_every_size(blk["size"], 40, rng, at_least=2500)
+    sz, _ = oracle_check_ransac_blocks(f, sel, table, 0.01, xyz_ord)
+    assert len(sz) >= 2500 and sz.min() < 6 and sz.max() == K and len(np.unique(sz)) == K
+    # the same cloud with K = 400: the voxels stay whole (about 305 points each) - blocks above 64 and
+    # above 255 points, the sizes that take k_ransac's upper range and k_ransac_big
+    f.subdivide(400)
+    blk = f.blocks
+    assert blk["size"].max() > 255 and (blk["size"] > 64).mean() > 0.99
+    sel = pick_blocks_of_every_size(blk["size"], 2, rng, at_least=300)
+    sz, _ = oracle_check_ransac_blocks(f, sel, table, 0.01, f.xyz)
+    assert (sz > 255).sum() >= 100
+    f.close()
+    # ... and 6 M of the points (about 183 per voxel, K = 400): blocks between 65 and 255 points
+    f = Forest(0, np.zeros(3), 1.0)
+    f.add_pose(pts[:6_000_000])
+    f.subdivide(400)
+    blk = f.blocks
+    sel = pick_blocks_of_every_size(blk["size"], 3, rng, at_least=300)
+    sz, _ = oracle_check_ransac_blocks(f, sel, table, 0.01, f.xyz)
+    assert ((sz > 64) & (sz <= 255)).sum() >= 250
     f.close()
 
 
@@ -180,8 +211,9 @@ def test_c4_manager_multi_pose_reduced_vs_oracle_and_full_properties():
     # full size: 64 poses x 1 M points in one cube, K = 4096 (union of 64 M points)
     P, n, K = 64, 1_000_000, 4096
     f = Forest(1, np.zeros(3), 1.0)
+    poses = [np.random.default_rng(100 + p).random((n, 3)) for p in range(P)]
     for p in range(P):
-        f.add_pose(np.random.default_rng(100 + p).random((n, 3)))
+        f.add_pose(poses[p])
     f.subdivide(K)
     nd, blk, perm = _check_structure(f, P * n, K)
     assert f.info.n_voxels == 1 and f.info.n_levels >= 4
@@ -189,4 +221,20 @@ def test_c4_manager_multi_pose_reduced_vs_oracle_and_full_properties():
     assert np.array_equal(np.unique(blk["slot"]), np.arange(P))
     same_leaf = blk["node"][1:] == blk["node"][:-1]
     assert (np.diff(blk["slot"])[same_leaf] > 0).all()
+    # ---- the oracle at this size: every node, and the leaf of every one of the 64 M points, per pose ----------
+    from tests._fullsize import oracle_check_every_leaf, oracle_check_ransac_blocks, pick_blocks_of_every_size
+
+    cs = oracle_check_every_leaf(f, poses, K, grid=False)
+    assert len(cs.edge) == len(nd["edge"]) and int(cs.is_leaf.sum()) > 10_000
+    # (leaf, pose) blocks of every size through the RANSAC operator against the oracle
+    np.random.seed(0)
+    table = np.random.random((1024, 6))
+    rng = np.random.default_rng(12)
+    sel = pick_blocks_of_every_size(blk["size"], 25, rng, at_least=2000)
+    sz, _ = oracle_check_ransac_blocks(f, sel, table, 0.01, f.xyz)
+    assert len(sz) >= 2000
+    # a scheme driven by a subset of the poses (octree_manager.py:46-61): poses outside it may keep leaves
+    # with more than K points
+    f.subdivide(K // 8, scheme_slots=[0, 5, 9, 33])
+    oracle_check_every_leaf(f, poses, K // 8, grid=False, scheme_slots=[0, 5, 9, 33])
     f.close()

@@ -69,7 +69,7 @@ def _same_bits(a, b):
     return (a.view(np.uint64) == b.view(np.uint64)) | both_nan
 
 
-def _plane_arith(num3, den, c, k):
+def _plane_arith(num3, den, c, k, certified=False):
     from octreelib_amd import _native as nat
 
     ctx = nat.get_context()
@@ -77,8 +77,9 @@ def _plane_arith(num3, den, c, k):
     q3 = np.empty((n, 3))
     ck = np.empty(n)
     sq = np.empty(n)
-    ctx.check(ctx.lib.octl_debug_plane_arith(ctx.handle, nat.ptr(np.ascontiguousarray(num3)), nat.ptr(np.ascontiguousarray(den)),
-                                             nat.ptr(np.ascontiguousarray(c)), k, n, nat.ptr(q3), nat.ptr(ck), nat.ptr(sq)))
+    fn = ctx.lib.octl_debug_plane_arith_certified if certified else ctx.lib.octl_debug_plane_arith
+    ctx.check(fn(ctx.handle, nat.ptr(np.ascontiguousarray(num3)), nat.ptr(np.ascontiguousarray(den)),
+                 nat.ptr(np.ascontiguousarray(c)), k, n, nat.ptr(q3), nat.ptr(ck), nat.ptr(sq)))
     return q3, ck, sq
 
 
@@ -157,3 +158,84 @@ def test_plane_fit_divisions_near_rounding_midpoints():
         assert _same_bits(q3, num / den[:, None]).all()
         assert _same_bits(ck, c / np.float64(k)).all()
         assert _same_bits(sq, np.sqrt(c)).all()
+
+
+def _certified_cases(seed, n=2_000_000):
+    """Operands inside the ranges the block certificate of csrc/ransac.hip (RS_BLKFAST) guarantees:
+    norm in [2^-200, 2^138], numerators zero or in [2^-552, norm (1 + 2^-52)], centroid sums +0.0 or in
+    [2^-82, 2^35), s in [2^-400, 2^276] - with the edges of every range over-represented."""
+    rng = np.random.default_rng(seed)
+    mant = rng.random(n) + 1.0
+    pick = rng.random(n)
+    mant = np.where(pick < 0.05, np.nextafter(2.0, 0.0), mant)
+    mant = np.where((pick >= 0.05) & (pick < 0.10), 1.0, mant)
+    mant = np.where((pick >= 0.10) & (pick < 0.15), 1.0 + 2.0 ** -52, mant)
+    e_den = rng.integers(-200, 138, n)
+    e_den = np.where(rng.random(n) < 0.1, rng.choice([-200, -199, 136, 137], n), e_den)
+    den = np.ldexp(mant, e_den)
+    den = np.minimum(den, 2.0 ** 138)
+    num3 = (rng.random((n, 3)) * 2 - 1) * den[:, None]
+    # tiny numerators down to the grid of the cofactors (2^-552), exact zeros of both signs, |a| = norm
+    tiny = np.ldexp(rng.random((n, 3)) + 1.0, rng.integers(-552, -100, (n, 3))) * rng.choice([-1.0, 1.0], (n, 3))
+    tiny = np.where(np.abs(tiny) <= den[:, None], tiny, den[:, None])
+    sp = rng.random((n, 3))
+    num3 = np.where(sp < 0.25, tiny, num3)
+    num3 = np.where((sp >= 0.25) & (sp < 0.30), 0.0, num3)
+    num3 = np.where((sp >= 0.30) & (sp < 0.33), -0.0, num3)
+    num3 = np.where((sp >= 0.33) & (sp < 0.36), den[:, None] * np.array([1.0, -1.0, 1.0]), num3)
+    num3 = np.where((sp >= 0.36) & (sp < 0.38), np.nextafter(den, np.inf)[:, None], num3)
+    num3 = np.where((np.abs(num3) < 2.0 ** -552) & (num3 != 0), np.copysign(2.0 ** -552, num3), num3)
+    # centroid sums: multiples of 2^-82 below 2^35 (what sums of certified coordinates are), incl. +0.0
+    c = np.ldexp(rng.random(n) + 1.0, rng.integers(-82, 34, n)) * rng.choice([-1.0, 1.0], n)
+    c = np.where(rng.random(n) < 0.3, (rng.random(n) * 2 - 1) * 64.0, c)
+    c = np.where(np.abs(c) < 2.0 ** -82, 2.0 ** -82, c)
+    c = np.where(rng.random(n) < 0.03, 0.0, c)
+    # the square root's operands
+    s = np.ldexp(rng.random(n) + 1.0, rng.integers(-400, 275, n))
+    s = np.where(rng.random(n) < 0.05, rng.choice([2.0 ** -400, 2.0 ** 276, 1.0, 4.0, np.nextafter(4.0, 0)], n), s)
+    return num3, den, c, s
+
+
+@pytest.mark.parametrize("seed", [10, 11, 12])
+def test_certified_plane_fit_arithmetic_is_ieee_without_guards(seed):
+    """A block whose coordinates are all +0.0 or in [2^-30, 2^31) runs the plane fit's division / square
+    root shortcuts WITHOUT their per-lane range guards (csrc/ransac.hip, RS_BLKFAST).  Over the operand
+    ranges that certificate implies the unguarded forms must still be the IEEE results."""
+    num3, den, c, s = _certified_cases(seed)
+    for k in (1, 3, 6, 7, 16):
+        q3, ck, _ = _plane_arith(num3, den, c, k, certified=True)
+        assert _same_bits(q3, num3 / den[:, None]).all()
+        assert _same_bits(ck, c / np.float64(k)).all()
+    _, _, sq = _plane_arith(num3, den, s, 6, certified=True)
+    assert _same_bits(sq, np.sqrt(s)).all()
+
+
+def test_blocks_outside_the_range_certificate_keep_the_guards():
+    """-0.0, denormal-scale and astronomically large coordinates make a block fail the certificate: the
+    guarded fit must still reproduce the oracle bit for bit."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(5)
+    blocks = []
+    base = rng.random((40, 3))
+    base[:, 2] = 0.3 * base[:, 0] + 0.1 * base[:, 1] + rng.normal(0, 0.003, 40)
+    blocks.append(base.copy())                                  # certified
+    b = base.copy(); b[3, 0] = -0.0; b[7, 1] = -0.0; blocks.append(b)          # a negative zero
+    b = base.copy() * 2.0 ** -40; blocks.append(b)              # below 2^-30
+    b = base.copy() * 2.0 ** 40; blocks.append(b)               # above 2^31
+    b = base.copy(); b[:, 0] = 0.0; blocks.append(b)            # a plane of exact +0.0: certified, zero sums
+    b = base.copy(); b[:, 0] = -0.0; blocks.append(b)           # ... of -0.0: not certified
+    b = base.copy(); b[5] = 1e-310; blocks.append(b)            # a denormal point
+    b = np.tile(base[:1], (12, 1)); blocks.append(b)            # identical points: norm == 0 (util.py:77-78)
+    sizes = np.array([len(b) for b in blocks], dtype=np.int32)
+    cloud = np.vstack(blocks)
+    for thr in (0.01, 0.01 * 2.0 ** -40, 0.01 * 2.0 ** 40):
+        np.random.seed(7)
+        op = CudaRansac(threshold=thr, hypotheses_number=1024, initial_points_number=6)
+        mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+        o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, thr, details=True)
+        assert np.array_equal(counts, o_count)
+        assert np.array_equal(index, o_index)
+        assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+        assert np.array_equal(mask, o_mask)

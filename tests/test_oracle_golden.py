@@ -336,3 +336,78 @@ def test_grid_callable_criterion():
     check("spread")
     og.subdivide(15)
     check("k15")
+
+
+# ------------------------------------------------------------------------------------------------
+# the count-only, level-synchronous oracle used at the configs' full sizes (oracle/count_scheme_np.py)
+# against the reference's golden vectors and against the recursive oracle
+# ------------------------------------------------------------------------------------------------
+def _count_scheme_leaf_rows(cs, pose, n_pose_points, root_ids=None):
+    """non-empty leaves of one pose as canonical ((corner bytes, edge bytes), sorted indices), unordered"""
+    lf = cs.leaf_of[pose]
+    order = np.argsort(lf, kind="stable")
+    ids, starts = np.unique(lf[order], return_index=True)
+    ends = np.append(starts[1:], len(order))
+    return {((cs.corner[i] + 0.0).tobytes(), np.float64(cs.edge[i]).tobytes()): tuple(sorted(order[a:b].tolist()))
+            for i, a, b in zip(ids, starts, ends)}
+
+
+@pytest.mark.parametrize("n", [2000, 20000])
+@pytest.mark.parametrize("k", [8, 32, 256])
+def test_count_scheme_octree_uniform_golden(n, k):
+    from oracle import count_scheme_np as cnp
+
+    g = load_golden(f"octree_uniform_{n}.npz")
+    cs = cnp.count_scheme([g["points"]], np.zeros((1, 3)), np.float64(1), k)
+    assert _count_scheme_leaf_rows(cs, 0, n) == dict(golden_canon(g, f"k{k}"))
+    n_nodes, n_leaves, n_points = g[f"k{k}_counts"]
+    assert len(cs.edge) == n_nodes and len(np.unique(cs.leaf_of[0])) == n_leaves
+    # every leaf incl. the empty ones, as a set of (corner, edge)
+    want = {(c.tobytes(), np.float64(e).tobytes()) for c, e in zip(g[f"k{k}_all_corners"], g[f"k{k}_all_edges"])}
+    got = {(cs.corner[i].tobytes(), np.float64(cs.edge[i]).tobytes()) for i in np.nonzero(cs.is_leaf)[0]}
+    assert got == want
+
+
+def test_count_scheme_grid_golden_and_manager_subset():
+    from oracle import count_scheme_np as cnp
+
+    g = load_golden("grid_L1_mixed.npz")
+    coords, roots = cnp.grid_roots([g["points"]], 1)
+    cs = cnp.count_scheme([g["points"]], coords, 1, 16, root_of=roots)
+    assert _count_scheme_leaf_rows(cs, 0, len(g["points"])) == dict(golden_canon(g, "k16"))
+    assert len(cs.edge) == g["k16_counts"][0]
+    # L = 5, two poses, then a refinement driven by pose 1 only (the reference builds the new scheme
+    # from scratch from the selected poses' counts, octree_manager.py:50-61)
+    g = load_golden("grid_L5_two_poses.npz")
+    poses = [g["points0"], g["points1"]]
+    coords, roots = cnp.grid_roots(poses, 5)
+    cs = cnp.count_scheme(poses, coords, 5, 24, root_of=roots)
+    for p in range(2):
+        assert _count_scheme_leaf_rows(cs, p, len(poses[p])) == dict(golden_canon(g, f"p{p}"))
+    # (a voxel without points of pose 1 keeps an unsplit scheme there: same rule, count 0)
+    cs = cnp.count_scheme(poses, coords, 5, 6, root_of=roots, scheme_poses=[1])
+    og = onp.OGrid(5)
+    for p in range(2):
+        og.insert_points(p, poses[p])
+    og.subdivide(6, [1])
+    for p in range(2):
+        assert _count_scheme_leaf_rows(cs, p, len(poses[p])) == dict(canon_from_list(og.leaf_table(p)))
+
+
+def test_count_scheme_manager_multi_pose_vs_recursive_oracle():
+    from oracle import count_scheme_np as cnp
+
+    P, n, K = 8, 5000, 256
+    poses = [np.random.default_rng(100 + p).random((n, 3)) for p in range(P)]
+    om = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(P):
+        om.insert_points(p, poses[p])
+    om.subdivide(K)
+    cs = cnp.count_scheme(poses, np.zeros((1, 3)), 1.0, K, chunk=1500)
+    for p in range(P):
+        want = {((np.asarray(v.corner, dtype=np.float64) + 0.0).tobytes(), np.float64(v.edge).tobytes()):
+                tuple(sorted(v.idx.tolist())) for v in om.octrees[p].leaves()}
+        assert _count_scheme_leaf_rows(cs, p, n) == want
+        assert len(cs.edge) == om.n_nodes(p)
+    with pytest.raises(RecursionError):
+        cnp.count_scheme([np.tile(np.array([[0.3, 0.3, 0.3]]), (5, 1))], np.zeros((1, 3)), 1.0, 2)
