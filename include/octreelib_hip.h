@@ -104,6 +104,15 @@ int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* 
  * the context (octl_forest_build, octl_ctx_sync, ...).                                      */
 int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n,
                                 int32_t* slot);
+/* Same, WITHOUT the copy: an empty forest reads the caller's device buffer in place as its first pose
+ * (Grid.insert_points' storage step, grid/grid.py:58-109, for a cloud that is in HBM already).  The library
+ * never writes to the buffer and never frees it; the caller keeps it alive and unchanged until the forest is
+ * cleared or destroyed, or until more points are added to it (octl_forest_add_pose*, octl_forest_extend_pose
+ * take a private copy first).  A forest that already holds points, or a pointer that is not 16-byte aligned,
+ * takes the copying path of octl_forest_add_pose_device.  The voxel bounding box of such a cloud is found by the
+ * build's own histogram pass when the context has built a cloud of the same scene before, by a box pass
+ * (24 B/point read) otherwise.                                                                    */
+int octl_forest_add_pose_adopt(octl_forest* f, const double* xyz_dev, int64_t n, int32_t* slot);
 /* Append more points to an EXISTING pose slot, any slot (OctreeManager.insert_points on a pose that
  * already has an octree, octree_manager.py:161-171; Octree.insert_points, octree.py:235-239).  The
  * points of later poses move up in the pose-major store.                                       */
@@ -280,6 +289,22 @@ int octl_dev_alloc(octl_ctx* ctx, int64_t bytes, void** dptr);
 int octl_dev_free(octl_ctx* ctx, void* dptr);
 int octl_dev_upload(octl_ctx* ctx, void* dptr, const void* src, int64_t bytes);
 int octl_dev_download(octl_ctx* ctx, void* dst, const void* dptr, int64_t bytes);
+/* ---- asynchronous host feed ---------------------------------------------------------------------
+ * Replaces the synchronous host-to-device copies of CudaRansac.evaluate (ransac/cuda_ransac.py:57-67) and of
+ * Grid.insert_points' storage step for a loop over scans: the upload of scan i+1 runs on a copy stream of
+ * its own while the context's compute stream builds and fits scan i.
+ *   octl_host_alloc / octl_host_free   page-locked host memory (a copy out of it is a DMA the host does not
+ *                                      wait for; out of pageable memory the call blocks while HIP stages it)
+ *   octl_dev_upload_async              enqueue the copy host -> dptr behind the compute work enqueued so far;
+ *                                      returns at once.  `src` must stay unchanged until octl_ctx_sync_uploads
+ *                                      (or octl_dev_free / octl_host_free of either end) has returned.
+ *   octl_ctx_sync_uploads              host waits for every upload enqueued so far
+ * octl_forest_add_pose_device / octl_forest_add_pose_adopt order the compute stream behind the uploads enqueued
+ * before them (on the device; the host does not wait).                                              */
+int octl_host_alloc(octl_ctx* ctx, int64_t bytes, void** p);
+int octl_host_free(octl_ctx* ctx, void* p);
+int octl_dev_upload_async(octl_ctx* ctx, void* dptr, const void* src, int64_t bytes);
+int octl_ctx_sync_uploads(octl_ctx* ctx);
 /* measured device copy bandwidth (bytes/s) over `bytes`, for the roofline report           */
 int octl_dev_copy_bandwidth(octl_ctx* ctx, int64_t bytes, int iters, double* bytes_per_s);
 

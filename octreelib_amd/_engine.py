@@ -41,12 +41,14 @@ class Forest:
         self._edge_int = int(edge) if mode == 0 else 1
         self._cube = (tuple(np.asarray(corner, dtype=np.float64).tolist()), float(edge))
         self._creation_codes = np.empty(0, dtype=np.int64)   # packed voxel keys, creation order
+        self._device_clouds = []                             # DeviceCloud objects whose buffers the store may read
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
             self.lib.octl_forest_destroy(self.handle)
             self.handle = C.c_void_p()
+            self._device_clouds = []
 
     def __del__(self):  # pragma: no cover
         try:
@@ -67,15 +69,25 @@ class Forest:
 
     # -- points -----------------------------------------------------------------------------
     def add_pose(self, points) -> int:
+        from octreelib_amd.feed import DeviceCloud
+
+        if isinstance(points, DeviceCloud):
+            # a cloud that is (being) uploaded already: read in place when it is the first pose, copied on
+            # the device otherwise; the forest keeps the object alive while it reads its buffer
+            self._device_clouds.append(points)
+            return self.add_pose_device(points.ptr, points.n, adopt=True)
         pts = nat.as_points(points)
         slot = C.c_int32(-1)
         self.ctx.check(self.lib.octl_forest_add_pose(self.handle, nat.ptr(pts), len(pts), C.byref(slot)))
         self._register_slot(len(pts))
         return slot.value
 
-    def add_pose_device(self, dptr, n: int) -> int:
+    def add_pose_device(self, dptr, n: int, adopt: bool = False) -> int:
+        """A cloud that is in device memory already.  adopt=True: an empty forest reads the caller's buffer in
+        place (no copy; the buffer must stay alive and unchanged until the forest is cleared or closed)."""
         slot = C.c_int32(-1)
-        self.ctx.check(self.lib.octl_forest_add_pose_device(self.handle, dptr, int(n), C.byref(slot)))
+        fn = self.lib.octl_forest_add_pose_adopt if adopt else self.lib.octl_forest_add_pose_device
+        self.ctx.check(fn(self.handle, dptr, int(n), C.byref(slot)))
         self._register_slot(int(n))
         return slot.value
 

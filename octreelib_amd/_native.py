@@ -65,6 +65,7 @@ SIGNATURES = {
     "octl_forest_clear": (C.c_int, [_p]),
     "octl_forest_add_pose": (C.c_int, [_p, _p, _i64, _pi32]),
     "octl_forest_add_pose_device": (C.c_int, [_p, _p, _i64, _pi32]),
+    "octl_forest_add_pose_adopt": (C.c_int, [_p, _p, _i64, _pi32]),
     "octl_forest_extend_pose": (C.c_int, [_p, _i32, _p, _i64]),
     "octl_forest_build": (C.c_int, [_p, _i64, _p, _i32, _i32, _i32, C.POINTER(BuildInfo)]),
     "octl_forest_set_scheme": (C.c_int, [_p, _p, _p, _i64, _i32]),
@@ -102,6 +103,10 @@ SIGNATURES = {
     "octl_dev_free": (C.c_int, [_p, _p]),
     "octl_dev_upload": (C.c_int, [_p, _p, _p, _i64]),
     "octl_dev_download": (C.c_int, [_p, _p, _p, _i64]),
+    "octl_host_alloc": (C.c_int, [_p, _i64, C.POINTER(_p)]),
+    "octl_host_free": (C.c_int, [_p, _p]),
+    "octl_dev_upload_async": (C.c_int, [_p, _p, _p, _i64]),
+    "octl_ctx_sync_uploads": (C.c_int, [_p]),
     "octl_dev_copy_bandwidth": (C.c_int, [_p, _i64, C.c_int, C.POINTER(_f64)]),
     "octl_debug_exclusive_scan": (C.c_int, [_p, _p, _i64, _p, _p]),
     "octl_debug_radix_sort": (C.c_int, [_p, _p, _p, _i64, C.c_int]),

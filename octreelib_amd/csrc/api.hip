@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void k_ingest(const double* __restrict__ src, 
     if (mode == 0) fold(t, 2);
   }
   if (mode != 0 && u0 < n_units) mn[0] = mn[1] = mn[2] = mx[0] = mx[1] = mx[2] = 0;
-  // alive flags: 16 per thread
-  {
+  // alive flags: 16 per thread (nullptr: the caller sets them otherwise)
+  if (alive) {
     const int64_t a0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
     if (a0 + 16 <= n && (reinterpret_cast<uintptr_t>(alive) & 15) == 0) {
       *reinterpret_cast<uint4*>(alive + a0) = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
@@ -355,6 +355,10 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
   const int64_t total = f->n_store + n;
   if (total >= ((int64_t)1 << 31))
     return octl_set_error(ctx, OCTL_E_INVALID, "more than 2^31-1 points in one forest");
+  // a store that is read in place from the caller's buffer becomes the forest's own before it grows; a
+  // cloud whose box has not been taken yet is folded in now (the kernel below only adds the new points)
+  if (f->store_borrowed) OCTL_TRY(store_materialize(f));
+  if (f->bbox_pending) OCTL_TRY(store_compute_bbox(f));
   OCTL_TRY(devbuf_reserve(ctx, f->xyz, (size_t)std::max<int64_t>(total, 1) * 24 + 16, 1));
   OCTL_TRY(devbuf_reserve(ctx, f->alive, (size_t)std::max<int64_t>(total, 1) + 2, 1));
   if (!f->bbox_dev.p) OCTL_TRY(bbox_reset(f));
@@ -394,6 +398,21 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
     // (the box stays on the device: the build forms the key geometry there, or fetches it when it has to)
     if (!from_device) HIP_TRY(ctx, hipStreamSynchronize(st));  // the host buffer is the caller's again
   }
+  return OCTL_OK;
+}
+
+// An EMPTY forest takes the n points that f->xyz already holds (a swapped-in routed buffer, a borrowed
+// caller buffer) as its first pose without touching them: alive flags by memset, the voxel box left to the
+// build (bbox_pending).
+int store_take_in_place(octl_forest* f, int64_t n) {
+  octl_ctx* ctx = f->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n >= ((int64_t)1 << 31))
+    return octl_set_error(ctx, OCTL_E_INVALID, "more than 2^31-1 points in one forest");
+  OCTL_TRY(devbuf_reserve(ctx, f->alive, (size_t)std::max<int64_t>(n, 1) + 2, 0));
+  if (!f->bbox_dev.p) OCTL_TRY(bbox_reset(f));
+  HIP_TRY(ctx, hipMemsetAsync(f->alive.p, 1, (size_t)n, ctx->stream));
+  f->bbox_pending = true;
   return OCTL_OK;
 }
 
@@ -473,10 +492,42 @@ int ensure_mask(octl_forest* f) {
 // An empty store takes over a library-owned device buffer that holds the cloud (and hands its own
 // buffer back in exchange) instead of copying it: the routed cloud of the multi-GPU path.
 int store_adopt(octl_forest* f, DevBuf& src, int64_t n, bool* adopted) {
-  *adopted = !(f->n_store != 0 || n <= 0 || src.cap < (size_t)n * 24 + 16);
+  *adopted = !(f->n_store != 0 || n <= 0 || src.cap < (size_t)n * 24 + 16 || f->store_borrowed);
   if (!*adopted) return store_append(f, src.as<double>(), n, true);
   std::swap(f->xyz, src);
-  return store_append(f, f->xyz.as<double>(), n, true);
+  return store_take_in_place(f, n);
+}
+
+int store_compute_bbox(octl_forest* f) {
+  octl_ctx* ctx = f->ctx;
+  f->bbox_pending = false;
+  const int64_t n = f->n_store;
+  if (n <= 0) return OCTL_OK;
+  if (!f->bbox_dev.p) OCTL_TRY(bbox_reset(f));
+  KTimer t(ctx, "ingest");
+  const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(3 * n / 2, 256 * ING_UNITS));
+  double* p = f->xyz.as<double>();
+  hipLaunchKernelGGL(k_ingest<false>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)p, p,
+                     (uint8_t*)nullptr, n, f->mode, f->edge, f->bbox_dev.as<int32_t>());
+  HIP_TRY(ctx, hipGetLastError());
+  return OCTL_OK;
+}
+
+int store_materialize(octl_forest* f) {
+  octl_ctx* ctx = f->ctx;
+  if (!f->store_borrowed) return OCTL_OK;
+  DevBuf own = f->xyz_own;
+  f->xyz_own = DevBuf{};
+  const int rc = devbuf_reserve(ctx, own, (size_t)std::max<int64_t>(f->n_store, 1) * 24 + 16, 0);
+  if (rc != OCTL_OK) {
+    f->xyz_own = own;
+    return rc;
+  }
+  if (f->n_store > 0)
+    HIP_TRY(ctx, hipMemcpyAsync(own.p, f->xyz.p, (size_t)f->n_store * 24, hipMemcpyDeviceToDevice, ctx->stream));
+  f->xyz = own;
+  f->store_borrowed = false;
+  return OCTL_OK;
 }
 
 
@@ -514,6 +565,11 @@ void octl_forest_destroy(octl_forest* f) {
   (void)hipStreamSynchronize(f->ctx->stream);
   nodes_free(f->ctx, f->nodes[0]);
   nodes_free(f->ctx, f->nodes[1]);
+  if (f->store_borrowed) {  // (the caller's buffer is not ours to release)
+    f->xyz = f->xyz_own;
+    f->xyz_own = DevBuf{};
+    f->store_borrowed = false;
+  }
   if (f->bbox_host) (void)hipHostFree(f->bbox_host);
   if (f->bbox_event) (void)hipEventDestroy(f->bbox_event);
   for (DevBuf* b :
@@ -533,6 +589,12 @@ void octl_forest_destroy(octl_forest* f) {
 int octl_forest_clear(octl_forest* f) {
   if (!f) return OCTL_E_INVALID;
   if (f->bbox_dev.p) OCTL_TRY(bbox_reset(f));  // (stream ordered: no synchronisation needed)
+  if (f->store_borrowed) {  // back to the forest's own block; the caller's buffer is the caller's again
+    f->xyz = f->xyz_own;
+    f->xyz_own = DevBuf{};
+    f->store_borrowed = false;
+  }
+  f->bbox_pending = false;
   f->pose_off.assign(1, 0);
   f->n_store = f->n_alive = 0;
   f->store_dirty = true;
@@ -570,7 +632,35 @@ int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* 
 
 int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n, int32_t* slot) {
   if (!f) return OCTL_E_INVALID;
+  // (the cloud may be the target of an octl_dev_upload_async that is still in flight)
+  if (n > 0) OCTL_TRY(ctx_wait_uploads(f->ctx, xyz_dev, (size_t)n * 24));
   OCTL_TRY(store_append(f, xyz_dev, n, true));
+  if (slot) *slot = (int32_t)f->pose_off.size() - 1;
+  f->n_store += n;
+  f->n_alive += n;
+  f->pose_off.push_back(f->n_store);
+  f->store_dirty = true;
+  return OCTL_OK;
+}
+
+int octl_forest_add_pose_adopt(octl_forest* f, const double* xyz_dev, int64_t n, int32_t* slot) {
+  if (!f) return OCTL_E_INVALID;
+  // only the first pose of an empty forest can be read in place (the store is one contiguous array); the
+  // kernels read 16 bytes at a time from the start of the cloud
+  if (f->n_store != 0 || n <= 0 || !xyz_dev || (reinterpret_cast<uintptr_t>(xyz_dev) & 15) != 0)
+    return octl_forest_add_pose_device(f, xyz_dev, n, slot);
+  // (the cloud may be the target of an octl_dev_upload_async that is still in flight)
+  OCTL_TRY(ctx_wait_uploads(f->ctx, xyz_dev, (size_t)n * 24));
+  if (!f->store_borrowed) f->xyz_own = f->xyz;
+  f->xyz = DevBuf{const_cast<double*>(xyz_dev), 0};
+  f->store_borrowed = true;
+  const int rc = store_take_in_place(f, n);
+  if (rc != OCTL_OK) {
+    f->xyz = f->xyz_own;
+    f->xyz_own = DevBuf{};
+    f->store_borrowed = false;
+    return rc;
+  }
   if (slot) *slot = (int32_t)f->pose_off.size() - 1;
   f->n_store += n;
   f->n_alive += n;

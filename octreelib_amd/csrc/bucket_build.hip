@@ -85,20 +85,20 @@ struct GeomDev {
   LinParams lp;
   int32_t bb[6];
   uint32_t valid;   // 1: the kernels run; 0: they return at once, and the host acts on `reason`
-  uint32_t reason;  // 1 a point outside the voxel domain, 2 nothing alive, 3 not a single-pass case
+  uint32_t reason;  // 1 a point outside the voxel domain, 2 nothing alive, 3 not a single-pass case,
+                    // 4 the hinted geometry did not hold (the box is known now: build again)
 };
-enum { GEOM_DOMAIN = 1, GEOM_EMPTY = 2, GEOM_RETRY = 3 };
+enum { GEOM_DOMAIN = 1, GEOM_EMPTY = 2, GEOM_RETRY = 3, GEOM_REHASH = 4 };
 static_assert(sizeof(GeomDev) <= 192, "GeomDev lives in the scalar block");
 
-__global__ void k_bucket_geom(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
-                              GeomDev* __restrict__ g) {
-  if (threadIdx.x != 0) return;
-  GeomDev o;
+// geometry of the box bb for `want` buckets (valid = 1), or the reason why this is not a single-pass case
+__device__ __forceinline__ void geom_from_box(const int32_t* bb, bool domain_error, uint64_t want,
+                                              const LinParams& base, GeomDev& o) {
   o.lp = base;
-  for (int a = 0; a < 6; ++a) o.bb[a] = bbox[a];
+  for (int a = 0; a < 6; ++a) o.bb[a] = bb[a];
   o.valid = 0;
   o.reason = 0;
-  if (bbox[6]) {
+  if (domain_error) {
     o.reason = GEOM_DOMAIN;
   } else if (o.bb[0] > o.bb[3]) {
     o.reason = GEOM_EMPTY;
@@ -129,6 +129,38 @@ __global__ void k_bucket_geom(const int32_t* __restrict__ bbox, uint64_t want, L
         o.valid = 1;
       }
     }
+  }
+}
+
+__global__ void k_bucket_geom(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+                              GeomDev* __restrict__ g) {
+  if (threadIdx.x != 0) return;
+  GeomDev o;
+  geom_from_box(bbox, bbox[6] != 0, want, base, o);
+  *g = o;
+}
+
+// Hinted geometry.  A cloud that was taken in place (octl_forest_add_pose_adopt, a routed cloud) has not been
+// through the box pass of the ingest kernel.  When the context has the geometry of its previous single-pass
+// build (a SLAM loop feeds scans of the same scene), the histogram pass runs under THAT geometry and finds the
+// true box on the way (k_part_hist<true>); k_geom_validate then keeps the hint when every point fell inside
+// its box and the true box asks for the same bucket width - otherwise it writes the geometry of the true box
+// with valid = 0 / reason = GEOM_REHASH, every later kernel of the build returns at once, and the host runs
+// the build again from the (now known) box.  A miss costs one histogram pass and one round trip.
+__global__ void k_geom_set(GeomDev hint, GeomDev* __restrict__ g) {
+  if (threadIdx.x == 0) *g = hint;
+}
+__global__ void k_geom_validate(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+                                GeomDev* __restrict__ g) {
+  if (threadIdx.x != 0) return;
+  GeomDev o;
+  geom_from_box(bbox, bbox[6] != 0, want, base, o);
+  const GeomDev h = *g;
+  const bool inside = bbox[7] == 0;  // no point outside the hint's box
+  if (o.valid && inside && o.lp.shift == h.lp.shift) return;  // the hint stands
+  if (o.valid) {
+    o.valid = 0;
+    o.reason = GEOM_REHASH;
   }
   *g = o;
 }
@@ -208,36 +240,131 @@ __device__ __forceinline__ uint32_t lin_corner_of(const LinParams& lp, double x,
 }
 
 constexpr int PH_THREADS = 1024;
+// The table is written [supertile][digit] - one coalesced row per workgroup - and transposed for the scan
+// (digit-major: the prefix of (digit, supertile) is where that supertile's share of the bucket starts) and
+// back for the scatter kernel: stored digit-major directly it was 4 bytes per 128-byte line, 93 MB of
+// write traffic for 12 MB of counts, and as much again when k_part_scatter fetched its column.
+// BBOX: the cloud has not been through the box pass; G holds a HINTED geometry.  Points outside the hint's
+// box are not counted (the flag bbox[7] invalidates the pass), the true box is reduced on the way.
+template <bool BBOX>
 __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restrict__ xyz,
                                                           const uint8_t* __restrict__ alive, int64_t N,
                                                           LinParams lp, const GeomDev* __restrict__ G,
                                                           uint32_t nst, uint32_t nd,
-                                                          int64_t st_items, uint32_t* __restrict__ table) {
+                                                          int64_t st_items, uint32_t* __restrict__ table_t,
+                                                          int32_t* __restrict__ bbox) {
   __shared__ uint32_t hist[PT_BINS];
-  if (G) {  // geometry formed on the device (k_bucket_geom)
+  __shared__ int s_bb[PH_THREADS / 64][8];
+  int hx = 0, hy = 0, hz = 0;  // extent of the hint's box in voxels (BBOX)
+  if (G) {  // geometry formed on the device (k_bucket_geom / k_geom_set)
     if (!G->valid) return;
     lp = G->lp;
+    if (BBOX) {
+      hx = G->bb[3] - G->bb[0] + 1;
+      hy = G->bb[4] - G->bb[1] + 1;
+      hz = G->bb[5] - G->bb[2] + 1;
+    }
   }
   for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) hist[d] = 0;
   __syncthreads();
+  const int big = 1 << 30;
+  int mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+  bool bad = false, outside = false;
+  const double lim = (double)OCTL_VOX_BIAS;
+  // (branch-free on purpose: early returns inside the loop body kept the loads of the next iteration behind
+  //  the branches of this one - the kernel ran at half the speed of the plain histogram)
+  auto count = [&](double x, double y, double z, bool live) {
+    if (!BBOX) {
+      if (live) atomicAdd(&hist[digit_of(lp, lin_of(lp, x, y, z))], 1u);
+      return;
+    }
+    double fx = 0.0, fy = 0.0, fz = 0.0;
+    if (lp.mode == 0) {
+      fx = floor_div_fast(x, lp.L);
+      fy = floor_div_fast(y, lp.L);
+      fz = floor_div_fast(z, lp.L);
+    }
+    const bool dom = fabs(fx) < lim && fabs(fy) < lim && fabs(fz) < lim;  // false for NaN / inf
+    const bool use = live && dom;
+    const int qx = use ? (int)fx : 0, qy = use ? (int)fy : 0, qz = use ? (int)fz : 0;
+    mn[0] = min(mn[0], use ? qx : big); mx[0] = max(mx[0], use ? qx : -big);
+    mn[1] = min(mn[1], use ? qy : big); mx[1] = max(mx[1], use ? qy : -big);
+    mn[2] = min(mn[2], use ? qz : big); mx[2] = max(mx[2], use ? qz : -big);
+    const uint32_t ax = (uint32_t)(qx - lp.minx), ay = (uint32_t)(qy - lp.miny), az = (uint32_t)(qz - lp.minz);
+    const bool in = lp.mode != 0 || (ax < (uint32_t)hx && ay < (uint32_t)hy && az < (uint32_t)hz);
+    bad = bad || (live && !dom);
+    outside = outside || (use && !in);
+    const uint32_t lin = lp.mode != 0 ? 0u : (ax * lp.ny + ay) * lp.nz + az;
+    if (use && in) atomicAdd(&hist[digit_of(lp, lin)], 1u);
+  };
   const int64_t base = (int64_t)blockIdx.x * st_items;
   // two points per thread and step: 48 contiguous bytes as three 16-byte loads (the store is
   // 16-byte aligned and base is even)
-  const int64_t lim = min(N, base + st_items);  // (st_items is even)
+  const int64_t lim_i = min(N, base + st_items);  // (st_items is even)
 #pragma unroll 2
-  for (int64_t i = base + 2 * (int64_t)threadIdx.x; i < lim; i += 2 * PH_THREADS) {
+  for (int64_t i = base + 2 * (int64_t)threadIdx.x; i < lim_i; i += 2 * PH_THREADS) {
     if (i + 1 < N) {
       const double2* s2 = reinterpret_cast<const double2*>(xyz + 3 * i);
       const double2 a = s2[0], b = s2[1], c = s2[2];
-      const uint16_t al = *reinterpret_cast<const uint16_t*>(alive + i);
-      if (al & 0xFF) atomicAdd(&hist[digit_of(lp, lin_of(lp, a.x, a.y, b.x))], 1u);
-      if (al >> 8) atomicAdd(&hist[digit_of(lp, lin_of(lp, b.y, c.x, c.y))], 1u);
-    } else if (i < N && alive[i]) {
-      atomicAdd(&hist[digit_of(lp, lin_of(lp, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]))], 1u);
+      const uint16_t al = alive ? *reinterpret_cast<const uint16_t*>(alive + i) : (uint16_t)0x0101;
+      count(a.x, a.y, b.x, (al & 0xFF) != 0);
+      count(b.y, c.x, c.y, (al >> 8) != 0);
+    } else if (i < N) {
+      count(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], !alive || alive[i]);
     }
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table[(size_t)d * nst + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table_t[(size_t)blockIdx.x * nd + d] = hist[d];
+  if (BBOX) {
+    // wave + block reduction, then at most six atomics per block and only when the block widens the box
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        mn[a] = min(mn[a], __shfl_xor(mn[a], off));
+        mx[a] = max(mx[a], __shfl_xor(mx[a], off));
+      }
+    }
+    const bool wbad = __any(bad), wout = __any(outside);
+    if ((threadIdx.x & 63) == 0) {
+      int* w = s_bb[threadIdx.x >> 6];
+      w[0] = mn[0]; w[1] = mn[1]; w[2] = mn[2]; w[3] = mx[0]; w[4] = mx[1]; w[5] = mx[2];
+      if (wbad) atomicExch(reinterpret_cast<uint32_t*>(bbox + 6), 1u);
+      if (wout) atomicExch(reinterpret_cast<uint32_t*>(bbox + 7), 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const int a = threadIdx.x;
+      int v = s_bb[0][a];
+      for (int w = 1; w < PH_THREADS / 64; ++w) v = (a < 3) ? min(v, s_bb[w][a]) : max(v, s_bb[w][a]);
+      if (a < 3) {
+        if (v != big && v < __hip_atomic_load(&bbox[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMin(&bbox[a], v);
+      } else {
+        if (v != -big && v > __hip_atomic_load(&bbox[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMax(&bbox[a], v);
+      }
+    }
+  }
+}
+
+// u32 matrix transpose through LDS tiles: in [R][C] -> out [C][R]
+__global__ __launch_bounds__(256) void k_transpose_u32(const uint32_t* __restrict__ in, uint32_t R, uint32_t C,
+                                                       uint32_t* __restrict__ out) {
+  __shared__ uint32_t tile[64][65];
+  const uint32_t c0 = blockIdx.x * 64u, r0 = blockIdx.y * 64u;
+  const uint32_t tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (uint32_t j = 0; j < 64; j += 4) {
+    const uint32_t r = r0 + ty + j, c = c0 + tx;
+    if (r < R && c < C) tile[ty + j][tx] = in[(size_t)r * C + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < 64; j += 4) {
+    const uint32_t c = c0 + ty + j, r = r0 + tx;
+    if (r < R && c < C) out[(size_t)c * R + r] = tile[tx][ty + j];
+  }
 }
 
 // second pass: the records of the first pass (they carry the full linear key)
@@ -253,7 +380,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist_rec(const uint4* __res
   for (int64_t i = base + threadIdx.x; i < lim; i += PH_THREADS)
     atomicAdd(&hist[digit_of(lp, recs[2 * i + 1].z)], 1u);
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table[(size_t)d * nst + blockIdx.x] = hist[d];
+  for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table[(size_t)blockIdx.x * nd + d] = hist[d];
 }
 
 // stable rank inside one wave's stream with 16-bit counters: a wave's counters are touched by that
@@ -288,7 +415,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
-    base[d] = table_scanned[(size_t)d * nst + blockIdx.x];
+    base[d] = table_scanned[(size_t)blockIdx.x * nd + d];  // ([supertile][digit]: see k_part_hist)
   constexpr int PT_TILE = PT_THREADS * PT_IPT;
   for (int t = 0; t < st_tiles; ++t) {
     const int64_t tbase = ((int64_t)blockIdx.x * st_tiles + t) * PT_TILE;
@@ -319,7 +446,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
         idxv[r] = b.w;
         live[r] = 1;
       } else {
-        live[r] = alive[i];
+        live[r] = alive ? alive[i] : (uint8_t)1;
         x[r] = xyz[3 * i];
         y[r] = xyz[3 * i + 1];
         z[r] = xyz[3 * i + 2];
@@ -1470,6 +1597,20 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // the host does not wait for the bounding box; all 4096 buckets exist then, the ones behind the last
   // voxel key are empty.  (OCTL_SYNC_GEOM: tests run the host-side form on small clouds too.)
   const bool async_geom = !force_sync && want <= (uint64_t)PT_BINS && !getenv("OCTL_SYNC_GEOM");
+  // a cloud taken in place has not been through the box pass: with the geometry of the context's previous
+  // single-pass build as a hint the histogram pass finds the box itself (k_part_hist<true>, k_geom_validate);
+  // without one the box pass runs now
+  bool hinted = false;
+  GeomDev hint;
+  if (f->bbox_pending) {
+    std::memcpy(&hint, ctx->geom_hint, sizeof(hint));
+    hinted = async_geom && ctx->geom_hint_valid && ctx->geom_hint_want == want && hint.lp.mode == f->mode &&
+             hint.lp.L == f->edge && hint.lp.c0x == f->corner[0] && hint.lp.c0y == f->corner[1] &&
+             hint.lp.c0z == f->corner[2] && !getenv("OCTL_NO_GEOM_HINT");
+    if (!hinted) OCTL_TRY(store_compute_bbox(f));
+  }
+  // every stored point is alive (nothing was removed since the poses were added): the flags are not read
+  const uint8_t* alive_p = f->n_alive == f->n_store ? nullptr : f->alive.as<uint8_t>();
   int bb[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ny = 1, nz = 1;
   int s = 0;
@@ -1528,8 +1669,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // ---- scratch ------------------------------------------------------------------------------------------------
   OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)n_alive * sizeof(PartRec)));
   if (two_pass) OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[1], (size_t)n_alive * sizeof(PartRec)));
-  OCTL_TRY(devbuf_reserve(ctx, f->bk_table,
-                          (std::max((size_t)nd_a * nst_a, (size_t)nd_b * nst_b) + (two_pass ? nb + 1 : 0) + 16) * 4));
+  // [supertile][digit] table | the same digit-major (scanned: the buckets' starts) | bucket bounds (two passes)
+  const size_t tab_elems = (std::max((size_t)nd_a * nst_a, (size_t)nd_b * nst_b) + 15) & ~(size_t)15;
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_table, (2 * tab_elems + (two_pass ? nb + 1 : 0) + 16) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, ((size_t)BK_ROWS * nb + 8) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 12));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_node, (size_t)n_alive * 12));
@@ -1542,11 +1684,19 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n_alive * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n_alive * 4));
   uint32_t* table = f->bk_table.as<uint32_t>();
+  uint32_t* table_dm = table + tab_elems;  // digit-major
+  auto transpose = [&](const uint32_t* in, uint32_t R, uint32_t Cc, uint32_t* out) {
+    hipLaunchKernelGGL(k_transpose_u32, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, R, Cc, out);
+    return hipGetLastError();
+  };
   // (SM_BK_FLAGS / SM_BK_TOTAL / SM_BK_TODO are zero: forest_build has reset the scalar block)
   GeomDev* gdev = nullptr;
   if (async_geom) {
     gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
-    hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want, lp, gdev);
+    if (hinted)
+      hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, hint, gdev);
+    else
+      hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want, lp, gdev);
     HIP_TRY(ctx, hipGetLastError());
   }
   // ---- partition ----------------------------------------------------------------------------------------------
@@ -1555,26 +1705,38 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   lp.raw_vp = two_pass ? 1 : 0;
   {
     KTimer t(ctx, "part_hist");
-    hipLaunchKernelGGL(k_part_hist, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
-                       (const uint8_t*)f->alive.as<uint8_t>(), N, lp, (const GeomDev*)gdev, nst_a, nd_a,
-                       (int64_t)st_tiles_a * tile, table);
+    if (hinted) {
+      hipLaunchKernelGGL(k_part_hist<true>, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+                         alive_p, N, lp, (const GeomDev*)gdev, nst_a, nd_a, (int64_t)st_tiles_a * tile, table,
+                         f->bbox_dev.as<int32_t>());
+      HIP_TRY(ctx, hipGetLastError());
+      f->bbox_pending = false;  // (the box is on the device now, whatever becomes of the hint)
+      hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
+                         lp, gdev);
+    } else {
+      hipLaunchKernelGGL(k_part_hist<false>, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+                         alive_p, N, lp, (const GeomDev*)gdev, nst_a, nd_a, (int64_t)st_tiles_a * tile, table,
+                         (int32_t*)nullptr);
+    }
     HIP_TRY(ctx, hipGetLastError());
   }
   {
     KTimer t(ctx, "part_scan");
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, table, table, (int64_t)nd_a * nst_a, nullptr));
+    HIP_TRY(ctx, transpose(table, nst_a, nd_a, table_dm));
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd_a * nst_a, nullptr));
+    HIP_TRY(ctx, transpose(table_dm, nd_a, nst_a, table));
   }
   {
     KTimer t(ctx, "part_scatter");
     hipLaunchKernelGGL((k_part_scatter<PT_IPT, false>), dim3(nst_a), dim3(PT_THREADS), 0, st,
-                       (const double*)f->xyz.as<double>(), (const uint8_t*)f->alive.as<uint8_t>(), N, lp,
+                       (const double*)f->xyz.as<double>(), alive_p, N, lp,
                        (const GeomDev*)gdev, nst_a, nd_a, st_tiles_a, (const uint32_t*)table,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
                        f->part_xyz[0].as<PartRec>());
     HIP_TRY(ctx, hipGetLastError());
   }
   const PartRec* recs = f->part_xyz[0].as<PartRec>();
-  const uint32_t* bstart = table;
+  const uint32_t* bstart = table_dm;
   uint32_t bstride = nst_a;
   if (two_pass) {
     // second (more significant) digit over the records of the first pass, then the bucket bounds
@@ -1590,7 +1752,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     }
     {
       KTimer t(ctx, "part_scan");
-      OCTL_TRY(octl_exclusive_scan_u32(ctx, table, table, (int64_t)nd_b * nst_b, nullptr));
+      HIP_TRY(ctx, transpose(table, nst_b, nd_b, table_dm));
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd_b * nst_b, nullptr));
+      HIP_TRY(ctx, transpose(table_dm, nd_b, nst_b, table));
     }
     {
       KTimer t(ctx, "part_scatter");
@@ -1600,7 +1764,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                          (const uint8_t*)nullptr, f->part_xyz[1].as<PartRec>());
       HIP_TRY(ctx, hipGetLastError());
     }
-    uint32_t* bounds = table + (((size_t)nd_b * nst_b + 3) & ~(size_t)3);
+    uint32_t* bounds = table + 2 * tab_elems;
     {
       KTimer t(ctx, "bucket_bounds");
       hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)ceil_div(n_alive, 256)), dim3(256), 0, st,
@@ -1656,9 +1820,17 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                               "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
                               OCTL_VOX_BIAS);
       if (g.reason == GEOM_EMPTY) return OCTL_OK;
+      // the hinted geometry did not hold: the box is on the device now, the build runs again from it
+      if (g.reason == GEOM_REHASH)
+        return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, false);
       // not a single-pass case after all (a sparse scene): the host-side form decides
       return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
     }
+    // the geometry of this build is the next build's hint
+    static_assert(sizeof(GeomDev) <= sizeof(ctx->geom_hint), "hint storage");
+    std::memcpy(ctx->geom_hint, &g, sizeof(g));
+    ctx->geom_hint_valid = true;
+    ctx->geom_hint_want = want;
     lp = g.lp;
     std::memcpy(bb, g.bb, sizeof(bb));
     ny = lp.ny;

@@ -70,10 +70,26 @@ struct octl_ctx {
   // epochs): recorded after the region's H2D copy, waited for before the region is written again
   hipEvent_t pin_event[3] = {nullptr, nullptr, nullptr};
   hipEvent_t handoff_event = nullptr;  // orders a buffer handed to another context behind this stream
+  // asynchronous host feed (octl_dev_upload_async): a second stream for host-to-device copies, so that the
+  // upload of scan i+1 overlaps the build and fit of scan i; copy_gate orders a copy behind the compute work
+  // enqueued before it (its destination may still be read), copy_done orders compute behind the copies
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_gate = nullptr;
+  struct Upload { const char* dst; size_t bytes; hipEvent_t done; };
+  std::vector<Upload> uploads;  // copies that may still be in flight, each with the event recorded behind it
   // device blocks handed back by destroyed forests, kept for the next one: a fresh Grid per scan
   // otherwise pays ~10 ms of hipMalloc / hipFree per build for its dozen large buffers
   std::vector<DevBuf> pool;
   size_t pool_bytes = 0;
+  // blocks handed out by octl_dev_alloc (pointer -> capacity): they come from and go back to the pool too - a
+  // hipMalloc / hipFree pair of a 240 MB scan buffer costs milliseconds and synchronises the device
+  std::map<void*, size_t> user_blocks;
+  // key geometry (voxel box, bucket shift) of the last single-pass bucket build on this context: the next
+  // build of a cloud that was taken in place starts its histogram pass under this geometry and finds the true
+  // box in the same pass (bucket_build.hip: hinted geometry); opaque here
+  unsigned char geom_hint[192] = {0};
+  bool geom_hint_valid = false;
+  uint64_t geom_hint_want = 0;
   // RCCL (route.hip)
   void* comm = nullptr;
   int n_ranks = 1, rank = 0;
@@ -85,6 +101,9 @@ struct octl_ctx {
 };
 
 int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...);
+// the compute stream waits (on the device, no host wait) for the uploads enqueued so far whose destination
+// overlaps [p, p + bytes); p == nullptr: for all of them
+int ctx_wait_uploads(octl_ctx* ctx, const void* p = nullptr, size_t bytes = 0);
 
 #define HIP_TRY(ctx, expr)                                                                 \
   do {                                                                                     \

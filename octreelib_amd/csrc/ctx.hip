@@ -150,6 +150,15 @@ int octl_collect_timings(octl_ctx* ctx) {
   return OCTL_OK;
 }
 
+int ctx_wait_uploads(octl_ctx* ctx, const void* p, size_t bytes) {
+  const char* a = static_cast<const char*>(p);
+  for (auto& u : ctx->uploads) {
+    if (a && (a + bytes <= u.dst || u.dst + u.bytes <= a)) continue;  // another buffer's upload
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, u.done, 0));
+  }
+  return OCTL_OK;
+}
+
 extern "C" {
 
 int octl_abi_version(void) { return OCTL_ABI_VERSION; }
@@ -207,6 +216,8 @@ void octl_ctx_destroy(octl_ctx* ctx) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& pb : ctx->pool) (void)hipFree(pb.p);
   ctx->pool.clear();
+  for (auto& ub : ctx->user_blocks) (void)hipFree(ub.first);  // (blocks the caller never gave back)
+  ctx->user_blocks.clear();
   for (auto& b : ctx->scan_tmp) devbuf_free(b);
   devbuf_free(ctx->scan_status);
   devbuf_free(ctx->small);
@@ -217,6 +228,12 @@ void octl_ctx_destroy(octl_ctx* ctx) {
     devbuf_free(*b);
   if (ctx->small_host) (void)hipHostFree(ctx->small_host);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->copy_stream) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+  }
+  if (ctx->copy_gate) (void)hipEventDestroy(ctx->copy_gate);
+  for (auto& u : ctx->uploads) (void)hipEventDestroy(u.done);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -226,6 +243,61 @@ const char* octl_last_error(const octl_ctx* ctx) { return ctx ? ctx->err.c_str()
 int octl_ctx_sync(octl_ctx* ctx) {
   if (!ctx) return OCTL_E_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+// ---- asynchronous host feed ----------------------------------------------------------------------------------
+// The reference copies every scan to the device inside evaluate() and waits for it (cuda_ransac.py:57-67); a
+// SLAM loop that hands scan i+1 over while scan i is being fitted hides the 240 MB / 4.9 ms of PCIe behind
+// the 5 ms of compute.  Page-locked host memory makes the copy a pure DMA the host does not wait for.
+int octl_host_alloc(octl_ctx* ctx, int64_t bytes, void** p) {
+  if (!ctx || !p || bytes < 0) return OCTL_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  hipError_t e = hipHostMalloc(p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault);
+  if (e != hipSuccess)
+    return octl_set_error(ctx, OCTL_E_NOMEM, "hipHostMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+  return OCTL_OK;
+}
+
+int octl_host_free(octl_ctx* ctx, void* p) {
+  if (!ctx) return OCTL_E_INVALID;
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);  // a copy out of it may be in flight
+  if (p) HIP_TRY(ctx, hipHostFree(p));
+  return OCTL_OK;
+}
+
+int octl_dev_upload_async(octl_ctx* ctx, void* dptr, const void* src, int64_t bytes) {
+  if (!ctx || bytes < 0 || (bytes > 0 && (!dptr || !src))) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->copy_stream) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->copy_gate, hipEventDisableTiming));
+  }
+  if (bytes == 0) return OCTL_OK;
+  // the destination may still be read by compute work that was enqueued before this call
+  HIP_TRY(ctx, hipEventRecord(ctx->copy_gate, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->copy_gate, 0));
+  HIP_TRY(ctx, hipMemcpyAsync(dptr, src, (size_t)bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  // finished uploads leave the list (their events are reused)
+  hipEvent_t ev = nullptr;
+  for (size_t i = 0; i < ctx->uploads.size();) {
+    if (hipEventQuery(ctx->uploads[i].done) == hipSuccess) {
+      if (!ev) ev = ctx->uploads[i].done; else (void)hipEventDestroy(ctx->uploads[i].done);
+      ctx->uploads.erase(ctx->uploads.begin() + (long)i);
+    } else {
+      (void)hipGetLastError();  // (hipErrorNotReady is not an error here)
+      ++i;
+    }
+  }
+  if (!ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventRecord(ev, ctx->copy_stream));
+  ctx->uploads.push_back(octl_ctx::Upload{static_cast<const char*>(dptr), (size_t)bytes, ev});
+  return OCTL_OK;
+}
+
+int octl_ctx_sync_uploads(octl_ctx* ctx) {
+  if (!ctx) return OCTL_E_INVALID;
+  if (ctx->copy_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
   return OCTL_OK;
 }
 
@@ -258,17 +330,30 @@ int octl_ctx_get_timings(octl_ctx* ctx, char* names, int name_stride, float* ms,
 int octl_dev_alloc(octl_ctx* ctx, int64_t bytes, void** dptr) {
   if (!ctx || !dptr || bytes < 0) return OCTL_E_INVALID;
   (void)hipSetDevice(ctx->device);
-  hipError_t e = hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 1));
-  if (e != hipSuccess)
-    return octl_set_error(ctx, OCTL_E_NOMEM, "hipMalloc(%lld) failed: %s", (long long)bytes,
-                          hipGetErrorString(e));
+  DevBuf b;  // (from the context's pool when a parked block fits)
+  OCTL_TRY(devbuf_reserve(ctx, b, (size_t)(bytes > 0 ? bytes : 1)));
+  ctx->user_blocks[b.p] = b.cap;
+  *dptr = b.p;
   return OCTL_OK;
 }
 
 int octl_dev_free(octl_ctx* ctx, void* dptr) {
   if (!ctx) return OCTL_E_INVALID;
+  if (!dptr) return OCTL_OK;
+  // uploads into the block and the compute work that may read it must have finished; other uploads carry on
+  const char* a = static_cast<const char*>(dptr);
+  auto it = ctx->user_blocks.find(dptr);
+  const size_t cap = it != ctx->user_blocks.end() ? it->second : 0;
+  for (auto& u : ctx->uploads)
+    if (!cap || !(a + cap <= u.dst || u.dst + u.bytes <= a)) (void)hipEventSynchronize(u.done);
   (void)hipStreamSynchronize(ctx->stream);
-  if (dptr) HIP_TRY(ctx, hipFree(dptr));
+  if (it == ctx->user_blocks.end()) {
+    HIP_TRY(ctx, hipFree(dptr));
+    return OCTL_OK;
+  }
+  DevBuf b{dptr, cap};
+  ctx->user_blocks.erase(it);
+  devbuf_release(ctx, b);
   return OCTL_OK;
 }
 

@@ -19,6 +19,15 @@ struct octl_forest {
   // point store: all poses concatenated in slot order (pose-major), insertion order inside
   DevBuf xyz;     // f64 [n_store][3]
   DevBuf alive;   // u8  [n_store]
+  // octl_forest_add_pose_adopt: xyz.p is the CALLER's device buffer (read in place, never written, never
+  // freed here); the forest's own block waits in xyz_own and the store is copied into it (store_materialize)
+  // before anything appends to or reorders the store
+  bool store_borrowed = false;
+  DevBuf xyz_own;
+  // the store's points have not been folded into bbox_dev yet (a cloud taken in place: adopted or routed).
+  // Only ever set while the store is that ONE pose; the build folds the box into its histogram pass when it
+  // has a geometry hint to work with, or runs the box pass first (store_compute_bbox)
+  bool bbox_pending = false;
   std::vector<int64_t> pose_off{0};  // [P+1] offsets into the store
   int64_t n_store = 0, n_alive = 0;
   bool store_dirty = true;  // points were added/removed since the last build
@@ -122,6 +131,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 // else would index outside the block in the sampling arithmetic (cuda_ransac.py:103-107)
 // api.hip: an empty store takes over a library-owned device buffer (swap) instead of copying it
 int store_adopt(octl_forest* f, DevBuf& src, int64_t n, bool* adopted);
+// api.hip: fold the whole store into bbox_dev (clears bbox_pending); copy a borrowed store into the forest's own block
+int store_compute_bbox(octl_forest* f);
+int store_materialize(octl_forest* f);
 int ransac_check_table(octl_ctx* ctx, const double* hyp, int32_t H, int32_t k);
 // build.hip: (re)build the (leaf, pose) block table from pos_node / ord_idx
 int forest_make_blocks(octl_forest* f);

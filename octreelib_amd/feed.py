@@ -1,0 +1,97 @@
+"""
+Asynchronous host feed: hand scan i+1 to the device while scan i is being built and fitted.
+
+The reference copies every cloud to the device inside the call that needs it and waits for it
+(ransac/cuda_ransac.py:57-67: cuda.to_device of the cloud, the kernel, copy_to_host).  A SLAM loop over scans
+can hide that copy - 240 MB, about 4.9 ms over PCIe Gen5 for 10 M points - behind the compute of the
+previous scan:
+
+    buf = [pinned_empty((n, 3)), pinned_empty((n, 3))]        # page-locked staging, filled by the front end
+    nxt = upload_async(buf[0])                                 # DMA on the copy stream, returns at once
+    for i in range(n_scans):
+        cur, nxt = nxt, (upload_async(buf[(i + 1) % 2]) if i + 1 < n_scans else None)
+        grid = Grid(GridConfig(voxel_edge_length=1))
+        grid.insert_points(0, cur)                             # read in place: no copy, no host wait
+        grid.subdivide([MaxPoints(64)])
+        grid.map_leaf_points_cuda_ransac()
+        ...
+        cur.release()
+
+Plain NumPy arrays work too (the copy then blocks the caller while HIP stages the pageable memory; it still
+overlaps device work that was enqueued before).
+"""
+
+import ctypes as C
+import weakref
+
+import numpy as np
+
+from octreelib_amd import _native as nat
+
+__all__ = ["DeviceCloud", "pinned_empty", "upload_async"]
+
+
+def pinned_empty(shape, dtype=np.float64, ctx=None) -> np.ndarray:
+    """np.empty in page-locked host memory (hipHostMalloc): uploads out of it are DMA transfers the host does
+    not wait for.  The memory is released when the array (and every view of it) is gone."""
+    ctx = ctx if ctx is not None else nat.get_context()
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dtype.itemsize
+    p = C.c_void_p()
+    ctx.check(ctx.lib.octl_host_alloc(ctx.handle, max(nbytes, 1), C.byref(p)))
+    buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+    weakref.finalize(buf, _free_pinned, ctx, p.value)
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def _free_pinned(ctx, address):
+    try:
+        if getattr(ctx, "handle", None) is not None and ctx.handle.value:
+            ctx.lib.octl_host_free(ctx.handle, C.c_void_p(address))
+    except Exception:  # pragma: no cover - interpreter shutdown
+        pass
+
+
+class DeviceCloud:
+    """An (n, 3) f64 cloud on its way into (or already in) device memory.  Grid.insert_points /
+    OctreeManager.insert_points / Octree.insert_points take it in place of the host array: the first pose of
+    an empty grid reads the device buffer in place (octl_forest_add_pose_adopt), any other pose copies it
+    device-to-device.  The object owns the device buffer: keep it alive while a grid reads it in place."""
+
+    def __init__(self, points, ctx=None):
+        self.ctx = ctx if ctx is not None else nat.get_context()
+        pts = nat.as_points(points)
+        self.n = len(pts)
+        self._host = pts  # must stay unchanged until the upload has finished
+        self.ptr = C.c_void_p()
+        self.ctx.check(self.ctx.lib.octl_dev_alloc(self.ctx.handle, max(pts.nbytes, 16), C.byref(self.ptr)))
+        try:
+            self.ctx.check(self.ctx.lib.octl_dev_upload_async(self.ctx.handle, self.ptr, nat.ptr(pts), pts.nbytes))
+        except Exception:
+            self.release()
+            raise
+
+    def wait(self):
+        """Host waits until the upload has finished (the host array may be overwritten afterwards)."""
+        self.ctx.check(self.ctx.lib.octl_ctx_sync_uploads(self.ctx.handle))
+        self._host = None
+
+    def release(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            self.ctx.lib.octl_dev_free(self.ctx.handle, self.ptr)  # (waits for both streams)
+            self.ptr = C.c_void_p()
+        self._host = None
+
+    def __len__(self):
+        return self.n
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def upload_async(points, ctx=None) -> DeviceCloud:
+    """Start the host-to-device copy of a cloud on the context's copy stream and return at once."""
+    return DeviceCloud(points, ctx)

@@ -1869,3 +1869,219 @@ def test_block_order_left_by_the_bucket_build_equals_order_hip(monkeypatch, seed
         # ... and not for the first (a small K may exceed what a bucket ranks in LDS, a tree deeper than the
         # bucket kernel's six levels is finished by the level loop: both leave the order to order.hip)
         assert "ransac_order" not in na
+
+
+# ------------------------------------------------------------------------------------------------
+# a cloud read in place (octl_forest_add_pose_adopt) and the hinted key geometry
+# ------------------------------------------------------------------------------------------------
+def _device_cloud(ctx, pts):
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+
+    d = C.c_void_p()
+    ctx.check(ctx.lib.octl_dev_alloc(ctx.handle, max(pts.nbytes, 16), C.byref(d)))
+    ctx.check(ctx.lib.octl_dev_upload(ctx.handle, d, nat.ptr(pts), pts.nbytes))
+    return d
+
+
+def _tables(f):
+    return ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()}, f.perm.copy(),
+            f.voxels.copy(), f.order.copy())
+
+
+def _assert_same_tables(a, b):
+    for x, y in zip(a[:2], b[:2]):
+        assert x.keys() == y.keys()
+        for k in x:
+            assert np.array_equal(x[k], y[k]), k
+    for x, y in zip(a[2:], b[2:]):
+        assert np.array_equal(x, y)
+
+
+def test_adopted_cloud_builds_the_same_forest_with_and_without_a_geometry_hint(monkeypatch):
+    """octl_forest_add_pose_adopt reads the caller's device buffer in place; the voxel box of such a cloud is
+    found by the build's own histogram pass under the geometry of the context's previous build (hit: same
+    scene; miss: a cloud that leaves the hinted box, a box of another size) or by the box pass (no hint).
+    Every variant must build exactly the tables of the copying path."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+    from octreelib_amd._engine import Forest
+
+    ctx = nat.get_context()
+    K = 48
+    scenes = {
+        "base": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=0),
+        "same_box": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=1),
+        "shifted": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=2) + np.array([3.0, -2.0, 0.0]),
+        "grown": np.vstack([synthetic.planar_cloud(199_990, (8, 8, 8), seed=1, stream=3), np.full((10, 3), 40.5) + np.arange(10)[:, None] * 1e-3]),
+        "shrunk": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=4, box=((2, 2, 2), (5, 5, 5))),
+        "negative": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=5) - 100.0,
+    }
+
+    def reference(pts):
+        f = Forest(0, np.zeros(3), 1.0)
+        f.add_pose(pts)
+        f.subdivide(K)
+        t = _tables(f)
+        f.close()
+        return t
+
+    want = {k: reference(v) for k, v in scenes.items()}
+    used_box_pass = []
+    for name in ["base", "same_box", "same_box", "shifted", "base", "grown", "shrunk", "negative", "base"]:
+        pts = scenes[name]
+        d = _device_cloud(ctx, pts)
+        g = Forest(0, np.zeros(3), 1.0)
+        ctx.set_profiling(True)
+        g.add_pose_device(d, len(pts), adopt=True)
+        g.subdivide(K)
+        ctx.sync()
+        used_box_pass.append("ingest" in ctx.timings())
+        ctx.set_profiling(False)
+        _assert_same_tables(_tables(g), want[name])
+        # RANSAC + apply_mask + a second subdivide on the adopted store (alive flags in play)
+        np.random.seed(0)
+        table = np.random.random((256, 6))
+        g.ransac_all(10, table, 0.01)
+        g.apply_device_mask()
+        g.subdivide(K // 2)
+        h = Forest(0, np.zeros(3), 1.0)
+        h.add_pose(pts)
+        h.subdivide(K)
+        h.ransac_all(10, table, 0.01)
+        h.apply_device_mask()
+        h.subdivide(K // 2)
+        _assert_same_tables(_tables(g), _tables(h))
+        g.close()
+        h.close()
+        ctx.check(ctx.lib.octl_dev_free(ctx.handle, d))
+    # the first build of the context's life may need the box pass; a build right after one of the same scene
+    # must not (the hint held: no "ingest" timer)
+    assert used_box_pass[1] is False and used_box_pass[2] is False
+    # with the hint disabled every build runs the box pass and still agrees
+    monkeypatch.setenv("OCTL_NO_GEOM_HINT", "1")
+    pts = scenes["same_box"]
+    d = _device_cloud(ctx, pts)
+    g = Forest(0, np.zeros(3), 1.0)
+    g.add_pose_device(d, len(pts), adopt=True)
+    g.subdivide(K)
+    _assert_same_tables(_tables(g), want["same_box"])
+    g.close()
+    ctx.check(ctx.lib.octl_dev_free(ctx.handle, d))
+
+
+def test_adopted_store_becomes_the_forests_own_when_it_grows():
+    """More poses after an adopted one, and points appended to the adopted pose: the store is copied into the
+    forest's own block first; the caller's buffer is never written."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    ctx = nat.get_context()
+    rng = np.random.default_rng(77)
+    a, b, extra = rng.random((5001, 3)) * 4, rng.random((3000, 3)) * 4 - 1.0, rng.random((777, 3)) * 4
+    d = _device_cloud(ctx, a)
+    g = Forest(0, np.zeros(3), 1.0)
+    g.add_pose_device(d, len(a), adopt=True)
+    g.add_pose(b)                      # before any build: the pending box is folded in, the store copied
+    g.subdivide(20)
+    h = Forest(0, np.zeros(3), 1.0)
+    h.add_pose(a)
+    h.add_pose(b)
+    h.subdivide(20)
+    _assert_same_tables(_tables(g), _tables(h))
+    g.extend_pose(0, extra)
+    h.extend_pose(0, extra)
+    g.build(0, keep_scheme=True)
+    h.build(0, keep_scheme=True)
+    g.subdivide(10)
+    h.subdivide(10)
+    _assert_same_tables(_tables(g), _tables(h))
+    back = np.empty_like(a)
+    ctx.check(ctx.lib.octl_dev_download(ctx.handle, nat.ptr(back), d, a.nbytes))
+    assert np.array_equal(back, a)
+    g.close()
+    h.close()
+    # adopt, build, then append to the adopted pose directly
+    g = Forest(0, np.zeros(3), 1.0)
+    g.add_pose_device(d, len(a), adopt=True)
+    g.subdivide(20)
+    g.extend_pose(0, extra)
+    g.subdivide(20)
+    h = Forest(0, np.zeros(3), 1.0)   # (the same history: the epochs of the internal nodes record it)
+    h.add_pose(a)
+    h.subdivide(20)
+    h.extend_pose(0, extra)
+    h.subdivide(20)
+    _assert_same_tables(_tables(g), _tables(h))
+    assert np.array_equal(np.sort(g.xyz, axis=0), np.sort(np.vstack([a, extra]), axis=0))
+    g.close()
+    h.close()
+    ctx.check(ctx.lib.octl_dev_download(ctx.handle, nat.ptr(back), d, a.nbytes))
+    assert np.array_equal(back, a)
+    ctx.check(ctx.lib.octl_dev_free(ctx.handle, d))
+
+
+def test_async_host_feed_builds_the_same_forest_and_overlaps_nothing_it_should_not():
+    """octreelib_amd.upload_async + Grid.insert_points(DeviceCloud): scans uploaded on the copy stream from
+    page-locked AND from pageable host memory, consumed in and out of order, must build exactly what the
+    synchronous path builds - first pose read in place, later poses copied on the device."""
+    import octreelib_amd as oa
+    from octreelib_amd import synthetic
+    from octreelib_amd.grid import Grid, GridConfig
+
+    scans = [synthetic.planar_cloud(150_000, (6, 6, 6), seed=1, stream=s) for s in range(4)]
+    K = 40
+
+    def reference(clouds):
+        g = Grid(GridConfig(voxel_edge_length=1))
+        for p, c in enumerate(clouds):
+            g.insert_points(p, c)
+        g.subdivide([oa.MaxPoints(K)])
+        np.random.seed(5)
+        g.map_leaf_points_cuda_ransac(hypotheses_number=128)
+        t = _tables(g._forest)
+        g._forest.close()
+        return t
+
+    want = [reference([s]) for s in scans]
+    pinned = [oa.pinned_empty((len(s), 3)) for s in scans]
+    for p, s in zip(pinned, scans):
+        p[:] = s
+    # a loop over scans: upload i+1 while i is processed
+    nxt = oa.upload_async(pinned[0])
+    for i in range(4):
+        cur = nxt
+        g = Grid(GridConfig(voxel_edge_length=1))
+        g.insert_points(0, cur)
+        nxt = oa.upload_async(pinned[i + 1] if i % 2 else scans[i + 1]) if i + 1 < 4 else None   # pinned / pageable
+        g.subdivide([oa.MaxPoints(K)])
+        np.random.seed(5)
+        g.map_leaf_points_cuda_ransac(hypotheses_number=128)
+        _assert_same_tables(_tables(g._forest), want[i])
+        g._forest.close()
+        cur.release()
+    # all uploads first, consumed in reverse order; a second pose from a DeviceCloud (device-to-device copy)
+    ups = [oa.upload_async(p) for p in pinned]
+    for i in (3, 1):
+        g = Grid(GridConfig(voxel_edge_length=1))
+        g.insert_points(0, ups[i])
+        g.subdivide([oa.MaxPoints(K)])
+        np.random.seed(5)
+        g.map_leaf_points_cuda_ransac(hypotheses_number=128)
+        _assert_same_tables(_tables(g._forest), want[i])
+        g._forest.close()
+    g = Grid(GridConfig(voxel_edge_length=1))
+    g.insert_points(0, ups[0])
+    g.insert_points(1, ups[2])
+    g.subdivide([oa.MaxPoints(K)])
+    np.random.seed(5)
+    g.map_leaf_points_cuda_ransac(hypotheses_number=128)
+    _assert_same_tables(_tables(g._forest), reference([scans[0], scans[2]]))
+    g._forest.close()
+    ups[0].wait()
+    pinned[0][:] = 0.0     # the host buffer is the caller's again after wait()
+    for u in ups:
+        u.release()

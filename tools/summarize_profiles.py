@@ -44,7 +44,7 @@ def main():
     fetch, write = counters(fetch_dir), counters(write_dir)
     out = {
         "_note": "HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate "
-                 "passes (bench.py --steps 3 --warmup 1, 10 M planar points); counter unit KiB; gfx950 "
+                 "passes (bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline: the headline scene only, 10 M planar points); counter unit KiB; gfx950 "
                  "correction of MI355X_MICROARCH.md applied to the read side (FETCH_SIZE x 2 for wide "
                  "coalesced reads; the raw value is kept), WRITE_SIZE as is.",
         "kernels": {},
