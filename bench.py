@@ -188,6 +188,8 @@ class Workload:
                 pts = synthetic.planar_cloud(m, dims, seed=1, stream=stream)
             elif cloud == "uniform32":   # BASELINE C2-U / C3-U: default_rng(0).random((n,3)) * 32
                 pts = np.random.default_rng(0).random((m, 3)) * 32.0
+            elif cloud == "sparse":      # a terrain sheet through a 256 x 256 x 32 box + one over-dense blob
+                pts = synthetic.sparse_scene(m, (256, 256, 32), seed=7 + stream)
             else:
                 pts = synthetic.uniform_cloud(m, dims, seed=1000 + stream)
             pts = np.ascontiguousarray(pts)
@@ -338,6 +340,18 @@ class Workload:
             self.ctx.check(self.lib.octl_dev_free(self.ctx.handle, d))
         for h in getattr(self, "pin", []):
             self.ctx.check(self.lib.octl_host_free(self.ctx.handle, h))
+
+
+def build_path(timer_names):
+    """Which build path a step took, from the library's timer names."""
+    bucket = "bucket_build" in timer_names
+    loop = "level_hist" in timer_names or "level_scatter" in timer_names
+    general = "keygen" in timer_names
+    if bucket and not general:
+        return "bucket" + (" + level loop for the voxels left behind" if loop else "")
+    if general:
+        return "general (keygen + radix sort + level loop)" + (" after a bucket attempt" if bucket else "")
+    return "incremental" if "inc_place" in timer_names else "unknown"
 
 
 _OWNED = {}
@@ -617,6 +631,63 @@ def main():
                 "note": "BASELINE C2-U / C3-U: np.random.default_rng(0).random((10 M, 3)) * 32, same step",
             }
             uw.close()
+            # a scene that is NOT dense in its bounding box (every other scene here fills all voxels of its box):
+            # 10 M points on a terrain sheet through a 256 x 256 x 32 box (about 8 % of its voxels occupied) + one
+            # blob at 20 x the density; which build path it takes is part of the figure
+            sw = Workload(ctx, ctx, 0, 1, n_local, (256, 256, 32), "sparse", args.k_split, False, False)
+            sw.step()
+            ctx.sync()
+            ctx.set_profiling(True)
+            sw.step_build_only()
+            names = set(ctx.timings())
+            ctx.set_profiling(False)
+            ms_full = timed(sw.step) * 1e3
+            ms_build = timed(sw.step_build_only) * 1e3
+            secondary["sparse_scene"] = {
+                "ms": ms_full, "Mpoints_per_s": n_local / ms_full / 1e3,
+                "insert_subdivide_only_ms": ms_build,
+                "insert_subdivide_only_Mpoints_per_s": n_local / ms_build / 1e3,
+                "voxels": int(sw.info.n_voxels), "leaves": int(sw.info.n_blocks), "levels": int(sw.info.n_levels),
+                "path": build_path(names),
+                "note": "octreelib_amd.synthetic.sparse_scene(10 M, (256, 256, 32)): terrain sheet ~1.6 voxels thick "
+                        "+ 3 % of the points in one blob at 20 x the density; same step as the headline",
+            }
+            sw.close()
+            # BASELINE config 4: one OctreeManager cube, 64 poses x 1 M points handed over from the host one by
+            # one, then subdivide(len > 4096) over the union of all poses (octree_manager.py:36-66)
+            P4, n4, K4 = 64, 1_000_000, 4096
+            poses4 = [np.random.default_rng(100 + p).random((n4, 3)) for p in range(P4)]
+            f4 = C.c_void_p()
+            ctx.check(lib.octl_forest_create(ctx.handle, 1, nat.ptr(np.zeros(3)), 1.0, C.byref(f4)))
+            info4 = nat.BuildInfo()
+            ins_ms, sub_ms = [], []
+            for rep in range(3):
+                ctx.check(lib.octl_forest_clear(f4))
+                ctx.sync()
+                t1 = time.perf_counter()
+                for p4 in poses4:
+                    ctx.check(lib.octl_forest_add_pose(f4, nat.ptr(p4), n4, None))
+                ctx.sync()
+                ins_ms.append((time.perf_counter() - t1) * 1e3)
+                if rep == 2:
+                    ctx.set_profiling(True)
+                t1 = time.perf_counter()
+                ctx.check(lib.octl_forest_build(f4, K4, None, 0, 0, 0, C.byref(info4)))
+                ctx.sync()
+                sub_ms.append((time.perf_counter() - t1) * 1e3)
+            names4 = set(ctx.timings())
+            ctx.set_profiling(False)
+            secondary["c4_manager"] = {
+                "insert_ms": min(ins_ms[1:]), "insert_first_ms": ins_ms[0],
+                "insert_GBs": P4 * n4 * 24 / (min(ins_ms[1:]) * 1e-3) / 1e9,
+                "subdivide_ms": min(sub_ms[1:]), "subdivide_Mpoints_per_s": P4 * n4 / min(sub_ms[1:]) / 1e3,
+                "nodes": int(info4.n_nodes), "levels": int(info4.n_levels), "path": build_path(names4),
+                "note": "BASELINE config 4: 64 poses x 1 M points from pageable host memory into one cube "
+                        "(insert: 1.5 GB over PCIe, first run incl. the growth of the store), subdivide(len > 4096) "
+                        "over the union of the 64 M points",
+            }
+            lib.octl_forest_destroy(f4)
+            del poses4
             # two independent step sequences (two contexts = two streams, two forests, two host threads): what
             # a pipeline over consecutive scans gains from overlapping the memory-bound build of one scan with
             # the VALU-bound RANSAC of another.  NOT the headline: a step there is strictly sequential.

@@ -335,11 +335,9 @@ inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
 int bbox_reset(octl_forest* f) {
   octl_ctx* ctx = f->ctx;
-  if (!f->bbox_dev.p) {
-    OCTL_TRY(devbuf_reserve(ctx, f->bbox_dev, 32));
-    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&f->bbox_host), 32, hipHostMallocDefault));
-    HIP_TRY(ctx, hipEventCreateWithFlags(&f->bbox_event, hipEventDisableTiming));
-  }
+  // (no page-locked mirror per forest: hipHostMalloc / hipHostFree synchronise the whole device - also the copy
+  //  stream's upload of the next scan; the one readback of the box goes through the context's scalar mirror)
+  if (!f->bbox_dev.p) OCTL_TRY(devbuf_reserve(ctx, f->bbox_dev, 32));
   hipLaunchKernelGGL(k_bbox_reset, dim3(1), dim3(64), 0, ctx->stream, f->bbox_dev.as<int32_t>());
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
@@ -570,8 +568,6 @@ void octl_forest_destroy(octl_forest* f) {
     f->xyz_own = DevBuf{};
     f->store_borrowed = false;
   }
-  if (f->bbox_host) (void)hipHostFree(f->bbox_host);
-  if (f->bbox_event) (void)hipEventDestroy(f->bbox_event);
   for (DevBuf* b :
        {&f->bbox_dev, &f->part_xyz[0], &f->part_xyz[1], &f->bk_table, &f->bk_tot, &f->bk_vox, &f->bk_node, &f->leafinfo,
         &f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
@@ -965,7 +961,6 @@ int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
   OCTL_TRY(devbuf_reserve(ctx, f->rs_order, (size_t)nb * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
   HIP_TRY(ctx, hipMemcpyAsync(f->rs_order.p, block_order, (size_t)nb * 4, hipMemcpyHostToDevice, st));
-  f->rs_hyp_host.clear();  // (octl_forest_ransac_all keeps a host copy of what rs_hyp holds)
   HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   float* plane_d = nullptr;
@@ -1080,8 +1075,11 @@ int octl_ransac_evaluate(octl_ctx* ctx, const double* point_cloud, int64_t M,
   DevBuf xyz, sizes, starts_d, hyp, mask, plane, count, index, scratch;
   int rc = OCTL_OK;
   auto cleanup = [&]() {
+    // (back to the context's pool, not to the allocator: hipFree synchronises the device, and the next
+    //  evaluate() of a loop over batches wants the same blocks again)
+    (void)hipStreamSynchronize(st);
     for (DevBuf* b : {&xyz, &sizes, &starts_d, &hyp, &mask, &plane, &count, &index, &scratch})
-      devbuf_free(*b);
+      devbuf_release(ctx, *b);
   };
 #define EV_TRY(expr)            \
   do {                          \

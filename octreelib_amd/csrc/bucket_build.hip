@@ -1618,10 +1618,11 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   bool two_pass = false;
   if (!async_geom) {
     // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
-    HIP_TRY(ctx, hipMemcpyAsync(f->bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
+    int32_t* bbox_host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + 3584);
+    HIP_TRY(ctx, hipMemcpyAsync(bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    std::memcpy(bb, f->bbox_host, sizeof(bb));
-    if (f->bbox_host[6])
+    std::memcpy(bb, bbox_host, sizeof(bb));
+    if (bbox_host[6])
       return octl_set_error(ctx, OCTL_E_DOMAIN,
                             "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
                             OCTL_VOX_BIAS);

@@ -1014,7 +1014,8 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     bb[0] = bb[1] = bb[2] = 1 << 30;
     bb[3] = bb[4] = bb[5] = -(1 << 30);
     std::memcpy(ctx->small_host, init, sizeof(init));
-    HIP_TRY(ctx, hipMemcpyAsync(small, ctx->small_host, sizeof(init), hipMemcpyHostToDevice, st));
+    // (a kernel copy, not a DMA: see octl_copy_from_pinned)
+    OCTL_TRY(octl_copy_from_pinned(ctx, small, ctx->small_host, sizeof(init)));
   }
 
   // ---- pose offsets / scheme mask on the device ----------------------------------------------
@@ -1036,7 +1037,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       src_off = pin;
     }
     if (f->pose_off_uploaded != f->pose_off) {  // (the same offsets step after step: nothing to upload)
-      HIP_TRY(ctx, hipMemcpyAsync(f->pose_off_dev.p, src_off, off_bytes, hipMemcpyHostToDevice, st));
+      if (fits)
+        OCTL_TRY(octl_copy_from_pinned(ctx, f->pose_off_dev.p, src_off, off_bytes));
+      else
+        HIP_TRY(ctx, hipMemcpyAsync(f->pose_off_dev.p, src_off, off_bytes, hipMemcpyHostToDevice, st));
       f->pose_off_uploaded = f->pose_off;
     }
     if (!all_scheme) {

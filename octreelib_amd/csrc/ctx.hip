@@ -1,6 +1,8 @@
 // Context, error plumbing, device buffers, kernel timers, small device utilities.
 #include <cstdarg>
 
+#include <algorithm>
+
 #include "common.h"
 
 int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...) {
@@ -34,6 +36,9 @@ int octl_ctx_cus(octl_ctx* ctx) {
 int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
   if (bytes <= b.cap) return OCTL_OK;
   size_t want = bytes + bytes / 4 + 256;  // grow with slack so level loops rarely realloc
+  // a buffer that is appended to (the point store: one pose after the other) doubles, so that P appends cost
+  // O(log P) reallocations and copies instead of one for every 25 % of growth (64 poses: 19 -> 6)
+  if (keep && b.p && b.cap) want = std::max(want, 2 * b.cap);
   void* np = nullptr;
   hipError_t e = hipSuccess;
   // the smallest pooled block that fits without wasting more than the request again
@@ -78,8 +83,10 @@ int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
 
 void devbuf_release(octl_ctx* ctx, DevBuf& b) {
   if (!b.p) return;
-  // small blocks and an over-full pool (> 48 GiB parked) go straight back to the allocator
-  if (ctx && b.cap >= (1u << 20) && ctx->pool_bytes + b.cap <= ((size_t)48 << 30) && ctx->pool.size() < 256) {
+  // Only an over-full pool (> 48 GiB or 2048 blocks parked) goes back to the allocator.  Small blocks are
+  // parked too: hipFree synchronises the WHOLE device - a 400 KB scratch block that grew in the middle of a
+  // scan made the compute stream wait 3 ms for the copy stream's upload of the next scan.
+  if (ctx && ctx->pool_bytes + b.cap <= ((size_t)48 << 30) && ctx->pool.size() < 2048) {
     ctx->pool.push_back(b);
     ctx->pool_bytes += b.cap;
   } else {
@@ -102,6 +109,22 @@ int pin_region_mark(octl_ctx* ctx, int r) {
   if (!ctx->pin_event[r])
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pin_event[r], hipEventDisableTiming));
   HIP_TRY(ctx, hipEventRecord(ctx->pin_event[r], ctx->stream));
+  return OCTL_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_copy_u64(const uint64_t* __restrict__ src, uint64_t* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+int octl_copy_from_pinned(octl_ctx* ctx, void* dst_dev, const void* src_pinned, size_t bytes) {
+  const size_t n = bytes / 8;
+  if (n == 0) return OCTL_OK;
+  const unsigned grid = (unsigned)std::min<size_t>(64, (n + 255) / 256);
+  hipLaunchKernelGGL(k_copy_u64, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(src_pinned),
+                     static_cast<uint64_t*>(dst_dev), n);
+  HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
 }
 
@@ -219,6 +242,7 @@ void octl_ctx_destroy(octl_ctx* ctx) {
   for (auto& ub : ctx->user_blocks) (void)hipFree(ub.first);  // (blocks the caller never gave back)
   ctx->user_blocks.clear();
   for (auto& b : ctx->scan_tmp) devbuf_free(b);
+  devbuf_free(ctx->hyp_dev);
   devbuf_free(ctx->scan_status);
   devbuf_free(ctx->small);
   devbuf_free(ctx->routed_xyz);

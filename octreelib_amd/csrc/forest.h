@@ -37,11 +37,8 @@ struct octl_forest {
   int built_poses = 0;
   bool append_only = true;
   // voxel bounding box of every point added since the last clear, kept by the ingest kernel
-  // (api.hip): int32 x 8 = {min x,y,z, max x,y,z, domain-error flag, unused}; bbox_host is a pinned
-  // mirror refreshed asynchronously after every ingest (bbox_event marks the copy)
+  // (api.hip): int32 x 8 = {min x,y,z, max x,y,z, domain-error flag, point outside a hinted box}
   DevBuf bbox_dev;
-  int32_t* bbox_host = nullptr;
-  hipEvent_t bbox_event = nullptr;
 
   // scheme of the last build
   NodeTable nodes[2];
@@ -80,8 +77,7 @@ struct octl_forest {
   // forest_reference_order takes this instead of computing it; any change of the blocks invalidates it
   DevBuf fast_order;
   bool fast_order_valid = false;
-  // what rs_hyp / pose_off_dev hold (a table or offsets that have not changed are not uploaded again)
-  std::vector<double> rs_hyp_host;
+  // what pose_off_dev holds (offsets that have not changed are not uploaded again)
   std::vector<int64_t> pose_off_uploaded;
   DevBuf ord_idx2, xyz_ord2;  // compaction targets (swapped with the live arrays)
   DevBuf blk_node2, blk_slot2, blk_start2, blk_size2;

@@ -383,12 +383,12 @@ static int ransac_all_impl(octl_forest* f, int32_t poses_per_batch, const int32_
     *mask_fresh = true;  // (the caller marks it valid once everything below has been enqueued)
   }
   if (f->n_blocks == 0) return OCTL_OK;
-  const size_t hyp_cap_before = f->rs_hyp.cap;
-  OCTL_TRY(devbuf_reserve(ctx, f->rs_hyp, (size_t)H * k * 8));
-  // the table of the previous call (CudaRansac draws it once per object, cuda_ransac.py:39-41; a SLAM loop
-  // hands the same one over for every batch): already on the device
-  const bool same_table = hyp_cap_before == f->rs_hyp.cap && f->rs_hyp_host.size() == (size_t)H * k &&
-                          std::memcmp(f->rs_hyp_host.data(), hypotheses, (size_t)H * k * 8) == 0;
+  const size_t hyp_cap_before = ctx->hyp_dev.cap;
+  OCTL_TRY(devbuf_reserve(ctx, ctx->hyp_dev, (size_t)H * k * 8));
+  // the table of the previous call on this context (CudaRansac draws it once per object, cuda_ransac.py:39-41; a
+  // loop over scans hands the same one over for every scan): already on the device
+  const bool same_table = hyp_cap_before == ctx->hyp_dev.cap && ctx->hyp_host.size() == (size_t)H * k &&
+                          std::memcmp(ctx->hyp_host.data(), hypotheses, (size_t)H * k * 8) == 0;
   if (same_table) {
     // nothing to upload
   } else if ((size_t)H * k * 8 <= 64 * 1024) {  // pinned staging: [128 KiB, 192 KiB) of ctx->pinned
@@ -397,20 +397,20 @@ static int ransac_all_impl(octl_forest* f, int32_t poses_per_batch, const int32_
     char* pin = static_cast<char*>(ctx->pinned) + 128 * 1024;
     OCTL_TRY(pin_region_wait(ctx, 1));
     std::memcpy(pin, hypotheses, (size_t)H * k * 8);
-    HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, pin, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+    OCTL_TRY(octl_copy_from_pinned(ctx, ctx->hyp_dev.p, pin, (size_t)H * k * 8));
     OCTL_TRY(pin_region_mark(ctx, 1));
   } else {
-    HIP_TRY(ctx, hipMemcpyAsync(f->rs_hyp.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hyp_dev.p, hypotheses, (size_t)H * k * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
   }
-  if (!same_table) f->rs_hyp_host.assign(hypotheses, hypotheses + (size_t)H * k);
+  if (!same_table) ctx->hyp_host.assign(hypotheses, hypotheses + (size_t)H * k);
   const bool one_batch = n_poses <= poses_per_batch;
   std::vector<uint32_t> slot_counts;
   OCTL_TRY(forest_reference_order(f, e0, slot_counts, !one_batch));
   if (one_batch) {
     OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
                            f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>(), f->n_blocks,
-                           f->rs_hyp.as<double>(), H, k, threshold, f->mask.as<uint8_t>(), nullptr,
+                           ctx->hyp_dev.as<double>(), H, k, threshold, f->mask.as<uint8_t>(), nullptr,
                            nullptr, nullptr, nullptr, f->rs_scratch));
     return OCTL_OK;
   }
@@ -422,7 +422,7 @@ static int ransac_all_impl(octl_forest* f, int32_t poses_per_batch, const int32_
     if (nbatch > 0)
       OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
                              f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>() + off, nbatch,
-                             f->rs_hyp.as<double>(), H, k, threshold, f->mask.as<uint8_t>(),
+                             ctx->hyp_dev.as<double>(), H, k, threshold, f->mask.as<uint8_t>(),
                              nullptr, nullptr, nullptr, nullptr, f->rs_scratch));
     off += nbatch;
   }

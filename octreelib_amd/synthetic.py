@@ -46,3 +46,29 @@ def planar_cloud(n: int, dims=(32, 32, 32), seed: int = 1, stream: int = 0,
     z = 0.5 + a * (local[:, 0] - 0.5) + b * (local[:, 1] - 0.5) + rng.normal(0.0, sigma, n)
     local[inl, 2] = np.clip(z[inl], 1e-9, 1.0 - 1e-9)
     return local + q.astype(np.float64)
+
+
+def sparse_scene(n: int, dims=(256, 256, 32), seed: int = 7, cluster_fraction: float = 0.03,
+                 cluster_density: float = 20.0) -> np.ndarray:
+    """A scene that is NOT dense in its bounding box - what a real scan looks like: a terrain sheet about 1.6
+    voxels thick through a dims[0] x dims[1] x dims[2] box of 1 m voxels (about 5 % of the voxels occupied,
+    ~95 points per occupied voxel at n = 10 M), plus one blob that holds `cluster_fraction` of the points at
+    `cluster_density` times the sheet's density."""
+    rng = np.random.default_rng(seed)
+    dims = np.asarray(dims, dtype=np.float64)
+    n_cl = int(n * cluster_fraction)
+    m = n - n_cl
+    x = rng.random(m) * dims[0]
+    y = rng.random(m) * dims[1]
+    zc = 0.5 * dims[2] + 0.45 * dims[2] * np.sin(x / 40.0) * np.cos(y / 55.0)
+    z = zc + (rng.random(m) - 0.5) * 1.6
+    sheet = np.stack([x, y, np.clip(z, 0.0, dims[2] - 1e-9)], axis=1)
+    # the blob: density = cluster_density x (points per unit volume of the sheet)
+    sheet_density = m / (dims[0] * dims[1] * 1.6)
+    vol = n_cl / (cluster_density * sheet_density)
+    r = vol ** (1.0 / 3.0)
+    c = np.array([0.37 * dims[0], 0.61 * dims[1], 0.5 * dims[2]])
+    blob = c + (rng.random((n_cl, 3)) - 0.5) * r
+    pts = np.vstack([sheet, blob])
+    rng.shuffle(pts)
+    return np.ascontiguousarray(pts)
