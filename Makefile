@@ -8,7 +8,7 @@ HDRS = $(wildcard octreelib_amd/csrc/*.h) include/octreelib_hip.h
 OBJS = $(patsubst octreelib_amd/csrc/%.hip,build/%.o,$(SRCS))
 LIB  = octreelib_amd/lib/liboctree_hip.so
 
-all: $(LIB)
+all: $(LIB) $(STUB)
 
 build/%.o: octreelib_amd/csrc/%.hip $(HDRS)
 	@mkdir -p build
@@ -18,7 +18,14 @@ $(LIB): $(OBJS)
 	@mkdir -p octreelib_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -ldl
 
-clean:
-	rm -rf build $(LIB)
+# test-only stand-in for RCCL (R > 1 rank processes on ONE GPU): tests/test_gpu_route_multirank.py
+STUB = tests/rccl_stub/librccl_stub.so
+$(STUB): tests/rccl_stub/rccl_stub.cpp
+	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared $< -o $@ -lrt -lpthread
 
-.PHONY: all clean
+stub: $(STUB)
+
+clean:
+	rm -rf build $(LIB) $(STUB)
+
+.PHONY: all clean stub

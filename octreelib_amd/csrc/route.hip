@@ -39,7 +39,14 @@ RcclApi g_rccl;
 
 const char* rccl_load() {
   if (g_rccl.handle) return nullptr;
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  // OCTL_RCCL_LIBRARY: another build of the collective library (a site's own RCCL; the tests' stand-in that
+  // lets R > 1 rank PROCESSES share one GPU, tests/rccl_stub/ - real RCCL refuses two ranks on one device)
+  void* h = nullptr;
+  if (const char* lib = getenv("OCTL_RCCL_LIBRARY")) {
+    h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return "the library named by OCTL_RCCL_LIBRARY could not be loaded";
+  }
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
   if (!h) return "librccl.so not found";
 #define RCCL_SYM(field, name)                                   \

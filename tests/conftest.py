@@ -17,6 +17,27 @@ def _gpu_present() -> bool:
     return os.path.exists("/dev/kfd")
 
 
+# Rank processes of the multi-rank routing test (tests/test_gpu_route_multirank.py) are forked by
+# multiprocessing's fork server.  The server is started HERE - when pytest imports conftest.py, before any test
+# has touched the GPU - so that no process that has initialised the GPU ever forks or execs (on the GPU pool an
+# exec from such a process is refused).  The server itself never touches the GPU; its children do.
+_RANK_SPAWNER = None
+if _gpu_present():
+    try:
+        import multiprocessing as _mp
+        from multiprocessing import forkserver as _forkserver
+
+        _RANK_SPAWNER = _mp.get_context("forkserver")
+        _forkserver.ensure_running()
+    except Exception:  # pragma: no cover - no fork server on this platform
+        _RANK_SPAWNER = None
+
+
+def rank_spawner():
+    """multiprocessing context whose Process objects are forked by the pre-started, GPU-free fork server."""
+    return _RANK_SPAWNER
+
+
 def pytest_collection_modifyitems(config, items):
     if _gpu_present():
         return
