@@ -113,6 +113,14 @@ int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n
  * build's own histogram pass when the context has built a cloud of the same scene before, by a box pass
  * (24 B/point read) otherwise.                                                                    */
 int octl_forest_add_pose_adopt(octl_forest* f, const double* xyz_dev, int64_t n, int32_t* slot);
+/* Replace the CONTENTS of the leaves and keep the scheme: OctreeNode.map_leaf_points (octree/octree.py:114-123)
+ * stores whatever the caller's function returned for a leaf's cloud - fewer rows, more rows, rows outside the
+ * leaf's cube.  The new non-empty (leaf, pose) blocks are given in storage order: leaf node, pose slot, size, and
+ * the rows of all blocks one after the other.  The point store is rebuilt (pose-major, a pose's points in the
+ * order of its blocks); a later subdivide re-places the points by their coordinates (a row outside its cube then
+ * fails where the reference raises IndexError).                                                          */
+int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* blk_node, const int32_t* blk_slot,
+                             const int32_t* blk_size, const double* xyz);
 /* Append more points to an EXISTING pose slot, any slot (OctreeManager.insert_points on a pose that
  * already has an octree, octree_manager.py:161-171; Octree.insert_points, octree.py:235-239).  The
  * points of later poses move up in the pose-major store.                                       */

@@ -492,6 +492,21 @@ class Forest:
         self.n_ord = n.value
         self._invalidate()
 
+    def set_contents(self, blk_node, blk_slot, blk_size, xyz):
+        """Replace the contents of the leaves, scheme kept (map_leaf_points with a transforming function)."""
+        self.ensure_built()
+        node = np.ascontiguousarray(blk_node, dtype=np.int32)
+        slot = np.ascontiguousarray(blk_slot, dtype=np.int32)
+        size = np.ascontiguousarray(blk_size, dtype=np.int32)
+        pts = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        assert int(size.sum()) == len(pts)
+        self.ctx.check(self.lib.octl_forest_set_contents(self.handle, len(node), nat.ptr(node), nat.ptr(slot),
+                                                         nat.ptr(size), nat.ptr(pts)))
+        self.n_ord = len(pts)
+        for s in range(self.n_slots):
+            self.slot_sizes[s] = int(size[slot == s].sum())
+        self._invalidate()
+
     def apply_device_mask(self):
         n = C.c_int64(0)
         self.ctx.check(self.lib.octl_forest_apply_mask(self.handle, C.byref(n)))

@@ -66,6 +66,7 @@ SIGNATURES = {
     "octl_forest_add_pose": (C.c_int, [_p, _p, _i64, _pi32]),
     "octl_forest_add_pose_device": (C.c_int, [_p, _p, _i64, _pi32]),
     "octl_forest_add_pose_adopt": (C.c_int, [_p, _p, _i64, _pi32]),
+    "octl_forest_set_contents": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "octl_forest_extend_pose": (C.c_int, [_p, _i32, _p, _i64]),
     "octl_forest_build": (C.c_int, [_p, _i64, _p, _i32, _i32, _i32, C.POINTER(BuildInfo)]),
     "octl_forest_set_scheme": (C.c_int, [_p, _p, _p, _i64, _i32]),

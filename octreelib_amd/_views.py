@@ -189,29 +189,58 @@ def filter_slots(forest, slots: Iterable[int], criteria: Sequence[Callable]):
 
 
 def map_slots(forest, slots: Iterable[int], function: Callable):
-    """OctreeNode.map_leaf_points (octree.py:114-123).  The reference stores whatever the
-    function returns as the leaf's new cloud; here the result must be a selection of the
-    leaf's own points (the RANSAC-like use), which becomes a device compaction."""
+    """OctreeNode.map_leaf_points (octree.py:114-123): every non-empty leaf of the selected poses keeps
+    whatever the function returns for its cloud.  The function is the caller's Python code and runs on the
+    host over the leaf arrays.  A result that is a SELECTION of the leaf's own rows (the RANSAC-like use)
+    becomes a device compaction - the points keep their identity and insertion order; anything else (fewer
+    rows, more rows, moved rows - rows may leave the leaf's cube, as upstream allows) replaces the contents
+    of the leaves (octl_forest_set_contents)."""
     xyz = forest.xyz
+    blk = forest.blocks
     keep = np.ones(forest.n_ord, dtype=np.uint8)
+    results = {}          # block id -> the (m, 3) array the function returned
+    selection = True
     for slot in slots:
-        starts, sizes = positions_of_slot(forest, slot)
-        for s, z in zip(starts.tolist(), sizes.tolist()):
+        for b in forest.slot_blocks(slot).tolist():
+            s, z = int(blk["start"][b]), int(blk["size"][b])
             pts = xyz[s : s + z]
-            res = np.asarray(function(pts.copy()), dtype=float).reshape(-1, 3)
-            sel = np.zeros(z, dtype=np.uint8)
-            # the returned rows are matched against the leaf's own rows by value (bytes of the three f64;
+            res = np.ascontiguousarray(np.asarray(function(pts.copy()), dtype=np.float64))
+            if res.size % 3 != 0 or (res.ndim == 2 and res.shape[1] != 3 and res.size):
+                raise ValueError(
+                    f"map_leaf_points: the function must return an (n, 3) point cloud, got shape {res.shape}")
+            res = res.reshape(-1, 3)
+            results[b] = res
+            if not selection:
+                continue
+            # rows matched against the leaf's own rows by value (+0.0 folds -0.0 into +0.0 on both sides;
             # equal rows are handed out in storage order), one dictionary per leaf
             where = {}
             for i in range(z - 1, -1, -1):
-                where.setdefault(pts[i].tobytes(), []).append(i)
-            for row in np.ascontiguousarray(res, dtype=np.float64):
-                hit = where.get(row.tobytes())
+                where.setdefault((pts[i] + 0.0).tobytes(), []).append(i)
+            sel = np.zeros(z, dtype=np.uint8)
+            for row in res:
+                hit = where.get((row + 0.0).tobytes())
                 if not hit:
-                    raise NotImplementedError(
-                        "map_leaf_points: the function returned a point that is not one of the "
-                        "leaf's points; only selections of the leaf's own points are supported"
-                    )
+                    selection = False
+                    break
                 sel[hit.pop()] = 1
             keep[s : s + z] = sel
-    forest.apply_host_mask(keep)
+    if selection:
+        forest.apply_host_mask(keep)
+        return
+    # contents replaced: every block in storage order, untouched ones with their own rows
+    nodes, slots_out, sizes, rows = [], [], [], []
+    for b in range(len(blk["node"])):
+        r = results.get(b)
+        if r is None:
+            s, z = int(blk["start"][b]), int(blk["size"][b])
+            r = xyz[s : s + z]
+        if len(r) == 0:
+            continue
+        nodes.append(int(blk["node"][b]))
+        slots_out.append(int(blk["slot"][b]))
+        sizes.append(len(r))
+        rows.append(r)
+    forest.set_contents(np.asarray(nodes, dtype=np.int32), np.asarray(slots_out, dtype=np.int32),
+                        np.asarray(sizes, dtype=np.int32),
+                        np.vstack(rows) if rows else np.empty((0, 3), dtype=np.float64))

@@ -591,6 +591,7 @@ int octl_forest_clear(octl_forest* f) {
     f->store_borrowed = false;
   }
   f->bbox_pending = false;
+  f->displaced_rows = false;
   f->pose_off.assign(1, 0);
   f->n_store = f->n_alive = 0;
   f->store_dirty = true;
@@ -756,6 +757,107 @@ int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int
   f->n_ord = 0;
   f->n_blocks = 0;
   f->mask_valid = false;
+  return OCTL_OK;
+}
+
+int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* blk_node, const int32_t* blk_slot,
+                             const int32_t* blk_size, const double* xyz) {
+  if (!f) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "set_contents needs a built forest");
+  if (n_blocks < 0 || (n_blocks > 0 && (!blk_node || !blk_slot || !blk_size)))
+    return octl_set_error(ctx, OCTL_E_INVALID, "bad block arrays");
+  const int n_poses = (int)f->pose_off.size() - 1;
+  const int64_t n_nodes = f->nodes[f->cur].n;
+  // new pose offsets: the store is pose-major, a pose's points in the storage order of its blocks
+  std::vector<int64_t> per_slot((size_t)std::max(n_poses, 1), 0);
+  int64_t total = 0;
+  for (int64_t b = 0; b < n_blocks; ++b) {
+    if (blk_size[b] <= 0) return octl_set_error(ctx, OCTL_E_INVALID, "block %lld is empty", (long long)b);
+    if (blk_slot[b] < 0 || blk_slot[b] >= n_poses || blk_node[b] < 0 || blk_node[b] >= n_nodes)
+      return octl_set_error(ctx, OCTL_E_INVALID, "block %lld: bad node or pose slot", (long long)b);
+    per_slot[(size_t)blk_slot[b]] += blk_size[b];
+    total += blk_size[b];
+  }
+  if (total >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "more than 2^31-1 points in one forest");
+  if (total > 0 && !xyz) return octl_set_error(ctx, OCTL_E_INVALID, "null point array");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  std::vector<int64_t> off((size_t)n_poses + 1, 0);
+  for (int p = 0; p < n_poses; ++p) off[(size_t)p + 1] = off[(size_t)p] + per_slot[(size_t)p];
+  std::vector<int64_t> cursor(off.begin(), off.end() - 1);
+  std::vector<double> store((size_t)std::max<int64_t>(total, 1) * 3);
+  std::vector<uint32_t> ord((size_t)std::max<int64_t>(total, 1)), starts((size_t)std::max<int64_t>(n_blocks, 1));
+  int64_t pos = 0;
+  for (int64_t b = 0; b < n_blocks; ++b) {
+    starts[(size_t)b] = (uint32_t)pos;
+    int64_t& c = cursor[(size_t)blk_slot[b]];
+    std::memcpy(store.data() + 3 * c, xyz + 3 * pos, (size_t)blk_size[b] * 24);
+    for (int32_t i = 0; i < blk_size[b]; ++i) ord[(size_t)(pos + i)] = (uint32_t)(c + i);
+    c += blk_size[b];
+    pos += blk_size[b];
+  }
+  // rows outside the cube of their leaf (the reference's test: floor((p - corner) / (edge / 2)) in {0, 1} per axis,
+  // octree.py:73-75,94-98 - i.e. 0 <= p - corner < edge with the rounded difference)
+  bool displaced = false;
+  if (total > 0) {
+    NodeTable& t = f->nodes[f->cur];
+    std::vector<double> corner((size_t)n_nodes * 3), edge((size_t)n_nodes);
+    HIP_TRY(ctx, hipMemcpyAsync(corner.data(), t.corner.p, (size_t)n_nodes * 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(edge.data(), t.edge.p, (size_t)n_nodes * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    int64_t q = 0;
+    for (int64_t b = 0; b < n_blocks && !displaced; ++b) {
+      const double* c = corner.data() + 3 * (size_t)blk_node[b];
+      const double e = edge[(size_t)blk_node[b]];
+      for (int32_t i = 0; i < blk_size[b] && !displaced; ++i, ++q) {
+        for (int a = 0; a < 3; ++a) {
+          const double d = xyz[3 * q + a] - c[a];
+          if (!(d >= 0.0 && d < e)) displaced = true;  // (also NaN)
+        }
+      }
+      if (displaced) break;
+    }
+  }
+  if (f->store_borrowed) {  // the new store is the forest's own
+    f->xyz = f->xyz_own;
+    f->xyz_own = DevBuf{};
+    f->store_borrowed = false;
+  }
+  const size_t n1 = (size_t)std::max<int64_t>(total, 1), nb1 = (size_t)std::max<int64_t>(n_blocks, 1);
+  OCTL_TRY(devbuf_reserve(ctx, f->xyz, n1 * 24 + 16));
+  OCTL_TRY(devbuf_reserve(ctx, f->alive, n1 + 2));
+  OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, n1 * 4));
+  OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, n1 * 24));
+  // (block buffers keep the capacity convention of forest_make_blocks: one block per point)
+  for (DevBuf* b : {&f->blk_node, &f->blk_slot, &f->blk_start, &f->blk_size})
+    OCTL_TRY(devbuf_reserve(ctx, *b, std::max(n1, nb1) * 4));
+  if (total > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(f->xyz.p, store.data(), (size_t)total * 24, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->xyz_ord.p, xyz, (size_t)total * 24, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->ord_idx.p, ord.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(f->alive.p, 1, (size_t)total, st));
+  }
+  if (n_blocks > 0) {
+    HIP_TRY(ctx, hipMemcpyAsync(f->blk_node.p, blk_node, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->blk_slot.p, blk_slot, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->blk_size.p, blk_size, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->blk_start.p, starts.data(), (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));  // (pageable sources)
+  f->pose_off = off;
+  f->n_store = f->n_alive = f->n_ord = total;
+  f->n_blocks = n_blocks;
+  f->built_store = total;
+  f->built_poses = n_poses;
+  f->append_only = true;
+  f->store_dirty = false;
+  f->mask_valid = false;
+  f->fast_order_valid = false;
+  // the voxel box of the new points is not known (rows may have left their cubes): the next build finds it
+  OCTL_TRY(bbox_reset(f));
+  f->bbox_pending = total > 0;
+  f->displaced_rows = displaced;
   return OCTL_OK;
 }
 

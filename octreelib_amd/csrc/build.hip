@@ -997,6 +997,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   if (scheme_mask && n_mask != n_poses)
     return octl_set_error(ctx, OCTL_E_INVALID, "scheme mask has %d entries for %d poses", n_mask,
                           n_poses);
+  if (f->displaced_rows && !keep_scheme)
+    return octl_set_error(ctx, OCTL_E_DOMAIN,
+                          "map_leaf_points left points outside the cube of their leaf: the reference keeps them "
+                          "there and raises IndexError when such a leaf is subdivided (octree.py:94-98)");
   if (max_depth <= 0) max_depth = 63;
   f->fast_order_valid = false;  // (the block table is about to change)
   BuildTrace trace;

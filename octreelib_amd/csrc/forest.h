@@ -28,6 +28,10 @@ struct octl_forest {
   // Only ever set while the store is that ONE pose; the build folds the box into its histogram pass when it
   // has a geometry hint to work with, or runs the box pass first (store_compute_bbox)
   bool bbox_pending = false;
+  // octl_forest_set_contents left rows OUTSIDE the cube of the leaf that holds them (map_leaf_points may return
+  // anything, octree.py:114-123).  The reference keeps such rows in that leaf and raises IndexError as soon as the
+  // leaf is split; a count-driven build here would silently re-bucket them by their coordinates - so it refuses.
+  bool displaced_rows = false;
   std::vector<int64_t> pose_off{0};  // [P+1] offsets into the store
   int64_t n_store = 0, n_alive = 0;
   bool store_dirty = true;  // points were added/removed since the last build

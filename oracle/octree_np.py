@@ -180,6 +180,16 @@ class OTree:
             if not all([c(self.points[leaf.idx]) for c in criteria]):
                 leaf.idx = np.empty(0, dtype=np.int64)
 
+    # octree.py:114-123, 230-233: a non-empty leaf keeps whatever the function returns for its cloud (any number
+    # of rows, anywhere).  The new rows are appended to the pose's point array and the leaf refers to them.
+    def map_leaf_points(self, function):
+        for leaf in self.cached.values():
+            if len(leaf.idx):
+                new = np.asarray(function(self.points[leaf.idx].copy()), dtype=float).reshape(-1, 3)
+                start = len(self.points)
+                self.points = np.vstack([self.points, new])
+                leaf.idx = np.arange(start, start + len(new), dtype=np.int64)
+
     @property
     def n_points(self):
         return sum(len(v.idx) for v in self.cached.values())
@@ -224,6 +234,14 @@ class OManager:
             v.idx = np.empty(0, dtype=np.int64)
         for p in self.octrees:
             self.octrees[p].subdivide_as(self.scheme)
+
+    # octree_manager.py:68-83
+    def map_leaf_points(self, function, pose_numbers=None):
+        if pose_numbers is None:
+            pose_numbers = list(self.octrees.keys())
+        for p in pose_numbers:
+            if p in self.octrees:
+                self.octrees[p].map_leaf_points(function)
 
     # octree_manager.py:85-99
     def filter(self, criteria, pose_numbers=None):
@@ -304,6 +322,20 @@ class OGrid:
 
     def n_points(self, pose):
         return sum(m.n_points(pose) for m in self.managers.values())
+
+    # grid.py:111-122
+    def map_leaf_points(self, function, pose_numbers=None):
+        for m in self.managers.values():
+            m.map_leaf_points(function, pose_numbers)
+
+    # leaves of a pose as (corner, edge, (n, 3) rows) - for clouds that map_leaf_points has replaced
+    def leaf_rows(self, pose: int, non_empty: bool = True):
+        out = []
+        for key in self.pose_voxels[pose]:
+            tree = self.managers[key].octrees[pose]
+            for leaf in tree.leaves(non_empty):
+                out.append((np.asarray(leaf.corner, dtype=np.float64), np.float64(leaf.edge), tree.points[leaf.idx]))
+        return out
 
     # grid.py:260-267: every voxel's manager, all poses
     def filter(self, criteria):

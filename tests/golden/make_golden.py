@@ -256,6 +256,63 @@ def gen_grid_callable():
 
 
 # --------------------------------------------------------------------------------------
+# G2h: map_leaf_points with functions that TRANSFORM the leaf's cloud (octree.py:114-123: the leaf keeps whatever
+#      the function returns - fewer rows, more rows, rows outside its cube).  The functions are independent of the
+#      order of the rows inside a leaf (the reference's is an artefact of an unstable argsort).
+# --------------------------------------------------------------------------------------
+def bbox_corners(points):
+    return np.vstack([points.min(axis=0), points.max(axis=0)])
+
+
+def halve_and_shift(points):
+    return points * 0.5 + 10.0
+
+
+def triple(points):
+    return np.vstack([points, points + 0.001, points.min(axis=0, keepdims=True)])
+
+
+def _leaf_rows(leaves):
+    corners = np.array([np.asarray(v.corner_min, dtype=np.float64) for v in leaves], dtype=np.float64).reshape(-1, 3)
+    edges = np.array([np.float64(v.edge_length) for v in leaves], dtype=np.float64)
+    sizes, rows = [], []
+    for v in leaves:
+        p = np.ascontiguousarray(v.get_points(), dtype=np.float64).reshape(-1, 3)
+        p = p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+        sizes.append(len(p))
+        rows.append(p)
+    return corners, edges, np.array(sizes, dtype=np.int64), (np.vstack(rows) if rows else np.empty((0, 3)))
+
+
+def gen_grid_map_transform():
+    rng = np.random.default_rng(83)
+    poses = [rng.random((2500, 3)) * 3.0, rng.random((1800, 3)) * 3.0 - 1.0]
+    g = Grid(GridConfig(voxel_edge_length=1))
+    out = {"L": np.float64(1), "n_poses": np.int64(2), "K": np.int64(25)}
+    for p, pts in enumerate(poses):
+        g.insert_points(p, pts)
+        out[f"points{p}"] = pts
+    g.subdivide(crit(25))
+
+    def snap(tag):
+        for p in range(2):
+            c, e, s, r = _leaf_rows(g.get_leaf_points(p))
+            out[f"{tag}_p{p}_corners"], out[f"{tag}_p{p}_edges"] = c, e
+            out[f"{tag}_p{p}_sizes"], out[f"{tag}_p{p}_rows"] = s, r
+            out[f"{tag}_p{p}_counts"] = np.array([g.n_nodes(p), g.n_leaves(p), g.n_points(p)])
+
+    g.map_leaf_points(bbox_corners, [0])          # fewer rows, pose 0 only
+    snap("bbox")
+    g.map_leaf_points(triple)                      # more rows, every pose
+    snap("triple")
+    g.map_leaf_points(halve_and_shift, [1])        # rows leave their cubes
+    snap("shift")
+    g.filter([lambda pts: len(pts) > 6])           # a count filter on the transformed leaves
+    snap("filtered")
+    _save("grid_map_transform.npz", **out)
+
+
+# --------------------------------------------------------------------------------------
 # G2d: OctreeManager, 4 poses: subdivide on a pose subset, then a late-inserted pose
 # --------------------------------------------------------------------------------------
 def gen_manager():
@@ -564,6 +621,7 @@ GENERATORS = {
     "grid_late_poses": gen_grid_late_poses,
     "grid_filter": gen_grid_filter,
     "grid_callable": gen_grid_callable,
+    "grid_map_transform": gen_grid_map_transform,
     "ransac": gen_ransac,
     "grid_ransac": gen_grid_ransac,
     "grid_ransac_batches": gen_grid_ransac_batches,

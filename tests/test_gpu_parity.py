@@ -2085,3 +2085,73 @@ def test_async_host_feed_builds_the_same_forest_and_overlaps_nothing_it_should_n
     pinned[0][:] = 0.0     # the host buffer is the caller's again after wait()
     for u in ups:
         u.release()
+
+
+# ------------------------------------------------------------------------------------------------
+# map_leaf_points with functions that REPLACE the leaf's cloud (octree.py:114-123)
+# ------------------------------------------------------------------------------------------------
+def test_grid_map_leaf_points_transform_golden():
+    """fewer rows (pose subset), more rows, rows that leave their cubes, then a count filter: the reference's
+    leaf contents at every stage (tests/golden/grid_map_transform.npz)."""
+    from octreelib_amd.grid import Grid, GridConfig
+    from tests.test_oracle_golden import canon_rows, golden_rows, run_map_transform_sequence
+
+    g = load_golden("grid_map_transform.npz")
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    for p in range(2):
+        grid.insert_points(p, g[f"points{p}"])
+    grid.subdivide(crit(int(g["K"])))
+
+    def snap(tag):
+        for p in range(2):
+            got = canon_rows([(v.corner_min, v.edge_length, v.get_points()) for v in grid.get_leaf_points(p)])
+            assert got == golden_rows(g, f"{tag}_p{p}")
+            assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    run_map_transform_sequence(grid, snap)
+    # get_points returns the transformed clouds
+    for p in range(2):
+        rows = np.vstack([np.empty((0, 3))] + [v.get_points() for v in grid.get_leaf_points(p)])
+        assert sorted(map(bytes, grid.get_points(p))) == sorted(map(bytes, rows))
+    assert grid.n_points(0) == 0 and grid.n_points(1) > 0   # (pose 0's five-row leaves did not pass len > 6)
+    # rows outside their cubes fail a later subdivide, as the reference's IndexError does
+    with pytest.raises((IndexError, ValueError)):
+        grid.subdivide(crit(3))
+
+
+def test_map_leaf_points_transform_on_manager_and_octree_vs_oracle():
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+    from oracle import octree_np as onp
+    from tests.test_oracle_golden import canon_rows
+
+    rng = np.random.default_rng(5)
+    poses = [rng.random((900, 3)), rng.random((700, 3)), rng.random((20, 3))]
+    m = OctreeManager(Octree, OctreeConfig(), np.array([0.0, 0.0, 0.0]), 1.0)
+    om = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p, c in enumerate(poses):
+        m.insert_points(p, c)
+        om.insert_points(p, c)
+    m.subdivide(crit(30))
+    om.subdivide(30)
+    shrink = lambda pts: (pts + pts.min(axis=0)) * 0.5     # stays inside the leaf's cube: a later subdivide works
+    halves = lambda pts: pts[pts[:, 0] >= np.median(pts[:, 0])] * 1.0 - 0.0   # a selection, handed back as new values
+    for fn, sel in ((shrink, [0, 2]), (halves, None), (lambda pts: np.empty((0, 3)), [1])):
+        m.map_leaf_points(fn, sel)
+        om.map_leaf_points(fn, sel)
+        for p in range(3):
+            got = canon_rows([(v.corner_min, v.edge_length, v.get_points()) for v in m.get_leaf_points(True, p)])
+            want = canon_rows([(v.corner, v.edge, om.octrees[p].points[v.idx]) for v in om.octrees[p].leaves()])
+            assert got == want
+            assert [m.n_nodes(p), m.n_leaves(p), m.n_points(p)] == [om.n_nodes(p), om.n_leaves(p), om.n_points(p)]
+    # the transformed clouds are ordinary points afterwards: the scheme is rebuilt from them
+    m.subdivide(crit(10))
+    clouds = {p: om.octrees[p].get_points() for p in range(3)}
+    om2 = onp.OManager(np.array([0.0, 0.0, 0.0]), 1.0)
+    for p in range(3):
+        om2.insert_points(p, clouds[p])
+    om2.subdivide(10)
+    for p in range(3):
+        got = canon_rows([(v.corner_min, v.edge_length, v.get_points()) for v in m.get_leaf_points(True, p)])
+        want = canon_rows([(v.corner, v.edge, om2.octrees[p].points[v.idx]) for v in om2.octrees[p].leaves()])
+        assert sorted(got) == sorted(want)   # (the listing order records the history: om2 has a shorter one)

@@ -411,3 +411,61 @@ def test_count_scheme_manager_multi_pose_vs_recursive_oracle():
         assert len(cs.edge) == om.n_nodes(p)
     with pytest.raises(RecursionError):
         cnp.count_scheme([np.tile(np.array([[0.3, 0.3, 0.3]]), (5, 1))], np.zeros((1, 3)), 1.0, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# map_leaf_points with functions that replace the leaf's cloud (octree.py:114-123)
+# ------------------------------------------------------------------------------------------------
+def map_fn_bbox_corners(points):
+    return np.vstack([points.min(axis=0), points.max(axis=0)])
+
+
+def map_fn_halve_and_shift(points):
+    return points * 0.5 + 10.0
+
+
+def map_fn_triple(points):
+    return np.vstack([points, points + 0.001, points.min(axis=0, keepdims=True)])
+
+
+def canon_rows(table):
+    """[(corner, edge, (n,3) rows)] -> [((corner bytes, edge bytes), rows sorted lexicographically as bytes)]"""
+    out = []
+    for corner, edge, rows in table:
+        r = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 3)
+        r = r[np.lexsort((r[:, 2], r[:, 1], r[:, 0]))]
+        out.append((((np.asarray(corner, dtype=np.float64) + 0.0).tobytes(), np.float64(edge).tobytes()), r.tobytes()))
+    return out
+
+
+def golden_rows(g, prefix):
+    off = np.concatenate(([0], np.cumsum(g[f"{prefix}_sizes"])))
+    return canon_rows([(g[f"{prefix}_corners"][i], g[f"{prefix}_edges"][i], g[f"{prefix}_rows"][off[i]:off[i + 1]])
+                       for i in range(len(g[f"{prefix}_edges"]))])
+
+
+def run_map_transform_sequence(grid, snap):
+    """the sequence tests/golden/make_golden.py:gen_grid_map_transform recorded from the reference"""
+    grid.map_leaf_points(map_fn_bbox_corners, [0])
+    snap("bbox")
+    grid.map_leaf_points(map_fn_triple)
+    snap("triple")
+    grid.map_leaf_points(map_fn_halve_and_shift, [1])
+    snap("shift")
+    grid.filter([lambda pts: len(pts) > 6])
+    snap("filtered")
+
+
+def test_grid_map_leaf_points_transform():
+    g = load_golden("grid_map_transform.npz")
+    og = onp.OGrid(1)
+    for p in range(2):
+        og.insert_points(p, g[f"points{p}"])
+    og.subdivide(int(g["K"]))
+
+    def snap(tag):
+        for p in range(2):
+            assert canon_rows(og.leaf_rows(p)) == golden_rows(g, f"{tag}_p{p}")
+            assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
+
+    run_map_transform_sequence(og, snap)
