@@ -41,6 +41,7 @@ class Forest:
         self._edge_int = int(edge) if mode == 0 else 1
         self._cube = (tuple(np.asarray(corner, dtype=np.float64).tolist()), float(edge))
         self._creation_codes = np.empty(0, dtype=np.int64)   # packed voxel keys, creation order
+        self._code_origin = None                              # voxel index the host-side codes are relative to
         self._device_clouds = []                             # DeviceCloud objects whose buffers the store may read
 
     # -- lifetime ---------------------------------------------------------------------------
@@ -300,7 +301,14 @@ class Forest:
     def _voxel_codes(self, keys: np.ndarray) -> np.ndarray:
         """(m,3) int64 voxel corners -> one int64 per voxel (bijective: |index| < 2^20 per axis,
         include/octreelib_hip.h)."""
-        q = np.asarray(keys, dtype=np.int64).reshape(-1, 3) // self._edge_int + (1 << 20)
+        q = np.asarray(keys, dtype=np.int64).reshape(-1, 3) // self._edge_int
+        if self._code_origin is None:
+            if len(q) == 0:
+                return np.empty(0, dtype=np.int64)
+            self._code_origin = q.min(axis=0)   # codes are relative to where the scene started (any int64 index)
+        q = q - self._code_origin + (1 << 20)
+        if len(q) and (q.min() < 0 or q.max() >= (1 << 21)):
+            raise nat.DomainError("the scene has moved more than 2^20 voxels away from where it started")
         return (q[:, 0] << 42) | (q[:, 1] << 21) | q[:, 2]
 
     def creation_ranks(self, keys: np.ndarray) -> np.ndarray:

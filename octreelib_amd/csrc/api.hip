@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_ingest(const double* __restrict__ src, 
   bool bad = false;
   const int64_t n_flat = 3 * n, n_units = n_flat / 2;
   const int64_t u0 = (int64_t)blockIdx.x * (256 * ING_UNITS) + threadIdx.x;
-  const double lim = (double)OCTL_VOX_BIAS;
+  const double lim = (double)OCTL_VOX_ABS_LIMIT;
   auto fold = [&](double v, int axis) {
     const double f = L == 1.0 ? floor(v) : floor_div_exact(v, L);  // (floor_div_exact(v, 1) == floor(v))
     if (fabs(f) < lim) {  // false for NaN / inf
@@ -601,6 +601,7 @@ int octl_forest_clear(octl_forest* f) {
   f->built = false;
   f->vkeys.clear();
   f->vkeys_stale = false;
+  f->vorg_set = false;
   f->vcode_valid = false;
   f->fast_order_valid = false;
   f->built_store = 0;
@@ -895,7 +896,7 @@ int octl_forest_get_voxels(octl_forest* f, int64_t cap, int64_t* coords, int64_t
   const int64_t n = std::min<int64_t>(cap, *n_voxels);
   for (int64_t v = 0; v < n; ++v) {
     int64_t q[3];
-    vkey_decode(f->vkeys[v], q);
+    vkey_decode(f->vkeys[v], f->vorg, q);
     // the reference's voxel coordinates are int(q * L): the corner, not the index
     for (int a = 0; a < 3; ++a)
       coords[3 * v + a] = f->mode == 0 ? (int64_t)((double)q[a] * f->edge) : 0;

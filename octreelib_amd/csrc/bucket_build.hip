@@ -270,7 +270,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
   const int big = 1 << 30;
   int mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
   bool bad = false, outside = false;
-  const double lim = (double)OCTL_VOX_BIAS;
+  const double lim = (double)OCTL_VOX_ABS_LIMIT;
   // (branch-free on purpose: early returns inside the loop body kept the loads of the next iteration behind
   //  the branches of this one - the kernel ran at half the speed of the plain histogram)
   auto count = [&](double x, double y, double z, bool live) {
@@ -1245,6 +1245,7 @@ struct NodeParams {
   const int32_t* old_epoch;
   const uint64_t* old_vcode;
   int64_t old_voxels;
+  VoxOrg org;  // voxel origin of the packed keys (old_vcode)
 };
 
 // One workgroup per bucket, three independent sweeps (nothing is a serial chain any more: the bucket
@@ -1279,8 +1280,7 @@ __device__ __forceinline__ int32_t old_root_of(const NodeParams& P, uint32_t lin
     qy = (int64_t)((lin / P.lp.nz) % P.lp.ny) + P.lp.miny;
     qx = (int64_t)(lin / (P.lp.nz * P.lp.ny)) + P.lp.minx;
   }
-  const uint64_t code = ((uint64_t)(qx + OCTL_VOX_BIAS) << 42) | ((uint64_t)(qy + OCTL_VOX_BIAS) << 21) |
-                        (uint64_t)(qz + OCTL_VOX_BIAS);
+  const uint64_t code = vkey_pack(qx, qy, qz, P.org);
   int64_t lo = 0, hi = P.old_voxels;
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
@@ -1293,12 +1293,13 @@ __device__ __forceinline__ int32_t old_root_of(const NodeParams& P, uint32_t lin
 // path cannot express): counts the ones that are not
 __global__ __launch_bounds__(256) void k_old_voxels_missing(const uint64_t* __restrict__ old_vcode, int64_t old_V,
                                                             const uint64_t* __restrict__ new_vlin, int64_t new_V,
-                                                            LinParams lp, int nx, uint32_t* __restrict__ missing) {
+                                                            LinParams lp, int nx, VoxOrg org,
+                                                            uint32_t* __restrict__ missing) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= old_V) return;
-  const uint64_t k = old_vcode[r];
-  const int64_t qx = (int64_t)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS, qy = (int64_t)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS,
-                qz = (int64_t)(k & 0x1FFFFF) - OCTL_VOX_BIAS;
+  int64_t qd[3];
+  vkey_decode(old_vcode[r], org, qd);
+  const int64_t qx = qd[0], qy = qd[1], qz = qd[2];
   bool found = false;
   if (lp.mode != 0) {
     found = new_V > 0;
@@ -1625,7 +1626,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     if (bbox_host[6])
       return octl_set_error(ctx, OCTL_E_DOMAIN,
                             "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
-                            OCTL_VOX_BIAS);
+                            OCTL_VOX_ABS_LIMIT);
     if (bb[0] > bb[3]) return OCTL_OK;
     const uint64_t nx = (uint64_t)(bb[3] - bb[0] + 1);
     ny = (uint64_t)(bb[4] - bb[1] + 1);
@@ -1819,7 +1820,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       if (g.reason == GEOM_DOMAIN)
         return octl_set_error(ctx, OCTL_E_DOMAIN,
                               "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
-                              OCTL_VOX_BIAS);
+                              OCTL_VOX_ABS_LIMIT);
       if (g.reason == GEOM_EMPTY) return OCTL_OK;
       // the hinted geometry did not hold: the box is on the device now, the build runs again from it
       if (g.reason == GEOM_REHASH)
@@ -1837,6 +1838,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     ny = lp.ny;
     nz = lp.nz;
   }
+  // the packed voxel keys of everything that follows (k_bucket_finish's walk over the previous scheme, the
+  // incremental insertion, the host's voxel list) are relative to the origin this fixes on the first build
+  if (f->mode == 0) OCTL_TRY(forest_fix_origin(f, bb));
   if (sm[SM_BK_FLAGS]) return OCTL_OK;  // some bucket / voxel does not fit: the caller runs the general path
   const int64_t V = sm[SM_NVOX];
   int64_t n_int = 0;
@@ -1871,6 +1875,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   np.old_epoch = a.old_epoch;
   np.old_vcode = a.old_vcode;
   np.old_voxels = a.old_voxels;
+  np.org = f->vorg;
   // the listing order of the blocks falls out of the same kernel for the common case: one pose, a fresh
   // scheme (one epoch), nothing left to the level loop, no bucket beyond what the kernel ranks in LDS
   const bool fast_order = n_poses == 1 && !a.old_fc && sm[SM_BK_TODO] == 0 && sm[SM_BK_NOORDER] == 0 &&
@@ -1901,7 +1906,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_MISSING, 0, 4, st));
     hipLaunchKernelGGL(k_old_voxels_missing, dim3((unsigned)ceil_div(a.old_voxels, 256)), dim3(256), 0, st,
                        a.old_vcode, a.old_voxels, (const uint64_t*)f->vlin_dev.as<uint64_t>(), V, lp,
-                       bb[3] - bb[0] + 1, small + SM_BK_MISSING);
+                       bb[3] - bb[0] + 1, f->vorg, small + SM_BK_MISSING);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t missing = 0;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small + SM_BK_MISSING, 4, hipMemcpyDeviceToHost, st));

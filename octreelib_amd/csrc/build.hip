@@ -107,7 +107,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 __global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
                                                 const uint8_t* __restrict__ alive, int64_t n,
                                                 int mode, double L, double c0x, double c0y,
-                                                double c0z, uint64_t* __restrict__ vkey,
+                                                double c0z, VoxOrg org, uint64_t* __restrict__ vkey,
                                                 uint64_t* __restrict__ path,
                                                 uint32_t* __restrict__ small) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,9 +120,10 @@ __global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
       // voxel_indices = ((points - corner) // L * L).astype(int)   (grid.py:72-76, corner = 0)
       const double fx = floor_div_exact(px, L), fy = floor_div_exact(py, L),
                    fz = floor_div_exact(pz, L);
-      const double lim = (double)OCTL_VOX_BIAS;
-      const bool in_range =
-          (fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim);  // false for NaN
+      const double lim = (double)OCTL_VOX_ABS_LIMIT;
+      // (false for NaN; the second test: inside the window of the packed keys around the forest's origin)
+      const bool in_range = (fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim) &&
+                            vkey_in_window((int64_t)fx, (int64_t)fy, (int64_t)fz, org);
       if (!in_range) {
         atomicExch(&small[SM_ERR], (uint32_t)(-OCTL_E_DOMAIN));
         live = false;
@@ -137,8 +138,7 @@ __global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
       }
     }
     if (live) {
-      vkey[i] = ((uint64_t)(qx + OCTL_VOX_BIAS) << 42) | ((uint64_t)(qy + OCTL_VOX_BIAS) << 21) |
-                (uint64_t)(qz + OCTL_VOX_BIAS);
+      vkey[i] = vkey_pack(qx, qy, qz, org);
       path[i] = compute_path(px, py, pz, cx, cy, cz, L);
     }
   }
@@ -186,7 +186,7 @@ __device__ __forceinline__ int find_slot(const int64_t* __restrict__ pose_off, i
 
 __global__ __launch_bounds__(256) void k_linkey(const uint64_t* __restrict__ vkey, int64_t n,
                                                 int minx, int miny, int minz, uint64_t ny,
-                                                uint64_t nz, uint64_t dead_lin,
+                                                uint64_t nz, uint64_t dead_lin, VoxOrg org,
                                                 const int64_t* __restrict__ pose_off, int n_poses,
                                                 const uint8_t* __restrict__ scheme,
                                                 uint64_t* __restrict__ lin,
@@ -196,10 +196,9 @@ __global__ __launch_bounds__(256) void k_linkey(const uint64_t* __restrict__ vke
   const uint64_t k = vkey[i];
   uint64_t l = dead_lin;
   if (k != OCTL_VOX_DEAD) {
-    const int64_t qx = (int64_t)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS;
-    const int64_t qy = (int64_t)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS;
-    const int64_t qz = (int64_t)(k & 0x1FFFFF) - OCTL_VOX_BIAS;
-    l = ((uint64_t)(qx - minx) * ny + (uint64_t)(qy - miny)) * nz + (uint64_t)(qz - minz);
+    int64_t qd[3];
+    vkey_decode(k, org, qd);
+    l = ((uint64_t)(qd[0] - minx) * ny + (uint64_t)(qd[1] - miny)) * nz + (uint64_t)(qd[2] - minz);
   }
   lin[i] = l;
   uint32_t v = (uint32_t)i;
@@ -813,9 +812,8 @@ int forest_sync_vkeys(octl_forest* f) {
   for (int64_t v = 0; v < f->n_voxels; ++v) {
     const uint64_t l = lin[v];
     const uint64_t qz = l % f->vl_nz, qy = (l / f->vl_nz) % f->vl_ny, qx = l / (f->vl_nz * f->vl_ny);
-    f->vkeys[v] = ((uint64_t)((int64_t)qx + f->vl_min[0] + OCTL_VOX_BIAS) << 42) |
-                  ((uint64_t)((int64_t)qy + f->vl_min[1] + OCTL_VOX_BIAS) << 21) |
-                  (uint64_t)((int64_t)qz + f->vl_min[2] + OCTL_VOX_BIAS);
+    f->vkeys[v] = vkey_pack((int64_t)qx + f->vl_min[0], (int64_t)qy + f->vl_min[1], (int64_t)qz + f->vl_min[2],
+                            f->vorg);
   }
   f->vkeys_stale = false;
   return OCTL_OK;
@@ -981,6 +979,38 @@ static int run_level_loop(LevelLoop& L) {
     ++L.level;
   }
   return OCTL_OK;
+}
+
+int forest_fix_origin(octl_forest* f, const int bb[6]) {
+  if (f->mode != 0 || bb[0] > bb[3]) return OCTL_OK;  // a single cube has voxel 0 only; an empty box fixes nothing
+  if (!f->vorg_set) {
+    f->vorg.x = bb[0];
+    f->vorg.y = bb[1];
+    f->vorg.z = bb[2];
+    f->vorg_set = true;
+  }
+  if (!vkey_in_window(bb[0], bb[1], bb[2], f->vorg) || !vkey_in_window(bb[3], bb[4], bb[5], f->vorg))
+    return octl_set_error(f->ctx, OCTL_E_DOMAIN,
+                          "the scene has moved more than %d voxels away from where it started (voxel box "
+                          "[%d..%d] x [%d..%d] x [%d..%d], origin %d %d %d): the packed voxel keys cannot hold it",
+                          OCTL_VOX_BIAS, bb[0], bb[3], bb[1], bb[4], bb[2], bb[5], f->vorg.x, f->vorg.y, f->vorg.z);
+  return OCTL_OK;
+}
+
+// the general path packs voxel keys before it knows the voxel box (k_keygen finds it on the way): a forest
+// that has no origin yet gets it from the box the ingest kernel keeps (one small readback, first build only)
+static int forest_ensure_origin(octl_forest* f) {
+  if (f->mode != 0 || f->vorg_set || f->n_store == 0) return OCTL_OK;
+  octl_ctx* ctx = f->ctx;
+  if (f->bbox_pending) OCTL_TRY(store_compute_bbox(f));
+  if (!f->bbox_dev.p) return OCTL_OK;
+  int32_t* host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + 3584);
+  HIP_TRY(ctx, hipMemcpyAsync(host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  int bb[6];
+  std::memcpy(bb, host, sizeof(bb));
+  if (host[6]) return OCTL_OK;  // (a non-finite coordinate: k_keygen reports it)
+  return forest_fix_origin(f, bb);
 }
 
 int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
@@ -1177,27 +1207,29 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   OCTL_TRY(forest_sync_vkeys(f));  // the previous scheme's voxels persist (no-op when fresh)
   trace.mark("sync_vkeys");
   // ---- 1. keys -----------------------------------------------------------------------------------
+  OCTL_TRY(forest_ensure_origin(f));
   if (N > 0) {
     OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));
     OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 8));
     KTimer t(ctx, "keygen");
     hipLaunchKernelGGL(k_keygen, dim3(grid_for(N)), dim3(256), 0, st, f->xyz.as<double>(),
                        f->alive.as<uint8_t>(), N, f->mode, f->edge, f->corner[0], f->corner[1],
-                       f->corner[2], f->vkey.as<uint64_t>(), f->path.as<uint64_t>(), small);
+                       f->corner[2], f->vorg, f->vkey.as<uint64_t>(), f->path.as<uint64_t>(), small);
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t sm[32];
   OCTL_TRY(read_small(ctx, 0, 32, sm));
   if (sm[SM_ERR])
     return octl_set_error(ctx, OCTL_E_DOMAIN,
-                          "a point has a non-finite coordinate or a top-level voxel index "
-                          "outside +-%d", OCTL_VOX_BIAS);
+                          "a point has a non-finite coordinate, a top-level voxel index outside +-%d, or "
+                          "lies more than %d voxels from where the scene started", OCTL_VOX_ABS_LIMIT,
+                          OCTL_VOX_BIAS);
   int bb[6];
   std::memcpy(bb, sm + SM_BBOX, sizeof(bb));
   // the voxels of the previous scheme persist even when they have lost all their points
   for (uint64_t k : f->vkeys) {
     int64_t q[3];
-    vkey_decode(k, q);
+    vkey_decode(k, f->vorg, q);
     for (int a = 0; a < 3; ++a) {
       bb[a] = std::min<int>(bb[a], (int)q[a]);
       bb[3 + a] = std::max<int>(bb[3 + a], (int)q[a]);
@@ -1212,14 +1244,12 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   const int key_bits = bits_for(dead_lin);
   auto lin_of = [&](uint64_t k) {
     int64_t q[3];
-    vkey_decode(k, q);
+    vkey_decode(k, f->vorg, q);
     return ((uint64_t)(q[0] - bb[0]) * ny + (uint64_t)(q[1] - bb[1])) * nz + (uint64_t)(q[2] - bb[2]);
   };
   auto vkey_of_lin = [&](uint64_t l) {
     const uint64_t qz = l % nz, qy = (l / nz) % ny, qx = l / (nz * ny);
-    return ((uint64_t)((int64_t)qx + bb[0] + OCTL_VOX_BIAS) << 42) |
-           ((uint64_t)((int64_t)qy + bb[1] + OCTL_VOX_BIAS) << 21) |
-           (uint64_t)((int64_t)qz + bb[2] + OCTL_VOX_BIAS);
+    return vkey_pack((int64_t)qx + bb[0], (int64_t)qy + bb[1], (int64_t)qz + bb[2], f->vorg);
   };
 
   trace.mark("keys + bbox readback");
@@ -1233,7 +1263,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     {
       KTimer t(ctx, "linkey");
       hipLaunchKernelGGL(k_linkey, dim3(grid_for(N)), dim3(256), 0, st, f->vkey.as<uint64_t>(), N,
-                         bb[0], bb[1], bb[2], ny, nz, dead_lin, f->pose_off_dev.as<int64_t>(),
+                         bb[0], bb[1], bb[2], ny, nz, dead_lin, f->vorg, f->pose_off_dev.as<int64_t>(),
                          n_poses, scheme_dev, f->lin[0].as<uint64_t>(), f->val[0].as<uint32_t>());
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -1328,8 +1358,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       }
     }
     if (f->mode == 1 && new_vkeys.empty()) {  // a cube without points still has its root
-      new_vkeys.push_back(((uint64_t)OCTL_VOX_BIAS << 42) | ((uint64_t)OCTL_VOX_BIAS << 21) |
-                          (uint64_t)OCTL_VOX_BIAS);
+      new_vkeys.push_back(vkey_pack(0, 0, 0, f->vorg));
       r_start.push_back(0);
       r_count.push_back(0);
       r_old.push_back(f->built ? 0 : -1);
@@ -1348,7 +1377,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
         i32[v] = (int32_t)v;
         if (f->mode == 0) {
           int64_t q[3];
-          vkey_decode(new_vkeys[v], q);
+          vkey_decode(new_vkeys[v], f->vorg, q);
           // np.array(voxel_coordinates): int64(q * L), L integer valued (grid.py:72-76,104)
           for (int ax = 0; ax < 3; ++ax) cor[3 * v + ax] = (double)(int64_t)((double)q[ax] * f->edge);
         } else {

@@ -2,6 +2,33 @@
 #pragma once
 #include "common.h"
 
+// packed voxel key: (qx-ox+B)<<42 | (qy-oy+B)<<21 | (qz-oz+B), B = 2^20; lexicographic (x,y,z) order of
+// the integer voxel coordinates == numeric order of the key (np.unique(axis=0) order,
+// grid/grid.py:79-81).  The key is RELATIVE to the forest's voxel origin o - the minimum voxel of the first
+// build after a clear (forest_fix_origin) - so that voxel indices of any size work (the reference takes any
+// int64, grid.py:72-76: UTM coordinates at 1 m voxels are 5 * 10^6) as long as the scene stays within 2^20
+// voxels of where it started; absolute indices are limited to +-2^30 (they travel as int32).
+#define OCTL_VOX_BIAS (1 << 20)
+#define OCTL_VOX_ABS_LIMIT (1 << 30)
+#define OCTL_VOX_DEAD (~0ull)
+struct VoxOrg {
+  int32_t x = 0, y = 0, z = 0;
+};
+__host__ __device__ static inline uint64_t vkey_pack(int64_t qx, int64_t qy, int64_t qz, const VoxOrg& g) {
+  return ((uint64_t)(qx - g.x + OCTL_VOX_BIAS) << 42) | ((uint64_t)(qy - g.y + OCTL_VOX_BIAS) << 21) |
+         (uint64_t)(qz - g.z + OCTL_VOX_BIAS);
+}
+__host__ __device__ static inline bool vkey_in_window(int64_t qx, int64_t qy, int64_t qz, const VoxOrg& g) {
+  const int64_t ax = qx - g.x, ay = qy - g.y, az = qz - g.z;
+  return ax > -OCTL_VOX_BIAS && ax < OCTL_VOX_BIAS && ay > -OCTL_VOX_BIAS && ay < OCTL_VOX_BIAS &&
+         az > -OCTL_VOX_BIAS && az < OCTL_VOX_BIAS;
+}
+__host__ __device__ static inline void vkey_decode(uint64_t k, const VoxOrg& g, int64_t q[3]) {
+  q[0] = (int64_t)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS + g.x;
+  q[1] = (int64_t)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS + g.y;
+  q[2] = (int64_t)(k & 0x1FFFFF) - OCTL_VOX_BIAS + g.z;
+}
+
 // Structure-of-arrays scheme node table on the device.
 struct NodeTable {
   DevBuf start, count, scount;  // u32: range in the level buffers, scheme-pose point count
@@ -49,6 +76,8 @@ struct octl_forest {
   int cur = 0;               // nodes[cur] is the current table
   int epoch = 0;             // number of K-driven builds so far
   bool built = false;
+  VoxOrg vorg;                  // voxel origin of the packed keys (fixed by the first build after a clear)
+  bool vorg_set = false;
   std::vector<uint64_t> vkeys;  // packed integer coordinates of the top-level voxels, sorted
                                 // (filled lazily from vlin_dev: forest_sync_vkeys)
   bool vkeys_stale = false;
@@ -105,17 +134,6 @@ struct octl_forest {
       split_tiles[2], child_sc, pose_off_dev, scheme_dev, root_up;
 };
 
-// packed voxel key: (qx+B)<<42 | (qy+B)<<21 | (qz+B), B = 2^20; lexicographic (x,y,z) order of
-// the integer voxel coordinates == numeric order of the key (np.unique(axis=0) order,
-// grid/grid.py:79-81)
-#define OCTL_VOX_BIAS (1 << 20)
-#define OCTL_VOX_DEAD (~0ull)
-static inline void vkey_decode(uint64_t k, int64_t q[3]) {
-  q[0] = (int64_t)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS;
-  q[1] = (int64_t)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS;
-  q[2] = (int64_t)(k & 0x1FFFFF) - OCTL_VOX_BIAS;
-}
-
 int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
                  int32_t keep_scheme, int32_t max_depth, octl_build_info* info);
 int nodes_reserve(octl_ctx* ctx, NodeTable& t, int64_t cap);
@@ -141,6 +159,9 @@ int forest_make_blocks(octl_forest* f);
 int forest_finish_blocks(octl_forest* f, uint32_t* err_out);
 // host copy of the voxel keys (synchronises when stale)
 int forest_sync_vkeys(octl_forest* f);
+// build.hip: fix the voxel origin of the packed keys from a voxel box (first build after a clear) and check
+// that the box lies inside the window of the keys; OCTL_E_DOMAIN otherwise
+int forest_fix_origin(octl_forest* f, const int bb[6]);
 // incremental.hip: device copy of the packed voxel keys; poses appended to a built forest placed into
 // its scheme in O(new points).  *done = 0: not applicable, nothing was changed
 int forest_sync_vcodes(octl_forest* f);

@@ -60,14 +60,13 @@ __device__ __forceinline__ int slot_of(const int64_t* __restrict__ pose_off, int
 
 // fresh builds keep their voxels as linear keys relative to the build's bounding box: -> packed codes
 __global__ __launch_bounds__(256) void k_lin_to_code(const uint64_t* __restrict__ lin, int64_t V, int m0,
-                                                     int m1, int m2, uint64_t ny, uint64_t nz,
+                                                     int m1, int m2, uint64_t ny, uint64_t nz, VoxOrg org,
                                                      uint64_t* __restrict__ code) {
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   const uint64_t l = lin[v];
   const uint64_t qz = l % nz, qy = (l / nz) % ny, qx = l / (nz * ny);
-  code[v] = ((uint64_t)((int64_t)qx + m0 + OCTL_VOX_BIAS) << 42) |
-            ((uint64_t)((int64_t)qy + m1 + OCTL_VOX_BIAS) << 21) | (uint64_t)((int64_t)qz + m2 + OCTL_VOX_BIAS);
+  code[v] = vkey_pack((int64_t)qx + m0, (int64_t)qy + m1, (int64_t)qz + m2, org);
 }
 
 // One new point: voxel (grid/grid.py:72-76), root by binary search, walk to the leaf
@@ -75,7 +74,7 @@ __global__ __launch_bounds__(256) void k_lin_to_code(const uint64_t* __restrict_
 // restated as exact comparisons on the same rounded differences, see compute_path in build.hip).
 __global__ __launch_bounds__(256) void k_inc_place(const double* __restrict__ xyz,
                                                    const uint8_t* __restrict__ alive, int64_t first,
-                                                   int64_t n_new, int mode, double L,
+                                                   int64_t n_new, int mode, double L, VoxOrg org,
                                                    const uint64_t* __restrict__ vcode, int64_t V,
                                                    const int32_t* __restrict__ first_child,
                                                    const double* __restrict__ corner,
@@ -95,8 +94,9 @@ __global__ __launch_bounds__(256) void k_inc_place(const double* __restrict__ xy
   int qx = 0, qy = 0, qz = 0;
   if (mode == 0) {
     const double fx = floor_div_exact(px, L), fy = floor_div_exact(py, L), fz = floor_div_exact(pz, L);
-    const double lim = (double)OCTL_VOX_BIAS;
-    if (!((fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim))) {  // also NaN
+    const double lim = (double)OCTL_VOX_ABS_LIMIT;
+    if (!((fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim) &&
+          vkey_in_window((int64_t)fx, (int64_t)fy, (int64_t)fz, org))) {  // also NaN
       atomicExch(&small[SM_ERR], (uint32_t)(-OCTL_E_DOMAIN));
       key[j] = KEY_DEAD;
       return;
@@ -105,8 +105,7 @@ __global__ __launch_bounds__(256) void k_inc_place(const double* __restrict__ xy
     qy = (int)fy;
     qz = (int)fz;
   }
-  const uint64_t code = ((uint64_t)(qx + OCTL_VOX_BIAS) << 42) | ((uint64_t)(qy + OCTL_VOX_BIAS) << 21) |
-                        (uint64_t)(qz + OCTL_VOX_BIAS);
+  const uint64_t code = vkey_pack(qx, qy, qz, org);
   const int64_t r = lower_bound_u64(vcode, V, code);
   if (r >= V || vcode[r] != code) {
     key[j] = KEY_MISS | code;
@@ -204,14 +203,14 @@ __global__ __launch_bounds__(256) void k_inc_copy_nodes(NodePtrs src, NodePtrs d
 __global__ __launch_bounds__(256) void k_inc_new_roots(const uint64_t* __restrict__ ucode,
                                                        const int32_t* __restrict__ new_root, int64_t U,
                                                        int mode, double L, double c0x, double c0y, double c0z,
-                                                       NodePtrs dst) {
+                                                       VoxOrg org, NodePtrs dst) {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= U) return;
   const int64_t y = new_root[j];
   const uint64_t k = ucode[j];
-  const long long qx = (long long)((k >> 42) & 0x1FFFFF) - OCTL_VOX_BIAS,
-                  qy = (long long)((k >> 21) & 0x1FFFFF) - OCTL_VOX_BIAS,
-                  qz = (long long)(k & 0x1FFFFF) - OCTL_VOX_BIAS;
+  int64_t qd[3];
+  vkey_decode(k, org, qd);
+  const long long qx = qd[0], qy = qd[1], qz = qd[2];
   dst.start[y] = 0;
   dst.count[y] = 0;
   dst.scount[y] = 0;
@@ -333,7 +332,7 @@ int forest_sync_vcodes(octl_forest* f) {
     if (f->vkeys_stale) {  // the last build left linear keys on the device
       hipLaunchKernelGGL(k_lin_to_code, dim3(grid_for(V)), dim3(256), 0, ctx->stream,
                          (const uint64_t*)f->vlin_dev.as<uint64_t>(), V, f->vl_min[0], f->vl_min[1], f->vl_min[2],
-                         f->vl_ny, f->vl_nz, f->vcode_dev[0].as<uint64_t>());
+                         f->vl_ny, f->vl_nz, f->vorg, f->vcode_dev[0].as<uint64_t>());
       HIP_TRY(ctx, hipGetLastError());
     } else {
       HIP_TRY(ctx, hipMemcpyAsync(f->vcode_dev[0].p, f->vkeys.data(), (size_t)V * 8, hipMemcpyHostToDevice,
@@ -370,7 +369,7 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
   {
     KTimer t(ctx, "inc_place");
     hipLaunchKernelGGL(k_inc_place, dim3(grid_for(n_new)), dim3(256), 0, st, (const double*)f->xyz.as<double>(),
-                       (const uint8_t*)f->alive.as<uint8_t>(), first, n_new, f->mode, f->edge,
+                       (const uint8_t*)f->alive.as<uint8_t>(), first, n_new, f->mode, f->edge, f->vorg,
                        (const uint64_t*)f->vcode_dev[0].as<uint64_t>(), V, (const int32_t*)nd.first_child,
                        (const double*)nd.corner, (const double*)nd.edge, keys[0], vals[0], small);
     HIP_TRY(ctx, hipGetLastError());
@@ -437,7 +436,8 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
                        (int32_t)U, (const int32_t*)shift_w);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_inc_new_roots, dim3(grid_for(U)), dim3(256), 0, st, (const uint64_t*)ucode,
-                       (const int32_t*)root_w, U, f->mode, f->edge, f->corner[0], f->corner[1], f->corner[2], dst);
+                       (const int32_t*)root_w, U, f->mode, f->edge, f->corner[0], f->corner[1], f->corner[2], f->vorg,
+                       dst);
     HIP_TRY(ctx, hipGetLastError());
     if (n_blocks > 0) {
       hipLaunchKernelGGL(k_inc_remap, dim3(grid_for(n_blocks)), dim3(256), 0, st, f->blk_node.as<int32_t>(),

@@ -83,7 +83,7 @@ constexpr int RT_TILE = RT_THREADS * RT_IPT;  // 2048 points per tile
 // (api.hip k_ingest / bucket_build.hip, grid.py:72-76)
 __device__ __forceinline__ int route_dest_of(double x, double y, double z, double L, int n_ranks, bool* bad) {
   const double fx = floor_div_exact(x, L), fy = floor_div_exact(y, L), fz = floor_div_exact(z, L);
-  const double lim = (double)OCTL_VOX_BIAS;
+  const double lim = (double)OCTL_VOX_ABS_LIMIT;
   if ((fabs(fx) < lim) && (fabs(fy) < lim) && (fabs(fz) < lim))
     return voxel_owner_hash((int64_t)fx, (int64_t)fy, (int64_t)fz, n_ranks);
   *bad = true;

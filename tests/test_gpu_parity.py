@@ -2155,3 +2155,90 @@ def test_map_leaf_points_transform_on_manager_and_octree_vs_oracle():
         got = canon_rows([(v.corner_min, v.edge_length, v.get_points()) for v in m.get_leaf_points(True, p)])
         want = canon_rows([(v.corner, v.edge, om2.octrees[p].points[v.idx]) for v in om2.octrees[p].leaves()])
         assert sorted(got) == sorted(want)   # (the listing order records the history: om2 has a shorter one)
+
+
+# ------------------------------------------------------------------------------------------------
+# voxel indices far beyond 2^20 (UTM-like coordinates at 1 m voxels): the reference takes any int64
+# (grid.py:72-76); the packed voxel keys are relative to where the scene started
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("general_path", [False, True])
+def test_grid_at_utm_scale_coordinates_vs_oracle(monkeypatch, general_path):
+    from octreelib_amd.grid import Grid, GridConfig
+    from oracle import octree_np as onp
+    from oracle import ransac_np as rnp
+
+    if general_path:
+        monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    rng = np.random.default_rng(123)
+    origin = np.array([5_432_100.0, -4_321_000.0, 1_250_000.0])   # |voxel index| up to 5.4e6 >> 2^20
+    poses = [origin + rng.random((6000, 3)) * 5.0, origin + rng.random((4000, 3)) * 5.0 + np.array([3.0, -2.0, 1.0]),
+             origin + rng.random((3000, 3)) * 4.0 + np.array([-6.0, 7.0, -3.0])]
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    og = onp.OGrid(1)
+    for p in range(2):
+        grid.insert_points(p, poses[p])
+        og.insert_points(p, poses[p])
+    grid.subdivide(crit(30))
+    og.subdivide(30)
+
+    def check(n_poses):
+        for p in range(n_poses):
+            index = index_map(poses[p])
+            assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(p), index)),
+                               canon_from_list(og.leaf_table(p)))
+            assert [grid.n_nodes(p), grid.n_leaves(p), grid.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+
+    check(2)
+    # a late pose with new voxels on both sides (incremental insertion), then a re-subdivide over the old scheme
+    grid.insert_points(2, poses[2])
+    og.insert_points(2, poses[2])
+    check(3)
+    # (all poses, smaller K: the new scheme is finer or equal everywhere - coarsening is outside the parity domain,
+    #  SURVEY 8 a8, and would leave the merged leaves of the oracle in child-major instead of insertion order)
+    grid.subdivide(crit(12))
+    og.subdivide(12)
+    check(3)
+    v = grid.get_leaf_points(1)[0]
+    assert np.abs(v.corner_min).max() > 1e6 and v.corner_min.dtype.kind in "if"
+    # RANSAC + apply_mask + filter at these coordinates
+    np.random.seed(9)
+    table = np.random.random((256, 6))
+    np.random.seed(9)
+    grid.map_leaf_points_cuda_ransac(poses_per_batch=2, hypotheses_number=256, threshold=0.05)
+    for batch in ((0, 1), (2,)):
+        rows = [og.leaf_table(p) for p in batch]
+        cloud = np.vstack([poses[p][i] for p, t in zip(batch, rows) for _, _, i in t])
+        sizes = np.array([len(i) for t in rows for _, _, i in t], dtype=np.int32)
+        mask = rnp.evaluate(cloud, sizes, table, 0.05)
+        off = 0
+        for p, t in zip(batch, rows):
+            n = sum(len(i) for _, _, i in t)
+            og.apply_mask(p, mask[off : off + n])
+            off += n
+    check(3)
+    grid.filter([lambda pts: len(pts) >= 4])
+    og.filter([lambda pts: len(pts) >= 4])
+    check(3)
+    # get_points: all managers in first-creation order
+    for p in range(3):
+        assert sorted(map(bytes, grid.get_points(p))) == sorted(map(bytes, np.vstack([poses[p][i] for _, _, i in og.leaf_table(p)] + [np.empty((0, 3))])))
+
+
+def test_scene_that_moves_more_than_2_pow_20_voxels_fails_loudly():
+    from octreelib_amd import _native as nat
+    from octreelib_amd.grid import Grid, GridConfig
+
+    rng = np.random.default_rng(1)
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    grid.insert_points(0, rng.random((500, 3)) * 3.0 + 7_000_000.0)
+    grid.subdivide(crit(20))
+    assert grid.n_points(0) == 500
+    grid.insert_points(1, rng.random((500, 3)) * 3.0 + 7_000_000.0 + 900_000.0)   # within 2^20 voxels: fine
+    assert grid.n_points(1) == 500
+    grid.insert_points(2, rng.random((500, 3)) * 3.0 + 7_000_000.0 + 1_200_000.0)   # beyond
+    with pytest.raises((nat.DomainError, IndexError, ValueError)):
+        grid.n_points(2)
+    with pytest.raises((nat.DomainError, IndexError, ValueError)):     # absolute index beyond int32 range
+        g2 = Grid(GridConfig(voxel_edge_length=1))
+        g2.insert_points(0, rng.random((10, 3)) + 3.0e9)
+        g2.n_points(0)
