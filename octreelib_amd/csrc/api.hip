@@ -569,7 +569,7 @@ void octl_forest_destroy(octl_forest* f) {
     f->store_borrowed = false;
   }
   for (DevBuf* b :
-       {&f->bbox_dev, &f->part_xyz[0], &f->part_xyz[1], &f->bk_table, &f->bk_tot, &f->bk_vox, &f->bk_node, &f->leafinfo,
+       {&f->bbox_dev, &f->part_xyz[0], &f->part_xyz[1], &f->bk_table, &f->bk_tot, &f->bk_chunks, &f->bk_vox, &f->bk_node, &f->leafinfo,
         &f->xyz, &f->alive, &f->ord_idx, &f->xyz_ord, &f->pos_node, &f->blk_node, &f->blk_slot,
         &f->blk_start, &f->blk_size, &f->blk_node2, &f->blk_slot2, &f->blk_start2, &f->blk_size2, &f->mask, &f->blk_eval, &f->rs_scratch, &f->rs_order, &f->fast_order,
         &f->rs_hyp, &f->rs_plane, &f->rs_count, &f->rs_index, &f->ord_idx2, &f->xyz_ord2,

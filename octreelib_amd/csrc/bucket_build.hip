@@ -987,13 +987,26 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   return 0u;
 }
 
-constexpr int BB_MAX_CHUNKS = 64;
+// A bucket with more than BB_CAP points (an over-dense region of a skewed scene; the hash ownership of the
+// multi-GPU shards puts 0...16 owned voxels into a bucket) is cut into CHUNKS: runs of whole voxels with at most
+// BB_CAP points each, planned per bucket (k_bucket_plan) and then worked off by ONE WORKGROUP PER CHUNK
+// (k_bucket_chunks) - round 2 had the bucket's own workgroup work its chunks off one after the other, which left a
+// dozen workgroups running for milliseconds behind an otherwise finished build (sparse_scene: 3.4 of 4.2 ms).
+// Chunks number their voxels, internal nodes and blocks from zero; k_bucket_finish adds the prefix over the chunks
+// in front of them inside the bucket on top of the bucket's bases from the global scan.
+struct __attribute__((aligned(16))) ChunkDesc {
+  uint32_t bucket;
+  uint32_t v_first, v_end;   // voxels (inside the bucket) [v_first, v_end)
+  uint32_t n;                // points
+  uint32_t cofs;             // first output position, relative to the bucket's start
+  uint32_t cvox;             // voxels with points in front of the chunk inside the bucket
+  uint32_t big;              // a single voxel with more than BB_CAP points: copied through as one leaf
+  uint32_t pad;
+};
+constexpr uint32_t CK_CAP = 1u << 16;  // chunks per build (beyond: the general path)
 
-// OVERSIZE = false: the buckets with at most BB_CAP points (all of them in an evenly filled scene);
-// OVERSIZE = true: a second launch that only works on the others (it needs 12 KB more LDS for its
-// chunk plan, which would cost the common kernel one workgroup per CU).
-template <bool OVERSIZE>
-__global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
+// normal buckets: at most BB_CAP points
+__global__ __launch_bounds__(BB_THREADS, 3) void k_bucket_build(
     const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
     const GeomDev* __restrict__ G,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
@@ -1010,166 +1023,225 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
   __shared__ uint32_t s_scr[8];
   __shared__ uint32_t s_tot[BK_ROWS];
   __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
-  // buckets with more than BB_CAP points are cut into chunks of whole voxels
-  __shared__ uint16_t s_src[OVERSIZE ? BB_CAP : 1];          // chunk item -> record of the bucket
-  __shared__ uint8_t s_chunk[OVERSIZE ? (1 << PT_BITS) : 1]; // voxel inside the bucket -> chunk
-  constexpr int NCH = OVERSIZE ? BB_MAX_CHUNKS : 1;
-  __shared__ uint32_t s_cofs[NCH];                           // first output position of the chunk
-  __shared__ uint16_t s_csize[NCH], s_cvox[NCH];
-  __shared__ uint16_t s_cbig[NCH];                           // voxel + 1 of a single-voxel chunk beyond BB_CAP
-  __shared__ int s_nchunks;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __shared__ uint16_t s_src[1];
+  const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
   const uint32_t start = bstart[(size_t)b * P.bstride];
   const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   const int n = (int)(end - start);
-  if (OVERSIZE ? n <= BB_CAP : n > BB_CAP) return;  // the other launch's bucket
+  if (n > BB_CAP) return;  // k_bucket_plan / k_bucket_chunks
   if (tid < BK_ROWS) s_tot[tid] = 0;
   if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
-  if (n == 0 || n > 65535) {
+  if (n == 0) {
     if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
-    if (tid == 0 && n > 0) atomicOr(&small[SM_BK_FLAGS], BF_OVERFLOW);
     return;
   }
   __syncthreads();
   const int s = P.lp.shift;
   const uint32_t lin0 = b << s;
   const PartRec* __restrict__ recs = part + start;
-  uint32_t fl = 0;
-  if (!OVERSIZE) {
-    fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
-                             bk_vox, bk_node, start, (uint32_t)n, s_bins, s_slot, s_cnt, s_scr, s_tot, s_base,
-                             s_todo, small);
-  } else {
-    // ---- plan: points per voxel, then greedy runs of voxels with at most BB_CAP points ------------------
-    const int nbins0 = 1 << s;
-    for (int d = tid; d < nbins0; d += BB_THREADS) s_bins[d] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += BB_THREADS)
-      atomicAdd(&s_bins[reinterpret_cast<const uint4*>(recs + i)[1].z >> 19], 1u);
-    __syncthreads();
+  const uint32_t fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
+                                          bk_vox, bk_node, start, (uint32_t)n, s_bins, s_slot, s_cnt, s_scr, s_tot,
+                                          s_base, s_todo, small);
+  if (fl) {  // the host runs the general path instead
+    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
+    if (tid == 0) atomicOr(&small[SM_BK_FLAGS], fl);
+    return;
+  }
+  __syncthreads();
+  if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = s_tot[tid];
+  if (tid == 0) {
+    uint32_t nrec = 0;
+    for (int l = 0; l < BB_LEVELS; ++l) nrec += s_tot[BK_NINT + l];
+    // (k_bucket_finish ranks the internal nodes and the blocks of a bucket among themselves in LDS)
+    if (nrec > FO_MAX || s_tot[BK_NBLK] > FO_MAX) atomicOr(&small[SM_BK_NOORDER], 1u);
+  }
+}
+
+// plan of the buckets with more than BB_CAP points: points per voxel, then greedy runs of voxels with at most
+// BB_CAP points; the chunk descriptors go to one global list (a range per bucket, claimed with one atomic)
+__global__ __launch_bounds__(BB_THREADS) void k_bucket_plan(
+    const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P, const GeomDev* __restrict__ G,
+    ChunkDesc* __restrict__ ck_desc, uint2* __restrict__ ck_of_bucket, uint32_t* __restrict__ bk_tot,
+    uint32_t* __restrict__ small) {
+  if (G) {
+    if (!G->valid) return;
+    P.lp = G->lp;
+  }
+  __shared__ uint32_t s_bins[1 << PT_BITS];
+  const int tid = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  const uint32_t start = bstart[(size_t)b * P.bstride];
+  const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
+  const int n = (int)(end - start);
+  if (n <= BB_CAP) {
+    if (tid == 0) ck_of_bucket[b] = uint2{0u, 0u};
+    return;
+  }
+  if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;  // (the chunks add their totals)
+  if (n > 65535) {  // (chunk items are 16-bit positions inside the bucket)
     if (tid == 0) {
-      // (one lane, <= 4096 bins: this is the rare path of a skewed bucket)
-      int c = 0, size = 0, vox = 0;
-      uint32_t cum = 0;
-      bool fits = true;
-      s_cofs[0] = 0;
-      s_cvox[0] = 0;
-      s_cbig[0] = 0;
-      auto close_chunk = [&]() {
-        s_csize[c] = (uint16_t)size;
-        if (++c >= BB_MAX_CHUNKS) {
-          fits = false;
-          c = BB_MAX_CHUNKS - 1;
-        }
+      ck_of_bucket[b] = uint2{0u, 0u};
+      atomicOr(&small[SM_BK_FLAGS], BF_OVERFLOW);
+    }
+    return;
+  }
+  const int nbins0 = 1 << P.lp.shift;
+  for (int d = tid; d < nbins0; d += BB_THREADS) s_bins[d] = 0;
+  __syncthreads();
+  const PartRec* __restrict__ recs = part + start;
+  for (int i = tid; i < n; i += BB_THREADS)
+    atomicAdd(&s_bins[reinterpret_cast<const uint4*>(recs + i)[1].z >> 19], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    // (one lane, <= 4096 bins, two sweeps: count the chunks, claim their range, emit them)
+    auto sweep = [&](ChunkDesc* out) {
+      uint32_t c = 0, size = 0, vox = 0, cum = 0, first = 0, cofs = 0, cvox = 0;
+      auto close_chunk = [&](uint32_t v_end, uint32_t big) {
+        if (out) out[c] = ChunkDesc{b, first, v_end, size, cofs, cvox, big, 0u};
+        ++c;
         size = 0;
-        s_cofs[c] = cum;
-        s_cvox[c] = (uint16_t)vox;
-        s_cbig[c] = 0;
+        first = v_end;
+        cofs = cum;
+        cvox = vox;
       };
       for (int d = 0; d < nbins0; ++d) {
-        const int cnt = (int)s_bins[d];
-        if (cnt == 0) {
-          s_chunk[d] = (uint8_t)c;
-          continue;
-        }
-        const bool big = cnt > BB_CAP;  // a single voxel beyond the LDS capacity: copied through as one leaf
-        if (size > 0 && (big || size + cnt > BB_CAP)) close_chunk();
-        s_chunk[d] = (uint8_t)c;
+        const uint32_t cnt = s_bins[d];
+        if (cnt == 0) continue;
+        const bool big = cnt > (uint32_t)BB_CAP;  // a single voxel beyond the LDS capacity: one leaf, copied through
+        if (size > 0 && (big || size + cnt > (uint32_t)BB_CAP)) close_chunk((uint32_t)d, 0u);
         size += cnt;
-        cum += (uint32_t)cnt;
+        cum += cnt;
         ++vox;
-        if (big) {
-          s_cbig[c] = (uint16_t)(d + 1);
-          close_chunk();
-        }
+        if (big) close_chunk((uint32_t)d + 1u, (uint32_t)d + 1u);
       }
-      if (size > 0) {
-        s_csize[c] = (uint16_t)size;
-        ++c;
-      }
-      s_nchunks = fits ? c : 0;
+      if (size > 0) close_chunk((uint32_t)nbins0, 0u);
+      return c;
+    };
+    const uint32_t nch = sweep(nullptr);
+    const uint32_t base = atomicAdd(&small[SM_CK_COUNT], nch);
+    if (base + nch > CK_CAP) {
+      ck_of_bucket[b] = uint2{0u, 0u};
+      atomicOr(&small[SM_BK_FLAGS], BF_OVERFLOW);
+    } else {
+      sweep(ck_desc + base);
+      ck_of_bucket[b] = uint2{base, nch};
     }
+    atomicOr(&small[SM_BK_NOORDER], 1u);  // (a chunked bucket's blocks are ordered by order.hip)
+  }
+}
+
+// one workgroup per chunk (the grid strides over the list: its length is on the device)
+__global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_chunks(
+    const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
+    const GeomDev* __restrict__ G, const ChunkDesc* __restrict__ ck_desc, uint32_t* __restrict__ ck_tot,
+    const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
+    uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_node,
+    uint32_t* __restrict__ bk_tot, uint32_t* __restrict__ small) {
+  if (G) {
+    if (!G->valid) return;
+    P.lp = G->lp;
+  }
+  __shared__ uint32_t s_bins[BB_BINS];
+  __shared__ uint32_t s_base[BK_ROWS];
+  __shared__ uint16_t s_slot[2][BB_CAP];
+  __shared__ uint32_t s_cnt[BB_THREADS / 64][256];
+  __shared__ uint32_t s_scr[8];
+  __shared__ uint32_t s_tot[BK_ROWS];
+  __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
+  __shared__ uint16_t s_src[BB_CAP];  // chunk item -> record of the bucket
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t total = min(small[SM_CK_COUNT], CK_CAP);
+  if (small[SM_BK_FLAGS] & BF_OVERFLOW) return;  // (the plan gave up: the general path takes the build)
+  for (uint32_t ci = blockIdx.x; ci < total; ci += gridDim.x) {
+    const ChunkDesc cd = ck_desc[ci];
+    const uint32_t b = cd.bucket;
+    const uint32_t start = bstart[(size_t)b * P.bstride];
+    const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
+    const int n = (int)(end - start);
+    const int s = P.lp.shift;
+    const uint32_t lin0 = b << s;
+    const PartRec* __restrict__ recs = part + start;
+    if (tid < BK_ROWS) s_tot[tid] = 0;
+    if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
+    if (tid < 8) s_scr[tid] = 0;
     __syncthreads();
-    const int nchunks = s_nchunks;
-    if (nchunks == 0) fl = BF_OVERFLOW;
-    for (int c = 0; c < nchunks && fl == 0; ++c) {
-      if (s_cbig[c]) {
-        // ---- one voxel with more than BB_CAP points: copied through in insertion order as ONE leaf (its
-        //      root), flagged for the level loop of build.hip --------------------------------------------------
-        const uint32_t vl = (uint32_t)s_cbig[c] - 1u;
-        const uint32_t out_base = start + s_cofs[c];
-        uint32_t* tmp = s_bins;  // [BB_THREADS] indices of the selected records of one pass
-        uint32_t basec = 0, last_idx = 0, nblk = 0, nsch = 0;
-        for (int i0 = 0; i0 < n; i0 += BB_THREADS) {
-          const int i = i0 + tid;
-          uint4 a = uint4{0, 0, 0, 0}, bq = uint4{0, 0, 0, 0};
-          if (i < n) {
-            a = reinterpret_cast<const uint4*>(recs + i)[0];
-            bq = reinterpret_cast<const uint4*>(recs + i)[1];
-          }
-          const bool sel = i < n && (bq.z >> 19) == vl;
-          const uint64_t m = __ballot(sel);
-          if (lane == 0) s_scr[wave] = (uint32_t)__popcll(m);
-          __syncthreads();
-          uint32_t off = 0, tot = 0;
-#pragma unroll
-          for (int w = 0; w < BB_THREADS / 64; ++w) {
-            if (w < wave) off += s_scr[w];
-            tot += s_scr[w];
-          }
-          off += (uint32_t)__popcll(m & lanemask_lt());
-          if (sel) tmp[off] = bq.w;
-          __syncthreads();
-          if (sel) {
-            const uint32_t idx = bq.w & IDX_MASK;
-            const bool first = basec + off == 0;
-            bool bhead = first;
-            if (!first && P.n_poses > 1) {
-              const uint32_t pidx = (off > 0 ? tmp[off - 1] : last_idx) & IDX_MASK;
-              bhead = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, pidx);
-            }
-            const size_t o = (size_t)out_base + basec + off;
-            leafinfo[o] = (uint32_t)s_cvox[c] | (first ? LI_VHEAD : 0u) | (bhead ? LI_BHEAD : 0u);  // depth 0
-            ord_idx[o] = idx;
-            reinterpret_cast<uint2*>(xyz_ord + 3 * o)[0] = uint2{a.x, a.y};
-            reinterpret_cast<uint2*>(xyz_ord + 3 * o)[1] = uint2{a.z, a.w};
-            reinterpret_cast<uint2*>(xyz_ord + 3 * o)[2] = uint2{bq.x, bq.y};
-            nblk += bhead ? 1u : 0u;
-            nsch += bq.w >> 31;
-          }
-          if (tot > 0) last_idx = tmp[tot - 1];
-          basec += tot;
-          __syncthreads();
+    uint32_t fl = 0;
+    if (cd.big) {
+      // ---- one voxel with more than BB_CAP points: copied through in insertion order as ONE leaf (its
+      //      root), flagged for the level loop of build.hip --------------------------------------------------
+      const uint32_t vl = cd.big - 1u;
+      const uint32_t out_base = start + cd.cofs;
+      uint32_t* tmp = s_bins;  // [BB_THREADS] indices of the selected records of one pass
+      uint32_t basec = 0, last_idx = 0, nblk = 0, nsch = 0;
+      for (int i0 = 0; i0 < n; i0 += BB_THREADS) {
+        const int i = i0 + tid;
+        uint4 a = uint4{0, 0, 0, 0}, bq = uint4{0, 0, 0, 0};
+        if (i < n) {
+          a = reinterpret_cast<const uint4*>(recs + i)[0];
+          bq = reinterpret_cast<const uint4*>(recs + i)[1];
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          nblk += __shfl_xor(nblk, off);
-          nsch += __shfl_xor(nsch, off);
-        }
-        if (lane == 0) {
-          atomicAdd(&s_tot[BK_NBLK], nblk);
-          atomicAdd(&s_scr[4], nsch);
-        }
-        if (tid == 0) s_scr[5] = 0;
+        const bool sel = i < n && (bq.z >> 19) == vl;
+        const uint64_t m = __ballot(sel);
+        if (lane == 0) s_scr[wave] = (uint32_t)__popcll(m);
         __syncthreads();
-        if (tid == 0) {
-          const size_t at = 3 * ((size_t)start + s_cvox[c]);
-          bk_vox[at] = lin0 + vl;
-          bk_vox[at + 1] = basec | 0x80000000u;
-          bk_vox[at + 2] = s_scr[4];
-          s_scr[4] = 0;
-          s_tot[BK_NVOX] += 1;
-          atomicAdd(&small[SM_BK_TODO], 1u);
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < BB_THREADS / 64; ++w) {
+          if (w < wave) off += s_scr[w];
+          tot += s_scr[w];
         }
+        off += (uint32_t)__popcll(m & lanemask_lt());
+        if (sel) tmp[off] = bq.w;
         __syncthreads();
-        continue;
+        if (sel) {
+          const uint32_t idx = bq.w & IDX_MASK;
+          const bool first = basec + off == 0;
+          bool bhead = first;
+          if (!first && P.n_poses > 1) {
+            const uint32_t pidx = (off > 0 ? tmp[off - 1] : last_idx) & IDX_MASK;
+            bhead = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, pidx);
+          }
+          const size_t o = (size_t)out_base + basec + off;
+          leafinfo[o] = 0u | (first ? LI_VHEAD : 0u) | (bhead ? LI_BHEAD : 0u);  // depth 0, voxel ordinal 0 of the chunk
+          ord_idx[o] = idx;
+          reinterpret_cast<uint2*>(xyz_ord + 3 * o)[0] = uint2{a.x, a.y};
+          reinterpret_cast<uint2*>(xyz_ord + 3 * o)[1] = uint2{a.z, a.w};
+          reinterpret_cast<uint2*>(xyz_ord + 3 * o)[2] = uint2{bq.x, bq.y};
+          nblk += bhead ? 1u : 0u;
+          nsch += bq.w >> 31;
+        }
+        if (tot > 0) last_idx = tmp[tot - 1];
+        basec += tot;
+        __syncthreads();
       }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        nblk += __shfl_xor(nblk, off);
+        nsch += __shfl_xor(nsch, off);
+      }
+      if (lane == 0) {
+        atomicAdd(&s_tot[BK_NBLK], nblk);
+        atomicAdd(&s_scr[4], nsch);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const size_t at = 3 * ((size_t)start + cd.cvox);
+        bk_vox[at] = lin0 + vl;
+        bk_vox[at + 1] = basec | 0x80000000u;
+        bk_vox[at + 2] = s_scr[4];
+        s_tot[BK_NVOX] += 1;
+        atomicAdd(&small[SM_BK_TODO], 1u);
+      }
+      __syncthreads();
+    } else {
       // stable compaction of the chunk's records: SRC[k] = k-th record of the bucket whose voxel is in the chunk
       uint32_t basec = 0;
       for (int i0 = 0; i0 < n; i0 += BB_THREADS) {
         const int i = i0 + tid;
-        const bool sel = i < n && s_chunk[reinterpret_cast<const uint4*>(recs + i)[1].z >> 19] == (uint8_t)c;
+        uint32_t vl = 0xFFFFFFFFu;
+        if (i < n) vl = reinterpret_cast<const uint4*>(recs + i)[1].z >> 19;
+        const bool sel = i < n && vl >= cd.v_first && vl < cd.v_end;
         const uint64_t m = __ballot(sel);
         if (lane == 0) s_scr[wave] = (uint32_t)__popcll(m);
         __syncthreads();
@@ -1183,23 +1255,20 @@ __global__ __launch_bounds__(BB_THREADS, OVERSIZE ? 2 : 3) void k_bucket_build(
         basec += tot;
         __syncthreads();
       }
-      fl = bucket_chunk<true>(recs, s_src, (int)s_csize[c], start + s_cofs[c], start + s_cvox[c], lin0, P,
-                              pose_off, ord_idx, xyz_ord, leafinfo, bk_vox, bk_node, start, (uint32_t)n, s_bins,
-                              s_slot, s_cnt, s_scr, s_tot, s_base, s_todo, small);
+      fl = bucket_chunk<true>(recs, s_src, (int)cd.n, start + cd.cofs, start + cd.cvox, lin0, P, pose_off, ord_idx,
+                              xyz_ord, leafinfo, bk_vox, bk_node, start + cd.cofs, cd.n, s_bins, s_slot, s_cnt, s_scr,
+                              s_tot, s_base, s_todo, small);
     }
-  }
-  if (fl) {  // the host runs the general path instead
-    if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
-    if (tid == 0) atomicOr(&small[SM_BK_FLAGS], fl);
-    return;
-  }
-  __syncthreads();
-  if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = s_tot[tid];
-  if (tid == 0) {
-    uint32_t nrec = 0;
-    for (int l = 0; l < BB_LEVELS; ++l) nrec += s_tot[BK_NINT + l];
-    // (k_bucket_finish ranks the internal nodes and the blocks of a bucket among themselves in LDS)
-    if (nrec > FO_MAX || s_tot[BK_NBLK] > FO_MAX) atomicOr(&small[SM_BK_NOORDER], 1u);
+    if (fl) {
+      if (tid == 0) atomicOr(&small[SM_BK_FLAGS], fl);
+    } else {
+      __syncthreads();
+      if (tid < BK_ROWS) {
+        ck_tot[(size_t)ci * BK_ROWS + tid] = s_tot[tid];
+        if (s_tot[tid]) atomicAdd(&bk_tot[(size_t)tid * P.nb + b], s_tot[tid]);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1323,6 +1392,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     const uint32_t* __restrict__ grand_total, const uint32_t* __restrict__ leafinfo,
     const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bk_vox,
     const uint32_t* __restrict__ bk_node, const int64_t* __restrict__ pose_off,
+    const ChunkDesc* __restrict__ ck_desc, const uint32_t* __restrict__ ck_tot, const uint2* __restrict__ ck_of_bucket,
     int32_t* __restrict__ pos_node, uint64_t* __restrict__ vlin,
     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot, uint32_t* __restrict__ blk_start,
     uint32_t* small) {
@@ -1332,12 +1402,13 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   __shared__ unsigned long long s_rk[FO_MAX];
   __shared__ uint32_t s_map[FO_MAX];
   __shared__ uint32_t s_bkey[FO_MAX];
+  __shared__ uint32_t lvl_off[BB_LEVELS];  // first slot of every level in s_map
+  __shared__ uint32_t s_lvlf[BB_LEVELS];   // first internal node of every level of the current piece (forest-wide)
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
-  const uint32_t start = bstart[(size_t)b * P.bstride];
-  const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
-  const int n = (int)(end - start);
-  if (n == 0) return;
+  const uint32_t bucket_start = bstart[(size_t)b * P.bstride];
+  const uint32_t bucket_end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
+  if (bucket_end == bucket_start) return;
   const uint32_t head_int = bk_base[(size_t)BK_NINT * P.nb], head_blk = bk_base[(size_t)BK_NBLK * P.nb];
   const int64_t V = (int64_t)head_int;                     // total of row BK_NVOX
   const int64_t n_int = (int64_t)(head_blk - head_int);    // total of the level rows
@@ -1350,22 +1421,56 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     const size_t i = (size_t)r * P.nb + q;
     return i < (size_t)BK_ROWS * P.nb ? bk_base[i] : *grand_total;
   };
-  const uint32_t vbase = at(BK_NVOX, b);
-  const uint32_t nvox = at(BK_NVOX, b + 1) - vbase;
+  // A bucket is ONE piece, or - when it held more than BB_CAP points - the chunks k_bucket_chunks built one by
+  // one: each piece numbered its voxels / internal nodes / blocks from zero, the bases below add the bucket's
+  // share of the global scan and the pieces in front of it inside the bucket.
+  const uint2 cko = ck_of_bucket ? ck_of_bucket[b] : uint2{0u, 0u};
+  const uint32_t n_pieces = cko.y ? cko.y : 1u;
+  uint32_t pre_vox = 0, pre_blk = 0, pre_lvl[BB_LEVELS];
+#pragma unroll
+  for (int l = 0; l < BB_LEVELS; ++l) pre_lvl[l] = 0;
+  for (uint32_t piece = 0; piece < n_pieces; ++piece) {
+  uint32_t start = bucket_start, vox_stage = bucket_start, node_stage = bucket_start;
+  int n = (int)(bucket_end - bucket_start);
+  uint32_t nvox, lvl_cnt[BB_LEVELS], nblk_piece = 0;
+  if (cko.y) {
+    const ChunkDesc cd = ck_desc[cko.x + piece];
+    start = bucket_start + cd.cofs;
+    vox_stage = bucket_start + cd.cvox;
+    node_stage = start;
+    n = (int)cd.n;
+    const uint32_t* t = ck_tot + (size_t)(cko.x + piece) * BK_ROWS;
+    nvox = t[BK_NVOX];
+#pragma unroll
+    for (int l = 0; l < BB_LEVELS; ++l) lvl_cnt[l] = t[BK_NINT + l];
+    nblk_piece = t[BK_NBLK];
+  } else {
+    nvox = at(BK_NVOX, b + 1) - at(BK_NVOX, b);
+#pragma unroll
+    for (int l = 0; l < BB_LEVELS; ++l) lvl_cnt[l] = at(BK_NINT + l, b + 1) - at(BK_NINT + l, b);
+  }
+  const uint32_t vbase = at(BK_NVOX, b) + pre_vox;
   uint32_t nrec = 0;
-  for (int l = 0; l < BB_LEVELS; ++l) nrec += at(BK_NINT + l, b + 1) - at(BK_NINT + l, b);
-  const uint32_t bbase = at(BK_NBLK, b) - head_blk;
+#pragma unroll
+  for (int l = 0; l < BB_LEVELS; ++l) nrec += lvl_cnt[l];
+  const uint32_t bbase = at(BK_NBLK, b) - head_blk + pre_blk;
+  // first internal node of level l of this piece, level-major over the whole forest (LDS: indexed at run time)
+#pragma unroll
+  for (int l = 0; l < BB_LEVELS; ++l)
+    if (tid == l) s_lvlf[l] = at(BK_NINT + l, b) - head_int + pre_lvl[l];
+  __syncthreads();
+  auto lvl_first = [&](int l) { return s_lvlf[l]; };
 
   // ---- roots --------------------------------------------------------------------------------------------------
-  // (first position of a voxel = bucket start + points of the voxels in front of it)
+  // (first position of a voxel = piece start + points of the voxels in front of it)
   uint32_t run = 0;
   for (uint32_t j0 = 0; j0 < nvox; j0 += 256) {
     const uint32_t j = j0 + tid;
     uint32_t lin = 0, cntw = 0, sc = 0;
     if (j < nvox) {
-      lin = bk_vox[3 * ((size_t)start + j)];
-      cntw = bk_vox[3 * ((size_t)start + j) + 1];
-      sc = bk_vox[3 * ((size_t)start + j) + 2];
+      lin = bk_vox[3 * ((size_t)vox_stage + j)];
+      cntw = bk_vox[3 * ((size_t)vox_stage + j) + 1];
+      sc = bk_vox[3 * ((size_t)vox_stage + j) + 2];
     }
     const uint32_t cntv = cntw & 0x7FFFFFFFu;  // (bit 31: the voxel is left to the level loop of build.hip)
     uint32_t tot;
@@ -1399,17 +1504,17 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   // ---- internal nodes and their children -----------------------------------------------------------------
   for (uint32_t j = (uint32_t)tid >> 3; j < nrec; j += 32) {
     const int c = tid & 7;
-    const size_t r = 3 * ((size_t)start + j);
+    const size_t r = 3 * ((size_t)node_stage + j);
     const uint32_t info = bk_node[r], w1 = bk_node[r + 1], up = bk_node[r + 2];
     const int l = (int)(w1 >> 28);
     const uint32_t own = w1 & 0xFFFFu, vord = info >> 18, prefix = info & 0x3FFFFu;  // l digits
     const int32_t v = (int32_t)(vbase + vord);
-    const int32_t cb = (int32_t)(V + 8 * (int64_t)(at(BK_NINT + l, b) - head_int + own));
+    const int32_t cb = (int32_t)(V + 8 * (int64_t)(lvl_first(l) + own));
     const int32_t xid =
-        l == 0 ? v : (int32_t)(V + 8 * (int64_t)(at(BK_NINT + l - 1, b) - head_int + up)) + (int32_t)(prefix & 7u);
+        l == 0 ? v : (int32_t)(V + 8 * (int64_t)(lvl_first(l - 1) + up)) + (int32_t)(prefix & 7u);
     double cx = P.lp.c0x, cy = P.lp.c0y, cz = P.lp.c0z, e = P.lp.L;
     if (P.lp.mode == 0) {
-      const uint32_t lin = bk_vox[3 * ((size_t)start + vord)];
+      const uint32_t lin = bk_vox[3 * ((size_t)vox_stage + vord)];
       const uint32_t qz = lin % P.lp.nz, qy = (lin / P.lp.nz) % P.lp.ny, qx = lin / (P.lp.nz * P.lp.ny);
       cx = (double)(long long)((double)((int)qx + P.lp.minx) * P.lp.L);
       cy = (double)(long long)((double)((int)qy + P.lp.miny) * P.lp.L);
@@ -1432,7 +1537,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       if (P.old_fc) {
         // the same node (voxel, path) of the previous scheme: internal there -> it keeps its epoch
         // (k_make_children of build.hip: epoch = old_epoch[old id] when the old node had children)
-        int32_t o = old_root_of(P, bk_vox[3 * ((size_t)start + vord)]);
+        int32_t o = old_root_of(P, bk_vox[3 * ((size_t)vox_stage + vord)]);
         for (int t = 0; t < l && o >= 0; ++t) {
           const int32_t ofc = P.old_fc[o];
           o = ofc >= 0 ? ofc + (int32_t)((prefix >> (3 * (l - 1 - t))) & 7u) : -1;
@@ -1459,19 +1564,19 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   // Octree.get_leaf_points lists the cached leaves: a leaf sorts by (preorder rank of its parent among the
   // internal nodes of its voxel, child index) - octree_base.py:152-158, octree.py:183-191 (see order.hip) -
   // voxels in lexicographic order.  All blocks of a voxel are in this bucket, and with ONE pose and ONE epoch
-  // the order of the whole forest is the buckets' orders one after the other.
-  const bool want_order = P.order_out != nullptr;
-  __shared__ uint32_t lvl_off[BB_LEVELS];  // first slot of every level in s_map
+  // the order of the whole forest is the buckets' orders one after the other.  (Never for a chunked bucket:
+  // the host does not ask for the order then, SM_BK_NOORDER.)
+  const bool want_order = P.order_out != nullptr && cko.y == 0;
   if (want_order) {
     if (tid == 0) {
       uint32_t o = 0;
       for (int l = 0; l < BB_LEVELS; ++l) {
         lvl_off[l] = o;
-        o += at(BK_NINT + l, b + 1) - at(BK_NINT + l, b);
+        o += lvl_cnt[l];
       }
     }
     for (uint32_t j = tid; j < nrec; j += 256) {
-      const size_t r = 3 * ((size_t)start + j);
+      const size_t r = 3 * ((size_t)node_stage + j);
       const uint32_t info = bk_node[r], w1 = bk_node[r + 1];
       const int l = (int)(w1 >> 28);
       const uint32_t prefix = info & 0x3FFFFu;
@@ -1485,7 +1590,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       const unsigned long long key = s_rk[j];
       uint32_t rk = 0;
       for (uint32_t i = 0; i < nrec; ++i) rk += s_rk[i] < key ? 1u : 0u;
-      const size_t r = 3 * ((size_t)start + j);
+      const size_t r = 3 * ((size_t)node_stage + j);
       const uint32_t w1 = bk_node[r + 1];
       s_map[lvl_off[w1 >> 28] + (w1 & 0xFFFFu)] = ((bk_node[r] >> 18) << 16) | rk;
     }
@@ -1504,8 +1609,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       const uint32_t dep = (li >> LC_DEPTH) & 7u, ob = li & 0xFFFFu;
       const int32_t leaf =
           dep == 0 ? (int32_t)(vbase + ob)
-                   : (int32_t)(V + 8 * (int64_t)(at(BK_NINT + (int)dep - 1, b) - head_int + ob)) +
-                         (int32_t)((li >> LC_DIGIT) & 7u);
+                   : (int32_t)(V + 8 * (int64_t)(lvl_first((int)dep - 1) + ob)) + (int32_t)((li >> LC_DIGIT) & 7u);
       if (P.write_pos) pos_node[(size_t)start + f] = leaf;
       if (bhead) {
         const uint32_t bo = bbase + brun + pre;
@@ -1540,6 +1644,13 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       P.order_out[bbase + rk] = (int32_t)(bbase + j);
     }
   }
+  // the next piece of a chunked bucket starts behind this one's voxels, internal nodes and blocks
+  pre_vox += nvox;
+  pre_blk += cko.y ? nblk_piece : brun;
+#pragma unroll
+  for (int l = 0; l < BB_LEVELS; ++l) pre_lvl[l] += lvl_cnt[l];
+  __syncthreads();
+  }  // pieces
 }
 
 __global__ __launch_bounds__(256) void k_block_sizes_dev(const uint32_t* __restrict__ blk_start,
@@ -1787,17 +1898,28 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   bp.n_poses = n_poses;
   bp.all_scheme = a.scheme_dev ? 0 : 1;
   uint32_t* bk_tot = f->bk_tot.as<uint32_t>();
+  // chunk plan of the buckets with more than BB_CAP points: [descriptors CK_CAP | totals CK_CAP x BK_ROWS | range per bucket]
+  const size_t ck_off_tot = (size_t)CK_CAP * sizeof(ChunkDesc);
+  const size_t ck_off_bkt = ck_off_tot + (size_t)CK_CAP * BK_ROWS * 4;
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_chunks, ck_off_bkt + (size_t)nb * 8 + 16));
+  ChunkDesc* ck_desc = reinterpret_cast<ChunkDesc*>(f->bk_chunks.p);
+  uint32_t* ck_tot = reinterpret_cast<uint32_t*>(static_cast<char*>(f->bk_chunks.p) + ck_off_tot);
+  uint2* ck_of_bucket = reinterpret_cast<uint2*>(static_cast<char*>(f->bk_chunks.p) + ck_off_bkt);
   {
     KTimer t(ctx, "bucket_build");
-    hipLaunchKernelGGL(k_bucket_build<false>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
+    hipLaunchKernelGGL(k_bucket_plan, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp, (const GeomDev*)gdev, ck_desc,
+                       ck_of_bucket, bk_tot, small);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
                        bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_bucket_build<true>, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
-                       (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
-                       f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
-                       bk_tot, small);
+    // one workgroup per chunk; the list's length is on the device, the grid strides over it
+    hipLaunchKernelGGL(k_bucket_chunks, dim3((unsigned)std::min<int64_t>(2 * (int64_t)cus, CK_CAP)), dim3(BB_THREADS), 0, st,
+                       recs, bstart, bp, (const GeomDev*)gdev, (const ChunkDesc*)ck_desc, ck_tot,
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
+                       f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(), bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
   }
   {
@@ -1891,7 +2013,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                        (const uint32_t*)f->bk_tot.as<uint32_t>(), (const uint32_t*)(small + SM_BK_TOTAL),
                        (const uint32_t*)f->leafinfo.as<uint32_t>(), (const uint32_t*)f->ord_idx.as<uint32_t>(),
                        (const uint32_t*)f->bk_vox.as<uint32_t>(), (const uint32_t*)f->bk_node.as<uint32_t>(),
-                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->pos_node.as<int32_t>(),
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), (const ChunkDesc*)ck_desc, (const uint32_t*)ck_tot,
+                       (const uint2*)ck_of_bucket, f->pos_node.as<int32_t>(),
                        f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
                        f->blk_start.as<uint32_t>(), small);
     HIP_TRY(ctx, hipGetLastError());

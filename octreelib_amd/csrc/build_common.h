@@ -19,7 +19,8 @@ enum {
   SM_BK_FLAGS = 25,     // bucket build: some bucket / voxel does not fit (BF_* bits)
   SM_BK_TOTAL = 26,     // bucket build: grand total of the scanned bucket table
   SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip
-  SM_BK_MISSING = 28,   // bucket build over a previous scheme: voxels of that scheme without points now
+  SM_BK_MISSING = 28,
+  SM_CK_COUNT = 29,     // bucket build: chunks of the buckets with more than 4096 points (k_bucket_plan)   // bucket build over a previous scheme: voxels of that scheme without points now
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)
   // 64..: slot histogram (RANSAC batches), 512..: allreduce
   SM_GEOM = 64,         // bucket build: key geometry formed on the device (GeomDev, <= 192 bytes; the region is

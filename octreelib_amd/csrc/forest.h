@@ -119,6 +119,7 @@ struct octl_forest {
   DevBuf part_xyz[2];  // 32-byte records {x, y, z, voxel | child digits, store index | scheme bit}, two passes
   DevBuf bk_table;     // u32 [digit][supertile] partition histogram (scanned in place)
   DevBuf bk_tot;       // u32 [BK_ROWS][n_buckets] per-bucket totals (scanned in place)
+  DevBuf bk_chunks;    // chunk plan of the buckets with more than 4096 points: descriptors, per-chunk totals, range per bucket
   DevBuf bk_vox;       // u32 x3 staging {linear key, points | todo, scheme points} of the j-th voxel of bucket b
                        // at [bucket start + j]
   DevBuf bk_node;      // u32 x3 staging {voxel << 18 | path, level << 28 | ordinal, parent ordinal} of the j-th internal
