@@ -773,7 +773,7 @@ def main():
             bdom = max(build_k, key=lambda k: kern[k]["ms_per_step"])
             b_ms = kern[bdom]["ms_per_step"]
             counters = profile_traffic()
-            alias = {"bucket_build": ["k_bucket_build<false>", "k_bucket_build<true>"],
+            alias = {"bucket_build": ["k_bucket_build", "k_bucket_plan", "k_bucket_chunks"],
                      "part_scatter": ["k_part_scatter<16,false>"], "part_hist": ["k_part_hist<true>", "k_part_hist<false>"],
                      "bucket_nodes": ["k_bucket_finish"], "ingest": ["k_ingest<false>", "k_ingest<true>"]}
 

@@ -75,7 +75,7 @@ def main():
                         "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8)",
                "kernels": rows}, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
     for k in sorted(set(rows) | set(out["kernels"])):
-        if not re.match(r"k_(ransac<|ingest|part_|bucket_|compact_tiles)", k):
+        if not re.match(r"k_(ransac<|ingest|part_|bucket_|compact_tiles|transpose)", k):
             continue
         if k in rows:
             print(k, json.dumps(rows[k]))
