@@ -774,7 +774,7 @@ def main():
             b_ms = kern[bdom]["ms_per_step"]
             counters = profile_traffic()
             alias = {"bucket_build": ["k_bucket_build", "k_bucket_plan", "k_bucket_chunks"],
-                     "part_scatter": ["k_part_scatter<16,false>"], "part_hist": ["k_part_hist<true>", "k_part_hist<false>"],
+                     "part_scatter": ["k_part_scatter<16,false>"], "part_hist": ["k_part_hist<true,true>", "k_part_hist<true,false>", "k_part_hist<false,true>", "k_part_hist<false,false>"],
                      "bucket_nodes": ["k_bucket_finish"], "ingest": ["k_ingest<false>", "k_ingest<true>"]}
 
             def counter_bytes(k):

@@ -246,7 +246,7 @@ constexpr int PH_THREADS = 1024;
 // write traffic for 12 MB of counts, and as much again when k_part_scatter fetched its column.
 // BBOX: the cloud has not been through the box pass; G holds a HINTED geometry.  Points outside the hint's
 // box are not counted (the flag bbox[7] invalidates the pass), the true box is reduced on the way.
-template <bool BBOX>
+template <bool BBOX, bool LONE>
 __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restrict__ xyz,
                                                           const uint8_t* __restrict__ alive, int64_t N,
                                                           LinParams lp, const GeomDev* __restrict__ G,
@@ -270,21 +270,24 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
   const int big = 1 << 30;
   int mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
   bool bad = false, outside = false;
-  // (branch-free on purpose: early returns inside the loop body kept the loads of the next iteration behind
-  //  the branches of this one - the kernel ran at half the speed of the plain histogram)
+  // LONE: voxel edge 1 (compile time: the test inside the loop kept the loads of the next points behind it)
+  auto fdiv = [&](double v) { return LONE ? floor(v) : floor_div_exact(v, lp.L); };
   auto count = [&](double x, double y, double z, bool live) {
-    if (!BBOX) {
-      if (live) atomicAdd(&hist[digit_of(lp, lin_of(lp, x, y, z))], 1u);
-      return;
-    }
     double fx = 0.0, fy = 0.0, fz = 0.0;
     if (lp.mode == 0) {
-      fx = floor_div_fast(x, lp.L);
-      fy = floor_div_fast(y, lp.L);
-      fz = floor_div_fast(z, lp.L);
+      fx = fdiv(x);
+      fy = fdiv(y);
+      fz = fdiv(z);
     }
-    // |f| < 2^30, not NaN / inf - on the exponent fields (integer compares; three f64 compares per point were a
-    // third of this kernel's instructions): exponent < 1023 + 30
+    if (!BBOX) {
+      // (the box pass has validated the domain)
+      const uint32_t lin = lp.mode != 0 ? 0u
+                                        : ((uint32_t)((int)fx - lp.minx) * lp.ny + (uint32_t)((int)fy - lp.miny)) * lp.nz +
+                                              (uint32_t)((int)fz - lp.minz);
+      if (live) atomicAdd(&hist[digit_of(lp, lin)], 1u);
+      return;
+    }
+    // |f| < 2^30, not NaN / inf - on the exponent fields (integer compares): exponent < 1023 + 30
     auto small_enough = [](double f) { return (((uint32_t)__double2hiint(f) >> 20) & 0x7FFu) < 1023u + 30u; };
     const bool dom = small_enough(fx) && small_enough(fy) && small_enough(fz);
     const bool use = live && dom;
@@ -300,31 +303,48 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
     if (use && in) atomicAdd(&hist[digit_of(lp, lin)], 1u);
   };
   const int64_t base = (int64_t)blockIdx.x * st_items;
-  // two points per thread and step: 48 contiguous bytes as three 16-byte loads (the store is
-  // 16-byte aligned and base is even)
+  // two points per thread and step: 48 contiguous bytes as three 16-byte loads (the store is 16-byte aligned and
+  // base is even).  Software pipelined by hand: the loads of the next pair are in flight while this one is counted.
   const int64_t lim_i = min(N, base + st_items);  // (st_items is even)
-#pragma unroll 2
-  for (int64_t i = base + 2 * (int64_t)threadIdx.x; i < lim_i; i += 2 * PH_THREADS) {
-    if (i + 1 < N) {
-      const double2* s2 = reinterpret_cast<const double2*>(xyz + 3 * i);
-      const double2 a = s2[0], b = s2[1], c = s2[2];
-      const uint16_t al = alive ? *reinterpret_cast<const uint16_t*>(alive + i) : (uint16_t)0x0101;
-      count(a.x, a.y, b.x, (al & 0xFF) != 0);
-      count(b.y, c.x, c.y, (al >> 8) != 0);
-    } else if (i < N) {
-      count(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], !alive || alive[i]);
-    }
+  const int64_t stride = 2 * PH_THREADS;
+  auto load = [&](int64_t j, double2& a, double2& b2, double2& c, uint32_t& al) {
+    const double2* s2 = reinterpret_cast<const double2*>(xyz + 3 * j);
+    a = s2[0];
+    b2 = s2[1];
+    c = s2[2];
+    al = alive ? (uint32_t)*reinterpret_cast<const uint16_t*>(alive + j) : 0x0101u;
+  };
+  int64_t i = base + 2 * (int64_t)threadIdx.x;
+  bool have = i < lim_i && i + 1 < N;
+  double2 a = double2{0, 0}, b2 = a, c = a, na = a, nb2 = a, nc = a;
+  uint32_t al = 0, nal = 0;
+  if (have) load(i, a, b2, c, al);
+  while (have) {
+    const int64_t j = i + stride;
+    const bool have_next = j < lim_i && j + 1 < N;
+    if (have_next) load(j, na, nb2, nc, nal);
+    count(a.x, a.y, b2.x, (al & 0xFF) != 0);
+    count(b2.y, c.x, c.y, (al >> 8) != 0);
+    a = na;
+    b2 = nb2;
+    c = nc;
+    al = nal;
+    i = j;
+    have = have_next;
   }
+  // the last point of an odd number of points
+  if ((N & 1) && threadIdx.x == 0 && N - 1 >= base && N - 1 < lim_i)
+    count(xyz[3 * (N - 1)], xyz[3 * (N - 1) + 1], xyz[3 * (N - 1) + 2], !alive || alive[N - 1]);
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table_t[(size_t)blockIdx.x * nd + d] = hist[d];
   if (BBOX) {
     // wave + block reduction, then at most six atomics per block and only when the block widens the box
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+    for (int ax = 0; ax < 3; ++ax) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
-        mn[a] = min(mn[a], __shfl_xor(mn[a], off));
-        mx[a] = max(mx[a], __shfl_xor(mx[a], off));
+        mn[ax] = min(mn[ax], __shfl_xor(mn[ax], off));
+        mx[ax] = max(mx[ax], __shfl_xor(mx[ax], off));
       }
     }
     const bool wbad = __any(bad), wout = __any(outside);
@@ -336,15 +356,15 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
     }
     __syncthreads();
     if (threadIdx.x < 6) {
-      const int a = threadIdx.x;
-      int v = s_bb[0][a];
-      for (int w = 1; w < PH_THREADS / 64; ++w) v = (a < 3) ? min(v, s_bb[w][a]) : max(v, s_bb[w][a]);
-      if (a < 3) {
-        if (v != big && v < __hip_atomic_load(&bbox[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-          atomicMin(&bbox[a], v);
+      const int ax = threadIdx.x;
+      int v = s_bb[0][ax];
+      for (int w = 1; w < PH_THREADS / 64; ++w) v = (ax < 3) ? min(v, s_bb[w][ax]) : max(v, s_bb[w][ax]);
+      if (ax < 3) {
+        if (v != big && v < __hip_atomic_load(&bbox[ax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMin(&bbox[ax], v);
       } else {
-        if (v != -big && v > __hip_atomic_load(&bbox[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-          atomicMax(&bbox[a], v);
+        if (v != -big && v > __hip_atomic_load(&bbox[ax], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+          atomicMax(&bbox[ax], v);
       }
     }
   }
@@ -1821,7 +1841,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   {
     KTimer t(ctx, "part_hist");
     if (hinted) {
-      hipLaunchKernelGGL(k_part_hist<true>, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+      auto kh = f->edge == 1.0 ? k_part_hist<true, true> : k_part_hist<true, false>;
+      hipLaunchKernelGGL(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
                          alive_p, N, lp, (const GeomDev*)gdev, nst_a, nd_a, (int64_t)st_tiles_a * tile, table,
                          f->bbox_dev.as<int32_t>());
       HIP_TRY(ctx, hipGetLastError());
@@ -1829,7 +1850,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
                          lp, gdev);
     } else {
-      hipLaunchKernelGGL(k_part_hist<false>, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+      auto kh = f->edge == 1.0 ? k_part_hist<false, true> : k_part_hist<false, false>;
+      hipLaunchKernelGGL(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
                          alive_p, N, lp, (const GeomDev*)gdev, nst_a, nd_a, (int64_t)st_tiles_a * tile, table,
                          (int32_t*)nullptr);
     }
