@@ -612,6 +612,45 @@ def gen_ransac_thick():
           ref_max_inliers=count)
 
 
+# --------------------------------------------------------------------------------------
+# G3c: blocks on which ONE hypothesis attains the maximal inlier count - the reference's CAS race among tied
+#      hypotheses (cuda_ransac.py:140-145) cannot choose, so its best_plane is THE answer and the |delta normal|
+#      <= 1e-5 bar of the parity contract applies to every block.  Candidates (noisy planar clouds, sigma close to
+#      the threshold: counts spread widely) are pre-screened with the restatement; the reference kernel then runs on
+#      the survivors and its recorded plane must be the restatement's.
+# --------------------------------------------------------------------------------------
+def gen_ransac_unique():
+    sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(67)
+    for H, want, seed in ((256, 160, 3031), (1024, 48, 3032)):
+        np.random.seed(seed)
+        table = np.random.random((H, 6))
+        blocks = []
+        while len(blocks) < want:
+            n = int(rng.integers(30, 220))
+            corner = rng.integers(-3, 28, 3).astype(np.float64)
+            edge = float(rng.choice([0.25, 0.5, 1.0]))
+            p = rng.random((n, 3)) * edge
+            a, b = rng.uniform(-0.6, 0.6, 2)
+            sigma = float(rng.choice([0.006, 0.009, 0.014]))
+            p[:, 2] = np.clip(0.5 * edge + a * (p[:, 0] - 0.5 * edge) + b * (p[:, 1] - 0.5 * edge)
+                              + rng.normal(0, sigma, n), 0.0, edge * (1 - 1e-9))
+            out = rng.random(n) < 0.15
+            p[out] = rng.random((int(out.sum()), 3)) * edge
+            cand = p + corner
+            _, _, _, _, tied = rnp.evaluate(cand, np.array([n], dtype=np.int32), table, 0.01, details=True)
+            if len(tied[0]) == 1:
+                blocks.append(cand)
+        cloud = np.vstack(blocks)
+        sizes = np.array([len(b) for b in blocks], dtype=np.int32)
+        table2, mask, plane, count = _evaluate_recorded(cloud, sizes, H, 6, 0.01, seed)
+        assert np.array_equal(table2, table)
+        _save(f"ransac_unique_h{H}.npz", cloud=cloud, block_sizes=sizes, hypotheses=table,
+              threshold=np.float64(0.01), seed=np.int64(seed), mask=mask, ref_plane=plane, ref_max_inliers=count)
+
+
 GENERATORS = {
     "octree": gen_octree,
     "grid": gen_grid,
@@ -625,6 +664,7 @@ GENERATORS = {
     "ransac": gen_ransac,
     "grid_ransac": gen_grid_ransac,
     "grid_ransac_batches": gen_grid_ransac_batches,
+    "ransac_unique": gen_ransac_unique,   # ~5 minutes
     "ransac_thick": gen_ransac_thick,   # ~10 minutes: 380 blocks x up to 1024 simulated threads
 }
 

@@ -185,6 +185,25 @@ def _plane_mask(plane32, blk, thr):
 
 
 @pytest.mark.parametrize("name", ["h1024", "h256"])
+def test_ransac_unique_maximiser_blocks_against_the_reference_plane(name):
+    """208 blocks on which one hypothesis attains the maximum: the reference kernel's own best_plane (no tie for
+    its race to decide) - HIP plane within 1e-5 on the normal (the same f32 bits), count and mask equal."""
+    from octreelib_amd.ransac import CudaRansac
+
+    g = load_golden(f"ransac_unique_{name}.npz")
+    cloud, sizes, hyp, thr = g["cloud"], g["block_sizes"], g["hypotheses"], float(g["threshold"])
+    H, k = hyp.shape
+    np.random.seed(int(g["seed"]))
+    op = CudaRansac(threshold=thr, hypotheses_number=H, initial_points_number=k)
+    assert np.array_equal(op.random_hypotheses, hyp)
+    mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+    assert np.array_equal(counts, g["ref_max_inliers"])
+    assert np.max(np.abs(planes[:, :3].astype(np.float64) - g["ref_plane"][:, :3])) <= 1e-5
+    assert np.array_equal(planes.view(np.uint32), g["ref_plane"].view(np.uint32))
+    assert np.array_equal(mask, g["mask"])
+
+
+@pytest.mark.parametrize("name", ["h1024", "h256"])
 def test_ransac_bench_leaves_against_recorded_reference_planes(name):
     """Blocks cut from the benchmark scene's own leaves (sizes 6..64, a few up to ~305) with the
     reference kernel's shared best_plane / max_inliers_number recorded per block

@@ -469,3 +469,18 @@ def test_grid_map_leaf_points_transform():
             assert [og.n_nodes(p), og.n_leaves(p), og.n_points(p)] == list(g[f"{tag}_p{p}_counts"])
 
     run_map_transform_sequence(og, snap)
+
+
+@pytest.mark.parametrize("name", ["h256", "h1024"])
+def test_ransac_unique_maximiser_blocks_against_the_reference_plane(name):
+    """Blocks on which ONE hypothesis attains the maximum (tests/golden/make_golden.py:gen_ransac_unique): the
+    reference's tie race cannot choose, so its recorded best_plane / mask ARE the answer - the restatement must
+    give the same f32 plane bits (north_star: |delta normal| <= 1e-5), count and mask on every block."""
+    g = load_golden(f"ransac_unique_{name}.npz")
+    cloud, sizes, hyp, thr = g["cloud"], g["block_sizes"], g["hypotheses"], float(g["threshold"])
+    mask, count, plane, index, tied = rnp.evaluate(cloud, sizes, hyp, thr, details=True)
+    assert all(len(t) == 1 for t in tied)
+    assert np.array_equal(count, g["ref_max_inliers"])
+    assert np.max(np.abs(plane[:, :3].astype(np.float64) - g["ref_plane"][:, :3])) <= 1e-5
+    assert np.array_equal(plane.view(np.uint32), g["ref_plane"].view(np.uint32))
+    assert np.array_equal(mask, g["mask"])
