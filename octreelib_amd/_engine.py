@@ -43,6 +43,7 @@ class Forest:
         self._creation_codes = np.empty(0, dtype=np.int64)   # packed voxel keys, creation order
         self._code_origin = None                              # voxel index the host-side codes are relative to
         self._device_clouds = []                             # DeviceCloud objects whose buffers the store may read
+        self._in_place = None                                # the DeviceCloud the store reads in place, if any
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -50,12 +51,16 @@ class Forest:
             self.lib.octl_forest_destroy(self.handle)
             self.handle = C.c_void_p()
             self._device_clouds = []
+            self._in_place = None
 
     def __del__(self):  # pragma: no cover
         try:
             self.close()
         except Exception:
             pass
+
+    def reads_in_place(self, cloud) -> bool:
+        return self._in_place is cloud
 
     def _invalidate(self):
         self._nodes = None
@@ -75,11 +80,21 @@ class Forest:
         if isinstance(points, DeviceCloud):
             # a cloud that is (being) uploaded already: read in place when it is the first pose, copied on
             # the device otherwise; the forest keeps the object alive while it reads its buffer
+            import weakref
+
+            first = sum(self.slot_sizes) == 0 and points.n > 0   # (the library adopts iff its store is empty)
             self._device_clouds.append(points)
-            return self.add_pose_device(points.ptr, points.n, adopt=True)
+            slot = self.add_pose_device(points.ptr, points.n, adopt=True)
+            if first:   # (only the first pose of an empty forest is read in place; later ones are copied)
+                self._in_place = points
+                points._readers.append(weakref.ref(self))
+            else:
+                self._in_place = None   # (the store grew: it is the forest's own now)
+            return slot
         pts = nat.as_points(points)
         slot = C.c_int32(-1)
         self.ctx.check(self.lib.octl_forest_add_pose(self.handle, nat.ptr(pts), len(pts), C.byref(slot)))
+        self._in_place = None
         self._register_slot(len(pts))
         return slot.value
 
@@ -109,6 +124,7 @@ class Forest:
     def extend_pose(self, slot: int, points):
         pts = nat.as_points(points)
         self.ctx.check(self.lib.octl_forest_extend_pose(self.handle, slot, nat.ptr(pts), len(pts)))
+        self._in_place = None
         self.slot_sizes[slot] += len(pts)
         self._dirty = True
         self._invalidate()
@@ -511,6 +527,7 @@ class Forest:
         self.ctx.check(self.lib.octl_forest_set_contents(self.handle, len(node), nat.ptr(node), nat.ptr(slot),
                                                          nat.ptr(size), nat.ptr(pts)))
         self.n_ord = len(pts)
+        self._in_place = None
         for s in range(self.n_slots):
             self.slot_sizes[s] = int(size[slot == s].sum())
         self._invalidate()

@@ -63,6 +63,7 @@ class DeviceCloud:
         pts = nat.as_points(points)
         self.n = len(pts)
         self._host = pts  # must stay unchanged until the upload has finished
+        self._readers = []  # weak references to the forests that read the buffer in place
         self.ptr = C.c_void_p()
         self.ctx.check(self.ctx.lib.octl_dev_alloc(self.ctx.handle, max(pts.nbytes, 16), C.byref(self.ptr)))
         try:
@@ -77,6 +78,12 @@ class DeviceCloud:
         self._host = None
 
     def release(self):
+        """Give the device buffer back.  Refused while a grid still reads it in place (close the grid first)."""
+        for ref in getattr(self, "_readers", []):
+            f = ref()
+            if f is not None and getattr(f, "handle", None) is not None and f.handle.value and f.reads_in_place(self):
+                raise RuntimeError("DeviceCloud.release(): a Grid / Octree still reads this buffer in place; "
+                                   "close it (or insert more points into it) first")
         if getattr(self, "ptr", None) is not None and self.ptr.value:
             self.ctx.lib.octl_dev_free(self.ctx.handle, self.ptr)  # (waits for both streams)
             self.ptr = C.c_void_p()
@@ -87,6 +94,7 @@ class DeviceCloud:
 
     def __del__(self):  # pragma: no cover
         try:
+            self._readers = []
             self.release()
         except Exception:
             pass

@@ -2080,6 +2080,8 @@ def test_async_host_feed_builds_the_same_forest_and_overlaps_nothing_it_should_n
         np.random.seed(5)
         g.map_leaf_points_cuda_ransac(hypotheses_number=128)
         _assert_same_tables(_tables(g._forest), want[i])
+        with pytest.raises(RuntimeError, match="reads this buffer in place"):
+            cur.release()          # the grid still reads the buffer
         g._forest.close()
         cur.release()
     # all uploads first, consumed in reverse order; a second pose from a DeviceCloud (device-to-device copy)
