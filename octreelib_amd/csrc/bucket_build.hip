@@ -643,6 +643,9 @@ __device__ __forceinline__ void load_rec(const PartRec* __restrict__ p, double& 
 // puts the bucket in the final order - voxel, leaf path, insertion order inside the leaf - and the
 // outputs are written with coalesced stores.
 constexpr int BB_BINS = 8192;          // histogram bins per level (nodes of a level x 8)
+constexpr int BB_SORT_BITS = 9;        // digit of the in-bucket radix sort
+constexpr int BB_SORT_BINS = 1 << BB_SORT_BITS;
+static_assert(BB_SORT_BINS == 2 * BB_THREADS, "two sort digits per thread in the offset scan");
 constexpr uint32_t NOT_OVER = 0xFFFFFFFFu;
 
 // One chunk of a bucket: n <= BB_CAP points (a run of whole voxels), records part[SRC[i]] (CHUNKED)
@@ -654,7 +657,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     const uint32_t vox_stage, const uint32_t lin0, const BkParams& P, const int64_t* __restrict__ pose_off,
     uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord, uint32_t* __restrict__ leafinfo,
     uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_node, const uint32_t node_stage, const uint32_t node_room,
-    uint32_t* s_bins, uint16_t (*s_slot)[BB_CAP], uint32_t (*s_cnt)[256],
+    uint32_t* s_bins, uint16_t (*s_slot)[BB_CAP], uint16_t (*s_cnt)[BB_SORT_BINS],
     uint32_t* s_scr, uint32_t* s_tot, uint32_t* s_base, uint32_t* s_todo, uint32_t* __restrict__ small) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s = P.lp.shift;
@@ -920,10 +923,15 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     for (int i = tid; i < n; i += BB_THREADS) s_slot[0][i] = (uint16_t)i;
     __syncthreads();
   }
-  for (int sh = 0; sh < kbits; sh += 8) {
+  // stable LSD radix sort of the item ids, BB_SORT_BITS = 9 bits per pass: the common bucket - 8 voxels, leaves two
+  // levels deep: 3 + 6 key bits - is sorted in ONE pass (with 8-bit digits it took two).  Per-wave digit counters
+  // are 16 bits wide (<= 4096 items) and touched by their wave only: plain accesses by the digit's leader lane.
+  for (int sh = 0; sh < kbits; sh += BB_SORT_BITS) {
     const bool first = sh == 0;
+    for (int d = tid; d < BB_SORT_BINS; d += BB_THREADS) {
 #pragma unroll
-    for (int w = 0; w < BB_THREADS / 64; ++w) s_cnt[w][tid] = 0;
+      for (int w = 0; w < BB_THREADS / 64; ++w) s_cnt[w][d] = 0;
+    }
     __syncthreads();
     uint16_t rank[BB_IPT];
 #pragma unroll
@@ -933,23 +941,31 @@ __device__ __forceinline__ uint32_t bucket_chunk(
         const int i = wave * per_wave + r * 64 + lane;
         const bool valid = i < n;
         const uint32_t it = valid ? (first ? (uint32_t)i : (uint32_t)s_slot[cur][i]) : 0u;
-        const uint32_t d = valid ? (KEY[it] >> sh) & 0xFFu : 0u;
-        rank[r] = (uint16_t)wave_stable_rank<8>(d, valid, s_cnt[wave]);
+        const uint32_t d = valid ? (KEY[it] >> sh) & (uint32_t)(BB_SORT_BINS - 1) : 0u;
+        rank[r] = (uint16_t)wave_rank_u16<BB_SORT_BITS>(d, valid, s_cnt[wave]);
       }
     }
     __syncthreads();
     {
-      const int d = tid;
-      uint32_t tot = 0;
+      // exclusive offsets: digits d = 2 tid, 2 tid + 1 (all waves of a digit one after the other)
+      uint32_t c[2][BB_THREADS / 64], tot = 0;
 #pragma unroll
-      for (int w = 0; w < BB_THREADS / 64; ++w) tot += s_cnt[w][d];
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int w = 0; w < BB_THREADS / 64; ++w) {
+          c[q][w] = s_cnt[w][2 * tid + q];
+          tot += c[q][w];
+        }
+      }
       uint32_t all;
       uint32_t run = block_excl_add(tot, &all, s_scr);
 #pragma unroll
-      for (int w = 0; w < BB_THREADS / 64; ++w) {
-        const uint32_t c = s_cnt[w][d];
-        s_cnt[w][d] = run;
-        run += c;
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int w = 0; w < BB_THREADS / 64; ++w) {
+          s_cnt[w][2 * tid + q] = (uint16_t)run;
+          run += c[q][w];
+        }
       }
     }
     __syncthreads();
@@ -961,8 +977,8 @@ __device__ __forceinline__ uint32_t bucket_chunk(
         if (i < n) {
           // (item and digit are re-read: cheaper than 32 registers held across the barriers)
           const uint32_t it = first ? (uint32_t)i : (uint32_t)s_slot[cur][i];
-          const uint32_t d = (KEY[it] >> sh) & 0xFFu;
-          s_slot[dst_buf][s_cnt[wave][d] + rank[r]] = (uint16_t)it;
+          const uint32_t d = (KEY[it] >> sh) & (uint32_t)(BB_SORT_BINS - 1);
+          s_slot[dst_buf][(uint32_t)s_cnt[wave][d] + rank[r]] = (uint16_t)it;
         }
       }
     }
@@ -1041,7 +1057,7 @@ __global__ __launch_bounds__(BB_THREADS, 3) void k_bucket_build(
   __shared__ uint32_t s_bins[BB_BINS];            // pyramid bins; afterwards KEY[BB_CAP] | INFO[BB_CAP]
   __shared__ uint32_t s_base[BK_ROWS];            // totals of the bucket before the current chunk
   __shared__ uint16_t s_slot[2][BB_CAP];          // sort buffers: positions -> item
-  __shared__ uint32_t s_cnt[BB_THREADS / 64][256];
+  __shared__ uint16_t s_cnt[BB_THREADS / 64][BB_SORT_BINS];
   __shared__ uint32_t s_scr[8];
   __shared__ uint32_t s_tot[BK_ROWS];
   __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
@@ -1167,7 +1183,7 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_chunks(
   __shared__ uint32_t s_bins[BB_BINS];
   __shared__ uint32_t s_base[BK_ROWS];
   __shared__ uint16_t s_slot[2][BB_CAP];
-  __shared__ uint32_t s_cnt[BB_THREADS / 64][256];
+  __shared__ uint16_t s_cnt[BB_THREADS / 64][BB_SORT_BINS];
   __shared__ uint32_t s_scr[8];
   __shared__ uint32_t s_tot[BK_ROWS];
   __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
