@@ -643,6 +643,26 @@ __device__ __forceinline__ void load_rec(const PartRec* __restrict__ p, double& 
 // puts the bucket in the final order - voxel, leaf path, insertion order inside the leaf - and the
 // outputs are written with coalesced stores.
 constexpr int BB_BINS = 8192;          // histogram bins per level (nodes of a level x 8)
+#ifndef BB_OUT_UNROLL
+#define BB_OUT_UNROLL 4
+#endif
+// -DBB_STAMPS: phase clocks of bucket_chunk (thread 0 of every workgroup adds its s_memtime deltas to a device
+// array; tools/bb_stamps.py reads it through octl_debug_bb_stamps).  Experiments only: not in the shipped library.
+#ifdef BB_STAMPS
+__device__ unsigned long long g_bb_stamps[16];
+#define BB_STAMP(k)                                                              \
+  do {                                                                           \
+    if (threadIdx.x == 0) {                                                      \
+      const unsigned long long _t = __builtin_readcyclecounter();                \
+      atomicAdd(&g_bb_stamps[k], _t - _stamp_t0);                                \
+      _stamp_t0 = _t;                                                            \
+    }                                                                            \
+  } while (0)
+#define BB_STAMP_INIT unsigned long long _stamp_t0 = __builtin_readcyclecounter()
+#else
+#define BB_STAMP(k) do {} while (0)
+#define BB_STAMP_INIT do {} while (0)
+#endif
 constexpr int BB_SORT_BITS = 9;        // digit of the in-bucket radix sort
 constexpr int BB_SORT_BINS = 1 << BB_SORT_BITS;
 static_assert(BB_SORT_BINS == 2 * BB_THREADS, "two sort digits per thread in the offset scan");
@@ -661,6 +681,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     uint32_t* s_scr, uint32_t* s_tot, uint32_t* s_base, uint32_t* s_todo, uint32_t* __restrict__ small) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s = P.lp.shift;
+  BB_STAMP_INIT;
   // ordinals are counted per chunk; the bucket-wide ones add what the earlier chunks of the bucket hold
   // (s_tot is stable here: the previous chunk ended with a barrier, this one updates it behind barriers)
   if (tid < BK_ROWS) s_base[tid] = s_tot[tid];
@@ -712,6 +733,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       }
     }
   }
+  BB_STAMP(0);  // records' tails loaded
   // (after the loop: a conditional LDS access between the loads serialises them)
   if (__any(bad_any)) {
 #pragma unroll
@@ -895,6 +917,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
     if (lane == 0 && c) atomicAdd(&small[SM_BK_TODO], c);
   }
+  BB_STAMP(1);  // level pyramid
   const int kshift = 3 * dmax;          // key = voxel << kshift | first d digits, left aligned in dmax digits
   const int kbits = s + kshift;
   if (kbits > 32) return BF_OVERFLOW;   // (s = 12 and 7 levels: cannot happen with 6)
@@ -985,11 +1008,12 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     __syncthreads();
     cur = dst_buf;
   }
+  BB_STAMP(2);  // keys + sort
   const uint16_t* __restrict__ RS = s_slot[cur];
 
   // ---- 5. outputs (coalesced) ------------------------------------------------------------------------------------
   uint32_t nblk = 0;
-#pragma unroll 4
+#pragma unroll BB_OUT_UNROLL
   for (int r = 0; r < BB_IPT; ++r) {
     const int f = r * BB_THREADS + tid;
     if (f < n) {
@@ -1022,6 +1046,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   if (lane == 0 && nblk) atomicAdd(&s_tot[BK_NBLK], nblk);
   if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
   __syncthreads();  // the LDS arrays are free for the next chunk
+  BB_STAMP(3);  // outputs
   return 0u;
 }
 
@@ -2092,3 +2117,16 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   *done = 1;
   return OCTL_OK;
 }
+
+#ifdef BB_STAMPS
+extern "C" int octl_debug_bb_stamps(octl_ctx* ctx, unsigned long long out[16], int reset) {
+  if (!ctx || !out) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bb_stamps), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_bb_stamps), z, sizeof(z)));
+  }
+  return OCTL_OK;
+}
+#endif

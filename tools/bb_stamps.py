@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Phase clocks of k_bucket_build (a library built with -DBB_STAMPS, see csrc/bucket_build.hip):
+   tools/build_variant.sh stamps "-DBB_STAMPS" && OCTREELIB_AMD_LIB=build/variants/stamps.so python tools/bb_stamps.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from octreelib_amd import _native as nat
+
+ctx = nat.Context(0)
+lib = ctx.lib
+lib.octl_debug_bb_stamps.restype = C.c_int
+lib.octl_debug_bb_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+wl = bench.Workload(ctx, ctx, 0, 1, 10_000_000, (32, 32, 32), "planar", 64, False, False)
+for _ in range(3):
+    wl.step_build_only()
+out = (C.c_ulonglong * 16)()
+ctx.check(lib.octl_debug_bb_stamps(ctx.handle, out, 1))
+reps = 5
+for _ in range(reps):
+    wl.step_build_only()
+ctx.check(lib.octl_debug_bb_stamps(ctx.handle, out, 0))
+names = ["load record tails", "level pyramid", "keys + sort", "outputs"]
+tot = sum(out[i] for i in range(4))
+for i, nm in enumerate(names):
+    print("%-20s %6.1f %%   %8.0f cycles per bucket" % (nm, 100.0 * out[i] / tot, out[i] / reps / 4096))
+print("total cycles per bucket: %.0f  (s_memtime ticks at 100 MHz?)" % (tot / reps / 4096))
+wl.close()
