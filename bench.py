@@ -230,7 +230,10 @@ class Workload:
         ctx.check(lib.octl_forest_clear(self.fh))
         if self.route:
             self.route_once()
-            ctx.check(lib.octl_forest_add_pose_routed(self.fh, C.byref(self.slot)))
+            if self.rctx is not ctx:   # (routing runs on its own context: the routed cloud is handed over from there)
+                ctx.check(lib.octl_forest_add_pose_routed_from(self.fh, self.rctx.handle, C.byref(self.slot)))
+            else:
+                ctx.check(lib.octl_forest_add_pose_routed(self.fh, C.byref(self.slot)))
         else:
             # (read in place: the cloud is resident in HBM, as the contract of the timed region says)
             ctx.check(lib.octl_forest_add_pose_adopt(self.fh, self.d_xyz, self.n_local, C.byref(self.slot)))
@@ -384,11 +387,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 code path on a one-GPU box: every rank on the same device, the collectives through the
+    # tests' RCCL stand-in (OCTL_RCCL_LIBRARY=tests/rccl_stub/librccl_stub.so); the numbers mean nothing then
+    if os.environ.get("OCTL_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["OCTL_BENCH_DEVICE"])
     dist = None
     if world > 1:
         import torch.distributed as dist  # plumbing only: rendezvous, barrier, max-reduce
 
-        dist.init_process_group(backend="gloo")
+        with stdout_to_stderr():  # (gloo announces its connections on stdout: the line of this run is the only thing there)
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
