@@ -525,6 +525,21 @@ def main():
                 "hbm_read_roofline_frac": 24.0 * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "BASELINE config 2: insert + subdivide alone, algorithmic 24 B/point",
             }
+            # what a build costs when the bucket path does not apply and the level-synchronous path takes it
+            # (more than 2^24 voxel keys in the box, a bucket beyond 65 535 points, a vanished voxel of a previous
+            # scheme ...): the same cloud, forced down that path
+            os.environ["OCTL_NO_BUCKET_BUILD"] = "1"
+            try:
+                wl.step_build_only()
+                ms_g = timed(wl.step_build_only) * 1e3
+            finally:
+                del os.environ["OCTL_NO_BUCKET_BUILD"]
+            secondary["insert_subdivide_general_path"] = {
+                "ms": ms_g, "Mpoints_per_s": n_local / ms_g / 1e3,
+                "note": "insert + subdivide of the same cloud through the level-synchronous path of build.hip (keygen, "
+                        "radix sort, level loop): the fallback of the bucket build",
+            }
+            wl.step_build_only()
             if wl.host_pts is not None:
                 ms = timed(wl.step_from_host) * 1e3
                 secondary["pcie_inclusive"] = {

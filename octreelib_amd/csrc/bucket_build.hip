@@ -1467,6 +1467,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   __shared__ uint32_t s_bkey[FO_MAX];
   __shared__ uint32_t lvl_off[BB_LEVELS];  // first slot of every level in s_map
   __shared__ uint32_t s_lvlf[BB_LEVELS];   // first internal node of every level of the current piece (forest-wide)
+  __shared__ uint32_t s_hc[65];            // block heads per (round, wave) of the piece, then their exclusive prefix | total
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
   const uint32_t bucket_start = bstart[(size_t)b * P.bstride];
@@ -1492,6 +1493,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   uint32_t pre_vox = 0, pre_blk = 0, pre_lvl[BB_LEVELS];
 #pragma unroll
   for (int l = 0; l < BB_LEVELS; ++l) pre_lvl[l] = 0;
+  BB_STAMP_INIT;
   for (uint32_t piece = 0; piece < n_pieces; ++piece) {
   uint32_t start = bucket_start, vox_stage = bucket_start, node_stage = bucket_start;
   int n = (int)(bucket_end - bucket_start);
@@ -1564,6 +1566,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     run += tot;
   }
 
+  BB_STAMP(4);  // finish: bases + roots
   // ---- internal nodes and their children -----------------------------------------------------------------
   for (uint32_t j = (uint32_t)tid >> 3; j < nrec; j += 32) {
     const int c = tid & 7;
@@ -1629,6 +1632,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   // voxels in lexicographic order.  All blocks of a voxel are in this bucket, and with ONE pose and ONE epoch
   // the order of the whole forest is the buckets' orders one after the other.  (Never for a chunked bucket:
   // the host does not ask for the order then, SM_BK_NOORDER.)
+  BB_STAMP(5);  // finish: internal nodes + children
   const bool want_order = P.order_out != nullptr && cko.y == 0;
   if (want_order) {
     if (tid == 0) {
@@ -1660,40 +1664,83 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     __syncthreads();
   }
 
+  BB_STAMP(6);  // finish: preorder ranks
   // ---- (leaf, pose) blocks, position -> leaf ------------------------------------------------------------------
   uint32_t brun = 0;
-  for (int f0 = 0; f0 < n; f0 += 256) {
-    const int f = f0 + tid;
-    const uint32_t li = f < n ? leafinfo[(size_t)start + f] : 0u;
-    const bool bhead = f < n && (li & LI_BHEAD);
-    uint32_t tot;
-    const uint32_t pre = block_excl_add(bhead ? 1u : 0u, &tot, s_scr);
-    if (f < n && (bhead || P.write_pos)) {
-      const uint32_t dep = (li >> LC_DEPTH) & 7u, ob = li & 0xFFFFu;
-      const int32_t leaf =
-          dep == 0 ? (int32_t)(vbase + ob)
-                   : (int32_t)(V + 8 * (int64_t)(lvl_first((int)dep - 1) + ob)) + (int32_t)((li >> LC_DIGIT) & 7u);
-      if (P.write_pos) pos_node[(size_t)start + f] = leaf;
-      if (bhead) {
-        const uint32_t bo = bbase + brun + pre;
-        if (want_order) {
-          // key: voxel, preorder rank of the parent, child digit (a root that is a leaf: the voxel alone)
-          uint32_t key;
-          if (dep == 0) {
-            key = ob << 13;
-          } else {
-            const uint32_t m = s_map[lvl_off[dep - 1] + ob];
-            key = ((m >> 16) << 13) | ((m & 0xFFFFu) << 3) | ((li >> LC_DIGIT) & 7u);
-          }
-          s_bkey[brun + pre] = key;
+  auto emit = [&](int f, uint32_t li, bool bhead, uint32_t blk_index) {
+    const uint32_t dep = (li >> LC_DEPTH) & 7u, ob = li & 0xFFFFu;
+    const int32_t leaf =
+        dep == 0 ? (int32_t)(vbase + ob)
+                 : (int32_t)(V + 8 * (int64_t)(lvl_first((int)dep - 1) + ob)) + (int32_t)((li >> LC_DIGIT) & 7u);
+    if (P.write_pos) pos_node[(size_t)start + f] = leaf;
+    if (bhead) {
+      const uint32_t bo = bbase + blk_index;
+      if (want_order) {
+        // key: voxel, preorder rank of the parent, child digit (a root that is a leaf: the voxel alone)
+        uint32_t key;
+        if (dep == 0) {
+          key = ob << 13;
+        } else {
+          const uint32_t m = s_map[lvl_off[dep - 1] + ob];
+          key = ((m >> 16) << 13) | ((m & 0xFFFFu) << 3) | ((li >> LC_DIGIT) & 7u);
         }
-        blk_node[bo] = leaf;
-        blk_slot[bo] = P.n_poses > 1 ? find_slot_dev(pose_off, P.n_poses, ord_idx[(size_t)start + f]) : 0;
-        blk_start[bo] = start + (uint32_t)f;
+        s_bkey[blk_index] = key;
       }
+      blk_node[bo] = leaf;
+      blk_slot[bo] = P.n_poses > 1 ? find_slot_dev(pose_off, P.n_poses, ord_idx[(size_t)start + f]) : 0;
+      blk_start[bo] = start + (uint32_t)f;
     }
-    brun += tot;
+  };
+  if (n <= BB_CAP) {
+    // The usual piece (<= 4096 positions): the leaf words of all <= 16 rounds are loaded at once, block heads are
+    // ranked by ballots, and ONE scan over the (round, wave) counts replaces a block scan (two barriers) per round.
+    constexpr int FR = BB_CAP / 256;
+    const int wave = tid >> 6, lane = tid & 63;
+    const uint64_t lt = lanemask_lt();
+    uint32_t li[FR], rk[FR];
+#pragma unroll
+    for (int r = 0; r < FR; ++r) {
+      const int f = r * 256 + tid;
+      li[r] = f < n ? leafinfo[(size_t)start + f] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < FR; ++r) {
+      const uint64_t bal = __ballot((li[r] & LI_BHEAD) != 0u);   // (positions behind n hold 0)
+      rk[r] = (uint32_t)__popcll(bal & lt);
+      if (lane == 0) s_hc[r * 4 + wave] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive prefix over the FR x 4 counts (position order: round, wave)
+      const uint32_t v = s_hc[tid];
+      uint32_t inc = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (tid >= off) inc += t;
+      }
+      s_hc[tid] = inc - v;
+      if (tid == 63) s_hc[64] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FR; ++r) {
+      const int f = r * 256 + tid;
+      const bool bhead = (li[r] & LI_BHEAD) != 0u;
+      if (f < n && (bhead || P.write_pos)) emit(f, li[r], bhead, s_hc[r * 4 + wave] + rk[r]);
+    }
+    brun = s_hc[64];
+  } else {
+    for (int f0 = 0; f0 < n; f0 += 256) {
+      const int f = f0 + tid;
+      const uint32_t li = f < n ? leafinfo[(size_t)start + f] : 0u;
+      const bool bhead = f < n && (li & LI_BHEAD);
+      uint32_t tot;
+      const uint32_t pre = block_excl_add(bhead ? 1u : 0u, &tot, s_scr);
+      if (f < n && (bhead || P.write_pos)) emit(f, li, bhead, brun + pre);
+      brun += tot;
+    }
   }
+  BB_STAMP(7);  // finish: blocks
   if (want_order) {
     __syncthreads();
     // (the blocks of a voxel are neighbours in storage order, and the listing order only permutes them
@@ -1707,6 +1754,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       P.order_out[bbase + rk] = (int32_t)(bbase + j);
     }
   }
+  BB_STAMP(8);  // finish: block order
   // the next piece of a chunked bucket starts behind this one's voxels, internal nodes and blocks
   pre_vox += nvox;
   pre_blk += cko.y ? nblk_piece : brun;

@@ -22,7 +22,14 @@ for _ in range(reps):
 ctx.check(lib.octl_debug_bb_stamps(ctx.handle, out, 0))
 names = ["load record tails", "level pyramid", "keys + sort", "outputs"]
 tot = sum(out[i] for i in range(4))
+print("k_bucket_build")
 for i, nm in enumerate(names):
-    print("%-20s %6.1f %%   %8.0f cycles per bucket" % (nm, 100.0 * out[i] / tot, out[i] / reps / 4096))
-print("total cycles per bucket: %.0f  (s_memtime ticks at 100 MHz?)" % (tot / reps / 4096))
+    print("  %-28s %6.1f %%   %8.0f cycles per bucket" % (nm, 100.0 * out[i] / tot, out[i] / reps / 4096))
+print("  total cycles per bucket: %.0f" % (tot / reps / 4096))
+names = ["bases + roots", "internal nodes + children", "preorder ranks", "blocks", "block order"]
+tot = sum(out[4 + i] for i in range(5))
+print("k_bucket_finish")
+for i, nm in enumerate(names):
+    print("  %-28s %6.1f %%   %8.0f cycles per bucket" % (nm, 100.0 * out[4 + i] / tot, out[4 + i] / reps / 4096))
+print("  total cycles per bucket: %.0f" % (tot / reps / 4096))
 wl.close()
