@@ -765,7 +765,8 @@ int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* bl
                              const int32_t* blk_size, const double* xyz) {
   if (!f) return OCTL_E_INVALID;
   octl_ctx* ctx = f->ctx;
-  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "set_contents needs a built forest");
+  if (!f->built || f->store_dirty)
+    return octl_set_error(ctx, OCTL_E_STATE, "set_contents needs a forest whose tables are up to date (build first)");
   if (n_blocks < 0 || (n_blocks > 0 && (!blk_node || !blk_slot || !blk_size)))
     return octl_set_error(ctx, OCTL_E_INVALID, "bad block arrays");
   const int n_poses = (int)f->pose_off.size() - 1;

@@ -1819,7 +1819,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // One partition pass (want <= 4096 buckets): the key geometry is formed on the device (k_bucket_geom) and
   // the host does not wait for the bounding box; all 4096 buckets exist then, the ones behind the last
   // voxel key are empty.  (OCTL_SYNC_GEOM: tests run the host-side form on small clouds too.)
-  const bool async_geom = !force_sync && want <= (uint64_t)PT_BINS && !getenv("OCTL_SYNC_GEOM");
+  const bool async_geom = !force_sync && !ctx->geom_sparse && want <= (uint64_t)PT_BINS && !getenv("OCTL_SYNC_GEOM");
   // a cloud taken in place has not been through the box pass: with the geometry of the context's previous
   // single-pass build as a hint the histogram pass finds the box itself (k_part_hist<true>, k_geom_validate);
   // without one the box pass runs now
@@ -1859,6 +1859,12 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     if (((R - 1) >> s) + 1 > ((uint64_t)PT_BINS << PT_BITS)) return OCTL_OK;  // a sparse scene: too many keys
     nb = (uint32_t)(((R - 1) >> s) + 1);
     two_pass = nb > (uint32_t)PT_BINS;
+    ctx->geom_sparse = two_pass && want <= (uint64_t)PT_BINS;
+    // Thin buckets: the 12-bit clamp on a bucket's key range left them under half their target.  A workgroup per
+    // bucket is mostly set-up then, and the cost grows with the BOX (10 M points in 1024 x 1024 x 64 voxels:
+    // 2.46 ms, in 8192 x 8192 x 64: 37 ms), while the level loop's depends on the points alone (1.5-1.7 ms for
+    // every box measured): it takes these scenes.
+    if (two_pass && (uint64_t)n_alive * 2 < (uint64_t)nb * target) return OCTL_OK;
   }
 
   LinParams lp;

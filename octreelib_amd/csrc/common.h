@@ -90,6 +90,8 @@ struct octl_ctx {
   unsigned char geom_hint[192] = {0};
   bool geom_hint_valid = false;
   uint64_t geom_hint_want = 0;
+  // the last build found a sparse scene (more than 4096 buckets): the next one skips the single-pass attempt
+  bool geom_sparse = false;
   // the hypothesis table of the last octl_forest_ransac_all on this context (CudaRansac draws it once per object,
   // cuda_ransac.py:39-41, and a loop over scans hands the same one over for every scan - to a fresh forest each
   // time): kept per CONTEXT so that it is uploaded once

@@ -2263,3 +2263,39 @@ def test_scene_that_moves_more_than_2_pow_20_voxels_fails_loudly():
         g2 = Grid(GridConfig(voxel_edge_length=1))
         g2.insert_points(0, rng.random((10, 3)) + 3.0e9)
         g2.n_points(0)
+
+
+def test_thin_buckets_go_to_the_level_loop_and_match_the_oracle():
+    """A scene that is sparse in a LARGE box (here 400 k points in 2048 x 2048 x 8 voxels: more than 4096 key
+    ranges of 2^12 voxel keys, ~50 points in each) is not the bucket build's case - a workgroup per bucket is
+    mostly set-up there.  The level loop takes it, and the result is the oracle's, leaf by leaf."""
+    from octreelib_amd import _native as nat, synthetic
+    from octreelib_amd._engine import Forest
+    from tests._fullsize import oracle_check_every_leaf
+
+    cloud = synthetic.sparse_scene(400_000, (2048, 2048, 8), seed=3)
+    poses = [cloud[:150_000], cloud[150_000:]]
+    ctx = nat.get_context()
+    for rounds in range(2):           # the second build knows the scene is sparse: no single-pass attempt
+        f = Forest(0, np.zeros(3), 1.0)
+        for c in poses:
+            f.add_pose(c)
+        ctx.set_profiling(True)
+        f.subdivide(6)
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        assert "keygen" in names                      # the general path built the tables
+        if rounds:
+            assert "bucket_build" not in names and "part_hist" not in names
+        oracle_check_every_leaf(f, poses, 6, grid=True)
+        f.close()
+    # a dense scene afterwards: the bucket build again
+    dense = np.random.default_rng(0).random((300_000, 3)) * np.array([24.0, 24.0, 24.0])
+    f = Forest(0, np.zeros(3), 1.0)
+    f.add_pose(dense)
+    ctx.set_profiling(True)
+    f.subdivide(6)
+    names = set(ctx.timings())
+    ctx.set_profiling(False)
+    f.close()
+    assert "bucket_build" in names and "keygen" not in names
