@@ -572,16 +572,6 @@ __global__ __launch_bounds__(256) void k_bucket_bounds(const uint4* __restrict__
 // ---------------------------------------------------------------------------------------------
 // helpers of the bucket kernel
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(v, off);
-    if (lane >= off) v += t;
-  }
-  return v;
-}
-
 // exclusive prefix of one value per thread over the 256-thread block; *total = block sum.
 // scratch: >= 4 words of LDS; two barriers inside.
 __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t* total, uint32_t* scratch) {

@@ -651,44 +651,108 @@ __global__ __launch_bounds__(256) void k_finalize_marked(const int32_t* __restri
   xyz_ord[3 * i + 2] = xyz[3 * (int64_t)v + 2];
 }
 
-__device__ __forceinline__ bool block_head(const int32_t* __restrict__ pos_node,
-                                           const uint32_t* __restrict__ ord_idx,
-                                           const int64_t* __restrict__ pose_off, int n_poses,
-                                           int64_t i, int* slot_out) {
-  const int slot = find_slot(pose_off, n_poses, ord_idx[i]);
-  *slot_out = slot;
-  if (i == 0) return true;
-  if (pos_node[i] != pos_node[i - 1]) return true;
-  return find_slot(pose_off, n_poses, ord_idx[i - 1]) != slot;
-}
+// ---- (leaf, pose) block table of the leaf-ordered arrays ------------------------------------------------------
+// A block starts where the leaf or the pose of a position differs from the position in front of it.  One
+// workgroup per tile of BLK_TILE consecutive positions, eight per thread; the poses' first indices sit in LDS
+// (pose of a stored index = binary search there).  k_block_count<false> leaves the heads per tile,
+// k_block_count<true> - after a scan over the TILES, not over the positions - writes the blocks.  (Round 2
+// flagged every position, scanned n flags and searched the poses four times per position in global memory:
+// 1.67 ms of BASELINE config 4's 8.9 ms, 64 M positions.)
+constexpr int BLK_IPT = 8;
+constexpr int BLK_TILE = 256 * BLK_IPT;
+constexpr int BLK_LDS_POSES = 2048;
 
-__global__ __launch_bounds__(256) void k_block_heads(const int32_t* __restrict__ pos_node,
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_block_tiles(const int32_t* __restrict__ pos_node,
                                                      const uint32_t* __restrict__ ord_idx,
-                                                     const int64_t* __restrict__ pose_off,
-                                                     int n_poses, int64_t n_alive,
-                                                     uint32_t* __restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_alive) return;
-  int slot;
-  flags[i] = block_head(pos_node, ord_idx, pose_off, n_poses, i, &slot) ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(256) void k_block_fill(const int32_t* __restrict__ pos_node,
-                                                    const uint32_t* __restrict__ ord_idx,
-                                                    const int64_t* __restrict__ pose_off,
-                                                    int n_poses, int64_t n_alive,
-                                                    const uint32_t* __restrict__ scanned,
-                                                    int32_t* __restrict__ blk_node,
-                                                    int32_t* __restrict__ blk_slot,
-                                                    uint32_t* __restrict__ blk_start) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_alive) return;
-  int slot;
-  if (block_head(pos_node, ord_idx, pose_off, n_poses, i, &slot)) {
-    const uint32_t b = scanned[i];
-    blk_node[b] = pos_node[i];
-    blk_slot[b] = slot;
-    blk_start[b] = (uint32_t)i;
+                                                     const int64_t* __restrict__ pose_off, int n_poses,
+                                                     int64_t n_alive, uint32_t* __restrict__ tile_cnt,
+                                                     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot,
+                                                     uint32_t* __restrict__ blk_start) {
+  __shared__ int64_t s_off[BLK_LDS_POSES + 1];
+  __shared__ uint32_t s_w[4];
+  const bool in_lds = n_poses <= BLK_LDS_POSES;
+  if (in_lds)
+    for (int p = threadIdx.x; p <= n_poses; p += 256) s_off[p] = pose_off[p];
+  __syncthreads();
+  auto slot_of = [&](uint32_t idx) {
+    if (n_poses <= 1) return 0;
+    int lo = 0, hi = n_poses;  // off[lo] <= idx < off[hi]
+    if (in_lds) {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_off[mid] <= (int64_t)idx) lo = mid; else hi = mid;
+      }
+    } else {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pose_off[mid] <= (int64_t)idx) lo = mid; else hi = mid;
+      }
+    }
+    return lo;
+  };
+  const int64_t first = (int64_t)blockIdx.x * BLK_TILE + (int64_t)threadIdx.x * BLK_IPT;
+  int32_t node[BLK_IPT];
+  uint32_t idx[BLK_IPT];
+  if (first + BLK_IPT <= n_alive) {  // (the arrays are 16-byte aligned, first is a multiple of 8)
+    const int4* pn = reinterpret_cast<const int4*>(pos_node + first);
+    const uint4* oi = reinterpret_cast<const uint4*>(ord_idx + first);
+    const int4 a = pn[0], b = pn[1];
+    const uint4 c = oi[0], d = oi[1];
+    node[0] = a.x; node[1] = a.y; node[2] = a.z; node[3] = a.w;
+    node[4] = b.x; node[5] = b.y; node[6] = b.z; node[7] = b.w;
+    idx[0] = c.x; idx[1] = c.y; idx[2] = c.z; idx[3] = c.w;
+    idx[4] = d.x; idx[5] = d.y; idx[6] = d.z; idx[7] = d.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < BLK_IPT; ++q) {
+      const int64_t i = first + q;
+      node[q] = i < n_alive ? pos_node[i] : -1;
+      idx[q] = i < n_alive ? ord_idx[i] : 0u;
+    }
+  }
+  // the position in front of this thread's run
+  int32_t pnode = -1;
+  int pslot = -1;
+  if (first > 0 && first < n_alive) {
+    pnode = pos_node[first - 1];
+    pslot = slot_of(ord_idx[first - 1]);
+  }
+  uint32_t heads = 0;  // bit q: position first + q starts a block
+  int slot[BLK_IPT];
+#pragma unroll
+  for (int q = 0; q < BLK_IPT; ++q) {
+    const bool live = first + q < n_alive;
+    // (inside a leaf the positions are in index order: the pose changes only where the index passes the end
+    //  of the previous position's pose, so most positions inherit the slot without a search)
+    int sl = pslot;
+    if (live && (pslot < 0 || (int64_t)idx[q] >= (in_lds ? s_off[pslot + 1] : pose_off[pslot + 1]) ||
+                 (int64_t)idx[q] < (in_lds ? s_off[pslot] : pose_off[pslot])))
+      sl = slot_of(idx[q]);
+    slot[q] = sl;
+    if (live && (first + q == 0 || node[q] != pnode || sl != pslot)) heads |= 1u << q;
+    pnode = node[q];
+    pslot = sl;
+  }
+  const uint32_t mine = (uint32_t)__popc(heads);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_inclusive_add(mine);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  if (!FILL) {
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return;
+  }
+  uint32_t b = tile_cnt[blockIdx.x] + inc - mine;  // (tile_cnt: scanned, exclusive)
+  for (int w = 0; w < wave; ++w) b += s_w[w];
+#pragma unroll
+  for (int q = 0; q < BLK_IPT; ++q) {
+    if ((heads >> q) & 1u) {
+      blk_node[b] = node[q];
+      blk_slot[b] = slot[q];
+      blk_start[b] = (uint32_t)(first + q);
+      ++b;
+    }
   }
 }
 
@@ -755,23 +819,23 @@ int forest_make_blocks(octl_forest* f) {
     return OCTL_OK;
   }
   KTimer t(ctx, "blocks");
-  OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n + 8) * 4));
-  uint32_t* flags = f->flags.as<uint32_t>();
+  const int64_t n_tiles = ceil_div(n, (int64_t)BLK_TILE);
+  OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n_tiles + 8) * 4));
+  uint32_t* tile_cnt = f->flags.as<uint32_t>();
   const int32_t* pos_node = f->pos_node.as<int32_t>();
   // capacity = one block per point (grow-only buffers): the count is not known on the host yet
   OCTL_TRY(devbuf_reserve(ctx, f->blk_node, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n * 4));
-  hipLaunchKernelGGL(k_block_heads, dim3(grid_for(n)), dim3(256), 0, st, pos_node,
-                     (const uint32_t*)f->ord_idx.as<uint32_t>(),
-                     (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, n, flags);
+  hipLaunchKernelGGL(k_block_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
+                     (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
+                     n_poses, n, tile_cnt, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
-  OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n, small + SM_NBLOCKS));
-  hipLaunchKernelGGL(k_block_fill, dim3(grid_for(n)), dim3(256), 0, st, pos_node,
-                     (const uint32_t*)f->ord_idx.as<uint32_t>(),
-                     (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, n,
-                     (const uint32_t*)flags, f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
+  OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_cnt, tile_cnt, n_tiles, small + SM_NBLOCKS));
+  hipLaunchKernelGGL(k_block_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
+                     (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
+                     n_poses, n, tile_cnt, f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
                      f->blk_start.as<uint32_t>());
   HIP_TRY(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_block_sizes, dim3(grid_for(n)), dim3(256), 0, st,

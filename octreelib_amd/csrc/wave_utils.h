@@ -17,6 +17,17 @@ __device__ __forceinline__ uint64_t wave_match(uint32_t digit, bool valid) {
   return peers;
 }
 
+// inclusive prefix sum over the wavefront
+__device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(v, off);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt() {
   const unsigned lane = threadIdx.x & 63u;
   return (lane == 0) ? 0ull : (~0ull >> (64u - lane));
