@@ -42,6 +42,8 @@ class Forest:
         self._cube = (tuple(np.asarray(corner, dtype=np.float64).tolist()), float(edge))
         self._creation_codes = np.empty(0, dtype=np.int64)   # packed voxel keys, creation order
         self._code_origin = None                              # voxel index the host-side codes are relative to
+        self._member_next = 0                                 # first slot whose voxels have not been captured yet
+        self._member_pending = []                             # (slot, voxel ids at capture time): keys not formed yet
         self._device_clouds = []                             # DeviceCloud objects whose buffers the store may read
         self._in_place = None                                # the DeviceCloud the store reads in place, if any
 
@@ -131,6 +133,7 @@ class Forest:
 
     # -- build ------------------------------------------------------------------------------
     def build(self, K: int, scheme_slots=None, keep_scheme=False, max_depth=0):
+        self._resolve_membership()   # (captured voxel ids refer to the voxel table this build may renumber)
         mask = None
         if scheme_slots is not None and not keep_scheme:
             mask = np.zeros(self.n_slots, dtype=np.uint8)
@@ -173,6 +176,7 @@ class Forest:
         The order of the rows handed to a criterion is pose-major / insertion order (the
         reference's order is an artefact of an unstable argsort)."""
         self.ensure_built()
+        self._resolve_membership()
         scheme = set(range(self.n_slots)) if scheme_slots is None else set(scheme_slots)
         # epochs of nodes that stay internal are inherited (cached-leaf order is history dependent)
         prev = {}
@@ -245,6 +249,7 @@ class Forest:
         merged (upstream's merge branch is defective, SURVEY 8 a8 - outside the parity domain)."""
         self.ensure_built()
         other.ensure_built()
+        self._resolve_membership()
         if self.mode != other.mode or self._cube != other._cube or not np.array_equal(self.voxels, other.voxels):
             raise ValueError("subdivide_as needs two octrees over the same cube")
         ond = other.nodes
@@ -280,6 +285,7 @@ class Forest:
         if self.has_scheme:
             self.build(0, None, keep_scheme=True)
         else:
+            self._resolve_membership()
             # K < 0: never split.  Not a subdivide call: the epoch does not advance.
             info = nat.BuildInfo()
             self.ctx.check(self.lib.octl_forest_build(self.handle, -1, None, 0, 0, 0, C.byref(info)))
@@ -291,14 +297,11 @@ class Forest:
             self._update_membership()
 
     def _update_membership(self):
-        """Record, for slots seen for the first time, the voxels they were inserted into
-        (Grid.__pose_voxel_coordinates, grid.py:53,108) and the voxel creation order."""
-        if all(k is not None for k in self.slot_voxel_keys):
-            return
-        vox = self.voxels
-        for s in range(self.n_slots):
-            if self.slot_voxel_keys[s] is not None:
-                continue
+        """Capture, for slots seen for the first time, the voxels they were inserted into
+        (Grid.__pose_voxel_coordinates, grid.py:53,108) - as voxel ids of the table of THIS build; the keys and
+        the voxel creation order are formed when someone asks or before the table can change
+        (_resolve_membership): a scan that is built, fitted and dropped never pays for them."""
+        for s in range(self._member_next, self.n_slots):
             n = C.c_int64(0)
             self.ctx.check(self.lib.octl_forest_get_slot_voxels(self.handle, s, 0, None, C.byref(n)))
             vids = np.empty(n.value, dtype=np.int32)
@@ -306,6 +309,22 @@ class Forest:
                 self.ctx.check(
                     self.lib.octl_forest_get_slot_voxels(self.handle, s, n.value, nat.ptr(vids), C.byref(n))
                 )
+            self._member_pending.append((s, vids))
+        self._member_next = self.n_slots
+
+    def _fetch_voxels(self) -> np.ndarray:
+        """The library's voxel table as it stands (no build is triggered)."""
+        n = C.c_int64(0)
+        self.ctx.check(self.lib.octl_forest_get_voxels(self.handle, 0, None, C.byref(n)))
+        v = np.empty((n.value, 3), dtype=np.int64)
+        self.ctx.check(self.lib.octl_forest_get_voxels(self.handle, n.value, nat.ptr(v), C.byref(n)))
+        return v
+
+    def _resolve_membership(self):
+        if not self._member_pending:
+            return
+        vox = self._voxels if self._voxels is not None else self._fetch_voxels()
+        for s, vids in self._member_pending:
             keys = vox[vids]
             self.slot_voxel_keys[s] = keys
             # voxels seen for the first time, in this pose's (lexicographic = np.unique) order
@@ -313,6 +332,7 @@ class Forest:
             fresh = codes[~np.isin(codes, self._creation_codes)]
             if len(fresh):
                 self._creation_codes = np.concatenate((self._creation_codes, fresh))
+        self._member_pending = []
 
     def _voxel_codes(self, keys: np.ndarray) -> np.ndarray:
         """(m,3) int64 voxel corners -> one int64 per voxel (bijective: |index| < 2^20 per axis,
@@ -330,6 +350,7 @@ class Forest:
     def creation_ranks(self, keys: np.ndarray) -> np.ndarray:
         """Position of every voxel of `keys` in the order voxels were first created
         (the dict order of Grid.__octrees, grid.py:56,100-109)."""
+        self._resolve_membership()
         order = np.argsort(self._creation_codes, kind="stable")
         pos = np.searchsorted(self._creation_codes[order], self._voxel_codes(keys))
         return order[pos].astype(np.int64)
@@ -485,6 +506,7 @@ class Forest:
     def slot_voxel_ranks(self, slot: int) -> np.ndarray:
         """Current voxel ranks of the voxels the slot was inserted into (lexicographic)."""
         self.ensure_built()
+        self._resolve_membership()
         keys = self.slot_voxel_keys[slot]
         if keys is None or len(keys) == 0:
             return np.empty(0, dtype=np.int64)
