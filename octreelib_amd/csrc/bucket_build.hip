@@ -405,6 +405,23 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist_rec(const uint4* __res
   for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table[(size_t)blockIdx.x * nd + d] = hist[d];
 }
 
+// -DBB_STAMPS: phase clocks of bucket_chunk (thread 0 of every workgroup adds its s_memtime deltas to a device
+// array; tools/bb_stamps.py reads it through octl_debug_bb_stamps).  Experiments only: not in the shipped library.
+#ifdef BB_STAMPS
+__device__ unsigned long long g_bb_stamps[16];
+#define BB_STAMP(k)                                                              \
+  do {                                                                           \
+    if (threadIdx.x == 0) {                                                      \
+      const unsigned long long _t = __builtin_readcyclecounter();                \
+      atomicAdd(&g_bb_stamps[k], _t - _stamp_t0);                                \
+      _stamp_t0 = _t;                                                            \
+    }                                                                            \
+  } while (0)
+#define BB_STAMP_INIT unsigned long long _stamp_t0 = __builtin_readcyclecounter()
+#else
+#define BB_STAMP(k) do {} while (0)
+#define BB_STAMP_INIT do {} while (0)
+#endif
 // stable rank inside one wave's stream with 16-bit counters: a wave's counters are touched by that
 // wave only and its rounds are sequential, so the leader of a digit updates them with plain accesses
 template <int BITS>
@@ -439,6 +456,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
   for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
     base[d] = table_scanned[(size_t)blockIdx.x * nd + d];  // ([supertile][digit]: see k_part_hist)
   constexpr int PT_TILE = PT_THREADS * PT_IPT;
+  BB_STAMP_INIT;
   for (int t = 0; t < st_tiles; ++t) {
     const int64_t tbase = ((int64_t)blockIdx.x * st_tiles + t) * PT_TILE;
     if (tbase >= N) break;
@@ -447,6 +465,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
       for (int w = 0; w < PT_THREADS / 64; ++w) cnt[w][d] = 0;
     }
     __syncthreads();
+    BB_STAMP(9);   // scatter: counters reset
     // wave w owns items [tbase + w*1024, +1024) in 16 rounds of 64 consecutive items: stream order
     // == memory order, so the partition is stable
     const int64_t wbase = tbase + (int64_t)wave * (64 * PT_IPT);
@@ -475,6 +494,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
         idxv[r] = 0;
       }
     }
+#ifdef BB_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);  // (experiments: the loads' latency apart from the keys and ranks)
+    BB_STAMP(15);  // scatter: loads arrived
+#endif
 #pragma unroll
     for (int r = 0; r < PT_IPT; ++r) {
       const int64_t i = wbase + r * 64 + lane;
@@ -493,7 +516,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
       }
       rank[r] = wave_rank_u16<PT_BITS>(digit_of(lp, lin[r]), valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
     }
+    BB_STAMP(10);  // scatter: loads, keys, ranks (wave 0)
     __syncthreads();
+    BB_STAMP(11);  // scatter: wait for the other waves
     // per bucket: exclusive offsets of the waves inside this tile; the tile's total moves the running
     // base once every item is placed
     uint32_t tile_tot[PT_BINS / PT_THREADS];
@@ -512,6 +537,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
       tile_tot[q] = run;
     }
     __syncthreads();
+    BB_STAMP(12);  // scatter: wave offsets
 #pragma unroll
     for (int r = 0; r < PT_IPT; ++r) {
       if (rank[r] >> 31) {
@@ -539,7 +565,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
         o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), lp.raw_vp ? lin[r] : ((vl << 19) | pbits[r]), v};
       }
     }
+    BB_STAMP(13);  // scatter: stores issued
     __syncthreads();
+    BB_STAMP(14);  // scatter: barrier behind the stores
 #pragma unroll
     for (int q = 0; q < PT_BINS / PT_THREADS; ++q) {
       const uint32_t d = q * PT_THREADS + threadIdx.x;
@@ -635,23 +663,6 @@ __device__ __forceinline__ void load_rec(const PartRec* __restrict__ p, double& 
 constexpr int BB_BINS = 8192;          // histogram bins per level (nodes of a level x 8)
 #ifndef BB_OUT_UNROLL
 #define BB_OUT_UNROLL 4
-#endif
-// -DBB_STAMPS: phase clocks of bucket_chunk (thread 0 of every workgroup adds its s_memtime deltas to a device
-// array; tools/bb_stamps.py reads it through octl_debug_bb_stamps).  Experiments only: not in the shipped library.
-#ifdef BB_STAMPS
-__device__ unsigned long long g_bb_stamps[16];
-#define BB_STAMP(k)                                                              \
-  do {                                                                           \
-    if (threadIdx.x == 0) {                                                      \
-      const unsigned long long _t = __builtin_readcyclecounter();                \
-      atomicAdd(&g_bb_stamps[k], _t - _stamp_t0);                                \
-      _stamp_t0 = _t;                                                            \
-    }                                                                            \
-  } while (0)
-#define BB_STAMP_INIT unsigned long long _stamp_t0 = __builtin_readcyclecounter()
-#else
-#define BB_STAMP(k) do {} while (0)
-#define BB_STAMP_INIT do {} while (0)
 #endif
 constexpr int BB_SORT_BITS = 9;        // digit of the in-bucket radix sort
 constexpr int BB_SORT_BINS = 1 << BB_SORT_BITS;
@@ -1884,8 +1895,12 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   int st_tiles_a = 1, st_tiles_b = 1;
   const uint32_t nst_a = supertiles(N, &st_tiles_a);
   const uint32_t nst_b = two_pass ? supertiles(n_alive, &st_tiles_b) : 0;
-  const uint32_t nd_a = two_pass ? (uint32_t)PT_BINS : nb;             // digits of the first pass
-  const uint32_t nd_b = two_pass ? ((nb - 1) >> PT_BITS) + 1 : 0;      // digits of the second pass
+  // Two passes split the bucket number's bits EVENLY (low half first, both passes stable): a tile of 4096
+  // records then leaves runs of ~16 records (512 B) per digit in both passes.  (Round 2 took 12 bits first: one
+  // record per digit and tile - isolated 32-byte stores at 2 TB/s, 0.61 ms per 10 M points at 125 M.)
+  const int bits_a = two_pass ? std::min(PT_BITS, (ceil_log2_u64(nb) + 1) / 2) : 0;
+  const uint32_t nd_a = two_pass ? (1u << bits_a) : nb;                // digits of the first pass
+  const uint32_t nd_b = two_pass ? ((nb - 1) >> bits_a) + 1 : 0;       // digits of the second pass
   // ---- scratch ------------------------------------------------------------------------------------------------
   OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)n_alive * sizeof(PartRec)));
   if (two_pass) OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[1], (size_t)n_alive * sizeof(PartRec)));
@@ -1921,7 +1936,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   }
   // ---- partition ----------------------------------------------------------------------------------------------
   lp.dshift = s;
-  lp.dmask = two_pass ? (uint32_t)(PT_BINS - 1) : 0xFFFFFFFFu;
+  lp.dmask = two_pass ? (nd_a - 1u) : 0xFFFFFFFFu;
   lp.raw_vp = two_pass ? 1 : 0;
   {
     KTimer t(ctx, "part_hist");
@@ -1962,7 +1977,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   uint32_t bstride = nst_a;
   if (two_pass) {
     // second (more significant) digit over the records of the first pass, then the bucket bounds
-    lp.dshift = s + PT_BITS;
+    lp.dshift = s + bits_a;
     lp.dmask = 0xFFFFFFFFu;
     lp.raw_vp = 0;
     {
