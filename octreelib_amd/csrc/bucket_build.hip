@@ -232,9 +232,12 @@ __device__ __forceinline__ uint32_t lin_corner_of(const LinParams& lp, double x,
     return 0u;
   }
   const double fx = floor_div_fast(x, lp.L), fy = floor_div_fast(y, lp.L), fz = floor_div_fast(z, lp.L);
-  cx = (double)(long long)(fx * lp.L);
-  cy = (double)(long long)(fy * lp.L);
-  cz = (double)(long long)(fz * lp.L);
+  // int64(q * L) back as a double: truncation towards zero, and a zero comes back as +0.0 (the `+ 0.0`).
+  // v_trunc_f64 instead of the two emulated f64 <-> i64 conversions (~14 f64-rate instructions per axis; the
+  // key arithmetic is 54 % of k_part_scatter's time).  Equal for |q * L| < 2^63 (|q| <= 2^30 here).
+  cx = trunc(fx * lp.L) + 0.0;
+  cy = trunc(fy * lp.L) + 0.0;
+  cz = trunc(fz * lp.L) + 0.0;
   return ((uint32_t)((int)fx - lp.minx) * lp.ny + (uint32_t)((int)fy - lp.miny)) * lp.nz +
          (uint32_t)((int)fz - lp.minz);
 }

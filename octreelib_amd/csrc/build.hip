@@ -132,9 +132,10 @@ __global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
         qy = (int)fy;
         qz = (int)fz;
         // the manager's corner is np.array(voxel_coords): int64(q*L) (grid.py:96-105)
-        cx = (double)(long long)(fx * L);
-        cy = (double)(long long)(fy * L);
-        cz = (double)(long long)(fz * L);
+        // (truncation towards zero, a zero comes back as +0.0: see lin_corner_of in bucket_build.hip)
+        cx = trunc(fx * L) + 0.0;
+        cy = trunc(fy * L) + 0.0;
+        cz = trunc(fz * L) + 0.0;
       }
     }
     if (live) {
