@@ -469,14 +469,14 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     }
     __syncthreads();
     BB_STAMP(9);   // scatter: counters reset
-    // wave w owns items [tbase + w*1024, +1024) in 16 rounds of 64 consecutive items: stream order
+    // wave w owns items [tbase + w * 64 * PT_IPT, + 64 * PT_IPT) in PT_IPT rounds of 64 consecutive items: stream order
     // == memory order, so the partition is stable
     const int64_t wbase = tbase + (int64_t)wave * (64 * PT_IPT);
     double x[PT_IPT], y[PT_IPT], z[PT_IPT];
     uint32_t lin[PT_IPT], rank[PT_IPT], pbits[PT_IPT], idxv[PT_IPT];
     uint8_t live[PT_IPT];
     // every load of the tile is issued before the first use: a load behind `if (alive[i])` waits for
-    // the flag first, and 16 rounds of two dependent HBM latencies were 50 us per tile
+    // the flag first, and 16 rounds of two dependent HBM latencies were 50 us per 4096-record tile
 #pragma unroll
     for (int r = 0; r < PT_IPT; ++r) {
       const int64_t i = min(wbase + r * 64 + lane, N - 1);
@@ -1889,10 +1889,18 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   uint32_t* small = ctx->small.as<uint32_t>();
   // supertiles: one round of workgroups (2 per CU) over the cloud, at most 16 tiles each
   const int cus = octl_ctx_cus(ctx);
-  constexpr int PT_IPT = 16;
+// (A/B on the headline scene, tools/ab_build.sh: 8 records per thread 0.264 ms, 16: 0.284, 4: 0.295, 12 with 3
+//  workgroups per CU: 0.329 - the kernel is latency bound at 2 waves per SIMD, 254 VGPRs with 16 records)
+#ifndef OCTL_PT_IPT
+#define OCTL_PT_IPT 8
+#endif
+#ifndef OCTL_PT_WGS
+#define OCTL_PT_WGS 2
+#endif
+  constexpr int PT_IPT = OCTL_PT_IPT;  // (records per thread and tile of the partition kernels; -D for experiments)
   constexpr int tile = PT_THREADS * PT_IPT;
   auto supertiles = [&](int64_t items, int* st_tiles) {
-    *st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(items, tile), (int64_t)cus * 2)));
+    *st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(items, tile), (int64_t)cus * OCTL_PT_WGS)));
     return (uint32_t)ceil_div(items, (int64_t)*st_tiles * tile);
   };
   int st_tiles_a = 1, st_tiles_b = 1;

@@ -34,9 +34,10 @@ for i, nm in enumerate(names):
 print("  total cycles per bucket: %.0f" % (tot / reps / 4096))
 names = ["counters reset", "loads, keys, ranks", "wait for the other waves", "wave offsets", "stores issued", "barrier behind the stores"]
 tot = sum(out[9 + i] for i in range(6))
-print("k_part_scatter (cycles per 4096-record tile)")
+TILES = -(-10_000_000 // (256 * 8))   # PT_THREADS x OCTL_PT_IPT records per tile
+print("k_part_scatter (cycles per %d-record tile)" % (256 * 8))
 for i, nm in enumerate(names):
-    print("  %-28s %6.1f %%   %8.0f" % (nm, 100.0 * out[9 + i] / max(tot, 1), out[9 + i] / reps / 2442))
-print("  total: %.0f" % (tot / reps / 2442))
-print("  (of 'loads, keys, ranks': waiting for the tile's loads %.0f)" % (out[15] / reps / 2442))
+    print("  %-28s %6.1f %%   %8.0f" % (nm, 100.0 * out[9 + i] / max(tot, 1), out[9 + i] / reps / TILES))
+print("  total: %.0f" % (tot / reps / TILES))
+print("  (of 'loads, keys, ranks': waiting for the tile's loads %.0f)" % (out[15] / reps / TILES))
 wl.close()
