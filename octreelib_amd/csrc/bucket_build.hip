@@ -513,7 +513,14 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
         if (!FROM_REC) lin[r] = l;
         if (!lp.raw_vp) {
           bool bad = false;
-          const uint32_t path = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
+          uint32_t path = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
+#ifdef PS_DUP_KEYS  // (experiments: the child digits computed twice - what they cost)
+          {
+            double x2 = x[r];
+            asm volatile("" : "+v"(x2));
+            path &= path_levels(x2, y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
+          }
+#endif
           pbits[r] = ((path >> 3) << 1) | (bad ? 1u : 0u);
         }
       }
@@ -566,6 +573,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
         o[0] = uint4{(uint32_t)xb, (uint32_t)(xb >> 32), (uint32_t)yb, (uint32_t)(yb >> 32)};
         const uint32_t vl = lin[r] & ((1u << lp.shift) - 1u);
         o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), lp.raw_vp ? lin[r] : ((vl << 19) | pbits[r]), v};
+#ifdef PS_DUP_STORE  // (experiments: the same record stored twice - what the scattered stores cost)
+        asm volatile("" ::: "memory");
+        o[0] = uint4{(uint32_t)xb, (uint32_t)(xb >> 32), (uint32_t)yb, (uint32_t)(yb >> 32)};
+        o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), lp.raw_vp ? lin[r] : ((vl << 19) | pbits[r]), v};
+#endif
       }
     }
     BB_STAMP(13);  // scatter: stores issued
