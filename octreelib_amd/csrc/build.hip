@@ -214,41 +214,139 @@ __global__ __launch_bounds__(256) void k_linkey(const uint64_t* __restrict__ vke
 // ---------------------------------------------------------------------------------------------
 // roots
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_heads(const uint64_t* __restrict__ lin, int64_t n_alive,
-                                               uint32_t* __restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_alive) return;
-  flags[i] = (i == 0 || lin[i] != lin[i - 1]) ? 1u : 0u;
+// Voxel heads of the sorted keys, per TILE of 2048 positions (eight per thread): k_root_tiles<false> counts them,
+// a scan over the tiles (not over the positions) gives every tile its first voxel ordinal, k_root_tiles<true>
+// writes the voxel list and k_init_level0 derives every position's voxel from the same tile bases.  (Round 2
+// wrote a flag per position, scanned n flags and read them back twice: ~20 B per point of traffic for a table
+// of a few thousand voxels.)
+constexpr int RT_IPT = 8;
+constexpr int RT_TILE = 256 * RT_IPT;
+
+// bit q of the result: position first + q starts a voxel (lin differs from the position in front of it);
+// positions behind n_alive never do
+__device__ __forceinline__ uint32_t tile_voxel_heads(const uint64_t* __restrict__ lin, int64_t first,
+                                                     int64_t n_alive) {
+  uint64_t k[RT_IPT];
+  if (first + RT_IPT <= n_alive) {  // (16-byte aligned: first is a multiple of 8)
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(lin + first);
+#pragma unroll
+    for (int q = 0; q < RT_IPT / 2; ++q) {
+      const ulonglong2 v = p[q];
+      k[2 * q] = v.x;
+      k[2 * q + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) k[q] = first + q < n_alive ? lin[first + q] : 0ull;
+  }
+  uint64_t prev = (first > 0 && first < n_alive) ? lin[first - 1] : 0ull;
+  uint32_t heads = 0;
+#pragma unroll
+  for (int q = 0; q < RT_IPT; ++q) {
+    if (first + q < n_alive && (first + q == 0 || k[q] != prev)) heads |= 1u << q;
+    prev = k[q];
+  }
+  return heads;
 }
 
-__global__ __launch_bounds__(256) void k_voxel_collect(const uint64_t* __restrict__ lin,
-                                                       const uint32_t* __restrict__ scanned,
-                                                       int64_t n_alive,
-                                                       uint64_t* __restrict__ vlin,
-                                                       uint32_t* __restrict__ vstart) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_alive) return;
-  if (i == 0 || lin[i] != lin[i - 1]) {
-    const uint32_t r = scanned[i];
-    vlin[r] = lin[i];
-    vstart[r] = (uint32_t)i;
+// exclusive prefix of `mine` over the 256 threads of the block (one barrier; s_w: 4 words of LDS)
+__device__ __forceinline__ uint32_t tile_excl_prefix(uint32_t mine, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_inclusive_add(mine);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t b = inc - mine;
+  for (int w = 0; w < wave; ++w) b += s_w[w];
+  *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return b;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_root_tiles(const uint64_t* __restrict__ lin, int64_t n_alive,
+                                                    uint32_t* __restrict__ tile_cnt,
+                                                    uint64_t* __restrict__ vlin,
+                                                    uint32_t* __restrict__ vstart) {
+  __shared__ uint32_t s_w[4];
+  const int64_t first = (int64_t)blockIdx.x * RT_TILE + (int64_t)threadIdx.x * RT_IPT;
+  const uint32_t heads = tile_voxel_heads(lin, first, n_alive);
+  uint32_t total;
+  uint32_t r = tile_excl_prefix((uint32_t)__popc(heads), s_w, &total);
+  if (!FILL) {
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+    return;
+  }
+  // the tile's voxels through LDS: written out in runs (a scene of nearly one point per voxel has a head at
+  // almost every position; from the threads' own registers that was eight strided stores each)
+  __shared__ uint64_t s_lin[RT_TILE];
+  __shared__ uint32_t s_pos[RT_TILE];
+#pragma unroll
+  for (int q = 0; q < RT_IPT; ++q) {
+    if ((heads >> q) & 1u) {
+      s_lin[r] = lin[first + q];
+      s_pos[r] = (uint32_t)(first + q);
+      ++r;
+    }
+  }
+  __syncthreads();
+  const uint32_t base = tile_cnt[blockIdx.x];  // (scanned, exclusive)
+  for (uint32_t j = threadIdx.x; j < total; j += 256) {
+    vlin[base + j] = s_lin[j];
+    vstart[base + j] = s_pos[j];
   }
 }
 
 // level-0 buffers: position -> root node, point index (+scheme bit), path word
 __global__ __launch_bounds__(256) void k_init_level0(
-    const uint64_t* __restrict__ lin, const uint32_t* __restrict__ scanned,
+    const uint64_t* __restrict__ lin, const uint32_t* __restrict__ tile_first,
     const uint32_t* __restrict__ val_sorted, const uint64_t* __restrict__ path, int64_t n_alive,
     const int32_t* __restrict__ local2root, int32_t* __restrict__ pos_node,
     uint32_t* __restrict__ idx0, uint64_t* __restrict__ path0) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_alive) return;
-  const uint32_t head = (i == 0 || lin[i] != lin[i - 1]) ? 1u : 0u;
-  const uint32_t local = scanned[i] + head - 1u;
-  pos_node[i] = local2root ? local2root[local] : (int32_t)local;
-  const uint32_t v = val_sorted[i];
-  idx0[i] = v;
-  path0[i] = path[v & IDX_MASK];
+  __shared__ uint32_t s_w[4];
+  const int64_t first = (int64_t)blockIdx.x * RT_TILE + (int64_t)threadIdx.x * RT_IPT;
+  const uint32_t heads = tile_voxel_heads(lin, first, n_alive);
+  uint32_t total;
+  const uint32_t before = tile_first[blockIdx.x] + tile_excl_prefix((uint32_t)__popc(heads), s_w, &total);
+  uint32_t v[RT_IPT];
+  if (first + RT_IPT <= n_alive) {
+    const uint4* p = reinterpret_cast<const uint4*>(val_sorted + first);
+    const uint4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) v[q] = first + q < n_alive ? val_sorted[first + q] : 0u;
+  }
+  uint64_t pw[RT_IPT];
+#pragma unroll
+  for (int q = 0; q < RT_IPT; ++q) pw[q] = first + q < n_alive ? path[v[q] & IDX_MASK] : 0ull;
+  int32_t pn[RT_IPT];
+#pragma unroll
+  for (int q = 0; q < RT_IPT; ++q) {
+    // voxels that start at or in front of this position, minus one
+    const uint32_t local = before + (uint32_t)__popc(heads & ((2u << q) - 1u)) - 1u;
+    pn[q] = first + q < n_alive ? (local2root ? local2root[local] : (int32_t)local) : 0;
+  }
+  if (first + RT_IPT <= n_alive) {  // whole run: 16-byte stores (a thread's eight positions are 32 / 64 bytes)
+    int4* o_n = reinterpret_cast<int4*>(pos_node + first);
+    o_n[0] = int4{pn[0], pn[1], pn[2], pn[3]};
+    o_n[1] = int4{pn[4], pn[5], pn[6], pn[7]};
+    uint4* o_i = reinterpret_cast<uint4*>(idx0 + first);
+    o_i[0] = uint4{v[0], v[1], v[2], v[3]};
+    o_i[1] = uint4{v[4], v[5], v[6], v[7]};
+    ulonglong2* o_p = reinterpret_cast<ulonglong2*>(path0 + first);
+#pragma unroll
+    for (int q = 0; q < RT_IPT / 2; ++q) o_p[q] = ulonglong2{pw[2 * q], pw[2 * q + 1]};
+  } else {
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) {
+      const int64_t i = first + q;
+      if (i < n_alive) {
+        pos_node[i] = pn[q];
+        idx0[i] = v[q];
+        path0[i] = pw[q];
+      }
+    }
+  }
 }
 
 // scheme-pose point count of every root (only when a pose subset drives the scheme)
@@ -1343,7 +1441,9 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
 
   trace.mark("sort (enqueue)");
   // ---- 3. roots ------------------------------------------------------------------------------------
-  OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(n_alive, 8) + 8) * 4));
+  // (first voxel ordinal of every tile of RT_TILE positions: k_root_tiles, k_init_level0)
+  const int64_t n_rtiles = ceil_div(std::max<int64_t>(n_alive, 1), (int64_t)RT_TILE);
+  OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n_rtiles + 8) * 4));
   uint32_t* flags = f->flags.as<uint32_t>();
   const bool have_old = f->built;
   const bool fresh = !have_old && f->vkeys.empty() && n_alive > 0;  // roots made on the device
@@ -1354,12 +1454,12 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   uint32_t* vstart_d = f->val[sorted ^ 1].as<uint32_t>();
   if (n_alive > 0) {
     KTimer t(ctx, "roots");
-    hipLaunchKernelGGL(k_heads, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted, n_alive,
-                       flags);
+    hipLaunchKernelGGL(k_root_tiles<false>, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted, n_alive, flags,
+                       (uint64_t*)nullptr, (uint32_t*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_alive, small + SM_NVOX));
-    hipLaunchKernelGGL(k_voxel_collect, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted,
-                       (const uint32_t*)flags, n_alive, vlin_d, vstart_d);
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_rtiles, small + SM_NVOX));
+    hipLaunchKernelGGL(k_root_tiles<true>, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted, n_alive, flags,
+                       vlin_d, vstart_d);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t nv;
     OCTL_TRY(read_small(ctx, SM_NVOX, 1, &nv));
@@ -1498,7 +1598,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       l2r = f->root_up.as<int32_t>();
     }
     KTimer t(ctx, "init_level0");
-    hipLaunchKernelGGL(k_init_level0, dim3(grid_for(n_alive)), dim3(256), 0, st, lin_sorted,
+    hipLaunchKernelGGL(k_init_level0, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted,
                        (const uint32_t*)flags, val_sorted, (const uint64_t*)f->path.as<uint64_t>(),
                        n_alive, l2r, pos_node,
                        f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint64_t>());
