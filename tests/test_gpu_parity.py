@@ -2289,6 +2289,22 @@ def test_thin_buckets_go_to_the_level_loop_and_match_the_oracle():
             assert "bucket_build" not in names and "part_hist" not in names
         oracle_check_every_leaf(f, poses, 6, grid=True)
         f.close()
+    # the same through a cloud that is read in place (uploaded from page-locked memory, adopted by the forest)
+    import octreelib_amd as oa
+    stage = oa.pinned_empty(cloud.shape)
+    stage[:] = cloud
+    dev = oa.upload_async(stage)
+    f = Forest(0, np.zeros(3), 1.0)
+    f.add_pose(dev)
+    assert f.reads_in_place(dev)
+    ctx.set_profiling(True)
+    f.subdivide(6)
+    names = set(ctx.timings())
+    ctx.set_profiling(False)
+    assert "keygen" in names and "bucket_build" not in names
+    oracle_check_every_leaf(f, [cloud], 6, grid=True)
+    f.close()
+    dev.release()
     # a dense scene afterwards: the bucket build again
     dense = np.random.default_rng(0).random((300_000, 3)) * np.array([24.0, 24.0, 24.0])
     f = Forest(0, np.zeros(3), 1.0)
