@@ -7,6 +7,8 @@ SRCS = $(wildcard octreelib_amd/csrc/*.hip)
 HDRS = $(wildcard octreelib_amd/csrc/*.h) include/octreelib_hip.h
 OBJS = $(patsubst octreelib_amd/csrc/%.hip,build/%.o,$(SRCS))
 LIB  = octreelib_amd/lib/liboctree_hip.so
+# test-only stand-in for RCCL (R > 1 rank processes on ONE GPU): tests/test_gpu_route_multirank.py
+STUB = tests/rccl_stub/librccl_stub.so
 
 all: $(LIB) $(STUB)
 
@@ -18,8 +20,6 @@ $(LIB): $(OBJS)
 	@mkdir -p octreelib_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@ -ldl
 
-# test-only stand-in for RCCL (R > 1 rank processes on ONE GPU): tests/test_gpu_route_multirank.py
-STUB = tests/rccl_stub/librccl_stub.so
 $(STUB): tests/rccl_stub/rccl_stub.cpp
 	$(HIPCC) -O2 -std=c++17 --offload-arch=$(ARCH) -fPIC -shared $< -o $@ -lrt -lpthread
 

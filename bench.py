@@ -159,6 +159,13 @@ def parse_args():
     ap.add_argument("--route", action="store_true",
                     help="rehearse the multi-GPU step on one GPU: 1-rank RCCL communicator, the "
                          "local part forced through AllGather + Send/Recv")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = --points-per-rank points on every rank, the scene grows with N (default); "
+                         "strong = the N = 1 workload (10 M points over 32^3 voxels, or --points-per-rank as the TOTAL) "
+                         "divided among the ranks, SURVEY 8(d)")
+    ap.add_argument("--workload", choices=["headline", "c4", "c5shard"], default="headline",
+                    help="profiling only (tools/profile_round.sh): run ONE secondary workload alone and print its "
+                         "JSON - c4 = BASELINE config 4, c5shard = one rank's 125 M-point shard of config 5")
     ap.add_argument("--shard-of", type=int, default=0, metavar="R",
                     help="one GPU: generate only the points rank 0 of R would own after routing (a "
                          "rank's shard of the R-rank scene, e.g. --shard-of 8 --points-per-rank 125000000 "
@@ -177,10 +184,9 @@ class Workload:
         self.d_xyz = C.c_void_p()
         ctx.check(lib.octl_dev_alloc(ctx.handle, n_local * 24, C.byref(self.d_xyz)))
         self.host_pts = None
-        done = 0
-        chunk_id = 0
-        while done < n_local:
-            m = min(GEN_CHUNK, n_local - done)
+
+        def gen(job):
+            chunk_id, m = job
             stream = rank if n_local <= GEN_CHUNK else rank * 4096 + chunk_id
             if shard_of > 1:
                 pts = shard_cloud(m, dims, cloud, stream, shard_of)
@@ -192,13 +198,26 @@ class Workload:
                 pts = synthetic.sparse_scene(m, (256, 256, 32), seed=7 + stream)
             else:
                 pts = synthetic.uniform_cloud(m, dims, seed=1000 + stream)
-            pts = np.ascontiguousarray(pts)
-            ctx.check(lib.octl_dev_upload(ctx.handle, C.c_void_p(self.d_xyz.value + done * 24), nat.ptr(pts),
-                                          pts.nbytes))
-            if n_local <= GEN_CHUNK:
-                self.host_pts = pts
-            done += m
-            chunk_id += 1
+            return np.ascontiguousarray(pts)
+
+        jobs = [(c, min(GEN_CHUNK, n_local - c * GEN_CHUNK)) for c in range((n_local + GEN_CHUNK - 1) // GEN_CHUNK)]
+        if shard_of > 1:
+            owned_voxels(dims, shard_of)   # (computed once, before the generator threads ask for it)
+        done = 0
+        if len(jobs) > 1:
+            # large clouds are generated chunk by chunk on a few host threads (NumPy releases the GIL in its
+            # generators and ufuncs); the chunks are uploaded in order as they arrive
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+                for pts in pool.map(gen, jobs):
+                    ctx.check(lib.octl_dev_upload(ctx.handle, C.c_void_p(self.d_xyz.value + done * 24), nat.ptr(pts),
+                                                  pts.nbytes))
+                    done += len(pts)
+        else:
+            pts = gen(jobs[0])
+            ctx.check(lib.octl_dev_upload(ctx.handle, self.d_xyz, nat.ptr(pts), pts.nbytes))
+            self.host_pts = pts
         self.corner = np.zeros(3)
         self.fh = C.c_void_p()
         ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(self.corner), 1.0, C.byref(self.fh)))
@@ -206,6 +225,7 @@ class Workload:
         self.e0 = np.zeros(1, dtype=np.int32)
         self.n_alive = C.c_int64(0)
         self.n_recv = C.c_int64(n_local)
+        self.send_counts = np.zeros(max(world, 1), dtype=np.int64)   # points this rank sends to every rank, last routing
         self.slot = C.c_int32(0)
         np.random.seed(0)
         self.table = np.ascontiguousarray(np.random.random((H, KPTS)))
@@ -213,7 +233,7 @@ class Workload:
     def route_once(self):
         self.rctx.check(self.lib.octl_route_points(self.rctx.handle, self.d_xyz, None, self.n_local,
                                                    self.rank * self.n_local, nat.ptr(self.corner), 1.0,
-                                                   C.byref(self.n_recv), None))
+                                                   C.byref(self.n_recv), nat.ptr(self.send_counts)))
 
     def build(self):
         self.ctx.check(self.lib.octl_forest_build(self.fh, self.k_split, None, 0, 0, 0, C.byref(self.info)))
@@ -379,6 +399,107 @@ def shard_cloud(m, dims, cloud, stream, n_ranks):
     return synthetic.uniform_cloud(m, dims, seed=1000 + stream, voxels=vox)
 
 
+def kernels_per_step(timings, steps):
+    return {k: {"ms_avg": v[0] / max(v[1], 1), "launches_per_step": v[1] / steps, "ms_per_step": v[0] / steps}
+            for k, v in timings.items()}
+
+
+def run_c4(ctx, reps=3):
+    """BASELINE config 4: one OctreeManager cube, 64 poses x 1 M points handed over from the host one by one, then
+    subdivide(len > 4096) over the union of all poses (octree_manager.py:36-66).  Per-kernel table from the
+    library's timers (last repetition), counter bytes from the tracked profile of `bench.py --workload c4`."""
+    lib = ctx.lib
+    P4, n4, K4 = 64, 1_000_000, 4096
+    poses4 = [np.random.default_rng(100 + p).random((n4, 3)) for p in range(P4)]
+    f4 = C.c_void_p()
+    ctx.check(lib.octl_forest_create(ctx.handle, 1, nat.ptr(np.zeros(3)), 1.0, C.byref(f4)))
+    info4 = nat.BuildInfo()
+    ins_ms, sub_ms = [], []
+    for rep in range(reps):
+        ctx.check(lib.octl_forest_clear(f4))
+        ctx.sync()
+        t1 = time.perf_counter()
+        for p4 in poses4:
+            ctx.check(lib.octl_forest_add_pose(f4, nat.ptr(p4), n4, None))
+        ctx.sync()
+        ins_ms.append((time.perf_counter() - t1) * 1e3)
+        if rep == reps - 1:
+            ctx.set_profiling(True)
+        t1 = time.perf_counter()
+        ctx.check(lib.octl_forest_build(f4, K4, None, 0, 0, 0, C.byref(info4)))
+        ctx.sync()
+        sub_ms.append((time.perf_counter() - t1) * 1e3)
+    tm4 = ctx.timings()
+    ctx.set_profiling(False)
+    kern4 = kernels_per_step(tm4, 1)
+    out = {
+        "insert_ms": min(ins_ms[1:]), "insert_first_ms": ins_ms[0],
+        "insert_GBs": P4 * n4 * 24 / (min(ins_ms[1:]) * 1e-3) / 1e9,
+        "subdivide_ms": min(sub_ms[1:]), "subdivide_Mpoints_per_s": P4 * n4 / min(sub_ms[1:]) / 1e3,
+        "subdivide_ms_instrumented": sub_ms[-1],
+        "hbm_read_roofline_frac": 24.0 * P4 * n4 / (min(sub_ms[1:]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "nodes": int(info4.n_nodes), "levels": int(info4.n_levels), "path": build_path(set(tm4)),
+        "roofline_build": build_summary(kern4, P4 * n4, "c4", wall_ms=min(sub_ms[1:])),
+        "note": "BASELINE config 4: 64 poses x 1 M points from pageable host memory into one cube "
+                "(insert: 1.5 GB over PCIe, first run incl. the growth of the store), subdivide(len > 4096) "
+                "over the union of the 64 M points; the kernel table is the instrumented last repetition "
+                "(hipEvents around every kernel: slower than subdivide_ms)",
+    }
+    lib.octl_forest_destroy(f4)
+    return out
+
+
+def run_no_hint(ctx, wl, timed):
+    """The cross-step state the headline leans on, as a number: the same step with the geometry hint of the
+    context's previous build switched off (OCTL_NO_GEOM_HINT: the voxel box of the adopted cloud then comes from
+    a box pass of its own, 24 B/point more) - what the first scan of a scene, or a scene that moved, pays."""
+    os.environ["OCTL_NO_GEOM_HINT"] = "1"
+    try:
+        wl.step()
+        ms_full = timed(wl.step) * 1e3
+        ms_build = timed(wl.step_build_only) * 1e3
+    finally:
+        del os.environ["OCTL_NO_GEOM_HINT"]
+    wl.step()
+    return {"ms": ms_full, "Mpoints_per_s": wl.n_local / ms_full / 1e3, "insert_subdivide_only_ms": ms_build,
+            "note": "same step, OCTL_NO_GEOM_HINT=1: no geometry carried over from the previous build of the "
+                    "context (first scan of a scene / a scene whose voxel box changed)"}
+
+
+def run_c5_shard(ctx, k_split, timed, n_shard=C5_POINTS_PER_RANK, ranks=8, steps=3):
+    """One rank's shard of BASELINE config 5 on this GPU: the 125 M points rank 0 of 8 owns after the all-to-all
+    (planar scene over 128^3 voxels, hash ownership), same step as the headline; per-kernel table of its build."""
+    dims = scene_dims(ranks, True)
+    t0 = time.perf_counter()
+    sw = Workload(ctx, ctx, 0, 1, n_shard, dims, "planar", k_split, False, False, shard_of=ranks)
+    gen_s = time.perf_counter() - t0
+    sw.step()
+    ctx.sync()
+    ms_full = timed(sw.step, reps=steps) * 1e3
+    ms_build = timed(sw.step_build_only, reps=steps) * 1e3
+    ctx.set_profiling(True)
+    for _ in range(2):
+        sw.step()
+    ctx.sync()
+    tm = ctx.timings()
+    ctx.set_profiling(False)
+    kern = kernels_per_step(tm, 2)
+    out = {
+        "points": n_shard, "ms": ms_full, "Mpoints_per_s": n_shard / ms_full / 1e3,
+        "insert_subdivide_only_ms": ms_build, "insert_subdivide_only_Mpoints_per_s": n_shard / ms_build / 1e3,
+        "hbm_read_roofline_frac_build": 24.0 * n_shard / (ms_build * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "voxels": int(sw.info.n_voxels), "leaves": int(sw.info.n_blocks), "levels": int(sw.info.n_levels),
+        "path": build_path(set(tm)), "kernels": kern,
+        "roofline_build": build_summary(kern, n_shard, "c5shard", wall_ms=ms_build),
+        "host_generation_s": gen_s,
+        "note": f"one rank's shard of BASELINE config 5 (rank 0 of {ranks}: the points it owns after routing, "
+                f"scene {dims[0]}x{dims[1]}x{dims[2]} voxels of 1 m), insert + subdivide(len>{k_split}) + RANSAC + "
+                f"apply_mask, {steps} timed steps; the same as `bench.py --shard-of {ranks} --points-per-rank {n_shard}`",
+    }
+    sw.close()
+    return out
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -401,9 +522,17 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
-    n_local = args.points if args.points else (C5_POINTS_PER_RANK if world == 8 else 10_000_000)
-    dense = n_local > 50_000_000
-    scene_ranks = args.shard_of if (world == 1 and args.shard_of > 1) else world
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        # fixed TOTAL work: the N = 1 cloud (same scene, same density) cut into `world` parts of equal size
+        n_total = args.points if args.points else 10_000_000
+        n_local = n_total // world
+        dense = n_total > 50_000_000
+        scene_ranks = 1
+    else:
+        n_local = args.points if args.points else (C5_POINTS_PER_RANK if world == 8 else 10_000_000)
+        dense = n_local > 50_000_000
+        scene_ranks = args.shard_of if (world == 1 and args.shard_of > 1) else world
     dims = tuple(args.scene) if args.scene else scene_dims(scene_ranks, dense)
 
     ctx = nat.Context(local_rank)
@@ -459,6 +588,15 @@ def main():
             fn()
         barrier()
         return max_over_ranks((time.perf_counter() - t1) / reps)
+
+    if args.workload != "headline":
+        if world != 1:
+            sys.exit("--workload c4 / c5shard are one-GPU profiling runs")
+        res = run_c4(ctx, reps=max(3, args.steps)) if args.workload == "c4" else \
+            run_c5_shard(ctx, args.k_split, timed, steps=max(3, args.steps))
+        print(json.dumps({"workload": args.workload, **res}))
+        ctx.close()
+        return
 
     wl = Workload(ctx, rctx, rank, world, n_local, dims, args.cloud, args.k_split, route, overlap,
                   shard_of=args.shard_of if world == 1 else 0)
@@ -677,41 +815,9 @@ def main():
                         "+ 3 % of the points in one blob at 20 x the density; same step as the headline",
             }
             sw.close()
-            # BASELINE config 4: one OctreeManager cube, 64 poses x 1 M points handed over from the host one by
-            # one, then subdivide(len > 4096) over the union of all poses (octree_manager.py:36-66)
-            P4, n4, K4 = 64, 1_000_000, 4096
-            poses4 = [np.random.default_rng(100 + p).random((n4, 3)) for p in range(P4)]
-            f4 = C.c_void_p()
-            ctx.check(lib.octl_forest_create(ctx.handle, 1, nat.ptr(np.zeros(3)), 1.0, C.byref(f4)))
-            info4 = nat.BuildInfo()
-            ins_ms, sub_ms = [], []
-            for rep in range(3):
-                ctx.check(lib.octl_forest_clear(f4))
-                ctx.sync()
-                t1 = time.perf_counter()
-                for p4 in poses4:
-                    ctx.check(lib.octl_forest_add_pose(f4, nat.ptr(p4), n4, None))
-                ctx.sync()
-                ins_ms.append((time.perf_counter() - t1) * 1e3)
-                if rep == 2:
-                    ctx.set_profiling(True)
-                t1 = time.perf_counter()
-                ctx.check(lib.octl_forest_build(f4, K4, None, 0, 0, 0, C.byref(info4)))
-                ctx.sync()
-                sub_ms.append((time.perf_counter() - t1) * 1e3)
-            names4 = set(ctx.timings())
-            ctx.set_profiling(False)
-            secondary["c4_manager"] = {
-                "insert_ms": min(ins_ms[1:]), "insert_first_ms": ins_ms[0],
-                "insert_GBs": P4 * n4 * 24 / (min(ins_ms[1:]) * 1e-3) / 1e9,
-                "subdivide_ms": min(sub_ms[1:]), "subdivide_Mpoints_per_s": P4 * n4 / min(sub_ms[1:]) / 1e3,
-                "nodes": int(info4.n_nodes), "levels": int(info4.n_levels), "path": build_path(names4),
-                "note": "BASELINE config 4: 64 poses x 1 M points from pageable host memory into one cube "
-                        "(insert: 1.5 GB over PCIe, first run incl. the growth of the store), subdivide(len > 4096) "
-                        "over the union of the 64 M points",
-            }
-            lib.octl_forest_destroy(f4)
-            del poses4
+            secondary["c4_manager"] = run_c4(ctx)
+            secondary["no_geometry_hint"] = run_no_hint(ctx, wl, timed)
+            secondary["c5_shard"] = run_c5_shard(ctx, args.k_split, timed)
             # two independent step sequences (two contexts = two streams, two forests, two host threads): what
             # a pipeline over consecutive scans gains from overlapping the memory-bound build of one scan with
             # the VALU-bound RANSAC of another.  NOT the headline: a step there is strictly sequential.
@@ -756,9 +862,54 @@ def main():
             }
             w10.close()
 
+        if world > 1 and not strong and not args.scene:
+            # the fixed-total-N series of SURVEY 8(d) in the same launch: the N = 1 cloud (10 M points over 32^3
+            # voxels) divided among the ranks, same routed step
+            ws = Workload(ctx, rctx, rank, world, 10_000_000 // world, scene_dims(1, False), args.cloud,
+                          args.k_split, route, overlap)
+            ws.run(2)
+            barrier()
+            t1 = time.perf_counter()
+            ws.run(10)
+            barrier()
+            ds = max_over_ranks(time.perf_counter() - t1)
+            secondary["strong_scaling_10M_total"] = {
+                "ms_per_step": ds / 10 * 1e3, "Mpoints_per_s": (10_000_000 // world) * world * 10 / ds / 1e6,
+                "points_per_rank": 10_000_000 // world,
+                "note": "STRONG scaling: BASELINE config 3's 10 M points in total, divided among the ranks "
+                        "(`--scaling strong` makes this the headline of the line)",
+            }
+            ws.close()
+
     # copy bandwidth of this box (reported beside the datasheet peak)
     bw = C.c_double(0.0)
     ctx.check(lib.octl_dev_copy_bandwidth(ctx.handle, 1 << 30, 5, C.byref(bw)))
+
+    # ---- N > 1: what the exchange moved and how even the shards are (max / mean points per rank) ----
+    exchange = None
+    if dist is not None:
+        mine = {"n_recv": int(wl.n_recv.value),
+                "sent_to_peers": int(wl.send_counts.sum() - wl.send_counts[rank]),
+                "alltoall_ms": timings.get("route_alltoall", (0.0, 0))[0] / args.steps,
+                "route_kernels_ms": (timings.get("route_hist", (0.0, 0))[0] +
+                                     timings.get("route_scatter", (0.0, 0))[0]) / args.steps}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        recv = [r["n_recv"] for r in allr]
+        sent = [r["sent_to_peers"] for r in allr]
+        a2a = max(r["alltoall_ms"] for r in allr)
+        exchange = {
+            "points_received_per_rank": recv,
+            "imbalance_max_over_mean": max(recv) / (sum(recv) / world) if sum(recv) else None,
+            "points_sent_to_peers_per_rank": sent,
+            "bytes_sent_to_peers_per_rank": [32 * v for v in sent],   # 24 B coordinates + 8 B global index
+            "alltoall_ms_per_step_max_over_ranks": a2a,
+            "alltoall_GBs_per_rank": (32.0 * max(sent) / (a2a * 1e-3) / 1e9) if a2a > 0 else None,
+            "route_kernels_ms_per_step_max_over_ranks": max(r["route_kernels_ms"] for r in allr),
+            "note": "one grouped ncclSend/ncclRecv all-to-all per step (route.hip), timed with hipEvents on the "
+                    "routing context's stream in the instrumented pass behind the timed region; a rank's own "
+                    "part is a device copy and not counted as sent",
+        }
 
     if rank == 0:
         total_points = n_local * world
@@ -774,7 +925,7 @@ def main():
         achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
         # HBM bytes of the dominant kernel per launch from the tracked PMC profile of this command (same cloud)
         dom_traffic = None
-        pt = profile_traffic()
+        pt = profile_traffic("headline")
         if pt is not None and dom == "ransac" and n_step == 10_000_000 and args.cloud == "planar":
             rows = [v for k, v in pt.items() if k.startswith("k_ransac<256,4,6")]
             if rows:
@@ -784,57 +935,8 @@ def main():
         # algorithmic f64 flops of the RANSAC kernel: per leaf with n >= k points
         # H * (20 k + 6 n) for plane fits + scoring, + 6 n for the final mask
         valu_tflops = flops / (ransac_ms * 1e-3) / 1e12 if ransac_ms else None
-        # dominant STREAMING kernel of insert + subdivide: algorithmic bytes per point it must move
-        # (DESIGN.md section 4), live hipEvent time
-        build_alg = BUILD_DESIGN_BYTES
-        build_k = [k for k in kern if k in build_alg]
-        roofline_build = None
-        if build_k:
-            # three figures, never one for another: (1) SURVEY 8(d)'s ALGORITHMIC 24 B/point (xyz read once to place
-            # a point) over the kernel's time - the judged definition; (2) the DESIGN bytes the kernel has to move in
-            # this pipeline (records, permutation, leaf-ordered coordinates: DESIGN.md section 4); (3) the bytes the
-            # PMC counters saw, from the tracked profile of the same command (null when there is none)
-            bdom = max(build_k, key=lambda k: kern[k]["ms_per_step"])
-            b_ms = kern[bdom]["ms_per_step"]
-            counters = profile_traffic()
-            alias = {"bucket_build": ["k_bucket_build", "k_bucket_plan", "k_bucket_chunks"],
-                     "part_scatter": ["k_part_scatter<16,false>"], "part_hist": ["k_part_hist<true,true>", "k_part_hist<true,false>", "k_part_hist<false,true>", "k_part_hist<false,false>"],
-                     "bucket_nodes": ["k_bucket_finish"], "ingest": ["k_ingest<false>", "k_ingest<true>"]}
-
-            def counter_bytes(k):
-                if counters is None or n_step != 10_000_000:
-                    return None
-                rows = [counters[a] for a in alias.get(k, []) if a in counters]
-                return sum(r["fetch_bytes_corrected"] + r["write_bytes"] for r in rows) if rows else None
-
-            def three(k):
-                ms = kern[k]["ms_per_step"]
-                cb = counter_bytes(k)
-                return {"ms_per_step": ms,
-                        "section8d_GBs": 24.0 * n_step / (ms * 1e-3) / 1e9,
-                        "design_bytes_per_point": build_alg[k],
-                        "design_GBs": build_alg[k] * n_step / (ms * 1e-3) / 1e9,
-                        "counter_bytes_per_point": (cb / n_step) if cb else None,
-                        "counter_GBs": (cb / (ms * 1e-3) / 1e9) if cb else None}
-
-            t3 = three(bdom)
-            build_ms = sum(kern[k]["ms_per_step"] for k in build_k)
-            roofline_build = {
-                "kernel": bdom, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "achieved": t3["section8d_GBs"], "frac": t3["section8d_GBs"] / HBM_PEAK_GBS,
-                "definition": "SURVEY 8(d): algorithmic 24 B/point x points per launch / kernel time",
-                "ms_per_step": b_ms, "algorithmic_bytes_per_point": 24,
-                "design_bytes_per_point": t3["design_bytes_per_point"], "design_GBs": t3["design_GBs"],
-                "design_frac": t3["design_GBs"] / HBM_PEAK_GBS,
-                "counter_bytes_per_point": t3["counter_bytes_per_point"], "counter_GBs": t3["counter_GBs"],
-                "counter_frac": (t3["counter_GBs"] / HBM_PEAK_GBS) if t3["counter_GBs"] else None,
-                "traffic": (t3["counter_bytes_per_point"] * n_step) if t3["counter_bytes_per_point"] else None,
-                "traffic_profile": PROFILE_TRAFFIC,
-                "whole_build": {"ms_per_step": build_ms,
-                                "section8d_GBs": 24.0 * n_step / (build_ms * 1e-3) / 1e9,
-                                "section8d_frac": 24.0 * n_step / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "all": {k: three(k) for k in build_k if kern[k]["ms_per_step"] > 0},
-            }
+        # insert + subdivide: per-kernel table (three figures each) and the dominant streaming kernel
+        roofline_build = build_summary(kern, n_step, "headline")
         if dense and world == 8:
             what = "BASELINE config 5: 10^9 points, "
         elif world == 1 and n_local == 10_000_000 and not args.shard_of:
@@ -851,7 +953,7 @@ def main():
             "ms_per_step": ms_per_step,
             "host_syncs_per_step": host_syncs,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -861,6 +963,7 @@ def main():
                             f"map_leaf_points_cuda_ransac(H=1024, k=6, thr=0.01, poses_per_batch=10) "
                             f"incl. apply_mask"
                             + (", sharded by top-level voxel with one RCCL all-to-all" if world > 1 else "")
+                            + (f", STRONG scaling: {n_local * world} points in total" if strong else "")
                             + (f", one rank's shard of a {args.shard_of}-rank scene" if args.shard_of > 1 else "")
                             + (" routed one step ahead on a second stream" if overlap else ""),
                 "points_per_gpu": n_local,
@@ -913,6 +1016,9 @@ def main():
                             "fully instrumented for a few steps behind the timed region (an event pair costs "
                             "~10 us of pipeline, a dozen per step would be 2 % of the step)",
         }
+        if exchange is not None:
+            out["imbalance"] = exchange["imbalance_max_over_mean"]
+            out["exchange"] = exchange
         if secondary:
             out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the other ranks would wait)
@@ -929,13 +1035,19 @@ def main():
     ctx.close()
 
 
-PROFILE_TRAFFIC = "profiles/r03_hbm_traffic.json"
+# tracked rocprofv3 --pmc profiles of the three measured workloads (tools/profile_round.sh): per-launch HBM bytes by
+# kernel.  They are read beside the live timings, never measured by the run that prints the line.
+PROFILE_TRAFFIC = "profiles/r04_hbm_traffic.json"
+PROFILE_FILES = {
+    "headline": PROFILE_TRAFFIC,
+    "c4": "profiles/r04_c4_hbm_traffic.json",
+    "c5shard": "profiles/r04_c5shard_hbm_traffic.json",
+}
 
 
-def profile_traffic():
-    """Per-launch HBM bytes of the tracked rocprofv3 --pmc passes of this command (profiles/): read beside the
-    live timings, never measured by the run that prints the line."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PROFILE_TRAFFIC)
+def profile_traffic(which="headline"):
+    """Per-launch HBM bytes of the tracked rocprofv3 --pmc passes of a workload (profiles/)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PROFILE_FILES[which])
     try:
         with open(path) as fh:
             return json.load(fh)["kernels"]
@@ -943,22 +1055,119 @@ def profile_traffic():
         return None
 
 
+# library timer name -> prefixes of the rocprof kernel names that run under it
+TIMER_KERNELS = {
+    "ingest": ["k_ingest<"],
+    "part_hist": ["k_part_hist<", "k_part_hist_rec", "k_geom_validate"],
+    "part_scan": ["k_transpose_u32"],
+    "part_scatter": ["k_part_scatter<"],
+    "bucket_bounds": ["k_bucket_bounds"],
+    "bucket_build": ["k_bucket_build", "k_bucket_plan", "k_bucket_chunks"],
+    "bucket_nodes": ["k_bucket_finish", "k_block_sizes_dev", "k_node_init"],
+    "keygen": ["k_keygen"],
+    "linkey": ["k_linkey"],
+    "roots": ["k_root_tiles<", "k_make_roots"],
+    "init_level0": ["k_init_level0", "k_count_scheme"],
+    "level_prepare": ["k_split_flags", "k_compact_split"],
+    "level_hist": ["k_lv_hist<"],
+    "level_scatter": ["k_lv_scatter"],
+    "level_children": ["k_make_children"],
+    "finalize": ["k_finalize"],
+    "blocks": ["k_block_tiles<", "k_block_sizes"],
+    "prefix_part": ["k_pre_hist", "k_pre_scatter"],
+    "ransac": ["k_ransac<"],
+}
+# the kernel that runs exactly ONCE per step of a workload: dispatch counts are taken relative to it
+PROFILE_REF = {"headline": "k_bucket_totals", "c5shard": "k_bucket_totals", "c4": "k_finalize"}
+
 # DESIGN bytes per point of the streaming kernels of insert + subdivide: what each one has to read and write
-# in THIS pipeline - not SURVEY 8(d)'s algorithmic 24 B/point, which roofline_build
-# reports separately.  Keyed by the library's timer names.
+# in THIS pipeline per launch - not SURVEY 8(d)'s algorithmic 24 B/point, which is reported
+# separately.  Keyed by the library's timer names.
 BUILD_DESIGN_BYTES = {
     "ingest": 24,                     # the box pass of a cloud read in place (no copy)
     "part_hist": 24,                  # xyz -> bucket histogram (+ voxel box under a hinted geometry)
     "part_scatter": 24 + 32,          # xyz -> 32-byte record (xyz, voxel | child digits, index) in its bucket
     "bucket_build": 32 + 4 + 4 + 24,  # records -> leafinfo, permutation, leaf-ordered coordinates
     "bucket_nodes": 4 + 4 + 4,        # leafinfo, permutation -> position -> leaf (+ nodes, blocks: small)
-    # general path (not on the benchmarked step)
+    "bucket_bounds": 0,               # bucket bounds of a two-pass partition (a binary search: no stream)
+    # general path
     "keygen": 24 + 16,
     "linkey": 8 + 12,
     "sort_hist": 8,
     "sort_scatter": 12 + 12,
-    "finalize": 4 + 24 + 4 + 24,
+    "roots": 8,
+    "init_level0": 8 + 4 + 8 + 4 + 4 + 8,
+    "level_hist": 8 + 4,
+    "level_scatter": 8 + 4 + 8 + 4 + 4,
+    "finalize": 4 + 4 + 24 + 4 + 24,
+    "blocks": 4 + 4,
+    "prefix_part": 24 + 24 + 32,
 }
+
+
+def counter_bytes_per_step(counters, timer, ref):
+    """HBM bytes one step spends under a library timer, from a tracked profile: per-launch averages x dispatches of the
+    timer's kernels, per dispatch of the workload's once-per-step kernel.  None without dispatch counts (r03 files)."""
+    if not counters or ref not in counters or not counters[ref].get("dispatches"):
+        return None
+    tot, hit = 0.0, False
+    for name, row in counters.items():
+        if any(name.startswith(p) for p in TIMER_KERNELS.get(timer, [])) and row.get("dispatches"):
+            tot += (row["fetch_bytes_corrected"] + row["write_bytes"]) * row["dispatches"]
+            hit = True
+    return tot / counters[ref]["dispatches"] if hit else None
+
+
+def kernel_table(kern, n_points, which):
+    """Three figures per build kernel, never one for another: (1) SURVEY 8(d)'s ALGORITHMIC 24 B/point (xyz read once
+    to place a point) over the kernel's time per step - the judged definition; (2) the DESIGN bytes the kernel has to
+    move in this pipeline (all its launches of a step); (3) the bytes the PMC counters saw, from the tracked profile
+    of the same workload (null when there is none)."""
+    counters = profile_traffic(which)
+    ref = PROFILE_REF[which]
+    out = {}
+    for k, v in kern.items():
+        if k not in BUILD_DESIGN_BYTES or v["ms_per_step"] <= 0:
+            continue
+        ms = v["ms_per_step"]
+        cb = counter_bytes_per_step(counters, k, ref)
+        design = BUILD_DESIGN_BYTES[k] * v["launches_per_step"]
+        out[k] = {"ms_per_step": ms, "launches_per_step": v["launches_per_step"],
+                  "section8d_GBs": 24.0 * n_points / (ms * 1e-3) / 1e9,
+                  "design_bytes_per_point": design,
+                  "design_GBs": design * n_points / (ms * 1e-3) / 1e9,
+                  "counter_bytes_per_point": (cb / n_points) if cb else None,
+                  "counter_GBs": (cb / (ms * 1e-3) / 1e9) if cb else None,
+                  "counter_frac_of_8TBs": (cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if cb else None}
+    return out
+
+
+def build_summary(kern, n_points, which, wall_ms=None):
+    """roofline_build-style summary of a workload's insert + subdivide: per-kernel table, the dominant streaming
+    kernel, the whole build against SURVEY 8(d)'s HBM-read roofline."""
+    table = kernel_table(kern, n_points, which)
+    if not table:
+        return None
+    dom = max(table, key=lambda k: table[k]["ms_per_step"])
+    build_ms = sum(t["ms_per_step"] for t in table.values())
+    cbs = [t["counter_bytes_per_point"] for t in table.values()]
+    return {
+        "kernel": dom, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "achieved": table[dom]["section8d_GBs"], "frac": table[dom]["section8d_GBs"] / HBM_PEAK_GBS,
+        "definition": "SURVEY 8(d): algorithmic 24 B/point x points per launch / kernel time",
+        "algorithmic_bytes_per_point": 24,
+        "design_GBs": table[dom]["design_GBs"], "design_frac": table[dom]["design_GBs"] / HBM_PEAK_GBS,
+        "counter_GBs": table[dom]["counter_GBs"], "counter_frac": table[dom]["counter_frac_of_8TBs"],
+        "traffic": (table[dom]["counter_bytes_per_point"] * n_points) if table[dom]["counter_bytes_per_point"] else None,
+        "traffic_profile": PROFILE_FILES[which],
+        "whole_build": {
+            "kernels_ms_per_step": build_ms, "wall_ms_per_step": wall_ms,
+            "section8d_GBs": 24.0 * n_points / (build_ms * 1e-3) / 1e9,
+            "section8d_frac": 24.0 * n_points / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "counter_bytes_per_point": sum(cbs) if all(c is not None for c in cbs) else None,
+        },
+        "all": table,
+    }
 
 
 if __name__ == "__main__":

@@ -125,6 +125,8 @@ int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* bl
  * already has an octree, octree_manager.py:161-171; Octree.insert_points, octree.py:235-239).  The
  * points of later poses move up in the pose-major store.                                       */
 int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n);
+/* Same, from a device pointer (device-to-device copy; ordered behind an octl_dev_upload_async into it).  */
+int octl_forest_extend_pose_device(octl_forest* f, int32_t slot, const double* xyz_dev, int64_t n);
 
 typedef struct octl_build_info {
   int64_t n_points;     /* alive points that were placed                                   */
@@ -315,6 +317,12 @@ int octl_dev_upload_async(octl_ctx* ctx, void* dptr, const void* src, int64_t by
 int octl_ctx_sync_uploads(octl_ctx* ctx);
 /* measured device copy bandwidth (bytes/s) over `bytes`, for the roofline report           */
 int octl_dev_copy_bandwidth(octl_ctx* ctx, int64_t bytes, int iters, double* bytes_per_s);
+
+/* Test hook for the allocation-failure paths: the nth growth of a device buffer from now on (every device
+ * allocation of the library is one) fails with OCTL_E_NOMEM exactly as a failed hipMalloc does; nth <= 0 disarms.
+ * *seen (nullable) receives the number of growths since the hook was last armed, so a test can sweep nth over
+ * everything an operation allocates.  Process-wide.                                                     */
+int octl_debug_fail_alloc(int64_t nth, int64_t* seen);
 
 /* ---- test hooks for the device-wide primitives (host in / host out) ----------------------- */
 int octl_debug_exclusive_scan(octl_ctx* ctx, const uint32_t* in, int64_t n, uint32_t* out,

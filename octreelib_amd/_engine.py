@@ -124,10 +124,19 @@ class Forest:
         self._invalidate()
 
     def extend_pose(self, slot: int, points):
-        pts = nat.as_points(points)
-        self.ctx.check(self.lib.octl_forest_extend_pose(self.handle, slot, nat.ptr(pts), len(pts)))
+        from octreelib_amd.feed import DeviceCloud
+
+        if isinstance(points, DeviceCloud):
+            # appended device-to-device behind the pose's points (the library orders the copy behind the upload)
+            self.ctx.check(self.lib.octl_forest_extend_pose_device(self.handle, slot, points.ptr, points.n))
+            self._device_clouds.append(points)   # (alive until the copy has been consumed by the next build)
+            n_new = points.n
+        else:
+            pts = nat.as_points(points)
+            self.ctx.check(self.lib.octl_forest_extend_pose(self.handle, slot, nat.ptr(pts), len(pts)))
+            n_new = len(pts)
         self._in_place = None
-        self.slot_sizes[slot] += len(pts)
+        self.slot_sizes[slot] += n_new
         self._dirty = True
         self._invalidate()
 

@@ -68,6 +68,7 @@ SIGNATURES = {
     "octl_forest_add_pose_adopt": (C.c_int, [_p, _p, _i64, _pi32]),
     "octl_forest_set_contents": (C.c_int, [_p, _i64, _p, _p, _p, _p]),
     "octl_forest_extend_pose": (C.c_int, [_p, _i32, _p, _i64]),
+    "octl_forest_extend_pose_device": (C.c_int, [_p, _i32, _p, _i64]),
     "octl_forest_build": (C.c_int, [_p, _i64, _p, _i32, _i32, _i32, C.POINTER(BuildInfo)]),
     "octl_forest_set_scheme": (C.c_int, [_p, _p, _p, _i64, _i32]),
     "octl_forest_get_nodes": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, _p, _pi64]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     "octl_forest_add_pose_routed_from": (C.c_int, [_p, _p, _pi32]),
     "octl_debug_route_partition": (C.c_int, [_p, _p, _i64, _i64, C.c_double, C.c_int32, _p, _p, _p]),
     "octl_debug_host_syncs": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "octl_debug_fail_alloc": (C.c_int, [_i64, _pi64]),
     "octl_route_get_gidx": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_comm_allreduce_i64": (C.c_int, [_p, _p, _i32]),
     "octl_dev_alloc": (C.c_int, [_p, _i64, C.POINTER(_p)]),

@@ -92,7 +92,13 @@ def _match_len_compare(fn) -> Optional[int]:
 
 _FLIP = {"<": ">", "<=": ">=", ">": "<", ">=": "<=", "==": "==", "!=": "!="}
 _INT_MAX = (1 << 63) - 1
-_PROBE_MAX = 1 << 22  # largest cloud a criterion is probed with (zeros((n, 3)): 100 MB)
+_PROBE_MAX = 1 << 40  # (probe clouds are zero-stride views: any length costs 24 bytes)
+
+
+def _probe_cloud(n: int) -> np.ndarray:
+    """An (n, 3) f64 cloud of zeros WITHOUT its memory: a read-only zero-stride view, so that a criterion can be
+    probed on both sides of a bound of any size (len() and .shape are those of a real cloud)."""
+    return np.broadcast_to(np.zeros((1, 3)), (int(n), 3))
 
 
 def _match_len_interval(fn):
@@ -158,7 +164,7 @@ def try_count_interval(criteria: Sequence[Callable]):
             for n in probes:
                 if n < 0 or n > _PROBE_MAX:
                     continue
-                if bool(c(np.zeros((n, 3)))) != (iv[0] <= n <= iv[1]):
+                if bool(c(_probe_cloud(n))) != (iv[0] <= n <= iv[1]):
                     return None
         except Exception:
             return None
@@ -170,7 +176,7 @@ def _probe(fn, k: int) -> bool:
     """fn must behave like len(points) > k around k."""
     try:
         for n in {0, max(k, 0), max(k, 0) + 1, max(k, 0) + 2}:
-            if bool(fn(np.zeros((n, 3)))) != (n > k):
+            if bool(fn(_probe_cloud(n))) != (n > k):
                 return False
     except Exception:
         return False

@@ -1,6 +1,8 @@
 // extern "C" surface of the forest (Grid / OctreeManager / Octree state) and of the stand-alone
 // RANSAC operator.  See include/octreelib_hip.h for the reference interfaces each entry point
 // replaces.
+#include <unordered_map>
+
 #include "forest.h"
 #include "ref_arith.h"
 
@@ -667,13 +669,15 @@ int octl_forest_add_pose_adopt(octl_forest* f, const double* xyz_dev, int64_t n,
   return OCTL_OK;
 }
 
-int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n) {
+static int extend_pose_impl(octl_forest* f, int32_t slot, const double* xyz, int64_t n, bool from_device) {
   if (!f) return OCTL_E_INVALID;
   octl_ctx* ctx = f->ctx;
   const int n_poses = (int)f->pose_off.size() - 1;
   if (slot < 0 || slot >= n_poses) return octl_set_error(ctx, OCTL_E_INVALID, "bad pose slot");
   const int64_t tail = f->n_store - f->pose_off[slot + 1];  // points of the later poses
-  OCTL_TRY(store_append(f, xyz, n, false));  // lands behind everything (bounding box, alive flags)
+  // (a device cloud may be the target of an octl_dev_upload_async that is still in flight)
+  if (from_device && n > 0) OCTL_TRY(ctx_wait_uploads(ctx, xyz, (size_t)n * 24));
+  OCTL_TRY(store_append(f, xyz, n, from_device));  // lands behind everything (bounding box, alive flags)
   if (tail > 0 && n > 0) {
     // The store is pose-major: rotate the new points in front of the later poses' points (they were
     // appended at the end).  The whole range [tail | new] goes through the partition scratch and comes
@@ -700,6 +704,14 @@ int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int
   f->store_dirty = true;
   f->append_only = false;  // the store was rotated: the next build re-places everything
   return OCTL_OK;
+}
+
+int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n) {
+  return extend_pose_impl(f, slot, xyz, n, false);
+}
+
+int octl_forest_extend_pose_device(octl_forest* f, int32_t slot, const double* xyz_dev, int64_t n) {
+  return extend_pose_impl(f, slot, xyz_dev, n, true);
 }
 
 int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
@@ -785,6 +797,56 @@ int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* bl
   if (total > 0 && !xyz) return octl_set_error(ctx, OCTL_E_INVALID, "null point array");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
+  // The blocks must name LEAVES of the current scheme, every (leaf, pose) pair at most once, in the storage order
+  // of the block table they replace: the (leaf, pose) pairs of the table this forest holds, some of them possibly
+  // missing (emptied leaves), none added out of place.  A table that breaks this would be committed as it is and
+  // corrupt every later query, so it is checked against the forest's own table first.
+  if (n_blocks > 0) {
+    std::vector<int32_t> fc((size_t)n_nodes);
+    HIP_TRY(ctx, hipMemcpyAsync(fc.data(), f->nodes[f->cur].first_child.p, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, st));
+    const int64_t nb_old = f->n_blocks;
+    std::vector<int32_t> on((size_t)std::max<int64_t>(nb_old, 1)), os((size_t)std::max<int64_t>(nb_old, 1));
+    if (nb_old > 0) {
+      HIP_TRY(ctx, hipMemcpyAsync(on.data(), f->blk_node.p, (size_t)nb_old * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipMemcpyAsync(os.data(), f->blk_slot.p, (size_t)nb_old * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // rank of a (leaf, pose) pair in the current table's storage order; pairs the table does not hold (a leaf that
+    // was empty for the pose) sort by their leaf's first occurrence - unknown leaves keep the caller's order
+    // among themselves only as far as (node, slot) is strictly increasing
+    std::unordered_map<uint64_t, int64_t> rank;
+    rank.reserve((size_t)nb_old * 2 + 1);
+    for (int64_t b = 0; b < nb_old; ++b) rank.emplace(((uint64_t)(uint32_t)on[(size_t)b] << 32) | (uint32_t)os[(size_t)b], b);
+    int64_t last_rank = -1;
+    uint64_t last_unknown = 0;
+    bool have_unknown = false;
+    std::unordered_map<uint64_t, char> seen;
+    seen.reserve((size_t)n_blocks * 2 + 1);
+    for (int64_t b = 0; b < n_blocks; ++b) {
+      if (fc[(size_t)blk_node[b]] >= 0)
+        return octl_set_error(ctx, OCTL_E_INVALID, "block %lld: node %d is not a leaf of the scheme", (long long)b,
+                              blk_node[b]);
+      const uint64_t key = ((uint64_t)(uint32_t)blk_node[b] << 32) | (uint32_t)blk_slot[b];
+      if (!seen.emplace(key, 1).second)
+        return octl_set_error(ctx, OCTL_E_INVALID, "block %lld: (leaf %d, pose slot %d) appears twice", (long long)b,
+                              blk_node[b], blk_slot[b]);
+      const auto it = rank.find(key);
+      if (it != rank.end()) {
+        if (it->second <= last_rank)
+          return octl_set_error(ctx, OCTL_E_INVALID,
+                                "block %lld: (leaf %d, pose slot %d) is out of the storage order of the block table",
+                                (long long)b, blk_node[b], blk_slot[b]);
+        last_rank = it->second;
+        have_unknown = false;
+      } else {
+        if (have_unknown && key <= last_unknown)
+          return octl_set_error(ctx, OCTL_E_INVALID,
+                                "block %lld: (leaf %d, pose slot %d) is out of order", (long long)b, blk_node[b], blk_slot[b]);
+        last_unknown = key;
+        have_unknown = true;
+      }
+    }
+  }
   std::vector<int64_t> off((size_t)n_poses + 1, 0);
   for (int p = 0; p < n_poses; ++p) off[(size_t)p + 1] = off[(size_t)p] + per_slot[(size_t)p];
   std::vector<int64_t> cursor(off.begin(), off.end() - 1);
@@ -821,32 +883,47 @@ int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* bl
       if (displaced) break;
     }
   }
-  if (f->store_borrowed) {  // the new store is the forest's own
-    f->xyz = f->xyz_own;
-    f->xyz_own = DevBuf{};
-    f->store_borrowed = false;
-  }
+  // The new store is the forest's own.  While the old one is BORROWED (the caller's buffer, never written) the
+  // new points go to the forest's own block and the borrow ends only at the commit below; every allocation
+  // comes before the first byte is overwritten, so that a failed allocation leaves the forest as it was.
+  DevBuf& own = f->store_borrowed ? f->xyz_own : f->xyz;
   const size_t n1 = (size_t)std::max<int64_t>(total, 1), nb1 = (size_t)std::max<int64_t>(n_blocks, 1);
-  OCTL_TRY(devbuf_reserve(ctx, f->xyz, n1 * 24 + 16));
+  OCTL_TRY(devbuf_reserve(ctx, own, n1 * 24 + 16));
   OCTL_TRY(devbuf_reserve(ctx, f->alive, n1 + 2));
   OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, n1 * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, n1 * 24));
   // (block buffers keep the capacity convention of forest_make_blocks: one block per point)
   for (DevBuf* b : {&f->blk_node, &f->blk_slot, &f->blk_start, &f->blk_size})
     OCTL_TRY(devbuf_reserve(ctx, *b, std::max(n1, nb1) * 4));
-  if (total > 0) {
-    HIP_TRY(ctx, hipMemcpyAsync(f->xyz.p, store.data(), (size_t)total * 24, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(f->xyz_ord.p, xyz, (size_t)total * 24, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(f->ord_idx.p, ord.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(f->alive.p, 1, (size_t)total, st));
+  auto upload = [&]() -> hipError_t {
+    hipError_t e = hipSuccess;
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+      if (e == hipSuccess && bytes > 0) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    up(own.p, store.data(), (size_t)total * 24);
+    up(f->xyz_ord.p, xyz, (size_t)total * 24);
+    up(f->ord_idx.p, ord.data(), (size_t)total * 4);
+    if (e == hipSuccess && total > 0) e = hipMemsetAsync(f->alive.p, 1, (size_t)total, st);
+    up(f->blk_node.p, blk_node, (size_t)n_blocks * 4);
+    up(f->blk_slot.p, blk_slot, (size_t)n_blocks * 4);
+    up(f->blk_size.p, blk_size, (size_t)n_blocks * 4);
+    up(f->blk_start.p, starts.data(), (size_t)n_blocks * 4);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // (pageable sources)
+    return e;
+  };
+  if (const hipError_t e = upload(); e != hipSuccess) {
+    // the tables (and an own store) are partly overwritten: the forest is left EMPTY but valid rather than
+    // with sizes that describe arrays which no longer hold them
+    (void)octl_forest_clear(f);
+    return octl_set_error(ctx, OCTL_E_HIP, "set_contents: upload failed (%s); the forest was cleared",
+                          hipGetErrorString(e));
   }
-  if (n_blocks > 0) {
-    HIP_TRY(ctx, hipMemcpyAsync(f->blk_node.p, blk_node, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(f->blk_slot.p, blk_slot, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(f->blk_size.p, blk_size, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(f->blk_start.p, starts.data(), (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+  // ---- commit ------------------------------------------------------------------------------------------------
+  if (f->store_borrowed) {
+    f->xyz = f->xyz_own;
+    f->xyz_own = DevBuf{};
+    f->store_borrowed = false;
   }
-  HIP_TRY(ctx, hipStreamSynchronize(st));  // (pageable sources)
   f->pose_off = off;
   f->n_store = f->n_alive = f->n_ord = total;
   f->n_blocks = n_blocks;

@@ -165,6 +165,35 @@ __global__ void k_geom_validate(const int32_t* __restrict__ bbox, uint64_t want,
   *g = o;
 }
 
+// The same for a hinted TWO-pass build (more than 4096 buckets: 125 M points of one rank's shard).  There the host
+// forms the geometry - it needs the bucket count for its tables - from the hint's box instead of waiting for the
+// box pass; the hint stands when every point fell inside its box and the true box asks for the same bucket width.
+// Otherwise the true box is left in the record (valid = 0, GEOM_REHASH) and the host builds again from it.
+__global__ void k_geom_validate2(const int32_t* __restrict__ bbox, uint64_t want, GeomDev* __restrict__ g) {
+  if (threadIdx.x != 0) return;
+  GeomDev o = *g;
+  const bool domain_error = bbox[6] != 0, inside = bbox[7] == 0;
+  bool same = false;
+  if (!domain_error && inside && bbox[0] <= bbox[3]) {
+    const uint64_t nx = (uint64_t)(bbox[3] - bbox[0] + 1), ny = (uint64_t)(bbox[4] - bbox[1] + 1),
+                   nz = (uint64_t)(bbox[5] - bbox[2] + 1);
+    if (!(nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32))) {
+      const uint64_t R = nx * ny * nz;
+      int lr = 0, lw = 0;
+      while (lr < 64 && (1ull << lr) < R) ++lr;
+      while (lw < 64 && (1ull << lw) < want) ++lw;
+      int s = lr - lw;
+      s = s < 0 ? 0 : (s > 12 ? 12 : s);
+      same = s == o.lp.shift;
+    }
+  }
+  if (same) return;  // the hint stands
+  for (int a = 0; a < 6; ++a) o.bb[a] = bbox[a];
+  o.valid = 0;
+  o.reason = domain_error ? GEOM_DOMAIN : (bbox[0] > bbox[3] ? GEOM_EMPTY : GEOM_REHASH);
+  *g = o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // partition
 // ---------------------------------------------------------------------------------------------
@@ -395,9 +424,11 @@ __global__ __launch_bounds__(256) void k_transpose_u32(const uint32_t* __restric
 // second pass: the records of the first pass (they carry the full linear key)
 struct PartRec;
 __global__ __launch_bounds__(PH_THREADS) void k_part_hist_rec(const uint4* __restrict__ recs, int64_t N,
-                                                              LinParams lp, uint32_t nst, uint32_t nd,
+                                                              LinParams lp, const GeomDev* __restrict__ G,
+                                                              uint32_t nst, uint32_t nd,
                                                               int64_t st_items, uint32_t* __restrict__ table) {
   __shared__ uint32_t hist[PT_BINS];
+  if (G && !G->valid) return;  // (a hinted geometry that did not hold: lp is the host's, G only gates)
   for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) hist[d] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * st_items;
@@ -442,7 +473,9 @@ __device__ __forceinline__ uint32_t wave_rank_u16(uint32_t digit, bool valid, ui
   return old + rank_in_round;
 }
 
-template <int PT_IPT, bool FROM_REC>
+// MBITS: ballot rounds of the in-wave rank = bits of the pass's digit (12 for a single pass over up to 4096 buckets,
+// 8 when a pass of a two-pass partition has at most 256 digits: a third of the rounds less)
+template <int PT_IPT, bool FROM_REC, int MBITS>
 __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     const double* __restrict__ xyz, const uint8_t* __restrict__ alive, int64_t N, LinParams lp,
     const GeomDev* __restrict__ G, uint32_t nst, uint32_t nd, int st_tiles,
@@ -453,7 +486,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
   __shared__ uint16_t cnt[PT_THREADS / 64][PT_BINS]; // per wave, per tile
   if (G) {
     if (!G->valid) return;
-    lp = G->lp;
+    if (!FROM_REC) lp = G->lp;  // (the second pass of a two-pass partition runs under the host's digit parameters)
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
@@ -524,7 +557,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
           pbits[r] = ((path >> 3) << 1) | (bad ? 1u : 0u);
         }
       }
-      rank[r] = wave_rank_u16<PT_BITS>(digit_of(lp, lin[r]), valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
+      rank[r] = wave_rank_u16<MBITS>(digit_of(lp, lin[r]), valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
     }
     BB_STAMP(10);  // scatter: loads, keys, ranks (wave 0)
     __syncthreads();
@@ -592,24 +625,27 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
   }
 }
 
-// first record of every bucket after a two-pass partition (one pass: the scanned table has them):
-// bstart[b] for b in [0, nb], from the sorted records' own coordinates
+// first record of every bucket after a two-pass partition (one pass: the scanned table has them): bstart[b] for b
+// in [0, nb] = the first record whose bucket is >= b, by binary search over the sorted records' own coordinates.
+// (Round 3 streamed all records through one thread each to find the boundaries: 4 GB of reads for 65 537 numbers,
+//  0.66 ms at 125 M points; the search reads ~27 records per boundary.)
 __global__ __launch_bounds__(256) void k_bucket_bounds(const uint4* __restrict__ recs, uint32_t n,
-                                                       LinParams lp, uint32_t nb,
+                                                       LinParams lp, const GeomDev* __restrict__ G, uint32_t nb,
                                                        uint32_t* __restrict__ bstart) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
+  const uint32_t bq = blockIdx.x * 256u + threadIdx.x;
+  if (bq > nb || (G && !G->valid)) return;
   auto bucket_at = [&](uint32_t j) {
     const uint4 a = recs[2 * (size_t)j], b = recs[2 * (size_t)j + 1];
     return lin_of(lp, __longlong_as_double((long long)(((uint64_t)a.y << 32) | a.x)),
                   __longlong_as_double((long long)(((uint64_t)a.w << 32) | a.z)),
                   __longlong_as_double((long long)(((uint64_t)b.y << 32) | b.x))) >> lp.shift;
   };
-  const uint32_t bi = bucket_at(i);
-  const uint32_t first = i == 0 ? 0u : bucket_at(i - 1) + 1u;  // buckets (prev, bi] start here
-  for (uint32_t bb = first; bb <= bi; ++bb) bstart[bb] = i;
-  if (i == n - 1)
-    for (uint32_t bb = bi + 1; bb <= nb; ++bb) bstart[bb] = n;
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (bucket_at(mid) < bq) lo = mid + 1; else hi = mid;
+  }
+  bstart[bq] = lo;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1839,14 +1875,17 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // a cloud taken in place has not been through the box pass: with the geometry of the context's previous
   // single-pass build as a hint the histogram pass finds the box itself (k_part_hist<true>, k_geom_validate);
   // without one the box pass runs now
-  bool hinted = false;
+  bool hinted = false;   // single pass: the geometry is formed on the device, the hint replaces the box pass
+  bool hinted2 = false;  // two passes: the HOST forms the geometry from the hint's box instead of waiting for the box
   GeomDev hint;
   if (f->bbox_pending) {
     std::memcpy(&hint, ctx->geom_hint, sizeof(hint));
-    hinted = async_geom && ctx->geom_hint_valid && ctx->geom_hint_want == want && hint.lp.mode == f->mode &&
-             hint.lp.L == f->edge && hint.lp.c0x == f->corner[0] && hint.lp.c0y == f->corner[1] &&
-             hint.lp.c0z == f->corner[2] && !getenv("OCTL_NO_GEOM_HINT");
-    if (!hinted) OCTL_TRY(store_compute_bbox(f));
+    const bool usable = ctx->geom_hint_valid && ctx->geom_hint_want == want && hint.lp.mode == f->mode &&
+                        hint.lp.L == f->edge && hint.lp.c0x == f->corner[0] && hint.lp.c0y == f->corner[1] &&
+                        hint.lp.c0z == f->corner[2] && !getenv("OCTL_NO_GEOM_HINT");
+    hinted = async_geom && usable && !ctx->geom_hint_two_pass;
+    hinted2 = !async_geom && !force_sync && usable && ctx->geom_hint_two_pass && f->mode == 0;
+    if (!hinted && !hinted2) OCTL_TRY(store_compute_bbox(f));
   }
   // every stored point is alive (nothing was removed since the poses were added): the flags are not read
   const uint8_t* alive_p = f->n_alive == f->n_store ? nullptr : f->alive.as<uint8_t>();
@@ -1856,15 +1895,20 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   uint32_t nb = (uint32_t)PT_BINS;
   bool two_pass = false;
   if (!async_geom) {
-    // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
-    int32_t* bbox_host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + 3584);
-    HIP_TRY(ctx, hipMemcpyAsync(bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    std::memcpy(bb, bbox_host, sizeof(bb));
-    if (bbox_host[6])
-      return octl_set_error(ctx, OCTL_E_DOMAIN,
-                            "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
-                            OCTL_VOX_ABS_LIMIT);
+    if (hinted2) {
+      // the box of the context's previous two-pass build: validated on the device by the histogram pass itself
+      std::memcpy(bb, hint.bb, sizeof(bb));
+    } else {
+      // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
+      int32_t* bbox_host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + 3584);
+      HIP_TRY(ctx, hipMemcpyAsync(bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
+      HIP_TRY(ctx, hipStreamSynchronize(st));
+      std::memcpy(bb, bbox_host, sizeof(bb));
+      if (bbox_host[6])
+        return octl_set_error(ctx, OCTL_E_DOMAIN,
+                              "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
+                              OCTL_VOX_ABS_LIMIT);
+    }
     if (bb[0] > bb[3]) return OCTL_OK;
     const uint64_t nx = (uint64_t)(bb[3] - bb[0] + 1);
     ny = (uint64_t)(bb[4] - bb[1] + 1);
@@ -1875,6 +1919,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     if (((R - 1) >> s) + 1 > ((uint64_t)PT_BINS << PT_BITS)) return OCTL_OK;  // a sparse scene: too many keys
     nb = (uint32_t)(((R - 1) >> s) + 1);
     two_pass = nb > (uint32_t)PT_BINS;
+    if (hinted2 && (!two_pass || s != hint.lp.shift))  // (cannot happen: same box, same `want`)
+      return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
     ctx->geom_sparse = two_pass && want <= (uint64_t)PT_BINS;
     // Thin buckets: the 12-bit clamp on a bucket's key range left them under half their target.  A workgroup per
     // bucket is mostly set-up then, and the cost grows with the BOX (10 M points in 1024 x 1024 x 64 voxels:
@@ -1948,30 +1994,49 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     return hipGetLastError();
   };
   // (SM_BK_FLAGS / SM_BK_TOTAL / SM_BK_TODO are zero: forest_build has reset the scalar block)
-  GeomDev* gdev = nullptr;
-  if (async_geom) {
-    gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
-    if (hinted)
-      hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, hint, gdev);
-    else
-      hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want, lp, gdev);
-    HIP_TRY(ctx, hipGetLastError());
-  }
   // ---- partition ----------------------------------------------------------------------------------------------
   lp.dshift = s;
   lp.dmask = two_pass ? (nd_a - 1u) : 0xFFFFFFFFu;
   lp.raw_vp = two_pass ? 1 : 0;
+  const LinParams lp_pass1 = lp;
+  GeomDev* gdev = nullptr;
+  if (async_geom) {
+    gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
+    if (hinted) {
+      hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, hint, gdev);
+    } else {
+      LinParams base = lp;
+      base.dshift = s;
+      hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want, base, gdev);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  } else if (hinted2) {
+    // the record holds the geometry the HOST formed from the hint's box (first-pass digit parameters); the kernels
+    // of the first pass read it from there, everything behind it only looks at `valid`
+    gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
+    GeomDev g2;
+    std::memset(&g2, 0, sizeof(g2));
+    g2.lp = lp_pass1;
+    std::memcpy(g2.bb, bb, sizeof(bb));
+    g2.valid = 1;
+    hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, g2, gdev);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   {
     KTimer t(ctx, "part_hist");
-    if (hinted) {
+    if (hinted || hinted2) {
       auto kh = f->edge == 1.0 ? k_part_hist<true, true> : k_part_hist<true, false>;
       hipLaunchKernelGGL(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
                          alive_p, N, lp, (const GeomDev*)gdev, nst_a, nd_a, (int64_t)st_tiles_a * tile, table,
                          f->bbox_dev.as<int32_t>());
       HIP_TRY(ctx, hipGetLastError());
       f->bbox_pending = false;  // (the box is on the device now, whatever becomes of the hint)
-      hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
-                         lp, gdev);
+      if (hinted)
+        hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
+                           lp, gdev);
+      else
+        hipLaunchKernelGGL(k_geom_validate2, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
+                           gdev);
     } else {
       auto kh = f->edge == 1.0 ? k_part_hist<false, true> : k_part_hist<false, false>;
       hipLaunchKernelGGL(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
@@ -1988,7 +2053,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   }
   {
     KTimer t(ctx, "part_scatter");
-    hipLaunchKernelGGL((k_part_scatter<PT_IPT, false>), dim3(nst_a), dim3(PT_THREADS), 0, st,
+    auto ks = nd_a <= 256u ? k_part_scatter<PT_IPT, false, 8> : k_part_scatter<PT_IPT, false, PT_BITS>;
+    hipLaunchKernelGGL(ks, dim3(nst_a), dim3(PT_THREADS), 0, st,
                        (const double*)f->xyz.as<double>(), alive_p, N, lp,
                        (const GeomDev*)gdev, nst_a, nd_a, st_tiles_a, (const uint32_t*)table,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
@@ -2006,7 +2072,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     {
       KTimer t(ctx, "part_hist");
       hipLaunchKernelGGL(k_part_hist_rec, dim3(nst_b), dim3(PH_THREADS), 0, st,
-                         (const uint4*)f->part_xyz[0].as<uint4>(), n_alive, lp, nst_b, nd_b,
+                         (const uint4*)f->part_xyz[0].as<uint4>(), n_alive, lp, (const GeomDev*)gdev, nst_b, nd_b,
                          (int64_t)st_tiles_b * tile, table);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -2018,17 +2084,18 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     }
     {
       KTimer t(ctx, "part_scatter");
-      hipLaunchKernelGGL((k_part_scatter<PT_IPT, true>), dim3(nst_b), dim3(PT_THREADS), 0, st,
+      auto ks = nd_b <= 256u ? k_part_scatter<PT_IPT, true, 8> : k_part_scatter<PT_IPT, true, PT_BITS>;
+      hipLaunchKernelGGL(ks, dim3(nst_b), dim3(PT_THREADS), 0, st,
                          (const double*)f->part_xyz[0].as<double>(), (const uint8_t*)nullptr, n_alive, lp,
-                         (const GeomDev*)nullptr, nst_b, nd_b, st_tiles_b, (const uint32_t*)table, (const int64_t*)nullptr, 0,
+                         (const GeomDev*)gdev, nst_b, nd_b, st_tiles_b, (const uint32_t*)table, (const int64_t*)nullptr, 0,
                          (const uint8_t*)nullptr, f->part_xyz[1].as<PartRec>());
       HIP_TRY(ctx, hipGetLastError());
     }
     uint32_t* bounds = table + 2 * tab_elems;
     {
       KTimer t(ctx, "bucket_bounds");
-      hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)ceil_div(n_alive, 256)), dim3(256), 0, st,
-                         (const uint4*)f->part_xyz[1].as<uint4>(), (uint32_t)n_alive, lp, nb, bounds);
+      hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)ceil_div((int64_t)nb + 1, 256)), dim3(256), 0, st,
+                         (const uint4*)f->part_xyz[1].as<uint4>(), (uint32_t)n_alive, lp, (const GeomDev*)gdev, nb, bounds);
       HIP_TRY(ctx, hipGetLastError());
     }
     recs = f->part_xyz[1].as<PartRec>();
@@ -2078,10 +2145,36 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   }
   uint32_t sm[64];
   static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small, sizeof(sm) + (async_geom ? sizeof(GeomDev) : 0),
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small, sizeof(sm) + (gdev ? sizeof(GeomDev) : 0),
                               hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   std::memcpy(sm, ctx->small_host, sizeof(sm));
+  if (hinted2) {
+    GeomDev g;
+    std::memcpy(&g, static_cast<char*>(ctx->small_host) + SM_GEOM * 4, sizeof(g));
+    if (!g.valid) {
+      if (g.reason == GEOM_DOMAIN)
+        return octl_set_error(ctx, OCTL_E_DOMAIN,
+                              "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
+                              OCTL_VOX_ABS_LIMIT);
+      if (g.reason == GEOM_EMPTY) return OCTL_OK;
+      // the hinted box did not hold: the true one is on the device now, the host-side form builds again from it
+      ctx->geom_hint_valid = false;
+      return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
+    }
+  } else if (!async_geom && two_pass && f->mode == 0) {
+    // the geometry of this two-pass build is the hint of the context's next one
+    GeomDev g;
+    std::memset(&g, 0, sizeof(g));
+    g.lp = lp_pass1;
+    std::memcpy(g.bb, bb, sizeof(bb));
+    g.valid = 1;
+    static_assert(sizeof(GeomDev) <= sizeof(ctx->geom_hint), "hint storage");
+    std::memcpy(ctx->geom_hint, &g, sizeof(g));
+    ctx->geom_hint_valid = true;
+    ctx->geom_hint_two_pass = true;
+    ctx->geom_hint_want = want;
+  }
   if (async_geom) {
     GeomDev g;
     std::memcpy(&g, static_cast<char*>(ctx->small_host) + SM_GEOM * 4, sizeof(g));
@@ -2101,6 +2194,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     static_assert(sizeof(GeomDev) <= sizeof(ctx->geom_hint), "hint storage");
     std::memcpy(ctx->geom_hint, &g, sizeof(g));
     ctx->geom_hint_valid = true;
+    ctx->geom_hint_two_pass = false;
     ctx->geom_hint_want = want;
     lp = g.lp;
     std::memcpy(bb, g.bb, sizeof(bb));

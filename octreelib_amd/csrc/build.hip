@@ -1266,6 +1266,14 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       if (unsplit_again) f->epoch += 1;
       return OCTL_OK;
     }
+    // the re-placement below keys every stored point by its coordinates again: a row that map_leaf_points moved
+    // out of its leaf's cube would silently change leaf (or voxel).  The reference keeps such a row where it is
+    // until that leaf is subdivided (octree.py:94-98,114-123); only the incremental path above does the same.
+    if (f->displaced_rows)
+      return octl_set_error(ctx, OCTL_E_DOMAIN,
+                            "map_leaf_points left points outside the cube of their leaf and the stored poses have "
+                            "to be placed again (a pose was extended or the scheme replaced since): the points "
+                            "cannot be kept in their leaves, as the reference does (octree.py:114-123)");
   }
   const int64_t n_alive = f->n_alive;
   // ---- 0. the bucket build does insert + subdivide in one go (bucket_build.hip): a fresh forest, or a

@@ -75,6 +75,10 @@ struct octl_ctx {
   // enqueued before it (its destination may still be read), copy_done orders compute behind the copies
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_gate = nullptr;
+  // route.hip: a rank's own part of the all-to-all is a device copy on a stream of its own, next to the RCCL
+  // transfers on the context's stream (self_gate: the send buffers are complete; self_done: the copies are)
+  hipStream_t self_stream = nullptr;
+  hipEvent_t self_gate = nullptr, self_done = nullptr;
   struct Upload { const char* dst; size_t bytes; hipEvent_t done; };
   std::vector<Upload> uploads;  // copies that may still be in flight, each with the event recorded behind it
   // device blocks handed back by destroyed forests, kept for the next one: a fresh Grid per scan
@@ -90,6 +94,7 @@ struct octl_ctx {
   unsigned char geom_hint[192] = {0};
   bool geom_hint_valid = false;
   uint64_t geom_hint_want = 0;
+  bool geom_hint_two_pass = false;  // the hint is the geometry of a TWO-pass build (> 4096 buckets, host-side form)
   // the last build found a sparse scene (more than 4096 buckets): the next one skips the single-pass attempt
   bool geom_sparse = false;
   // the hypothesis table of the last octl_forest_ransac_all on this context (CudaRansac draws it once per object,

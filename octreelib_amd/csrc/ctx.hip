@@ -33,8 +33,28 @@ int octl_ctx_cus(octl_ctx* ctx) {
   return ctx->cus;
 }
 
+// Test hook (octl_debug_fail_alloc): the n-th GROWTH of a device buffer from the moment the hook is armed fails the
+// way a failed hipMalloc does.  Every device allocation of the library goes through devbuf_reserve, so sweeping n
+// over an operation visits every allocation-failure path it has.
+static std::atomic<int64_t> g_fail_alloc_at{0};    // 0: disarmed
+static std::atomic<int64_t> g_alloc_growths{0};    // growths since the hook was last armed
+
+extern "C" int octl_debug_fail_alloc(int64_t nth, int64_t* seen) {
+  if (seen) *seen = g_alloc_growths.load(std::memory_order_relaxed);
+  g_alloc_growths.store(0, std::memory_order_relaxed);
+  g_fail_alloc_at.store(nth > 0 ? nth : 0, std::memory_order_relaxed);
+  return OCTL_OK;
+}
+
 int devbuf_reserve(octl_ctx* ctx, DevBuf& b, size_t bytes, int keep) {
   if (bytes <= b.cap) return OCTL_OK;
+  {
+    const int64_t k = g_alloc_growths.fetch_add(1, std::memory_order_relaxed) + 1;
+    const int64_t at = g_fail_alloc_at.load(std::memory_order_relaxed);
+    if (at > 0 && k == at)
+      return octl_set_error(ctx, OCTL_E_NOMEM, "hipMalloc(%zu) failed: injected by octl_debug_fail_alloc (growth %lld)",
+                            bytes, (long long)k);
+  }
   size_t want = bytes + bytes / 4 + 256;  // grow with slack so level loops rarely realloc
   // a buffer that is appended to (the point store: one pose after the other) doubles, so that P appends cost
   // O(log P) reallocations and copies instead of one for every 25 % of growth (64 poses: 19 -> 6)
@@ -252,6 +272,12 @@ void octl_ctx_destroy(octl_ctx* ctx) {
     devbuf_free(*b);
   if (ctx->small_host) (void)hipHostFree(ctx->small_host);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->self_stream) {
+    (void)hipStreamSynchronize(ctx->self_stream);
+    (void)hipStreamDestroy(ctx->self_stream);
+    if (ctx->self_gate) (void)hipEventDestroy(ctx->self_gate);
+    if (ctx->self_done) (void)hipEventDestroy(ctx->self_done);
+  }
   if (ctx->copy_stream) {
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
@@ -390,6 +416,8 @@ int octl_dev_upload(octl_ctx* ctx, void* dptr, const void* src, int64_t bytes) {
 
 int octl_dev_download(octl_ctx* ctx, void* dst, const void* dptr, int64_t bytes) {
   if (!ctx || (bytes > 0 && (!dptr || !dst))) return OCTL_E_INVALID;
+  // (the source may be the target of an octl_dev_upload_async that is still in flight on the copy stream)
+  if (bytes > 0) OCTL_TRY(ctx_wait_uploads(ctx, dptr, (size_t)bytes));
   HIP_TRY(ctx, hipMemcpyAsync(dst, dptr, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return OCTL_OK;

@@ -302,6 +302,11 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  // (the cloud / its indices may be the target of an octl_dev_upload_async of this context that is still in flight)
+  if (n > 0) {
+    OCTL_TRY(ctx_wait_uploads(ctx, xyz_dev, (size_t)n * 24));
+    if (gidx_dev) OCTL_TRY(ctx_wait_uploads(ctx, gidx_dev, (size_t)n * 8));
+  }
 
   // --- 1-2. destinations, counts, stable partition, packed send buffers ---------------------------------
   DevBuf& counts_d = ctx->rt_counts;
@@ -408,14 +413,38 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   {
     KTimer t(ctx, "route_alltoall");
     const int64_t self = cnt(me, me);
+    bool self_side = false;
     if (self > 0 && !self_rccl) {
+      // The rank's own part never leaves the device: two copies.  With peers to talk to they run on a stream of
+      // their own, NEXT TO the transfers of the group below (on the context's stream they were queued in front
+      // of it); alone (one rank) the context's stream takes them.
+      hipStream_t cs = st;
+      if (use_rccl) {
+        if (!ctx->self_stream) {
+          self_rc = hipStreamCreateWithFlags(&ctx->self_stream, hipStreamNonBlocking);
+          if (self_rc == hipSuccess) self_rc = hipEventCreateWithFlags(&ctx->self_gate, hipEventDisableTiming);
+          if (self_rc == hipSuccess) self_rc = hipEventCreateWithFlags(&ctx->self_done, hipEventDisableTiming);
+          if (self_rc != hipSuccess) {
+            // (a stream that could not be created is not fatal: the context's stream does the copies)
+            ctx->self_stream = nullptr;
+            self_rc = hipSuccess;
+          }
+        }
+        if (ctx->self_stream && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
+            hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
+          cs = ctx->self_stream;
+          self_side = true;
+        }
+      }
       self_rc = hipMemcpyAsync(ctx->routed_xyz.as<double>() + 3 * roff[me],
                                send_xyz.as<double>() + 3 * soff[me], (size_t)self * 24,
-                               hipMemcpyDeviceToDevice, st);
+                               hipMemcpyDeviceToDevice, cs);
       if (self_rc == hipSuccess)
         self_rc = hipMemcpyAsync(ctx->routed_gidx.as<int64_t>() + roff[me],
                                  send_gidx.as<int64_t>() + soff[me], (size_t)self * 8,
-                                 hipMemcpyDeviceToDevice, st);
+                                 hipMemcpyDeviceToDevice, cs);
+      // (the context's stream - and with it this call's final synchronisation and the timer - waits for them)
+      if (self_side && self_rc == hipSuccess) self_rc = hipEventRecord(ctx->self_done, cs);
     }
     if (use_rccl) {
       ncclResult_t r = g_rccl.GroupStart();
@@ -442,6 +471,7 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
         return octl_set_error(ctx, OCTL_E_COMM, "all-to-all failed: %s", g_rccl.GetErrorString(r));
       }
     }
+    if (self_side && self_rc == hipSuccess) self_rc = hipStreamWaitEvent(st, ctx->self_done, 0);
   }
   // (the transfers of the group are posted by now on every rank: a local failure below no longer
   //  leaves a peer waiting)

@@ -84,19 +84,33 @@ class ShardedGrid:
         self.forest = Forest(0, np.zeros(3), self.L, ctx=self.ctx)
         self._corner = np.zeros(3)
 
+    def upload_async(self, points):
+        """Start the upload of this rank's part of a pose on THIS grid's context (octreelib_amd.upload_async with
+        the right context): hand the result to insert_points while the previous pose is still being built."""
+        from octreelib_amd.feed import DeviceCloud
+
+        return DeviceCloud(points, ctx=self.ctx)
+
     def insert_points(self, points, index_base: int = 0) -> int:
         """Route this rank's part of a pose to the owners and insert what this rank receives.
-        Returns the number of points received.  Global point index = index_base + local index."""
-        pts = nat.as_points(points)
-        d = C.c_void_p()
-        self.ctx.check(self.lib.octl_dev_alloc(self.ctx.handle, max(pts.nbytes, 8), C.byref(d)))
-        try:
-            self.ctx.check(self.lib.octl_dev_upload(self.ctx.handle, d, nat.ptr(pts), pts.nbytes))
-            n_recv = C.c_int64(0)
-            self.ctx.check(self.lib.octl_route_points(self.ctx.handle, d, None, len(pts), int(index_base),
-                                                      nat.ptr(self._corner), self.L, C.byref(n_recv), None))
-        finally:
-            self.ctx.check(self.lib.octl_dev_free(self.ctx.handle, d))
+        Returns the number of points received.  Global point index = index_base + local index.
+        `points`: a host array, or a DeviceCloud from self.upload_async (its copy may still be in flight: the
+        routing kernels are ordered behind it on the device).  The staging buffers of host arrays come from the
+        context's pool and are given back one pose later - no allocation, no free and no host wait per pose."""
+        from octreelib_amd.feed import DeviceCloud
+
+        if isinstance(points, DeviceCloud):
+            if points.ctx is not self.ctx:
+                raise ValueError("the DeviceCloud lives on another context: use ShardedGrid.upload_async")
+            cloud, own = points, False
+        else:
+            cloud, own = DeviceCloud(points, ctx=self.ctx), True
+        n_recv = C.c_int64(0)
+        self.ctx.check(self.lib.octl_route_points(self.ctx.handle, cloud.ptr, None, cloud.n, int(index_base),
+                                                  nat.ptr(self._corner), self.L, C.byref(n_recv), None))
+        # (octl_route_points returns after its stream has drained: the cloud has been consumed)
+        if own:
+            cloud.release()
         self.forest.add_pose_routed(n_recv.value)
         return n_recv.value
 

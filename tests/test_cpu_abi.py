@@ -114,6 +114,24 @@ def test_filter_interval_recognition_handles_non_finite_constants_and_probes_bot
     shifty = Shifty()
     assert try_count_interval([lambda p: len(p) < shifty]) is None
 
+    # the same mismatch far above any cloud one would allocate: the probes are zero-stride views, so both ends of
+    # an interval of ANY size are checked behaviourally (a bound above 4 M used to be accepted on the pattern alone)
+    class ShiftyBig(Shifty):
+        def __float__(self):
+            return 1e10
+
+        def __gt__(self, n):
+            return n < 5_000_000_000
+
+        __rlt__ = __gt__
+
+    big = ShiftyBig()
+    assert try_count_interval([lambda p: len(p) < big]) is None
+    assert try_count_interval([lambda p: len(p) < 10_000_000_000]) == (0, 9_999_999_999)
+    from octreelib_amd.criteria import count_threshold
+
+    assert count_threshold([lambda p: len(p) > 8_000_000_000]) == 8_000_000_000
+
 
 def test_voxel_value_type():
     # reference: internal/voxel.py - equal voxels share an id, hash/eq on (corner, edge)

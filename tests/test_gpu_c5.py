@@ -157,3 +157,27 @@ def test_c5_reduced_size_shard_against_oracle():
     assert_same_leaves(canon_from_list(views_table(grid.get_leaf_points(0), index)),
                        canon_from_list(og.leaf_table(0)))
     assert grid.n_points(0) == og.n_points(0)
+
+
+def test_eight_rank_partition_of_a_skewed_scene_is_balanced():
+    """The device half of the exchange for 8 ranks on a scene that is NOT uniform (synthetic.sparse_scene: terrain
+    sheet + one blob at 20 x the density): counts and packed send buffers equal the host mirror's stable partition,
+    and the largest shard stays within 25 % of the mean (max / mean points per rank)."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+    from octreelib_amd.distributed import voxel_indices_np, voxel_owner_np
+
+    ctx = nat.get_context()
+    lib = ctx.lib
+    m, n_ranks = 3_000_000, 8
+    pts = synthetic.sparse_scene(m, (256, 256, 32), seed=7)
+    counts = np.zeros(n_ranks, dtype=np.int64)
+    out_xyz = np.empty((m, 3))
+    out_idx = np.empty(m, dtype=np.int64)
+    ctx.check(lib.octl_debug_route_partition(ctx.handle, nat.ptr(pts), m, 0, 1.0, n_ranks, nat.ptr(counts),
+                                             nat.ptr(out_xyz), nat.ptr(out_idx)))
+    owner = voxel_owner_np(voxel_indices_np(pts, 1.0), n_ranks)
+    assert np.array_equal(counts, np.bincount(owner, minlength=n_ranks))
+    order = np.argsort(owner, kind="stable")
+    assert np.array_equal(out_idx, order) and np.array_equal(out_xyz, pts[order])
+    assert counts.max() / counts.mean() <= 1.25, counts

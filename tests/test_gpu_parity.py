@@ -1918,11 +1918,14 @@ def _assert_same_tables(a, b):
         assert np.array_equal(x, y)
 
 
-def test_adopted_cloud_builds_the_same_forest_with_and_without_a_geometry_hint(monkeypatch):
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_adopted_cloud_builds_the_same_forest_with_and_without_a_geometry_hint(monkeypatch, two_pass):
     """octl_forest_add_pose_adopt reads the caller's device buffer in place; the voxel box of such a cloud is
     found by the build's own histogram pass under the geometry of the context's previous build (hit: same
     scene; miss: a cloud that leaves the hinted box, a box of another size) or by the box pass (no hint).
-    Every variant must build exactly the tables of the copying path."""
+    Every variant must build exactly the tables of the copying path.  two_pass: many small buckets over more
+    than 4096 voxel keys - the two-pass partition of the large clouds (one rank's 125 M points of BASELINE config
+    5), where the HOST forms the geometry from the hint's box instead of waiting for the box pass."""
     import ctypes as C
 
     from octreelib_amd import _native as nat
@@ -1931,13 +1934,16 @@ def test_adopted_cloud_builds_the_same_forest_with_and_without_a_geometry_hint(m
 
     ctx = nat.get_context()
     K = 48
+    dm = (20, 20, 20) if two_pass else (8, 8, 8)
+    if two_pass:
+        monkeypatch.setenv("OCTL_BUCKET_POINTS", "16")
     scenes = {
-        "base": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=0),
-        "same_box": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=1),
-        "shifted": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=2) + np.array([3.0, -2.0, 0.0]),
-        "grown": np.vstack([synthetic.planar_cloud(199_990, (8, 8, 8), seed=1, stream=3), np.full((10, 3), 40.5) + np.arange(10)[:, None] * 1e-3]),
-        "shrunk": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=4, box=((2, 2, 2), (5, 5, 5))),
-        "negative": synthetic.planar_cloud(200_000, (8, 8, 8), seed=1, stream=5) - 100.0,
+        "base": synthetic.planar_cloud(200_000, dm, seed=1, stream=0),
+        "same_box": synthetic.planar_cloud(200_000, dm, seed=1, stream=1),
+        "shifted": synthetic.planar_cloud(200_000, dm, seed=1, stream=2) + np.array([3.0, -2.0, 0.0]),
+        "grown": np.vstack([synthetic.planar_cloud(199_990, dm, seed=1, stream=3), np.full((10, 3), 40.5) + np.arange(10)[:, None] * 1e-3]),
+        "shrunk": synthetic.planar_cloud(200_000, dm, seed=1, stream=4, box=((2, 2, 2), (5, 5, 5))),
+        "negative": synthetic.planar_cloud(200_000, dm, seed=1, stream=5) - 100.0,
     }
 
     def reference(pts):
@@ -1958,7 +1964,10 @@ def test_adopted_cloud_builds_the_same_forest_with_and_without_a_geometry_hint(m
         g.add_pose_device(d, len(pts), adopt=True)
         g.subdivide(K)
         ctx.sync()
-        used_box_pass.append("ingest" in ctx.timings())
+        tm = ctx.timings()
+        used_box_pass.append("ingest" in tm)
+        if name in ("base", "same_box"):
+            assert ("bucket_bounds" in tm) == two_pass      # (the partition really took the path under test)
         ctx.set_profiling(False)
         _assert_same_tables(_tables(g), want[name])
         # RANSAC + apply_mask + a second subdivide on the adopted store (alive flags in play)

@@ -10,7 +10,7 @@
 # 3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters), as MI355X_MICROARCH.md asks
 # 4. the same kernel-stats pass on the uniform scene               -> profiles/TAG_uniform_kernel_stats.csv
 # then tools/summarize_profiles.py condenses them into profiles/TAG_*.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 HEAD="--no-secondary --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
@@ -22,5 +22,17 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES 
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_uniform -- python3 $R/bench.py --steps 10 --warmup 2 --cloud uniform $HEAD > $R/gpurun_out/prof_${TAG}_uniform_bench.json 2> $R/gpurun_out/prof_${TAG}_uniform.err || exit 6
 cd $R && python3 tools/summarize_profiles.py $TAG gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_sq_$TAG gpurun_out/prof_${TAG}_bench.json && cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
 cp $(ls gpurun_out/prof_${TAG}_uniform/*/*kernel_stats.csv | head -1) profiles/${TAG}_uniform_kernel_stats.csv
+# 5. the two largest BASELINE configs alone (bench.py --workload c4 / c5shard): kernel stats + FETCH / WRITE passes
+#    -> profiles/TAG_c4_*, profiles/TAG_c5shard_*
+if [ -z "$OCTL_PROFILE_HEADLINE_ONLY" ]; then
+  cd /tmp
+  for W in c4 c5shard; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$W -- python3 $R/bench.py --workload $W --steps 3 > $R/gpurun_out/prof_${TAG}_${W}_bench.json 2> $R/gpurun_out/prof_${TAG}_$W.err || exit 7
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_${TAG}_$W -- python3 $R/bench.py --workload $W --steps 3 > /dev/null 2>&1 || exit 8
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_${TAG}_$W -- python3 $R/bench.py --workload $W --steps 3 > /dev/null 2>&1 || exit 9
+    (cd $R && python3 tools/summarize_profiles.py ${TAG}_$W gpurun_out/prof_${TAG}_$W gpurun_out/pmc_fetch_${TAG}_$W gpurun_out/pmc_write_${TAG}_$W - gpurun_out/prof_${TAG}_${W}_bench.json "bench.py --workload $W --steps 3") || exit 10
+  done
+  cd $R
+fi
 # profiles/ is not writable back from the box: the condensed files are copied to gpurun_out/ too
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/

@@ -26,7 +26,10 @@ def counters(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for (k, _d, c), v in per.items():
         agg[k][c].append(v)
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    for k, cs in agg.items():   # dispatches of the kernel in the profiled run (every counter saw each of them once)
+        out[k]["_dispatches"] = max(len(v) for v in cs.values())
+    return out
 
 
 def durations(d):
@@ -39,12 +42,13 @@ def durations(d):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir, sq_dir, bench_json = sys.argv[1:7]
+    what = sys.argv[7] if len(sys.argv) > 7 else "bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline: the headline scene only, 10 M planar points"
     shutil.copy(glob.glob(f"{stats_dir}/*/*kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
     shutil.copy(bench_json, f"profiles/{tag}_bench_under_rocprof.json")
     fetch, write = counters(fetch_dir), counters(write_dir)
     out = {
         "_note": "HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate "
-                 "passes (bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline: the headline scene only, 10 M planar points); counter unit KiB; gfx950 "
+                 "passes (" + what + "); per-launch averages, `dispatches` = launches of the kernel in the whole profiled run (warm-up, timed and instrumented steps); counter unit KiB; gfx950 "
                  "correction of MI355X_MICROARCH.md applied to the read side (FETCH_SIZE x 2 for wide "
                  "coalesced reads; the raw value is kept), WRITE_SIZE as is.",
         "kernels": {},
@@ -52,8 +56,13 @@ def main():
     for k in fetch:
         f = fetch[k].get("FETCH_SIZE", 0.0)
         w = write.get(k, {}).get("WRITE_SIZE", 0.0)
-        out["kernels"][k] = {"fetch_KiB_raw": f, "fetch_bytes_corrected": 2048.0 * f, "write_bytes": 1024.0 * w}
+        out["kernels"][k] = {"fetch_KiB_raw": f, "fetch_bytes_corrected": 2048.0 * f, "write_bytes": 1024.0 * w,
+                             "dispatches": fetch[k].get("_dispatches", 0)}
     json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+    if sq_dir == "-":   # (secondary workloads: kernel stats + traffic only)
+        for k in sorted(out["kernels"], key=lambda k: -out["kernels"][k]["fetch_bytes_corrected"] * out["kernels"][k]["dispatches"])[:14]:
+            print(k, json.dumps(out["kernels"][k]))
+        return
     sq, dur = counters(sq_dir), durations(sq_dir)
     rows = {}
     for k, c in sq.items():
