@@ -374,6 +374,8 @@ def build_path(timer_names):
         return "bucket" + (" + level loop for the voxels left behind" if loop else "")
     if general:
         return "general (keygen + radix sort + level loop)" + (" after a bucket attempt" if bucket else "")
+    if loop:
+        return "general (a single cube: one fused level-0 pass + level loop)"
     return "incremental" if "inc_place" in timer_names else "unknown"
 
 
@@ -751,7 +753,32 @@ def main():
                         "staging array) -> Grid.insert_points(pose, DeviceCloud) reads the uploaded buffer in place; "
                         "16 scans (the first one's upload is not hidden: 1/16 of ~5 ms), a fresh Grid per scan",
             }
-            del stage
+            # ... and through the two-context scan pipeline of the package (octreelib_amd.ScanPipeline): scan i+1 is
+            # uploaded, inserted and subdivided on context B while scan i is still being fitted on context A
+            ring = stage + [oa.pinned_empty((n_local, 3)), oa.pinned_empty((n_local, 3))]
+            ring[2][:] = wl.host_pts
+            ring[3][:] = wl.host_pts
+
+            def fit(grid, i):
+                grid.subdivide([MaxPoints(args.k_split)])
+                # (two threads: the table is handed over instead of drawn from NumPy's global generator per scan)
+                grid.map_leaf_points_cuda_ransac(hypotheses=wl.table)
+                return grid.n_points(0)
+
+            with oa.ScanPipeline(2) as pipe:
+                list(pipe.map((ring[i & 3] for i in range(4)), fit))
+                t1 = time.perf_counter()
+                kept2 = list(pipe.map((ring[i & 3] for i in range(16)), fit))
+                ms = (time.perf_counter() - t1) * 1e3 / 16
+            secondary["api_pipelined_2ctx"] = {
+                "ms": ms, "Mpoints_per_s": n_local / ms / 1e3, "points_after_ransac": int(kept2[-1]),
+                "same_result_every_scan": bool(all(k == kept for k in kept2)),
+                "note": "octreelib_amd.ScanPipeline(2): 16 scans out of a ring of 4 pinned staging buffers, two worker "
+                        "threads with a context each take them alternately - Grid.insert_points(DeviceCloud) + "
+                        "subdivide + RANSAC + apply_mask + n_points per scan; the build of one scan overlaps the "
+                        "fit of the other.  The headline stays sequential.",
+            }
+            del stage, ring
             # poses that arrive one at a time: 12 poses x 0.5 M points into a 16^3-voxel scheme
             # fixed by the first pose - the cost of a late pose must not grow with what is stored
             from octreelib_amd import synthetic as _syn

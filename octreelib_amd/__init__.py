@@ -13,7 +13,7 @@ raises.
 """
 
 from octreelib_amd.criteria import MaxPoints
-from octreelib_amd.feed import DeviceCloud, pinned_empty, upload_async
+from octreelib_amd.feed import DeviceCloud, ScanPipeline, pinned_empty, upload_async
 
 __version__ = "0.1.0"
-__all__ = ["MaxPoints", "DeviceCloud", "pinned_empty", "upload_async", "__version__"]
+__all__ = ["MaxPoints", "DeviceCloud", "ScanPipeline", "pinned_empty", "upload_async", "__version__"]

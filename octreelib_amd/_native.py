@@ -238,8 +238,33 @@ def default_device() -> int:
     return 0
 
 
+_thread_ctx = threading.local()
+
+
+class use_context:
+    """`with use_context(ctx):` - every Grid / Octree / OctreeManager / CudaRansac / DeviceCloud created by THIS
+    thread inside the block lives on `ctx` instead of the process-wide context (a context is one HIP stream and is
+    not thread safe: a second host thread that wants to overlap its scans with the first one's brings its own,
+    octreelib_amd.feed.ScanPipeline)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self._prev = getattr(_thread_ctx, "ctx", None)
+        _thread_ctx.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _thread_ctx.ctx = self._prev
+
+
 def get_context(device=None) -> Context:
-    """Process-wide context of a device (created on first use)."""
+    """The calling thread's context (use_context) or the process-wide context of a device (created on first use)."""
+    if device is None:
+        ctx = getattr(_thread_ctx, "ctx", None)
+        if ctx is not None:
+            return ctx
     device = default_device() if device is None else int(device)
     ctx = _default_ctx.get(device)
     if ctx is None:

@@ -73,6 +73,7 @@ struct LinParams {
   int dshift;
   uint32_t dmask;
   int raw_vp;        // 1: this pass is not the last one, records carry the full linear key
+  int exact_digits;  // 0: child digits always level by level (OCTL_NO_EXACT_DIGITS, tests)
 };
 __device__ __forceinline__ uint32_t digit_of(const LinParams& lp, uint32_t lin) {
   return (lin >> lp.dshift) & lp.dmask;
@@ -476,14 +477,18 @@ __device__ __forceinline__ uint32_t wave_rank_u16(uint32_t digit, bool valid, ui
 // MBITS: ballot rounds of the in-wave rank = bits of the pass's digit (12 for a single pass over up to 4096 buckets,
 // 8 when a pass of a two-pass partition has at most 256 digits: a third of the rounds less)
 template <int PT_IPT, bool FROM_REC, int MBITS>
-__global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
+__global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter(
     const double* __restrict__ xyz, const uint8_t* __restrict__ alive, int64_t N, LinParams lp,
     const GeomDev* __restrict__ G, uint32_t nst, uint32_t nd, int st_tiles,
     const uint32_t* __restrict__ table_scanned,
     const int64_t* __restrict__ pose_off, int n_poses, const uint8_t* __restrict__ scheme,
     PartRec* __restrict__ out) {
-  __shared__ uint32_t base[PT_BINS];                 // running destination of every bucket
-  __shared__ uint16_t cnt[PT_THREADS / 64][PT_BINS]; // per wave, per tile
+  // (sized by the pass's digit: 48 KB for the 4096 digits of a single pass, 3 KB for the <= 256 of a two-pass
+  //  partition - whose tiles then also zero and scan a sixteenth of the counters)
+  constexpr int NB = 1 << MBITS;
+  static_assert(NB % PT_THREADS == 0 && NB <= PT_BINS, "digits per thread in the offset scan");
+  __shared__ uint32_t base[NB];                 // running destination of every bucket
+  __shared__ uint16_t cnt[PT_THREADS / 64][NB]; // per wave, per tile
   if (G) {
     if (!G->valid) return;
     if (!FROM_REC) lp = G->lp;  // (the second pass of a two-pass partition runs under the host's digit parameters)
@@ -492,6 +497,14 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
   for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
     base[d] = table_scanned[(size_t)blockIdx.x * nd + d];  // ([supertile][digit]: see k_part_hist)
   constexpr int PT_TILE = PT_THREADS * PT_IPT;
+  // (kernel-uniform) the cubes the digits are taken against have integer-valued, non-negative corners and edges:
+  // always in a grid (corner = q L, edge = L, L integer) for a non-negative point; a single cube when its own
+  // corner and edge are; OCTL_NO_EXACT_DIGITS (host: lp.exact_digits) switches the short form off for tests
+  const bool exact_cube = lp.exact_digits && nonneg_integer_below_2p45(lp.L) && lp.L >= 1.0 &&
+                          (lp.mode == 0 || (nonneg_integer_below_2p45(lp.c0x) && nonneg_integer_below_2p45(lp.c0y) &&
+                                            nonneg_integer_below_2p45(lp.c0z)));
+  const bool edge_pow2 = (__double_as_longlong(lp.L) & 0xFFFFFFFFFFFFFll) == 0;
+  const double inv64 = 64.0 / lp.L;
   BB_STAMP_INIT;
   for (int t = 0; t < st_tiles; ++t) {
     const int64_t tbase = ((int64_t)blockIdx.x * st_tiles + t) * PT_TILE;
@@ -546,15 +559,24 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
         if (!FROM_REC) lin[r] = l;
         if (!lp.raw_vp) {
           bool bad = false;
-          uint32_t path = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
+          uint32_t d18;
+          // non-negative coordinates below an integer cube: the six rounded subtractions per axis of the
+          // reference are exact and the digits are the leading bits of p - corner (ref_arith.h: digits18_exact);
+          // anything else (negative coordinates, a cube at a fractional corner) walks the levels
+          if (exact_cube && coord_takes_exact_digits(x[r]) && coord_takes_exact_digits(y[r]) &&
+              coord_takes_exact_digits(z[r])) {
+            d18 = digits18_exact(x[r], y[r], z[r], cx, cy, cz, lp.L, edge_pow2, inv64, &bad);
+          } else {
+            d18 = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad) >> 3;
+          }
 #ifdef PS_DUP_KEYS  // (experiments: the child digits computed twice - what they cost)
           {
             double x2 = x[r];
             asm volatile("" : "+v"(x2));
-            path &= path_levels(x2, y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad);
+            d18 &= path_levels(x2, y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad) >> 3;
           }
 #endif
-          pbits[r] = ((path >> 3) << 1) | (bad ? 1u : 0u);
+          pbits[r] = (d18 << 1) | (bad ? 1u : 0u);
         }
       }
       rank[r] = wave_rank_u16<MBITS>(digit_of(lp, lin[r]), valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
@@ -564,9 +586,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     BB_STAMP(11);  // scatter: wait for the other waves
     // per bucket: exclusive offsets of the waves inside this tile; the tile's total moves the running
     // base once every item is placed
-    uint32_t tile_tot[PT_BINS / PT_THREADS];
+    uint32_t tile_tot[NB / PT_THREADS];
 #pragma unroll
-    for (int q = 0; q < PT_BINS / PT_THREADS; ++q) {
+    for (int q = 0; q < NB / PT_THREADS; ++q) {
       const uint32_t d = q * PT_THREADS + threadIdx.x;
       uint32_t run = 0;
       if (d < nd) {
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_part_scatter(
     __syncthreads();
     BB_STAMP(14);  // scatter: barrier behind the stores
 #pragma unroll
-    for (int q = 0; q < PT_BINS / PT_THREADS; ++q) {
+    for (int q = 0; q < NB / PT_THREADS; ++q) {
       const uint32_t d = q * PT_THREADS + threadIdx.x;
       if (d < nd) base[d] += tile_tot[q];
     }
@@ -1882,7 +1904,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     std::memcpy(&hint, ctx->geom_hint, sizeof(hint));
     const bool usable = ctx->geom_hint_valid && ctx->geom_hint_want == want && hint.lp.mode == f->mode &&
                         hint.lp.L == f->edge && hint.lp.c0x == f->corner[0] && hint.lp.c0y == f->corner[1] &&
-                        hint.lp.c0z == f->corner[2] && !getenv("OCTL_NO_GEOM_HINT");
+                        hint.lp.c0z == f->corner[2] && !getenv("OCTL_NO_GEOM_HINT") &&
+                        hint.lp.exact_digits == (getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1);
     hinted = async_geom && usable && !ctx->geom_hint_two_pass;
     hinted2 = !async_geom && !force_sync && usable && ctx->geom_hint_two_pass && f->mode == 0;
     if (!hinted && !hinted2) OCTL_TRY(store_compute_bbox(f));
@@ -1944,6 +1967,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   lp.dshift = s;
   lp.dmask = 0xFFFFFFFFu;
   lp.raw_vp = 0;
+  lp.exact_digits = getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1;
   uint32_t* small = ctx->small.as<uint32_t>();
   // supertiles: one round of workgroups (2 per CU) over the cloud, at most 16 tiles each
   const int cus = octl_ctx_cus(ctx);
@@ -1958,7 +1982,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   constexpr int PT_IPT = OCTL_PT_IPT;  // (records per thread and tile of the partition kernels; -D for experiments)
   constexpr int tile = PT_THREADS * PT_IPT;
   auto supertiles = [&](int64_t items, int* st_tiles) {
-    *st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(items, tile), (int64_t)cus * OCTL_PT_WGS)));
+    // (a pass with at most 256 digits keeps 3 KB of counters: three workgroups per CU instead of two)
+    const int wgs = two_pass ? std::max(OCTL_PT_WGS, 3) : OCTL_PT_WGS;
+    *st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(items, tile), (int64_t)cus * wgs)));
     return (uint32_t)ceil_div(items, (int64_t)*st_tiles * tile);
   };
   int st_tiles_a = 1, st_tiles_b = 1;

@@ -66,21 +66,23 @@ constexpr int PATH_LEVELS = OCTL_PATH_LEVELS;
 //     child_id = 4*ix + 2*iy + iz ; child corner = corner + idx * (edge / 2) ; child edge = edge / 2
 // floor((p-c)/h) in {0,1} <=> 0 <= fl(p-c) < 2h, and it is 1 <=> fl(p-c) >= h: the division is
 // replaced by exact comparisons on the same rounded difference the reference forms.
-// Layout: digit of level j at bits [61-3j, 63-3j]; bit 0 = "bad" (some level had idx outside
+// Layout (32 bits: the level loop streams this word once per level, 8 bytes were a quarter of its traffic):
+// digit of level j at bits [29-3j, 31-3j], j < PATH_LEVELS = 6; bit 0 = "bad" (some level had idx outside
 // {0,1}, or a non-finite coordinate) - such a point takes the slow path and raises a domain
 // error only if a node containing it is actually split, as in the reference.
-__device__ __forceinline__ uint64_t compute_path(double px, double py, double pz, double cx,
+static_assert(OCTL_PATH_LEVELS >= 1 && OCTL_PATH_LEVELS <= 10, "the path word holds at most 10 digits above the bad bit");
+__device__ __forceinline__ uint32_t compute_path(double px, double py, double pz, double cx,
                                                  double cy, double cz, double e) {
-  uint64_t path = 0;
+  uint32_t path = 0;
   double h = e / 2.0;
 #pragma unroll 1
   for (int j = 0; j < PATH_LEVELS; ++j) {
     const double ax = px - cx, ay = py - cy, az = pz - cz;
     const bool ok = (ax >= 0.0) && (ax < e) && (ay >= 0.0) && (ay < e) && (az >= 0.0) && (az < e);
-    if (!ok) return path | 1ull;
+    if (!ok) return path | 1u;
     const bool bx = ax >= h, by = ay >= h, bz = az >= h;
-    const uint64_t digit = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
-    path |= digit << (61 - 3 * j);
+    const uint32_t digit = (bx ? 4u : 0u) | (by ? 2u : 0u) | (bz ? 1u : 0u);
+    path |= digit << (29 - 3 * j);
     cx = cx + (bx ? h : 0.0);
     cy = cy + (by ? h : 0.0);
     cz = cz + (bz ? h : 0.0);
@@ -88,6 +90,20 @@ __device__ __forceinline__ uint64_t compute_path(double px, double py, double pz
     h = e / 2.0;
   }
   return path;
+}
+
+// compute_path for the cube of a top-level voxel / a whole single cube: non-negative coordinates below an
+// integer-valued cube take the exact short form (ref_arith.h: digits18_exact), everything else the levels
+__device__ __forceinline__ uint32_t compute_path_root(double px, double py, double pz, double cx, double cy,
+                                                      double cz, double e, bool exact_cube, bool edge_pow2,
+                                                      double inv64) {
+  if (PATH_LEVELS == 6 && exact_cube && coord_takes_exact_digits(px) && coord_takes_exact_digits(py) &&
+      coord_takes_exact_digits(pz)) {
+    bool bad = false;
+    const uint32_t d18 = digits18_exact(px, py, pz, cx, cy, cz, e, edge_pow2, inv64, &bad);
+    return (d18 << 14) | (bad ? 1u : 0u);
+  }
+  return compute_path(px, py, pz, cx, cy, cz, e);
 }
 
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -107,12 +123,18 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 __global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
                                                 const uint8_t* __restrict__ alive, int64_t n,
                                                 int mode, double L, double c0x, double c0y,
-                                                double c0z, VoxOrg org, uint64_t* __restrict__ vkey,
-                                                uint64_t* __restrict__ path,
+                                                double c0z, VoxOrg org, int exact_digits,
+                                                uint64_t* __restrict__ vkey, uint32_t* __restrict__ path,
                                                 uint32_t* __restrict__ small) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool live = (i < n) && alive[i];
   int qx = 0, qy = 0, qz = 0;
+  // (kernel-uniform: see compute_path_root)
+  const bool exact_cube = exact_digits && nonneg_integer_below_2p45(L) && L >= 1.0 &&
+                          (mode == 0 || (nonneg_integer_below_2p45(c0x) && nonneg_integer_below_2p45(c0y) &&
+                                         nonneg_integer_below_2p45(c0z)));
+  const bool edge_pow2 = (__double_as_longlong(L) & 0xFFFFFFFFFFFFFll) == 0;
+  const double inv64 = 64.0 / L;
   if (live) {
     const double px = xyz[3 * i + 0], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
     double cx = c0x, cy = c0y, cz = c0z;
@@ -140,7 +162,7 @@ __global__ __launch_bounds__(256) void k_keygen(const double* __restrict__ xyz,
     }
     if (live) {
       vkey[i] = vkey_pack(qx, qy, qz, org);
-      path[i] = compute_path(px, py, pz, cx, cy, cz, L);
+      path[i] = compute_path_root(px, py, pz, cx, cy, cz, L, exact_cube, edge_pow2, inv64);
     }
   }
   if (i < n && !live) {
@@ -298,9 +320,9 @@ __global__ __launch_bounds__(256) void k_root_tiles(const uint64_t* __restrict__
 // level-0 buffers: position -> root node, point index (+scheme bit), path word
 __global__ __launch_bounds__(256) void k_init_level0(
     const uint64_t* __restrict__ lin, const uint32_t* __restrict__ tile_first,
-    const uint32_t* __restrict__ val_sorted, const uint64_t* __restrict__ path, int64_t n_alive,
+    const uint32_t* __restrict__ val_sorted, const uint32_t* __restrict__ path, int64_t n_alive,
     const int32_t* __restrict__ local2root, int32_t* __restrict__ pos_node,
-    uint32_t* __restrict__ idx0, uint64_t* __restrict__ path0) {
+    uint32_t* __restrict__ idx0, uint32_t* __restrict__ path0) {
   __shared__ uint32_t s_w[4];
   const int64_t first = (int64_t)blockIdx.x * RT_TILE + (int64_t)threadIdx.x * RT_IPT;
   const uint32_t heads = tile_voxel_heads(lin, first, n_alive);
@@ -316,9 +338,9 @@ __global__ __launch_bounds__(256) void k_init_level0(
 #pragma unroll
     for (int q = 0; q < RT_IPT; ++q) v[q] = first + q < n_alive ? val_sorted[first + q] : 0u;
   }
-  uint64_t pw[RT_IPT];
+  uint32_t pw[RT_IPT];
 #pragma unroll
-  for (int q = 0; q < RT_IPT; ++q) pw[q] = first + q < n_alive ? path[v[q] & IDX_MASK] : 0ull;
+  for (int q = 0; q < RT_IPT; ++q) pw[q] = first + q < n_alive ? path[v[q] & IDX_MASK] : 0u;
   int32_t pn[RT_IPT];
 #pragma unroll
   for (int q = 0; q < RT_IPT; ++q) {
@@ -333,9 +355,9 @@ __global__ __launch_bounds__(256) void k_init_level0(
     uint4* o_i = reinterpret_cast<uint4*>(idx0 + first);
     o_i[0] = uint4{v[0], v[1], v[2], v[3]};
     o_i[1] = uint4{v[4], v[5], v[6], v[7]};
-    ulonglong2* o_p = reinterpret_cast<ulonglong2*>(path0 + first);
-#pragma unroll
-    for (int q = 0; q < RT_IPT / 2; ++q) o_p[q] = ulonglong2{pw[2 * q], pw[2 * q + 1]};
+    uint4* o_p = reinterpret_cast<uint4*>(path0 + first);
+    o_p[0] = uint4{pw[0], pw[1], pw[2], pw[3]};
+    o_p[1] = uint4{pw[4], pw[5], pw[6], pw[7]};
   } else {
 #pragma unroll
     for (int q = 0; q < RT_IPT; ++q) {
@@ -347,6 +369,27 @@ __global__ __launch_bounds__(256) void k_init_level0(
       }
     }
   }
+}
+
+// A fresh single cube (bare Octree / OctreeManager, mode 1) whose points are all alive needs none of the voxel
+// machinery: there is ONE root, the store order is the level-0 order.  One pass replaces k_keygen + k_linkey +
+// k_root_tiles x 2 + k_init_level0 (BASELINE config 4, 64 M points: 1.66 ms of its 7.2 ms -> 0.6 ms).
+__global__ __launch_bounds__(256) void k_cube_level0(const double* __restrict__ xyz, int64_t n, double L, double c0x,
+                                                     double c0y, double c0z, const int64_t* __restrict__ pose_off,
+                                                     int n_poses, const uint8_t* __restrict__ scheme,
+                                                     int exact_digits, int32_t* __restrict__ pos_node,
+                                                     uint32_t* __restrict__ idx0, uint32_t* __restrict__ path0) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool exact_cube = exact_digits && nonneg_integer_below_2p45(L) && L >= 1.0 && nonneg_integer_below_2p45(c0x) &&
+                          nonneg_integer_below_2p45(c0y) && nonneg_integer_below_2p45(c0z);
+  const bool edge_pow2 = (__double_as_longlong(L) & 0xFFFFFFFFFFFFFll) == 0;
+  const double px = xyz[3 * i + 0], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+  path0[i] = compute_path_root(px, py, pz, c0x, c0y, c0z, L, exact_cube, edge_pow2, 64.0 / L);
+  uint32_t v = (uint32_t)i;
+  if (!scheme || scheme[find_slot(pose_off, n_poses, i)]) v |= 0x80000000u;
+  idx0[i] = v;
+  pos_node[i] = 0;
 }
 
 // scheme-pose point count of every root (only when a pose subset drives the scheme)
@@ -504,7 +547,7 @@ __device__ __forceinline__ uint32_t slow_digit(const double* __restrict__ xyz, u
 __global__ __launch_bounds__(LV_THREADS) void k_lv_rekey(
     const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
     uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
-    uint64_t* __restrict__ path_io, const double* __restrict__ xyz) {
+    uint32_t* __restrict__ path_io, const double* __restrict__ xyz) {
   const TileRef tr = locate_tile(tile_base, ns, n_tiles, blockIdx.x);
   const int32_t node = split_nodes[tr.s];
   const uint32_t nstart = nd.start[node], nend = nstart + nd.count[node];
@@ -550,7 +593,7 @@ template <bool SCHEME_SUBSET>
 __global__ __launch_bounds__(LV_THREADS) void k_lv_hist(
     const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
     uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
-    const uint64_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
+    const uint32_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
     uint32_t* __restrict__ entries, uint32_t* __restrict__ child_sc,
     uint32_t* __restrict__ small) {
   __shared__ uint32_t wc[LV_WAVES][8], wsc[LV_WAVES][8];
@@ -566,10 +609,10 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_hist(
     const bool valid = i < nend;
     uint32_t d = 0, v = 0;
     if (valid) {
-      const uint64_t pw = path_in[i];
+      const uint32_t pw = path_in[i];
       v = idx_in[i];
-      d = (pw & 1ull) ? slow_digit(xyz, v, nd.corner + 3 * (int64_t)node, nd.edge[node], small)
-                      : (uint32_t)(pw >> shift) & 7u;
+      d = (pw & 1u) ? slow_digit(xyz, v, nd.corner + 3 * (int64_t)node, nd.edge[node], small)
+                    : (pw >> shift) & 7u;
     }
     const uint64_t sm = SCHEME_SUBSET ? __ballot(valid && (v >> 31)) : 0ull;
 #pragma unroll
@@ -603,11 +646,17 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_hist(
 __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
     const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
     uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
-    const uint64_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
+    const uint32_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
     const uint32_t* __restrict__ entries_scanned, int32_t child_base,
-    uint32_t* __restrict__ idx_out, uint64_t* __restrict__ path_out,
-    int32_t* __restrict__ pos_node, uint32_t* __restrict__ small) {
+    uint32_t* __restrict__ idx_out, uint32_t* __restrict__ path_out,
+    int32_t* __restrict__ pos_node, uint32_t* __restrict__ small, int64_t K_leaf) {
   __shared__ uint32_t cnt[LV_WAVES][8];
+  // position -> node is only READ behind the level loop (k_finalize, the block table): a point that moves into a
+  // child which splits again gets its entry from that deeper level, so only children that stay LEAVES write it
+  // here.  K_leaf >= 0: a child stays a leaf iff its count is at most K_leaf (count-driven split over all poses:
+  // scount == count); K_leaf < 0: every child writes (scheme from a pose subset, keep_scheme, resumed builds).
+  // BASELINE config 4 (64 M points, 5 levels): 4 bytes per point and level less, 1 GB of 9 GB of the loop.
+  __shared__ uint32_t leaf_child[8];
   const TileRef tr = locate_tile(tile_base, ns, n_tiles, blockIdx.x);
   const int32_t node = split_nodes[tr.s];
   const uint32_t nstart = nd.start[node], nend = nstart + nd.count[node];
@@ -616,7 +665,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
   __syncthreads();
   const uint32_t wbase = nstart + tr.tl * LV_TILE + wave * LV_WAVE_ITEMS;
   uint32_t v[LV_IPT], d[LV_IPT], rank[LV_IPT];
-  uint64_t pw[LV_IPT];
+  uint32_t pw[LV_IPT];
 #pragma unroll
   for (int r = 0; r < LV_IPT; ++r) {
     const uint32_t i = wbase + r * 64 + lane;
@@ -625,9 +674,9 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
     if (valid) {
       pw[r] = path_in[i];
       v[r] = idx_in[i];
-      d[r] = (pw[r] & 1ull)
+      d[r] = (pw[r] & 1u)
                  ? slow_digit(xyz, v[r], nd.corner + 3 * (int64_t)node, nd.edge[node], small)
-                 : (uint32_t)(pw[r] >> shift) & 7u;
+                 : (pw[r] >> shift) & 7u;
     }
     rank[r] = wave_stable_rank<3>(d[r], valid, cnt[wave]);
   }
@@ -635,6 +684,14 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
   if (threadIdx.x < 8) {
     const int b = threadIdx.x;
     const size_t ebase = (size_t)8 * tr.tile_base;
+    {
+      // points of child b of the node (as k_make_children counts them)
+      const uint32_t lo = entries_scanned[ebase + (size_t)b * tr.nt];
+      const uint32_t hi = (b < 7 || (size_t)8 * (tr.tile_base + tr.nt) < (size_t)8 * n_tiles)
+                              ? entries_scanned[ebase + (size_t)(b + 1) * tr.nt]
+                              : small[SM_ETOTAL];
+      leaf_child[b] = (K_leaf < 0 || (int64_t)(hi - lo) <= K_leaf) ? 1u : 0u;
+    }
     // destination of the first item with digit b of this tile, relative to the node start
     uint32_t run = entries_scanned[ebase + (size_t)b * tr.nt + tr.tl] - entries_scanned[ebase];
 #pragma unroll
@@ -653,7 +710,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
       const uint32_t dst = nstart + cnt[wave][d[r]] + rank[r];
       idx_out[dst] = v[r];
       path_out[dst] = pw[r];
-      pos_node[dst] = first_child + (int32_t)d[r];
+      if (leaf_child[d[r]]) pos_node[dst] = first_child + (int32_t)d[r];
     }
   }
 }
@@ -1066,7 +1123,7 @@ static int run_level_loop(LevelLoop& L) {
       HIP_TRY(ctx, hipMemsetAsync(f->child_sc.p, 0, (size_t)8 * ns * 4, st));
     }
     const int src = L.level & 1;
-    const int shift = 61 - 3 * (L.level % PATH_LEVELS);
+    const int shift = 29 - 3 * (L.level % PATH_LEVELS);
     uint32_t* entries = nullptr;
     if (n_tiles > 0) {
       OCTL_TRY(devbuf_reserve(ctx, f->entries, ((size_t)8 * n_tiles + 8) * 4));
@@ -1086,7 +1143,7 @@ static int run_level_loop(LevelLoop& L) {
         hipLaunchKernelGGL(k_lv_rekey, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                            (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
                            (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                           f->pathbuf[src].as<uint64_t>(), (const double*)f->xyz.as<double>());
+                           f->pathbuf[src].as<uint32_t>(), (const double*)f->xyz.as<double>());
         HIP_TRY(ctx, hipGetLastError());
       }
       {
@@ -1095,14 +1152,14 @@ static int run_level_loop(LevelLoop& L) {
           hipLaunchKernelGGL(k_lv_hist<true>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                              (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
                              nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                             (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
                              (const double*)f->xyz.as<double>(), shift, entries,
                              f->child_sc.as<uint32_t>(), small);
         else
           hipLaunchKernelGGL(k_lv_hist<false>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                              (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
                              nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                             (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                             (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
                              (const double*)f->xyz.as<double>(), shift, entries,
                              (uint32_t*)nullptr, small);
         HIP_TRY(ctx, hipGetLastError());
@@ -1117,10 +1174,12 @@ static int run_level_loop(LevelLoop& L) {
         hipLaunchKernelGGL(k_lv_scatter, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                            (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
                            (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                           (const uint64_t*)f->pathbuf[src].as<uint64_t>(),
+                           (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
                            (const double*)f->xyz.as<double>(), shift, (const uint32_t*)entries,
                            (int32_t)child_base, f->idxbuf[src ^ 1].as<uint32_t>(),
-                           f->pathbuf[src ^ 1].as<uint64_t>(), pos_node, small);
+                           f->pathbuf[src ^ 1].as<uint32_t>(), pos_node, small,
+                           (L.all_scheme && !L.keep_scheme && !L.resume && L.K >= 0 && L.level + 1 < L.max_depth)
+                               ? L.K : (int64_t)-1);
         HIP_TRY(ctx, hipGetLastError());
       }
     }
@@ -1305,7 +1364,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       // outside its cube): the level loop subdivides exactly those roots, the rest of the build stands
       for (int b = 0; b < 2; ++b) {
         OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)n_alive * 4));
-        OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)n_alive * 8));
+        OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)n_alive * 4));
       }
       LevelLoop L{f, &bt, K, 0, all_scheme, scheme_dev, ba.old_fc, ba.old_epoch, cur_epoch, max_depth, n_alive,
                   true, 0, nv, 0, 0, &segs};
@@ -1379,24 +1438,30 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   trace.mark("sync_vkeys");
   // ---- 1. keys -----------------------------------------------------------------------------------
   OCTL_TRY(forest_ensure_origin(f));
-  if (N > 0) {
+  // a fresh single cube with every point alive: one root, the store order is the level-0 order (k_cube_level0)
+  const bool cube_fast = f->mode == 1 && N > 0 && n_alive == N && !f->built && f->vkeys.empty() &&
+                         !getenv("OCTL_NO_CUBE_FAST");
+  if (N > 0 && !cube_fast) {
     OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));
-    OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 8));
+    OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 4));
     KTimer t(ctx, "keygen");
     hipLaunchKernelGGL(k_keygen, dim3(grid_for(N)), dim3(256), 0, st, f->xyz.as<double>(),
                        f->alive.as<uint8_t>(), N, f->mode, f->edge, f->corner[0], f->corner[1],
-                       f->corner[2], f->vorg, f->vkey.as<uint64_t>(), f->path.as<uint64_t>(), small);
+                       f->corner[2], f->vorg, getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1, f->vkey.as<uint64_t>(),
+                       f->path.as<uint32_t>(), small);
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t sm[32];
-  OCTL_TRY(read_small(ctx, 0, 32, sm));
-  if (sm[SM_ERR])
-    return octl_set_error(ctx, OCTL_E_DOMAIN,
-                          "a point has a non-finite coordinate, a top-level voxel index outside +-%d, or "
-                          "lies more than %d voxels from where the scene started", OCTL_VOX_ABS_LIMIT,
-                          OCTL_VOX_BIAS);
-  int bb[6];
-  std::memcpy(bb, sm + SM_BBOX, sizeof(bb));
+  int bb[6] = {0, 0, 0, 0, 0, 0};  // (a single cube is voxel 0)
+  if (!cube_fast) {
+    OCTL_TRY(read_small(ctx, 0, 32, sm));
+    if (sm[SM_ERR])
+      return octl_set_error(ctx, OCTL_E_DOMAIN,
+                            "a point has a non-finite coordinate, a top-level voxel index outside +-%d, or "
+                            "lies more than %d voxels from where the scene started", OCTL_VOX_ABS_LIMIT,
+                            OCTL_VOX_BIAS);
+    std::memcpy(bb, sm + SM_BBOX, sizeof(bb));
+  }
   // the voxels of the previous scheme persist even when they have lost all their points
   for (uint64_t k : f->vkeys) {
     int64_t q[3];
@@ -1426,7 +1491,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   trace.mark("keys + bbox readback");
   // ---- 2. sort by top-level voxel ---------------------------------------------------------------
   int sorted = 0;
-  if (N > 0) {
+  if (cube_fast) {  // (the voxel table of one entry is staged where the sort's second buffers would be)
+    OCTL_TRY(devbuf_reserve(ctx, f->lin[1], 64));
+    OCTL_TRY(devbuf_reserve(ctx, f->val[1], 64));
+  } else if (N > 0) {
     for (int b = 0; b < 2; ++b) {
       OCTL_TRY(devbuf_reserve(ctx, f->lin[b], (size_t)N * 8));
       OCTL_TRY(devbuf_reserve(ctx, f->val[b], (size_t)N * 4));
@@ -1460,7 +1528,11 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   std::vector<uint32_t> vstart_h;
   uint64_t* vlin_d = f->lin[sorted ^ 1].as<uint64_t>();   // free now: staging for the voxel table
   uint32_t* vstart_d = f->val[sorted ^ 1].as<uint32_t>();
-  if (n_alive > 0) {
+  if (cube_fast) {
+    HIP_TRY(ctx, hipMemsetAsync(vlin_d, 0, 8, st));    // voxel 0 ...
+    HIP_TRY(ctx, hipMemsetAsync(vstart_d, 0, 4, st));  // ... starts at position 0
+    v_pts = 1;
+  } else if (n_alive > 0) {
     KTimer t(ctx, "roots");
     hipLaunchKernelGGL(k_root_tiles<false>, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted, n_alive, flags,
                        (uint64_t*)nullptr, (uint32_t*)nullptr);
@@ -1592,7 +1664,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   // ---- 4. level-0 buffers ---------------------------------------------------------------------------
   for (int b = 0; b < 2; ++b) {
     OCTL_TRY(devbuf_reserve(ctx, f->idxbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 4));
-    OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 8));
+    OCTL_TRY(devbuf_reserve(ctx, f->pathbuf[b], (size_t)std::max<int64_t>(n_alive, 1) * 4));
   }
   OCTL_TRY(devbuf_reserve(ctx, f->pos_node, (size_t)std::max<int64_t>(n_alive, 1) * 4));
   pos_node = f->pos_node.as<int32_t>();
@@ -1606,10 +1678,17 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       l2r = f->root_up.as<int32_t>();
     }
     KTimer t(ctx, "init_level0");
-    hipLaunchKernelGGL(k_init_level0, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted,
-                       (const uint32_t*)flags, val_sorted, (const uint64_t*)f->path.as<uint64_t>(),
-                       n_alive, l2r, pos_node,
-                       f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint64_t>());
+    if (cube_fast)
+      hipLaunchKernelGGL(k_cube_level0, dim3(grid_for(N)), dim3(256), 0, st, (const double*)f->xyz.as<double>(), N,
+                         f->edge, f->corner[0], f->corner[1], f->corner[2],
+                         (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, scheme_dev,
+                         getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1, pos_node,
+                         f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint32_t>());
+    else
+      hipLaunchKernelGGL(k_init_level0, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted,
+                         (const uint32_t*)flags, val_sorted, (const uint32_t*)f->path.as<uint32_t>(),
+                         n_alive, l2r, pos_node,
+                         f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
     if (!all_scheme && !keep_scheme) {
       hipLaunchKernelGGL(k_count_scheme, dim3((unsigned)ceil_div(n_alive, 2048)), dim3(256), 0, st,

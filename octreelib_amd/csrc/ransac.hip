@@ -495,14 +495,44 @@ __device__ __forceinline__ float min3abs(float m, float a, float b) {
   return r;
 }
 
+// Maximum over the wavefront as six DPP-modified v_max (quad swaps, half-row / row mirrors, the two row
+// broadcasts of gfx9) and one v_readlane - instead of six ds_bpermute round trips through the LDS crossbar per
+// 32-bit word (the block's winner key and the block's extent are reduced once per block by every wave: with
+// 64-bit keys that was 18 bpermutes + 6 64-bit compare / select pairs per wave and block).
+#ifndef RS_DPP_REDUCE
+#define RS_DPP_REDUCE 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  // (lanes the row mask leaves out keep `old` = their own value: max(v, v) = v)
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#if RS_DPP_REDUCE
+  v = max(v, dpp_u32<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
+  v = max(v, dpp_u32<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
+  v = max(v, dpp_u32<0x141, 0xF>(v));  // row_half_mirror
+  v = max(v, dpp_u32<0x140, 0xF>(v));  // row_mirror: every lane of a row holds the row's maximum
+  v = max(v, dpp_u32<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
+  v = max(v, dpp_u32<0x143, 0xC>(v));  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#else
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+  return v;
+#endif
+}
+// (non-negative floats order like their bit patterns; +inf included, NaN excluded by the caller)
+__device__ __forceinline__ float wave_max_nonneg_f32(float m) {
+  return __uint_as_float(wave_max_u32(__float_as_uint(m)));
+}
+
 // block-local f32 coordinates of the point a lane is staging (relative to the block's first
-// point, read with a wave-uniform scalar load) and the per-wave maximum of their magnitudes
+// point, loaded wave-uniformly by the caller well ahead of this call) and the per-wave maximum of their magnitudes
 template <int THREADS>
-__device__ __forceinline__ void stage_local(const double* __restrict__ xyz, const BlockDesc& d,
+__device__ __forceinline__ void stage_local(double ox, double oy, double oz, const BlockDesc& d,
                                             double px, double py, double pz, f4* loc,
                                             float* wext, uint32_t* wfast) {
-  const double ox = xyz[3 * (int64_t)d.pstart], oy = xyz[3 * (int64_t)d.pstart + 1],
-               oz = xyz[3 * (int64_t)d.pstart + 2];
   float m = 0.f;
   if ((int)threadIdx.x < d.n) {
     const float u = (float)(px - ox), v = (float)(py - oy), w = (float)(pz - oz);
@@ -511,8 +541,7 @@ __device__ __forceinline__ void stage_local(const double* __restrict__ xyz, cons
     // a NaN coordinate would be dropped by fmaxf: force "everything is ambiguous" instead
     if (!(m == m) || u != u || v != v || w != w) m = __int_as_float(0x7f800000);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  m = wave_max_nonneg_f32(m);
   // the range certificate of the plane fit's shortcuts (see RS_BLKFAST): lanes that stage nothing hold +0.0
   const bool inr = coord_in_fast_range(px) && coord_in_fast_range(py) && coord_in_fast_range(pz);
   const bool wave_fast = __all(inr);
@@ -578,6 +607,40 @@ __device__ __forceinline__ void screen_group(const f4* __restrict__ loc, int n, 
 }
 #endif
 
+// -DRS_STAMPS: phase clocks of k_ransac (experiments only, like BB_STAMPS in bucket_build.hip).  Wave 0 of every
+// workgroup reads s_memtime at the phase boundaries of every block and keeps the sums in SGPRs; at the end of the
+// kernel they are added to a device array that tools/rs_stamps.py reads through octl_debug_rs_stamps:
+//   [0] iteration head (descriptor prefetch, next block's loads issued, sample positions when the size changes)
+//   [1] plane fits of hypothesis group 0 (LDS gathers included)      [2] scoring of group 0 (screen + recounts)
+//   [3] plane fits of groups 1..HPL-1                                [4] their scoring
+//   [5] reduction over the lane / wave + staging of the next block   [6] the block's barrier
+//   [7] winner, outputs, final mask
+//   [8] blocks  [9] blocks that skipped pass 2  [10] workgroups  [11] sum of block sizes
+#ifdef RS_STAMPS
+__device__ unsigned long long g_rs_stamps[16];
+#define RS_STAMP_INIT unsigned long long _rs_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+                      unsigned long long _rs_t0 = __builtin_readcyclecounter()
+#define RS_STAMP(k)                                                   \
+  do {                                                                \
+    const unsigned long long _t = __builtin_readcyclecounter();       \
+    _rs_acc[k] += _t - _rs_t0;                                        \
+    _rs_t0 = _t;                                                      \
+  } while (0)
+#define RS_COUNT(k, v) _rs_acc[k] += (unsigned long long)(v)
+#define RS_STAMP_FLUSH                                                                  \
+  do {                                                                                  \
+    if (threadIdx.x == 0) {                                                             \
+      _rs_acc[10] += 1;                                                                 \
+      for (int _k = 0; _k < 12; ++_k) atomicAdd(&g_rs_stamps[_k], _rs_acc[_k]);         \
+    }                                                                                   \
+  } while (0)
+#else
+#define RS_STAMP_INIT do {} while (0)
+#define RS_STAMP(k) do {} while (0)
+#define RS_COUNT(k, v) do {} while (0)
+#define RS_STAMP_FLUSH do {} while (0)
+#endif
+
 // Persistent workgroups over the descriptors of all blocks with k <= n <= THREADS-1 points,
 // SORTED BY SIZE (largest first): workgroup w handles a contiguous chunk of the list
 //   * the grid is oversubscribed (64 workgroups per CU, 4 resident): the chunks with the largest
@@ -602,7 +665,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   constexpr int W = THREADS / 64;
   const int k = KT > 0 ? KT : k_rt;
   __shared__ double s_pts[3][3][THREADS];        // rotated: block t lives in buffer t % 3
-  __shared__ unsigned long long s_wbest[2][W];   // by block parity
+  __shared__ uint32_t s_wbest[2][W];             // by block parity
   __shared__ float s_wplane[2][W][4];
 #if RS_SCREEN
   // f32 screening of the scoring loop (see "screening" below): block-local f32 coordinates
@@ -634,11 +697,13 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       s_pts[0][2][threadIdx.x] = pz;
     }
 #if RS_SCREEN
-    stage_local<THREADS>(xyz, cur, px, py, pz, s_loc[0], s_wext[0], s_wfast[0]);
+    stage_local<THREADS>(xyz[3 * (int64_t)cur.pstart], xyz[3 * (int64_t)cur.pstart + 1],
+                         xyz[3 * (int64_t)cur.pstart + 2], cur, px, py, pz, s_loc[0], s_wext[0], s_wfast[0]);
 #endif
   }
   __syncthreads();
   int buf = 0, par = 0, cached_n = -1;
+  RS_STAMP_INIT;
   bool any_risk = false;
   uint32_t gpk[HPL][GW];
   uint32_t risk[HPL];
@@ -666,6 +731,14 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       rx = xyz[3 * p];
       ry = xyz[3 * p + 1];
       rz = xyz[3 * p + 2];
+    }
+    // ... and its first point, the origin of its block-local coordinates: a wave-uniform load whose latency
+    // used to sit in front of the staging at the END of the iteration (behind the sched_barriers of the fits)
+    double nox = 0.0, noy = 0.0, noz = 0.0;
+    if (has_next) {
+      nox = xyz[3 * (int64_t)nxt.pstart];
+      noy = xyz[3 * (int64_t)nxt.pstart + 1];
+      noz = xyz[3 * (int64_t)nxt.pstart + 2];
     }
     const int n = cur.n;
     const int be = (int)cur.pad[1];
@@ -702,6 +775,9 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       any_risk = __any(risk_any != 0);
     }
 
+    RS_STAMP(0);
+    RS_COUNT(8, 1);
+    RS_COUNT(11, n);
     // ---- the block's hypotheses -------------------------------------------------------------
     // Screening.  The H x n distance tests are evaluated in f32 on block-local coordinates; a
     // pair is decided there only when its f32 distance is farther from the threshold than a
@@ -860,7 +936,9 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     bool skipped = false;  // pass 2 not evaluated (wave-uniform)
 #pragma unroll
     for (int q = 0; q < F; ++q) fit(q);
+    RS_STAMP(1);
     score(std::integral_constant<int, F>{}, 0);
+    RS_STAMP(2);
     if (HPL > F) {
       // does a hypothesis of pass 1 hold every point?  (every index of pass 2 is higher: nothing
       // there can beat it, and a tie goes to the lower index).  Decided per wavefront, no
@@ -873,31 +951,31 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       if (!skipped) {
 #pragma unroll
         for (int q = F; q < HPL; ++q) fit(q);
+        RS_STAMP(3);
         score(std::integral_constant<int, (HPL > F ? HPL - F : 1)>{}, F);
+        RS_STAMP(4);
+      } else {
+        RS_COUNT(9, 1);
       }
     }
     // maximum over the lane, then over the wave; lowest hypothesis index among the tied
     // (cuda_ransac.py:125-146)
-    unsigned long long best = 0;
+    // (one 32-bit key: (count + 1) << 10 | 1023 - index; count <= 255, index < 1024 <= H_max; 0 = no hypothesis)
+    static_assert(THREADS * HPL <= 1024, "hypothesis index in 10 bits");
+    uint32_t best = 0;
     float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
 #pragma unroll
     for (int q = 0; q < HPL; ++q) {
       const int t = tx + q * THREADS;
       if (t < H && (q < F || !skipped)) {
-        const unsigned long long key =
-            ((unsigned long long)(unsigned)cnt[q] << 32) | (unsigned)(0x7FFFFFFF - t);
+        const uint32_t key = ((uint32_t)(cnt[q] + 1) << 10) | (uint32_t)(1023 - t);
         if (key > best) {
           best = key;
           wa = fa[q]; wb = fb[q]; wc = fc[q]; wd = fd[q];
         }
       }
     }
-    unsigned long long wbest = best;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const unsigned long long o = __shfl_xor(wbest, off);
-      wbest = o > wbest ? o : wbest;
-    }
+    const uint32_t wbest = wave_max_u32(best);
     if (best == wbest && best != 0) {  // exactly one lane: keys are unique
       const int w = tx >> 6;
       s_wbest[par][w] = best;
@@ -918,10 +996,12 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       s_pts[nbuf][2][tx] = rz;
     }
 #if RS_SCREEN
-    if (has_next) stage_local<THREADS>(xyz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf], s_wfast[nbuf]);
+    if (has_next) stage_local<THREADS>(nox, noy, noz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf], s_wfast[nbuf]);
 #endif
+    RS_STAMP(5);
     __syncthreads();
-    unsigned long long gbest = s_wbest[par][0];
+    RS_STAMP(6);
+    uint32_t gbest = s_wbest[par][0];
     int gw = 0;
 #pragma unroll
     for (int w = 1; w < W; ++w) {
@@ -937,8 +1017,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         out.plane[4 * (int64_t)be + 0] = f0; out.plane[4 * (int64_t)be + 1] = f1;
         out.plane[4 * (int64_t)be + 2] = f2; out.plane[4 * (int64_t)be + 3] = f3;
       }
-      if (out.count) out.count[be] = (int32_t)(gbest >> 32);
-      if (out.index) out.index[be] = 0x7FFFFFFF - (int)(unsigned)(gbest & 0xFFFFFFFFu);
+      if (out.count) out.count[be] = (int32_t)(gbest >> 10) - 1;
+      if (out.index) out.index[be] = 1023 - (int)(gbest & 1023u);
     }
     // final mask with the winning f32 plane (cuda_ransac.py:149-155); n <= THREADS - 1
     if ((int)tx < n) {
@@ -946,6 +1026,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
                                          lx[tx], ly[tx], lz[tx]);
       out.mask[(int64_t)cur.pstart + tx] = (dist < thr) ? 1 : 0;
     }
+    RS_STAMP(7);
     if (!has_next) break;
     cur = nxt;
     nxt = nxt2;
@@ -953,6 +1034,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     buf = nbuf;
     par ^= 1;
   }
+  RS_STAMP_FLUSH;
 }
 
 #if RS_SCREEN
@@ -1476,3 +1558,16 @@ static int debug_plane_arith(octl_ctx* ctx, const double* num3, const double* de
   devbuf_free(buf);
   return rc == OCTL_OK ? OCTL_OK : octl_set_error(ctx, rc, "octl_debug_plane_arith failed");
 }
+
+#ifdef RS_STAMPS
+extern "C" int octl_debug_rs_stamps(octl_ctx* ctx, unsigned long long out[16], int reset) {
+  if (!ctx || !out) return OCTL_E_INVALID;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_stamps), sizeof(unsigned long long) * 16));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_rs_stamps), z, sizeof(z)));
+  }
+  return OCTL_OK;
+}
+#endif

@@ -28,7 +28,7 @@ import numpy as np
 
 from octreelib_amd import _native as nat
 
-__all__ = ["DeviceCloud", "pinned_empty", "upload_async"]
+__all__ = ["DeviceCloud", "ScanPipeline", "pinned_empty", "upload_async"]
 
 
 def pinned_empty(shape, dtype=np.float64, ctx=None) -> np.ndarray:
@@ -103,3 +103,117 @@ class DeviceCloud:
 def upload_async(points, ctx=None) -> DeviceCloud:
     """Start the host-to-device copy of a cloud on the context's copy stream and return at once."""
     return DeviceCloud(points, ctx)
+
+
+class ScanPipeline:
+    """Scans through the drop-in classes on TWO device contexts, so that consecutive scans overlap on the GPU.
+
+    One scan is strictly sequential - upload, insert, subdivide, RANSAC, apply_mask - and its phases load different
+    parts of the chip: the build is memory bound (~0.8 ms of a 10 M-point scan), the RANSAC scoring is VALU bound
+    (~4 ms).  The reference runs scans one after the other and waits for every copy (ransac/cuda_ransac.py:57-80);
+    here scan i+1 is uploaded, inserted and subdivided on context B while scan i is still being fitted on context
+    A: two worker threads, each with its own context (stream, copy stream, scratch, buffer pool), take the scans
+    alternately and call `fn(grid, index)` with a fresh Grid that already holds the scan as pose 0.  The library
+    calls release the GIL, so the two threads' kernels interleave on the device.  Every scan's result is exactly
+    what the sequential loop gives (the scans share nothing); results come back in submission order.
+
+        pipe = ScanPipeline()
+        def fit(grid, i):
+            grid.subdivide([MaxPoints(64)])
+            np.random.seed(0)
+            grid.map_leaf_points_cuda_ransac()
+            return grid.n_points(0)
+        for kept in pipe.map(scans, fit):      # scans: (n, 3) arrays, ideally in pinned_empty() memory
+            ...
+        pipe.close()
+    """
+
+    def __init__(self, n_contexts: int = 2, voxel_edge_length=1, device=None):
+        import queue
+        import threading
+
+        if n_contexts < 1:
+            raise ValueError("n_contexts must be at least 1")
+        self._device = nat.default_device() if device is None else int(device)
+        self._edge = voxel_edge_length
+        self._jobs = [queue.Queue() for _ in range(n_contexts)]
+        self._threads = []
+        self._next = 0
+        self._closed = False
+        for w in range(n_contexts):
+            t = threading.Thread(target=self._worker, args=(w,), name=f"octl-scan-{w}", daemon=True)
+            t.start()
+            self._threads.append(t)
+
+    def _worker(self, w):
+        from octreelib_amd.grid import Grid, GridConfig
+
+        ctx = nat.Context(self._device)
+        try:
+            with nat.use_context(ctx):
+                while True:
+                    job = self._jobs[w].get()
+                    if job is None:
+                        return
+                    points, fn, index, fut = job
+                    if not fut.set_running_or_notify_cancel():
+                        continue
+                    grid = cloud = None
+                    try:
+                        cloud = points if isinstance(points, DeviceCloud) else DeviceCloud(points, ctx)
+                        grid = Grid(GridConfig(voxel_edge_length=self._edge))
+                        grid.insert_points(0, cloud)
+                        fut.set_result(fn(grid, index))
+                    except BaseException as e:  # delivered to whoever waits for the result
+                        fut.set_exception(e)
+                    finally:
+                        if grid is not None:
+                            grid._forest.close()
+                        if cloud is not None and cloud is not points:
+                            cloud.release()
+        finally:
+            ctx.close()
+
+    def submit(self, points, fn):
+        """Queue one scan; returns a concurrent.futures.Future of fn(grid, index).  `points` must stay unchanged
+        until the future is done (its upload starts when a worker picks the scan up)."""
+        from concurrent.futures import Future
+
+        if self._closed:
+            raise RuntimeError("ScanPipeline is closed")
+        fut = Future()
+        i = self._next
+        self._next += 1
+        self._jobs[i % len(self._jobs)].put((points, fn, i, fut))
+        return fut
+
+    def map(self, scans, fn, depth=None):
+        """fn(grid, index) for every scan, results in submission order.  At most `depth` scans (default: one per
+        context plus one waiting, so that no worker idles) are queued or running: before scan k is submitted the
+        result of scan k - depth has been delivered.  A front end that refills staging buffers therefore needs a ring
+        of depth + 1 of them (the iterator is asked for scan k before that wait)."""
+        from collections import deque
+
+        depth = len(self._jobs) + 1 if depth is None else max(1, int(depth))
+        pending = deque()
+        for pts in scans:
+            if len(pending) >= depth:
+                yield pending.popleft().result()
+            pending.append(self.submit(pts, fn))
+        while pending:
+            yield pending.popleft().result()
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        for q in self._jobs:
+            q.put(None)
+        for t in self._threads:
+            t.join()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -44,28 +44,35 @@ class Grid(GridBase):
                 "voxel coordinates with astype(int) (grid.py:72-76), merging fractional voxels"
             )
         # the reference's plug seam (grid_base.py:66-87, grid.py:100-106): it instantiates
-        # octree_manager_type(octree_type, octree_config, corner, L) per top-level voxel.  Here the whole
-        # grid is ONE device-resident forest; a user-supplied subclass would never be instantiated, so it
-        # is refused instead of being silently ignored.
+        # octree_manager_type(octree_type, octree_config, corner, L) per top-level voxel.  With the package's own
+        # types the whole grid is ONE device-resident forest.
         from octreelib_amd.octree import Octree
         from octreelib_amd.octree_manager import OctreeManager
 
-        if grid_config.octree_manager_type is not OctreeManager or grid_config.octree_type is not Octree:
-            raise NotImplementedError(
-                "GridConfig.octree_manager_type / octree_type other than octreelib_amd's own OctreeManager / "
-                "Octree are not supported: the device-resident grid does not instantiate per-voxel managers"
-            )
-        self._forest = Forest(0, corner, float(L))
         self._slots: Dict[int, int] = {}  # pose number -> slot
+        self._plug = None
+        self._forest = None
+        if grid_config.octree_manager_type is not OctreeManager or grid_config.octree_type is not Octree:
+            # the caller's own types: served on the host, one manager_type(octree_type, config, corner, L) per
+            # top-level voxel as the reference instantiates them (grid/_plugged.py) - slow and correct
+            from octreelib_amd.grid._plugged import PluggedGrid
+
+            self._plug = PluggedGrid(grid_config)
+        else:
+            self._forest = Forest(0, corner, float(L))
 
     # grid.py:58-109
     def insert_points(self, pose_number: int, points):
+        if self._plug is not None:
+            return self._plug.insert_points(pose_number, points)
         if pose_number in self._slots:
             raise ValueError(f"Cannot insert points to existing pose {pose_number}")
         self._slots[pose_number] = self._forest.add_pose(points)
 
     # grid.py:244-258
     def subdivide(self, subdivision_criteria: List[Callable], pose_numbers: Optional[List[int]] = None):
+        if self._plug is not None:
+            return self._plug.subdivide(subdivision_criteria, pose_numbers)
         k = try_count_threshold(subdivision_criteria)
         scheme = None if pose_numbers is None else [self._slots[p] for p in pose_numbers]
         if k is None:
@@ -75,10 +82,14 @@ class Grid(GridBase):
 
     # grid.py:217-232
     def get_leaf_points(self, pose_number: int, non_empty: bool = True) -> List[Voxel]:
+        if self._plug is not None:
+            return self._plug.get_leaf_points(pose_number, non_empty)
         return _views.leaf_views(self._forest, self._slots[pose_number], non_empty)
 
     # grid.py:234-242: all managers in first-creation order, DFS order inside a manager
     def get_points(self, pose_number: int):
+        if self._plug is not None:
+            return self._plug.get_points(pose_number)
         f = self._forest
         slot = self._slots[pose_number]
         blk = f.blocks
@@ -94,10 +105,14 @@ class Grid(GridBase):
 
     # grid.py:260-267
     def filter(self, filtering_criteria: List[Callable]):
+        if self._plug is not None:
+            return self._plug.filter(filtering_criteria)
         _views.filter_slots(self._forest, list(self._slots.values()), filtering_criteria)
 
     # grid.py:111-122
     def map_leaf_points(self, function: Callable, pose_numbers: Optional[List[int]] = None):
+        if self._plug is not None:
+            return self._plug.map_leaf_points(function, pose_numbers)
         if pose_numbers is None:
             slots = list(self._slots.values())
         else:
@@ -111,7 +126,17 @@ class Grid(GridBase):
         threshold: float = 0.01,
         hypotheses_number: int = 1024,
         initial_points_number: int = 6,
+        *,
+        hypotheses=None,
     ):
+        """`hypotheses` (extension, keyword only): the (H, k) table itself instead of one drawn from NumPy's global
+        generator - for callers that fit scans from several threads (octreelib_amd.ScanPipeline) and want every
+        scan to see the same table without serialising on the generator."""
+        if hypotheses is not None:
+            hypotheses = np.ascontiguousarray(hypotheses, dtype=np.float64)
+            if hypotheses.ndim != 2:
+                raise ValueError("hypotheses must be an (H, k) table")
+            hypotheses_number, initial_points_number = hypotheses.shape
         if threshold <= 0:
             raise ValueError("Threshold must be positive")
         if hypotheses_number < 1:
@@ -121,13 +146,19 @@ class Grid(GridBase):
                 "Number of RANSAC hypotheses must be <= 1024 "
                 "because of the CUDA thread limit."
             )
+        if self._plug is not None:
+            return self._plug.ransac(poses_per_batch, threshold, min(hypotheses_number, RANSAC_MAX_HYPOTHESES),
+                                     initial_points_number, hypotheses)
         f = self._forest
         n_poses = len(self._slots)
         if n_poses == 0:
             return
         # the hypothesis table: ONE draw from NumPy's global generator, shared by all leaves
         # and batches (ransac/cuda_ransac.py:39-41)
-        table = np.random.random((min(hypotheses_number, RANSAC_MAX_HYPOTHESES), initial_points_number))
+        if hypotheses is not None:
+            table = hypotheses
+        else:
+            table = np.random.random((min(hypotheses_number, RANSAC_MAX_HYPOTHESES), initial_points_number))
         # batches are ranges of pose INDICES used as pose numbers (grid.py:149-157)
         for p in range(n_poses):
             if p not in self._slots:
@@ -146,10 +177,16 @@ class Grid(GridBase):
 
     # grid.py:343-362
     def n_leaves(self, pose_number: int) -> int:
+        if self._plug is not None:
+            return self._plug.count("n_leaves", pose_number)
         return self._forest.n_leaves(self._slots[pose_number])
 
     def n_points(self, pose_number: int) -> int:
+        if self._plug is not None:
+            return self._plug.count("n_points", pose_number)
         return self._forest.n_points(self._slots[pose_number])
 
     def n_nodes(self, pose_number: int) -> int:
+        if self._plug is not None:
+            return self._plug.count("n_nodes", pose_number)
         return self._forest.n_nodes(self._slots[pose_number])

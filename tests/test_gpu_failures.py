@@ -39,7 +39,7 @@ def _cloud(seed, n, side=3):
 STEPS = ["insert+subdivide", "late pose", "ransac+apply_mask", "second subdivide"]
 
 
-def _run_life(fail_step, nth):
+def _run_life(fail_step, nth, big=False):
     """One Grid through its whole life next to the oracle; the growth `nth` of step `fail_step` fails.
     Returns (raised, growths seen in that step).
 
@@ -53,7 +53,8 @@ def _run_life(fail_step, nth):
 
     lib, ctx = nat.load(), nat.get_context()
     grid, og = Grid(GridConfig(voxel_edge_length=1)), onp.OGrid(1)
-    poses = {0: _cloud(11, 2600, side=2), 1: _cloud(12, 1500, side=2)}
+    # big: 27 voxels in one bucket of more than 4096 points - the chunked bucket path, block order from order.hip
+    poses = {0: _cloud(11, 9000), 1: _cloud(12, 5000)} if big else {0: _cloud(11, 2600, side=2), 1: _cloud(12, 1500, side=2)}
     idx = {p: index_map(c) for p, c in poses.items()}
     table_seed, H, thr = 5, 64, 0.01
     np.random.seed(table_seed)
@@ -117,14 +118,18 @@ def _run_life(fail_step, nth):
     return raised, seen
 
 
-@pytest.mark.parametrize("fail_step", range(len(STEPS)), ids=STEPS)
-def test_allocation_failure_sweep(fail_step):
+@pytest.mark.parametrize("fail_step,big", [(0, False), (1, False), (2, False), (3, False), (0, True)],
+                         ids=STEPS + ["insert+subdivide, chunked bucket"])
+def test_allocation_failure_sweep(fail_step, big):
     nth, hits, problems = 1, 0, []
     while True:
         try:
-            raised, seen = _run_life(fail_step, nth)
+            raised, seen = _run_life(fail_step, nth, big)
         except Exception as e:     # (the whole sweep is reported, not only its first casualty)
-            problems.append(f"growth {nth}: {type(e).__name__}: {str(e)[:300]}")
+            import traceback
+
+            where = [ln.strip() for ln in traceback.format_exc().splitlines() if "test_gpu_failures.py" in ln or "_util.py" in ln]
+            problems.append(f"growth {nth}: {type(e).__name__}: {str(e)[:200]} @ {where[-3:]}")
             _arm(0)
             raised, seen = True, nth
             if len(problems) > 6:
@@ -343,3 +348,46 @@ def test_set_contents_rejects_tables_that_are_not_the_forests_own():
     assert (grid.n_leaves(0), grid.n_points(0)) == before    # nothing was committed
     f.set_contents(node, slot, size, rows)                    # the forest's own table goes through
     assert (grid.n_leaves(0), grid.n_points(0)) == before
+
+
+def test_scan_pipeline_on_two_contexts_gives_the_sequential_results():
+    """octreelib_amd.ScanPipeline: 16 scans (four different clouds, sizes differ) taken alternately by two worker
+    threads with a context each.  Every scan's surviving points and leaf count equal those of the plain sequential
+    loop over the same clouds; errors inside a scan come back through its future."""
+    import octreelib_amd as oa
+    from octreelib_amd import MaxPoints, synthetic
+    from octreelib_amd.grid import Grid, GridConfig
+
+    clouds = [synthetic.planar_cloud(300_000 - 21_000 * j, (10, 10, 10), seed=1, stream=j) for j in range(4)]
+    np.random.seed(3)
+    table = np.random.random((512, 6))
+
+    def fit(grid, i):
+        grid.subdivide([MaxPoints(64)])
+        grid.map_leaf_points_cuda_ransac(hypotheses=table)
+        pts = grid.get_points(0)
+        return grid.n_points(0), grid.n_leaves(0), float(pts.sum())
+
+    want = []
+    for c in clouds:
+        g = Grid(GridConfig(voxel_edge_length=1))
+        g.insert_points(0, c)
+        want.append(fit(g, 0))
+        g._forest.close()
+    ring = [oa.pinned_empty((300_000, 3)) for _ in range(4)]
+
+    def scans():
+        for i in range(16):
+            c = clouds[i % 4]
+            ring[i % 4][: len(c)] = c
+            yield ring[i % 4][: len(c)]
+
+    with oa.ScanPipeline(2) as pipe:
+        got = list(pipe.map(scans(), fit))
+        assert got == [want[i % 4] for i in range(16)]
+        # a failing scan does not take the pipeline down
+        bad = pipe.submit(np.full((10, 3), np.nan), lambda grid, i: grid.subdivide([MaxPoints(2)]))
+        ok = pipe.submit(clouds[1], fit)
+        with pytest.raises((ValueError, IndexError)):
+            bad.result()
+        assert ok.result() == want[1]

@@ -941,24 +941,86 @@ def test_grid_filter_count_criteria_on_device_vs_oracle_and_host_path():
             assert [g.n_leaves(p), g.n_points(p)] == [og.n_leaves(p), og.n_points(p)]
 
 
-def test_grid_refuses_foreign_manager_and_octree_types():
-    """The reference's plug seam (grid_base.py:66-87, grid.py:100-106): a type that is not a subclass is a
-    TypeError (message asserted upstream), a subclass that this build cannot honour is refused loudly."""
+@pytest.mark.parametrize("plug", ["manager", "octree", "both"])
+def test_grid_serves_the_plug_seam_with_user_subclasses(plug):
+    """The reference's plug seam (grid_base.py:66-87, grid.py:100-106): GridConfig.octree_manager_type /
+    octree_type name the classes the grid instantiates per top-level voxel / per pose.  With a caller's own
+    subclasses the grid is served on the host: the instances exist, their (overridden) methods are called, and the
+    results - here through insert, subdivide from a pose subset, a late pose, filter, RANSAC - equal the device
+    path's and the oracle's.  The reference's own seam test (test_grid.py:148-182: TypeError for non-subclasses)
+    is in tests/test_cpu_abi.py."""
     from octreelib_amd.grid import Grid, GridConfig
-    from octreelib_amd.octree import Octree
+    from octreelib_amd.octree import Octree, OctreeConfig
     from octreelib_amd.octree_manager import OctreeManager
+    from oracle import octree_np as onp
+
+    calls = {"manager_init": 0, "manager_insert": 0, "octree_init": 0, "octree_subdivide_as": 0}
 
     class MyManager(OctreeManager):
-        pass
+        def __init__(self, *a, **k):
+            calls["manager_init"] += 1
+            super().__init__(*a, **k)
+
+        def insert_points(self, pose_number, points):
+            calls["manager_insert"] += 1
+            return super().insert_points(pose_number, points)
 
     class MyOctree(Octree):
-        pass
+        def __init__(self, *a, **k):
+            calls["octree_init"] += 1
+            super().__init__(*a, **k)
 
-    with pytest.raises(NotImplementedError, match="octree_manager_type"):
-        Grid(GridConfig(octree_manager_type=MyManager))
-    with pytest.raises(NotImplementedError, match="octree_type"):
-        Grid(GridConfig(octree_type=MyOctree))
-    Grid(GridConfig(octree_manager_type=OctreeManager, octree_type=Octree))
+        def subdivide_as(self, other):
+            calls["octree_subdivide_as"] += 1
+            return super().subdivide_as(other)
+
+    cfg = {"manager": dict(octree_manager_type=MyManager), "octree": dict(octree_type=MyOctree),
+           "both": dict(octree_manager_type=MyManager, octree_type=MyOctree)}[plug]
+    rng = np.random.default_rng(17)
+    poses = {p: np.unique(rng.uniform(-2.0, 2.0, (900, 3)), axis=0) for p in range(3)}
+    idx = {p: index_map(c) for p, c in poses.items()}
+    g = Grid(GridConfig(voxel_edge_length=2, octree_config=OctreeConfig(), **cfg))
+    d = Grid(GridConfig(voxel_edge_length=2))
+    og = onp.OGrid(2)
+
+    def same(ps):
+        for p in ps:
+            got = canon_from_list(views_table(g.get_leaf_points(p), idx[p]))
+            assert_same_leaves(got, canon_from_list(og.leaf_table(p)))
+            assert_same_leaves(got, canon_from_list(views_table(d.get_leaf_points(p), idx[p])))
+            assert [g.n_nodes(p), g.n_leaves(p), g.n_points(p)] == [og.n_nodes(p), og.n_leaves(p), og.n_points(p)]
+            assert sorted(map(bytes, g.get_points(p))) == sorted(map(bytes, d.get_points(p)))
+
+    for p in (0, 1):
+        for x in (g, d, og):
+            x.insert_points(p, poses[p])
+    same([0, 1])
+    with pytest.raises(ValueError, match="Cannot insert points to existing pose 1"):
+        g.insert_points(1, poses[1])
+    g.subdivide(crit(20), [0])
+    d.subdivide(crit(20), [0])
+    og.subdivide(20, [0])
+    same([0, 1])
+    for x in (g, d, og):
+        x.insert_points(2, poses[2])      # a late pose inherits the scheme
+    same([0, 1, 2])
+    keep = [lambda pts: len(pts) >= 3]
+    g.filter(keep)
+    d.filter(keep)
+    og.filter(keep)
+    same([0, 1, 2])
+    np.random.seed(4)
+    table = np.random.random((128, 6))
+    g.map_leaf_points_cuda_ransac(poses_per_batch=2, threshold=0.05, hypotheses=table)
+    d.map_leaf_points_cuda_ransac(poses_per_batch=2, threshold=0.05, hypotheses=table)
+    for p in range(3):
+        assert sorted(map(bytes, g.get_points(p))) == sorted(map(bytes, d.get_points(p)))
+        assert g.n_points(p) == d.n_points(p)
+    # the plug types really were instantiated and called
+    if plug in ("manager", "both"):
+        assert calls["manager_init"] >= 8 and calls["manager_insert"] >= calls["manager_init"]
+    if plug in ("octree", "both"):
+        assert calls["octree_init"] >= 3 * 8 and calls["octree_subdivide_as"] >= 3 * 8
 
 
 def test_manager_insert_points_into_any_existing_pose_vs_oracle():
@@ -2324,3 +2386,77 @@ def test_thin_buckets_go_to_the_level_loop_and_match_the_oracle():
     ctx.set_profiling(False)
     f.close()
     assert "bucket_build" in names and "keygen" not in names
+
+
+# ------------------------------------------------------------------------------------------------
+# the six child digits of a record at once (ref_arith.h: digits18_exact) against the level-by-level form
+# ------------------------------------------------------------------------------------------------
+def _digit_boundary_cloud(rng, n, L, lo, hi):
+    """Uniform points plus points ON and one / two ulps beside the cube faces of the first seven levels."""
+    base = rng.uniform(lo, hi, (n, 3))
+    k = rng.integers(int(lo * 128 / L), int(hi * 128 / L), (n // 2, 3)).astype(np.float64) * (L / 128.0)
+    edge = [k, np.nextafter(k, np.inf), np.nextafter(np.nextafter(k, np.inf), np.inf)]
+    if lo >= 0:
+        # (one ulp BELOW a face only for non-negative coordinates: a negative coordinate within ~2^-54 of a cube's
+        #  upper face rounds p - corner to the full edge - the reference's IndexError, SURVEY 8a, a DomainError here)
+        edge.append(np.nextafter(k, -np.inf))
+    mix = [np.where(rng.random(k.shape) < 0.5, e, rng.uniform(lo, hi, k.shape)) for e in edge]
+    pts = np.vstack([base] + mix)
+    pts = pts[(pts >= lo).all(axis=1) & (pts < hi).all(axis=1)]
+    return np.unique(pts, axis=0)
+
+
+@pytest.mark.parametrize("L,lo,hi", [(1, 0.0, 6.0), (2, 0.0, 12.0), (5, 0.0, 20.0), (4, -8.0, 8.0), (1, 1000.0, 1004.0)])
+@pytest.mark.parametrize("general_path", [False, True])
+def test_six_digits_at_once_equal_the_level_by_level_form(monkeypatch, L, lo, hi, general_path):
+    """Non-negative coordinates under an integer cube: every rounded subtraction p - corner of the reference's
+    descent (octree.py:73-75) is exact, so the six child digits a partition record carries are the leading bits of
+    p - corner (one multiply and one conversion per axis for a power-of-two edge, the walk on the exact remainder
+    for L = 5).  The builds with the short form switched off (OCTL_NO_EXACT_DIGITS: the reference's own operation
+    order, level by level) must give the same tables bit for bit - on both build paths, with points on and one
+    ulp beside the faces of every level, and with negative coordinates in the cloud (they keep the long form)."""
+    from octreelib_amd._engine import Forest
+
+    if general_path:
+        monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    rng = np.random.default_rng(int(L * 100 + hi))
+    pts = _digit_boundary_cloud(rng, 60_000, float(L), lo, hi)
+
+    def tables(K):
+        f = Forest(0, np.zeros(3), float(L))
+        f.add_pose(pts)
+        f.subdivide(K)
+        t = _tables(f)
+        f.close()
+        return t
+
+    for K in (40, 3):
+        fast = tables(K)
+        monkeypatch.setenv("OCTL_NO_EXACT_DIGITS", "1")
+        slow = tables(K)
+        monkeypatch.delenv("OCTL_NO_EXACT_DIGITS")
+        _assert_same_tables(fast, slow)
+        assert int(fast[0]["depth"].max()) >= (2 if K == 40 else 4)
+
+
+def test_six_digits_at_once_in_a_single_cube(monkeypatch):
+    """The same for a bare Octree over an integer cube (more than 65 535 points: the level loop's fused level-0
+    pass) and for a cube at a fractional corner, which keeps the long form whatever the switch says."""
+    from octreelib_amd.octree import Octree, OctreeConfig
+
+    rng = np.random.default_rng(77)
+    for corner, edge in ((np.array([3.0, 0.0, 7.0]), 2.0), (np.array([0.25, 0.5, 0.125]), 1.0)):
+        pts = corner + _digit_boundary_cloud(rng, 70_000, edge, 0.0, edge)
+        pts = pts[((pts >= corner) & (pts < corner + edge)).all(axis=1)]
+        tabs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("OCTL_NO_EXACT_DIGITS", "1")
+            oc = Octree(OctreeConfig(), corner, np.float64(edge))
+            oc.insert_points(pts)
+            oc.subdivide(crit(50))
+            tabs.append(_tables(oc._forest))
+            if off:
+                monkeypatch.delenv("OCTL_NO_EXACT_DIGITS")
+        _assert_same_tables(tabs[0], tabs[1])
+        assert len(pts) > 65_535 and int(tabs[0][0]["depth"].max()) >= 3
