@@ -755,9 +755,9 @@ def main():
             }
             # ... and through the two-context scan pipeline of the package (octreelib_amd.ScanPipeline): scan i+1 is
             # uploaded, inserted and subdivided on context B while scan i is still being fitted on context A
-            ring = stage + [oa.pinned_empty((n_local, 3)), oa.pinned_empty((n_local, 3))]
-            ring[2][:] = wl.host_pts
-            ring[3][:] = wl.host_pts
+            ring = stage + [oa.pinned_empty((n_local, 3)) for _ in range(3)]   # (depth 4 + the one being drawn)
+            for r in ring[2:]:
+                r[:] = wl.host_pts
 
             def fit(grid, i):
                 grid.subdivide([MaxPoints(args.k_split)])
@@ -766,14 +766,14 @@ def main():
                 return grid.n_points(0)
 
             with oa.ScanPipeline(2) as pipe:
-                list(pipe.map((ring[i & 3] for i in range(4)), fit))
+                list(pipe.map((ring[i % 5] for i in range(6)), fit))
                 t1 = time.perf_counter()
-                kept2 = list(pipe.map((ring[i & 3] for i in range(16)), fit))
-                ms = (time.perf_counter() - t1) * 1e3 / 16
+                kept2 = list(pipe.map((ring[i % 5] for i in range(24)), fit))
+                ms = (time.perf_counter() - t1) * 1e3 / 24
             secondary["api_pipelined_2ctx"] = {
                 "ms": ms, "Mpoints_per_s": n_local / ms / 1e3, "points_after_ransac": int(kept2[-1]),
                 "same_result_every_scan": bool(all(k == kept for k in kept2)),
-                "note": "octreelib_amd.ScanPipeline(2): 16 scans out of a ring of 4 pinned staging buffers, two worker "
+                "note": "octreelib_amd.ScanPipeline(2): 24 scans out of a ring of 5 pinned staging buffers, two worker "
                         "threads with a context each take them alternately - Grid.insert_points(DeviceCloud) + "
                         "subdivide + RANSAC + apply_mask + n_points per scan; the build of one scan overlaps the "
                         "fit of the other.  The headline stays sequential.",

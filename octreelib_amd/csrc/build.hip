@@ -45,7 +45,10 @@ namespace {
 
 constexpr int LV_THREADS = 256;
 constexpr int LV_WAVES = LV_THREADS / 64;
-constexpr int LV_IPT = 4;
+#ifndef OCTL_LV_IPT
+#define OCTL_LV_IPT 4
+#endif
+constexpr int LV_IPT = OCTL_LV_IPT;  // (positions per thread of a level tile; -D for experiments)
 constexpr int LV_TILE = LV_THREADS * LV_IPT;  // 1024 positions per tile
 constexpr int LV_WAVE_ITEMS = 64 * LV_IPT;
 // child digits precomputed per path word.  The word has room for 21; trees are rarely deeper
@@ -912,6 +915,108 @@ __global__ __launch_bounds__(256) void k_block_tiles(const int32_t* __restrict__
   }
 }
 
+// k_finalize and the COUNT pass of the block table in one: a workgroup takes one block tile (2048 consecutive
+// positions, eight per thread), gathers the leaf-ordered permutation and coordinates, and - holding node and index
+// of every position anyway - leaves the tile's number of (leaf, pose) block heads behind, so that the block table
+// needs only its fill pass (BASELINE config 4: one 512 MB pass over position -> leaf and the permutation less).
+__global__ __launch_bounds__(256) void k_finalize_tiles(const int32_t* __restrict__ pos_node,
+                                                        const int32_t* __restrict__ depth,
+                                                        const uint32_t* __restrict__ idx_a,
+                                                        const uint32_t* __restrict__ idx_b,
+                                                        const double* __restrict__ xyz,
+                                                        const int64_t* __restrict__ pose_off, int n_poses,
+                                                        int64_t n_alive, uint32_t* __restrict__ ord_idx,
+                                                        double* __restrict__ xyz_ord,
+                                                        uint32_t* __restrict__ tile_cnt) {
+  __shared__ int64_t s_off[BLK_LDS_POSES + 1];
+  __shared__ uint32_t s_w[4];
+  const bool in_lds = n_poses <= BLK_LDS_POSES;
+  if (in_lds)
+    for (int p = threadIdx.x; p <= n_poses; p += 256) s_off[p] = pose_off[p];
+  __syncthreads();
+  auto off_at = [&](int p) { return in_lds ? s_off[p] : pose_off[p]; };
+  auto slot_of = [&](uint32_t idx) {
+    if (n_poses <= 1) return 0;
+    int lo = 0, hi = n_poses;  // off[lo] <= idx < off[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (off_at(mid) <= (int64_t)idx) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  auto index_at = [&](int64_t i, int32_t node) {
+    return ((depth[node] & 1) ? idx_b[i] : idx_a[i]) & IDX_MASK;
+  };
+  const int64_t first = (int64_t)blockIdx.x * BLK_TILE + (int64_t)threadIdx.x * BLK_IPT;
+  int32_t node[BLK_IPT];
+  uint32_t idx[BLK_IPT];
+#pragma unroll
+  for (int q = 0; q < BLK_IPT; ++q) {
+    const int64_t i = first + q;
+    node[q] = i < n_alive ? pos_node[i] : -1;
+  }
+#pragma unroll
+  for (int q = 0; q < BLK_IPT; ++q) {
+    const int64_t i = first + q;
+    idx[q] = i < n_alive ? index_at(i, node[q]) : 0u;
+  }
+  // ---- the gather (k_finalize): permutation and coordinates in leaf order --------------------------------------
+  double px[BLK_IPT], py[BLK_IPT], pz[BLK_IPT];
+#pragma unroll
+  for (int q = 0; q < BLK_IPT; ++q) {
+    const int64_t v = (int64_t)idx[q];
+    const bool live = first + q < n_alive;
+    px[q] = live ? xyz[3 * v] : 0.0;
+    py[q] = live ? xyz[3 * v + 1] : 0.0;
+    pz[q] = live ? xyz[3 * v + 2] : 0.0;
+  }
+  if (first + BLK_IPT <= n_alive) {  // (16-byte aligned: first is a multiple of 8; 192 contiguous bytes of coordinates)
+    uint4* oi = reinterpret_cast<uint4*>(ord_idx + first);
+    oi[0] = uint4{idx[0], idx[1], idx[2], idx[3]};
+    oi[1] = uint4{idx[4], idx[5], idx[6], idx[7]};
+    double2* ox = reinterpret_cast<double2*>(xyz_ord + 3 * first);
+#pragma unroll
+    for (int q = 0; q < BLK_IPT; q += 2) {
+      ox[3 * (q / 2) + 0] = double2{px[q], py[q]};
+      ox[3 * (q / 2) + 1] = double2{pz[q], px[q + 1]};
+      ox[3 * (q / 2) + 2] = double2{py[q + 1], pz[q + 1]};
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < BLK_IPT; ++q) {
+      const int64_t i = first + q;
+      if (i < n_alive) {
+        ord_idx[i] = idx[q];
+        xyz_ord[3 * i] = px[q];
+        xyz_ord[3 * i + 1] = py[q];
+        xyz_ord[3 * i + 2] = pz[q];
+      }
+    }
+  }
+  // ---- block heads of the tile (k_block_tiles<false>) ------------------------------------------------------------
+  int32_t pnode = -1;
+  int pslot = -1;
+  if (first > 0 && first < n_alive) {
+    pnode = pos_node[first - 1];
+    pslot = slot_of(index_at(first - 1, pnode));
+  }
+  uint32_t heads = 0;
+#pragma unroll
+  for (int q = 0; q < BLK_IPT; ++q) {
+    const bool live = first + q < n_alive;
+    int sl = pslot;
+    if (live && (pslot < 0 || (int64_t)idx[q] >= off_at(pslot + 1) || (int64_t)idx[q] < off_at(pslot)))
+      sl = slot_of(idx[q]);
+    if (live && (first + q == 0 || node[q] != pnode || sl != pslot)) heads |= 1u << q;
+    pnode = node[q];
+    pslot = sl;
+  }
+  const uint32_t inc = wave_inclusive_add((uint32_t)__popc(heads));
+  if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
 __global__ __launch_bounds__(256) void k_block_sizes(const uint32_t* __restrict__ blk_start,
                                                      const uint32_t* __restrict__ nb_dev,
                                                      int64_t n_alive,
@@ -963,7 +1068,7 @@ static int read_small(octl_ctx* ctx, int first, int count, uint32_t* out) {
 
 // (Re)build the (leaf, pose) block table from pos_node / ord_idx.  Asynchronous: the block count
 // is left in small[SM_NBLOCKS]; forest_finish_blocks reads it (one synchronisation).
-int forest_make_blocks(octl_forest* f) {
+int forest_make_blocks(octl_forest* f, bool tiles_counted) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
   const int64_t n = f->n_ord;
@@ -984,10 +1089,12 @@ int forest_make_blocks(octl_forest* f) {
   OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n * 4));
-  hipLaunchKernelGGL(k_block_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
-                     (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
-                     n_poses, n, tile_cnt, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
-  HIP_TRY(ctx, hipGetLastError());
+  if (!tiles_counted) {  // (k_finalize_tiles has left the heads per tile in f->flags already)
+    hipLaunchKernelGGL(k_block_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
+                       (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
+                       n_poses, n, tile_cnt, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
+    HIP_TRY(ctx, hipGetLastError());
+  }
   OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_cnt, tile_cnt, n_tiles, small + SM_NBLOCKS));
   hipLaunchKernelGGL(k_block_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
                      (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
@@ -1714,12 +1821,16 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, (size_t)n_alive * 24));
     {
       KTimer t(ctx, "finalize");
-      hipLaunchKernelGGL(k_finalize, dim3(grid_for(n_alive)), dim3(256), 0, st,
+      // (the gather and the count pass of the block table in one: the heads per tile land in f->flags)
+      const int64_t n_btiles = ceil_div(n_alive, (int64_t)BLK_TILE);
+      OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n_btiles + 8) * 4));
+      hipLaunchKernelGGL(k_finalize_tiles, dim3((unsigned)n_btiles), dim3(256), 0, st,
                          (const int32_t*)pos_node, (const int32_t*)nd.depth,
                          (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
                          (const uint32_t*)f->idxbuf[1].as<uint32_t>(),
-                         (const double*)f->xyz.as<double>(), n_alive, f->ord_idx.as<uint32_t>(),
-                         f->xyz_ord.as<double>());
+                         (const double*)f->xyz.as<double>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
+                         n_poses, n_alive, f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
+                         f->flags.as<uint32_t>());
       HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -1727,7 +1838,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   int64_t n_blocks = 0;
   const int64_t n_ord_before = f->n_ord;
   f->n_ord = n_alive;
-  OCTL_TRY(forest_make_blocks(f));
+  OCTL_TRY(forest_make_blocks(f, n_alive > 0));
   {
     uint32_t e = 0;
     OCTL_TRY(forest_finish_blocks(f, &e));  // the build's final synchronisation

@@ -655,7 +655,9 @@ __device__ unsigned long long g_rs_stamps[16];
 //     per-lane LDS gathers (conflict free up to 32 points), the scoring loop reads each point as
 //     a wave-uniform broadcast;
 //   * ONE barrier per block (three rotating point buffers, reduction slots by parity).
-template <int THREADS, int HPL, int KT, int ABL>
+// FULLH: the table has exactly THREADS x HPL hypotheses (the default 1024): every lane owns HPL of them and the
+// `index < H` guards (a compare, an EXEC save / restore and six zero-initialisations per plane fit) fold away.
+template <int THREADS, int HPL, int KT, int ABL, bool FULLH>
 __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ xyz, const BlockDesc* __restrict__ sdesc,
     const uint32_t* __restrict__ n_sorted_ptr, const double* __restrict__ hyp, int H, int k_rt,
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         risk[q] = 0;
 #pragma unroll
         for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
-        if (t < H) {
+        if (FULLH || t < H) {
           const double* __restrict__ row = hyp + (int64_t)t * k;
 #pragma unroll
           for (int i = 0; i < KS; ++i) {
@@ -833,7 +835,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       const int t = tx + q * THREADS;
       cnt[q] = 0;
       fa[q] = fb[q] = fc[q] = fd[q] = sto[q] = sdl[q] = 0.f;
-      if (t < H) {
+      if (FULLH || t < H) {
         double sx[KS], sy[KS], sz[KS];
         if (!any_risk) {  // wave-uniform: practically always
 #pragma unroll
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #ifdef RS_NO_REDO  // timing experiment only: results are wrong where the screen cannot decide
         const bool redo = false;
 #else
-        const bool redo = (int)tx + q * THREADS < H && !(margin[h] > sdl[q]);  // (NaN: recount)
+        const bool redo = (FULLH || (int)tx + q * THREADS < H) && !(margin[h] > sdl[q]);  // (NaN: recount)
 #endif
         // The recount is done by the whole wavefront for one flagged lane at a time (almost
         // always exactly one): its plane is broadcast, every lane tests one point per round and
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       // hypothesis; a wave without one carries on (a barrier + shared flag measured no better).
       bool full = false;
 #pragma unroll
-      for (int q = 0; q < F; ++q) full = full || ((int)tx + q * THREADS < H && cnt[q] == n);
+      for (int q = 0; q < F; ++q) full = full || ((FULLH || (int)tx + q * THREADS < H) && cnt[q] == n);
       skipped = RS_EARLY_EXIT && __any(full);
       if (!skipped) {
 #pragma unroll
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #pragma unroll
     for (int q = 0; q < HPL; ++q) {
       const int t = tx + q * THREADS;
-      if (t < H && (q < F || !skipped)) {
+      if ((FULLH || t < H) && (q < F || !skipped)) {
         const uint32_t key = ((uint32_t)(cnt[q] + 1) << 10) | (uint32_t)(1023 - t);
         if (key > best) {
           best = key;
@@ -1428,9 +1430,14 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 #define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU)                                        \
   do {                                                                                           \
     const unsigned g = (unsigned)std::min<int64_t>(nb, (int64_t)cus * (PER_CU));                 \
-    hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL>), dim3(g), dim3(THREADS), 0, st,          \
-                       xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(counters + RC_SORTED), \
-                       hyp_dev, H, k, thr, out);                                                  \
+    if (H == (THREADS) * (HPL))                                                                  \
+      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, true>), dim3(g), dim3(THREADS), 0, st,  \
+                         xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(counters + RC_SORTED), \
+                         hyp_dev, H, k, thr, out);                                                \
+    else                                                                                         \
+      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, false>), dim3(g), dim3(THREADS), 0, st, \
+                         xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(counters + RC_SORTED), \
+                         hyp_dev, H, k, thr, out);                                                \
   } while (0)
   if (any_k) {
     // (nothing was put on the sorted list)

@@ -105,30 +105,55 @@ def upload_async(points, ctx=None) -> DeviceCloud:
     return DeviceCloud(points, ctx)
 
 
+class _StagedCloud(DeviceCloud):
+    """A scan in one of the pipeline's device staging buffers: fully uploaded before a worker sees it; release()
+    hands the buffer back to the uploader instead of freeing it."""
+
+    def __init__(self, ctx, ptr, n, give_back):
+        self.ctx, self.ptr, self.n = ctx, ptr, int(n)
+        self._host = None
+        self._readers = []
+        self._give_back = give_back
+
+    def wait(self):
+        pass
+
+    def release(self):
+        if self._give_back is not None:
+            give_back, self._give_back = self._give_back, None
+            give_back()
+
+    def __del__(self):  # pragma: no cover
+        pass
+
+
 class ScanPipeline:
     """Scans through the drop-in classes on TWO device contexts, so that consecutive scans overlap on the GPU.
 
     One scan is strictly sequential - upload, insert, subdivide, RANSAC, apply_mask - and its phases load different
-    parts of the chip: the build is memory bound (~0.8 ms of a 10 M-point scan), the RANSAC scoring is VALU bound
-    (~4 ms).  The reference runs scans one after the other and waits for every copy (ransac/cuda_ransac.py:57-80);
-    here scan i+1 is uploaded, inserted and subdivided on context B while scan i is still being fitted on context
-    A: two worker threads, each with its own context (stream, copy stream, scratch, buffer pool), take the scans
-    alternately and call `fn(grid, index)` with a fresh Grid that already holds the scan as pose 0.  The library
-    calls release the GIL, so the two threads' kernels interleave on the device.  Every scan's result is exactly
-    what the sequential loop gives (the scans share nothing); results come back in submission order.
+    parts of the machine: the upload is PCIe (4.4 ms of a 10 M-point scan), the build is memory bound (~0.9 ms),
+    the RANSAC scoring VALU bound (~4 ms).  The reference runs scans one after the other and waits for every copy
+    (ransac/cuda_ransac.py:57-80).  Here
+      * ONE uploader thread with a context of its own copies the scans, one at a time, into a small ring of device
+        staging buffers (PCIe is a serial resource: two uploads at once only delay both);
+      * `n_contexts` worker threads, each with its own context (stream, scratch, buffer pool), take the uploaded
+        scans alternately and call `fn(grid, index)` with a fresh Grid that holds the scan as pose 0 (read in place
+        from the staging buffer): while worker A fits scan i, worker B builds and fits scan i+1 and the uploader
+        copies scan i+2.  The library calls release the GIL, so the threads' work interleaves on the device.
+    Every scan's result is exactly what the sequential loop gives (the scans share nothing); results come back in
+    submission order.
 
         pipe = ScanPipeline()
         def fit(grid, i):
             grid.subdivide([MaxPoints(64)])
-            np.random.seed(0)
-            grid.map_leaf_points_cuda_ransac()
+            grid.map_leaf_points_cuda_ransac(hypotheses=table)   # (NumPy's global generator is not per thread)
             return grid.n_points(0)
         for kept in pipe.map(scans, fit):      # scans: (n, 3) arrays, ideally in pinned_empty() memory
             ...
         pipe.close()
     """
 
-    def __init__(self, n_contexts: int = 2, voxel_edge_length=1, device=None):
+    def __init__(self, n_contexts: int = 2, voxel_edge_length=1, device=None, staging_buffers=None):
         import queue
         import threading
 
@@ -136,14 +161,62 @@ class ScanPipeline:
             raise ValueError("n_contexts must be at least 1")
         self._device = nat.default_device() if device is None else int(device)
         self._edge = voxel_edge_length
-        self._jobs = [queue.Queue() for _ in range(n_contexts)]
+        self._n_staging = n_contexts + 1 if staging_buffers is None else max(1, int(staging_buffers))
+        self._inbox = queue.Queue()                                   # (points, fn, index, future) -> the uploader
+        self._jobs = [queue.Queue() for _ in range(n_contexts)]       # (job, staged cloud) -> the workers
+        self._free = queue.Queue()                                    # staging buffers handed back by the workers
         self._threads = []
         self._next = 0
         self._closed = False
+        up = threading.Thread(target=self._uploader, name="octl-scan-upload", daemon=True)
+        up.start()
+        self._threads.append(up)
         for w in range(n_contexts):
             t = threading.Thread(target=self._worker, args=(w,), name=f"octl-scan-{w}", daemon=True)
             t.start()
             self._threads.append(t)
+
+    def _uploader(self):
+        ctx = nat.Context(self._device)
+        lib = ctx.lib
+        bufs = []                     # [pointer, capacity in bytes]
+        for _ in range(self._n_staging):
+            bufs.append([C.c_void_p(), 0])
+            self._free.put(len(bufs) - 1)
+        try:
+            while True:
+                job = self._inbox.get()
+                if job is None:
+                    return
+                points, fn, index, fut = job
+                if not fut.set_running_or_notify_cancel():
+                    continue
+                b = self._free.get()  # (back-pressure: at most n_staging scans are uploaded ahead of their fit)
+                try:
+                    if isinstance(points, DeviceCloud):
+                        cloud = points
+                        self._free.put(b)
+                    else:
+                        pts = nat.as_points(points)
+                        if pts.nbytes > bufs[b][1]:
+                            if bufs[b][0].value:
+                                ctx.check(lib.octl_dev_free(ctx.handle, bufs[b][0]))
+                            bufs[b] = [C.c_void_p(), 0]
+                            ctx.check(lib.octl_dev_alloc(ctx.handle, max(pts.nbytes, 16), C.byref(bufs[b][0])))
+                            bufs[b][1] = max(pts.nbytes, 16)
+                        ctx.check(lib.octl_dev_upload_async(ctx.handle, bufs[b][0], nat.ptr(pts), pts.nbytes))
+                        ctx.check(lib.octl_ctx_sync_uploads(ctx.handle))   # this thread waits, nobody else does
+                        cloud = _StagedCloud(ctx, bufs[b][0], len(pts), lambda b=b: self._free.put(b))
+                except BaseException as e:
+                    self._free.put(b)
+                    fut.set_exception(e)
+                    continue
+                self._jobs[index % len(self._jobs)].put((job, cloud))
+        finally:
+            for q in self._jobs:
+                q.put(None)
+            # (the workers have drained their queues when close() joins them; the buffers go back then)
+            self._staging_to_free = (ctx, bufs)
 
     def _worker(self, w):
         from octreelib_amd.grid import Grid, GridConfig
@@ -152,15 +225,12 @@ class ScanPipeline:
         try:
             with nat.use_context(ctx):
                 while True:
-                    job = self._jobs[w].get()
-                    if job is None:
+                    item = self._jobs[w].get()
+                    if item is None:
                         return
-                    points, fn, index, fut = job
-                    if not fut.set_running_or_notify_cancel():
-                        continue
-                    grid = cloud = None
+                    (points, fn, index, fut), cloud = item
+                    grid = None
                     try:
-                        cloud = points if isinstance(points, DeviceCloud) else DeviceCloud(points, ctx)
                         grid = Grid(GridConfig(voxel_edge_length=self._edge))
                         grid.insert_points(0, cloud)
                         fut.set_result(fn(grid, index))
@@ -168,15 +238,15 @@ class ScanPipeline:
                         fut.set_exception(e)
                     finally:
                         if grid is not None:
-                            grid._forest.close()
-                        if cloud is not None and cloud is not points:
+                            grid._forest.close()   # (synchronises this context: the staging buffer is free again)
+                        if cloud is not points:
                             cloud.release()
         finally:
             ctx.close()
 
     def submit(self, points, fn):
         """Queue one scan; returns a concurrent.futures.Future of fn(grid, index).  `points` must stay unchanged
-        until the future is done (its upload starts when a worker picks the scan up)."""
+        until the future is done (it is uploaded when a staging buffer is free)."""
         from concurrent.futures import Future
 
         if self._closed:
@@ -184,13 +254,13 @@ class ScanPipeline:
         fut = Future()
         i = self._next
         self._next += 1
-        self._jobs[i % len(self._jobs)].put((points, fn, i, fut))
+        self._inbox.put((points, fn, i, fut))
         return fut
 
     def map(self, scans, fn, depth=None):
         """fn(grid, index) for every scan, results in submission order.  At most `depth` scans (default: one per
-        context plus one waiting, so that no worker idles) are queued or running: before scan k is submitted the
-        result of scan k - depth has been delivered.  A front end that refills staging buffers therefore needs a ring
+        context being fitted plus one being uploaded) are queued or running: before scan k is submitted the result
+        of scan k - depth has been delivered.  A front end that refills host staging arrays therefore needs a ring
         of depth + 1 of them (the iterator is asked for scan k before that wait)."""
         from collections import deque
 
@@ -207,10 +277,17 @@ class ScanPipeline:
         if self._closed:
             return
         self._closed = True
-        for q in self._jobs:
-            q.put(None)
+        self._inbox.put(None)
         for t in self._threads:
             t.join()
+        held = getattr(self, "_staging_to_free", None)
+        if held is not None:
+            ctx, bufs = held
+            for ptr, cap in bufs:
+                if ptr.value:
+                    ctx.lib.octl_dev_free(ctx.handle, ptr)
+            ctx.close()
+            self._staging_to_free = None
 
     def __enter__(self):
         return self

@@ -36,7 +36,9 @@ def _cloud(seed, n, side=3):
     return synthetic.planar_cloud(n, (side, side, side), seed=seed)
 
 
-STEPS = ["insert+subdivide", "late pose", "ransac+apply_mask", "second subdivide"]
+# (RANSAC last: it empties leaves, and a subdivide behind it can ask for a COARSER scheme than the poses have - the
+#  reference's defective merge branch, outside the parity domain)
+STEPS = ["insert+subdivide", "late pose", "second subdivide", "ransac+apply_mask"]
 
 
 def _run_life(fail_step, nth, big=False):
@@ -53,7 +55,7 @@ def _run_life(fail_step, nth, big=False):
 
     lib, ctx = nat.load(), nat.get_context()
     grid, og = Grid(GridConfig(voxel_edge_length=1)), onp.OGrid(1)
-    # big: 27 voxels in one bucket of more than 4096 points - the chunked bucket path, block order from order.hip
+    # big: 27 voxels over four buckets, three levels deep
     poses = {0: _cloud(11, 9000), 1: _cloud(12, 5000)} if big else {0: _cloud(11, 2600, side=2), 1: _cloud(12, 1500, side=2)}
     idx = {p: index_map(c) for p, c in poses.items()}
     table_seed, H, thr = 5, 64, 0.01
@@ -85,9 +87,9 @@ def _run_life(fail_step, nth, big=False):
          # the pose may or may not have been stored before the failure; the scheme is gone: rebuild it from pose 0
          lambda: ((1 in grid._slots) or grid.insert_points(1, poses[1]), grid.subdivide(crit(24), [0])),
          lambda: og.subdivide(24, [0]), [0, 1]),
-        (ransac, lambda: _oracle_grid_ransac(og, poses, [0, 1], table, thr, 2), ransac, lambda: None, [0, 1]),
         (lambda: (grid.subdivide(crit(10)), grid.n_leaves(0)), lambda: og.subdivide(10),
          lambda: grid.subdivide(crit(10)), lambda: None, [0, 1]),
+        (ransac, lambda: _oracle_grid_ransac(og, poses, [0, 1], table, thr, 2), ransac, lambda: None, [0, 1]),
     ]
 
     grid.insert_points(0, poses[0])
@@ -110,16 +112,19 @@ def _run_life(fail_step, nth, big=False):
                 assert grid.n_points(0) in (len(poses[0]), og.n_points(0))
                 dev_recover()       # ... and the same request, nothing injected, completes
                 ref_recover()
-                state["ordered"] = state["ordered"] and s in (0, 2)
+                state["ordered"] = state["ordered"] and s in (0, 3)
         else:
             dev()
             ref()
-        check(ps)               # ... in agreement with the oracle
+        try:
+            check(ps)           # ... in agreement with the oracle
+        except AssertionError as e:
+            raise AssertionError(f"after step {s} ({STEPS[s]}), failure injected in step {fail_step}: {e}") from e
     return raised, seen
 
 
 @pytest.mark.parametrize("fail_step,big", [(0, False), (1, False), (2, False), (3, False), (0, True)],
-                         ids=STEPS + ["insert+subdivide, chunked bucket"])
+                         ids=STEPS + ["insert+subdivide, four buckets"])
 def test_allocation_failure_sweep(fail_step, big):
     nth, hits, problems = 1, 0, []
     while True:
@@ -132,7 +137,7 @@ def test_allocation_failure_sweep(fail_step, big):
             problems.append(f"growth {nth}: {type(e).__name__}: {str(e)[:200]} @ {where[-3:]}")
             _arm(0)
             raised, seen = True, nth
-            if len(problems) > 6:
+            if len(problems) > 8:
                 break
         if not raised:
             assert seen < nth          # the step finished: it allocates fewer than nth buffers
@@ -374,13 +379,13 @@ def test_scan_pipeline_on_two_contexts_gives_the_sequential_results():
         g.insert_points(0, c)
         want.append(fit(g, 0))
         g._forest.close()
-    ring = [oa.pinned_empty((300_000, 3)) for _ in range(4)]
+    ring = [oa.pinned_empty((300_000, 3)) for _ in range(5)]   # (map keeps 3 scans in flight + the one being drawn)
 
     def scans():
         for i in range(16):
             c = clouds[i % 4]
-            ring[i % 4][: len(c)] = c
-            yield ring[i % 4][: len(c)]
+            ring[i % 5][: len(c)] = c
+            yield ring[i % 5][: len(c)]
 
     with oa.ScanPipeline(2) as pipe:
         got = list(pipe.map(scans(), fit))

@@ -18,19 +18,21 @@ og.subdivide(24)
 want = canon_from_list(og.leaf_table(0))
 
 
-def run(env):
-    for k in ("OCTL_NO_FAST_ORDER", "OCTL_NO_BUCKET_BUILD"):
+def run(env, prebuild=False):
+    for k in ("OCTL_NO_FAST_ORDER", "OCTL_NO_BUCKET_BUILD", "OCTL_NO_BUCKET_HISTORY"):
         os.environ.pop(k, None)
     os.environ.update(env)
     g = Grid(GridConfig(voxel_edge_length=1))
     g.insert_points(0, pts)
+    if prebuild:
+        g.n_points(0)      # builds the top-level voxels (K < 0): the subdivide then runs over a previous scheme
     g.subdivide([lambda p: len(p) > 24])
     got = canon_from_list(views_table(g.get_leaf_points(0), idx))
     same_set = dict(got) == dict(want)
     same_order = [k for k, _ in got] == [k for k, _ in want]
     first = next((i for i, (a, b) in enumerate(zip(got, want)) if a[0] != b[0]), None)
     f = g._forest
-    print(env, "leaves", len(got), len(want), "set", same_set, "order", same_order, "first diff", first,
+    print(env, "prebuild", prebuild, "leaves", len(got), len(want), "set", same_set, "order", same_order, "first diff", first,
           "blocks", f.info.n_blocks, "internal", f.info.n_internal, "levels", f.info.n_levels)
     if first is not None:
         for i in range(max(0, first - 2), min(len(got), first + 6)):
@@ -43,3 +45,6 @@ def run(env):
 run({})
 run({"OCTL_NO_FAST_ORDER": "1"})
 run({"OCTL_NO_BUCKET_BUILD": "1"})
+run({}, True)
+run({"OCTL_NO_BUCKET_HISTORY": "1"}, True)
+run({"OCTL_NO_BUCKET_BUILD": "1"}, True)

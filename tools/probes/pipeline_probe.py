@@ -8,7 +8,7 @@ from octreelib_amd import MaxPoints, synthetic
 
 n = 10_000_000
 pts = synthetic.planar_cloud(n, (32, 32, 32), seed=1)
-ring = [oa.pinned_empty((n, 3)) for _ in range(4)]
+ring = [oa.pinned_empty((n, 3)) for _ in range(7)]
 for r in ring:
     r[:] = pts
 np.random.seed(0)
@@ -28,11 +28,11 @@ def fit(grid, i):
 
 for nctx in (1, 2, 3):
     with oa.ScanPipeline(nctx) as pipe:
-        list(pipe.map((ring[i & 3] for i in range(4)), fit))
+        list(pipe.map((ring[i % 7] for i in range(4)), fit))
         log.clear()
         T0 = time.perf_counter()
         t1 = time.perf_counter()
-        kept = list(pipe.map((ring[i & 3] for i in range(12)), fit))
+        kept = list(pipe.map((ring[i % 7] for i in range(12)), fit))
         ms = (time.perf_counter() - t1) * 1e3 / 12
     print("contexts", nctx, "ms per scan %.2f" % ms, "kept", set(kept))
     for row in sorted(log):

@@ -11,7 +11,7 @@ with tempfile.TemporaryDirectory() as d:
                     f"-I{ROOT}/include", "-S", "--cuda-device-only", f"{ROOT}/octreelib_amd/csrc/ransac.hip", "-o", out],
                    check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*k_ransacILi256ELi4ELi6ELi0E.*:", l))
+start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*k_ransacILi256ELi4ELi6ELi0ELb1E.*:", l))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
 
