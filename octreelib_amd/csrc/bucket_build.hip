@@ -62,7 +62,8 @@ constexpr uint32_t FO_MAX = 1024;       // internal nodes / blocks per bucket k_
 constexpr uint32_t BF_OVERFLOW = 1u;      // a bucket beyond what the oversize launch handles: whole build -> general path
 
 struct LinParams {
-  int mode;          // 0 grid, 1 single cube
+  int mode;          // 0 grid, 1 single cube, 2 single cube keyed by the child digits of its first pm levels
+  int pm;            // mode 2: levels of the key (the "voxels" of the partition are the cube's depth-pm nodes)
   double L;          // voxel edge
   double c0x, c0y, c0z;  // cube corner (mode 1)
   int minx, miny, minz;  // voxel bounding box
@@ -303,6 +304,12 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
   const int big = 1 << 30;
   int mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
   bool bad = false, outside = false;
+  // (kernel-uniform; mode 2 only: see k_part_scatter)
+  const bool exact_cube = lp.exact_digits && nonneg_integer_below_2p45(lp.L) && lp.L >= 1.0 &&
+                          nonneg_integer_below_2p45(lp.c0x) && nonneg_integer_below_2p45(lp.c0y) &&
+                          nonneg_integer_below_2p45(lp.c0z);
+  const bool edge_pow2 = (__double_as_longlong(lp.L) & 0xFFFFFFFFFFFFFll) == 0;
+  const double inv64 = 64.0 / lp.L;
   // LONE: voxel edge 1 (compile time: the test inside the loop kept the loads of the next points behind it)
   auto fdiv = [&](double v) { return LONE ? floor(v) : floor_div_exact(v, lp.L); };
   auto count = [&](double x, double y, double z, bool live) {
@@ -314,9 +321,21 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
     }
     if (!BBOX) {
       // (the box pass has validated the domain)
-      const uint32_t lin = lp.mode != 0 ? 0u
-                                        : ((uint32_t)((int)fx - lp.minx) * lp.ny + (uint32_t)((int)fy - lp.miny)) * lp.nz +
-                                              (uint32_t)((int)fz - lp.minz);
+      uint32_t lin = lp.mode != 0 ? 0u
+                                  : ((uint32_t)((int)fx - lp.minx) * lp.ny + (uint32_t)((int)fy - lp.miny)) * lp.nz +
+                                        (uint32_t)((int)fz - lp.minz);
+      if (lp.mode == 2) {
+        // a big single cube partitioned by its first pm levels (build.hip: cube_prefix_build): the key is the
+        // digits themselves; a point outside the cube makes the caller take the plain path (flag in bbox[0])
+        bool pbad = false;
+        uint32_t d18;
+        if (exact_cube && coord_takes_exact_digits(x) && coord_takes_exact_digits(y) && coord_takes_exact_digits(z))
+          d18 = digits18_exact(x, y, z, lp.c0x, lp.c0y, lp.c0z, lp.L, edge_pow2, inv64, &pbad);
+        else
+          d18 = path_levels(x, y, z, lp.c0x, lp.c0y, lp.c0z, lp.L, PATH_EAGER, &pbad) >> 3;
+        lin = d18 >> (18 - 3 * lp.pm);
+        bad = bad || (live && pbad);
+      }
       if (live) atomicAdd(&hist[digit_of(lp, lin)], 1u);
       return;
     }
@@ -370,6 +389,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restri
     count(xyz[3 * (N - 1)], xyz[3 * (N - 1) + 1], xyz[3 * (N - 1) + 2], !alive || alive[N - 1]);
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < nd; d += PH_THREADS) table_t[(size_t)blockIdx.x * nd + d] = hist[d];
+  if (!BBOX && lp.mode == 2 && bbox && __any(bad) && (threadIdx.x & 63) == 0) atomicExch(reinterpret_cast<uint32_t*>(bbox), 1u);
   if (BBOX) {
     // wave + block reduction, then at most six atomics per block and only when the block widens the box
 #pragma unroll
@@ -577,6 +597,7 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
           }
 #endif
           pbits[r] = (d18 << 1) | (bad ? 1u : 0u);
+          if (!FROM_REC && lp.mode == 2) lin[r] = d18 >> (18 - 3 * lp.pm);  // (the key IS the first pm digits)
         }
       }
       rank[r] = wave_rank_u16<MBITS>(digit_of(lp, lin[r]), valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
@@ -2317,6 +2338,77 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   geom->nz = nz;
   geom->order_done = fast_order;
   *done = 1;
+  return OCTL_OK;
+}
+
+// A big single cube (bare Octree / OctreeManager with millions of points) partitioned ONCE by the child digits of
+// its first pm levels - the partition kernels above under mode 2: 8^pm "buckets" = the cube's depth-pm nodes in
+// path order, 32-byte records (coordinates, the six digits, store index) - so that the level loop of build.hip
+// starts at level pm over data that is already grouped and gathers from a 500 KB neighbourhood instead of the
+// whole store (build.hip: cube_prefix_build).  Outputs stay in the forest's scratch: records in part_xyz[0], the
+// first record of every bucket in *bstart (stride *bstride), a flag word that is non-zero when some point lies
+// outside the cube (*bad_flag, device).
+int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const uint32_t** bstart, uint32_t* bstride,
+                            const uint32_t** bad_flag) {
+  octl_ctx* ctx = f->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t N = f->n_store;
+  const int n_poses = (int)f->pose_off.size() - 1;
+  LinParams lp;
+  std::memset(&lp, 0, sizeof(lp));
+  lp.mode = 2;
+  lp.pm = pm;
+  lp.L = f->edge;
+  lp.c0x = f->corner[0];
+  lp.c0y = f->corner[1];
+  lp.c0z = f->corner[2];
+  lp.ny = lp.nz = 1;
+  lp.shift = 0;
+  lp.dshift = 0;
+  lp.dmask = 0xFFFFFFFFu;
+  lp.raw_vp = 0;
+  lp.exact_digits = getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1;
+  const uint32_t nd = 1u << (3 * pm);
+  const int cus = octl_ctx_cus(ctx);
+  constexpr int PT_IPT = OCTL_PT_IPT;
+  constexpr int tile = PT_THREADS * PT_IPT;
+  const int st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(N, tile), (int64_t)cus * OCTL_PT_WGS)));
+  const uint32_t nst = (uint32_t)ceil_div(N, (int64_t)st_tiles * tile);
+  OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)N * sizeof(PartRec)));
+  const size_t tab_elems = (((size_t)nd * nst) + 15) & ~(size_t)15;
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_table, (2 * tab_elems + 16) * 4));
+  uint32_t* table = f->bk_table.as<uint32_t>();
+  uint32_t* table_dm = table + tab_elems;
+  uint32_t* flag = table + 2 * tab_elems;
+  HIP_TRY(ctx, hipMemsetAsync(flag, 0, 4, st));
+  auto transpose = [&](const uint32_t* in, uint32_t R, uint32_t Cc, uint32_t* out) {
+    hipLaunchKernelGGL(k_transpose_u32, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, R, Cc, out);
+    return hipGetLastError();
+  };
+  {
+    KTimer t(ctx, "prefix_hist");
+    auto kh = f->edge == 1.0 ? k_part_hist<false, true> : k_part_hist<false, false>;
+    hipLaunchKernelGGL(kh, dim3(nst), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(), (const uint8_t*)nullptr,
+                       N, lp, (const GeomDev*)nullptr, nst, nd, (int64_t)st_tiles * tile, table,
+                       reinterpret_cast<int32_t*>(flag));
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, transpose(table, nst, nd, table_dm));
+    OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd * nst, nullptr));
+    HIP_TRY(ctx, transpose(table_dm, nd, nst, table));
+  }
+  {
+    KTimer t(ctx, "prefix_scatter");
+    auto ks = nd <= 256u ? k_part_scatter<PT_IPT, false, 8> : k_part_scatter<PT_IPT, false, PT_BITS>;
+    hipLaunchKernelGGL(ks, dim3(nst), dim3(PT_THREADS), 0, st, (const double*)f->xyz.as<double>(), (const uint8_t*)nullptr, N,
+                       lp, (const GeomDev*)nullptr, nst, nd, st_tiles, (const uint32_t*)table,
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, (const uint8_t*)nullptr,
+                       f->part_xyz[0].as<PartRec>());
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  *recs_out = f->part_xyz[0].p;
+  *bstart = table_dm;
+  *bstride = nst;
+  *bad_flag = flag;
   return OCTL_OK;
 }
 

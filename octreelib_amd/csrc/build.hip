@@ -395,6 +395,89 @@ __global__ __launch_bounds__(256) void k_cube_level0(const double* __restrict__ 
   pos_node[i] = 0;
 }
 
+// ---- a big single cube whose store was partitioned by its first pm levels (bucket_build.hip:
+//      forest_prefix_partition): the complete top of the tree and the level buffers of level pm ------------------
+// Depth d of the top tree has all 8^d nodes, node (d, path p) at id (8^d - 1) / 7 + p: exactly the numbering the
+// level loop produces when every node above depth pm splits (children of the k-th internal node of a level are
+// consecutive, levels follow each other) - which is what this path requires (*flag otherwise: the caller builds
+// the plain way).  Ranges come from the bucket starts of the partition, corners and edges from the reference's
+// own descent (octree.py:181-191).
+__host__ __device__ __forceinline__ int64_t top_base(int d) { return ((int64_t(1) << (3 * d)) - 1) / 7; }
+
+__global__ __launch_bounds__(256) void k_top_tree(const uint32_t* __restrict__ bstart, uint32_t bstride, int pm,
+                                                  int64_t n_alive, int64_t K, double L, double c0x, double c0y,
+                                                  double c0z, int cur_epoch, NodePtrs nd,
+                                                  uint32_t* __restrict__ flag) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= top_base(pm + 1)) return;
+  int d = 0;
+  while (g >= top_base(d + 1)) ++d;
+  const uint32_t p = (uint32_t)(g - top_base(d));
+  const uint32_t nb = 1u << (3 * pm), span = 1u << (3 * (pm - d)), first = p * span;
+  const uint32_t s = bstart[(size_t)first * bstride];
+  const uint32_t e = (first + span < nb) ? bstart[(size_t)(first + span) * bstride] : (uint32_t)n_alive;
+  nd.start[g] = s;
+  nd.count[g] = e - s;
+  nd.scount[g] = e - s;
+  nd.depth[g] = d;
+  nd.voxel[g] = 0;
+  nd.parent[g] = d > 0 ? (int32_t)(top_base(d - 1) + (p >> 3)) : -1;
+  nd.first_child[g] = d < pm ? (int32_t)(top_base(d + 1) + 8 * (int64_t)p) : -1;
+  nd.old_id[g] = -1;
+  nd.epoch[g] = d < pm ? cur_epoch : 0;
+  double cx = c0x, cy = c0y, cz = c0z, ed = L;
+  for (int t = 0; t < d; ++t) {
+    const uint32_t dg = (p >> (3 * (d - 1 - t))) & 7u;
+    const double h = ed / 2.0;
+    cx = cx + ((dg & 4u) ? h : 0.0);
+    cy = cy + ((dg & 2u) ? h : 0.0);
+    cz = cz + ((dg & 1u) ? h : 0.0);
+    ed = h;
+  }
+  nd.edge[g] = ed;
+  nd.corner[3 * g + 0] = cx;
+  nd.corner[3 * g + 1] = cy;
+  nd.corner[3 * g + 2] = cz;
+  // a node above depth pm that the count criterion would NOT split (octree.py:26) is a leaf in the reference:
+  // the complete top tree does not apply
+  if (d < pm && !((int64_t)(e - s) > K)) atomicExch(flag, 1u);
+}
+
+// level-pm buffers from the partition records: position = record, "index" = the record's own position (the level
+// loop and the final gather then read coordinates out of the records, i.e. out of the 15 000-point neighbourhood
+// of their depth-pm node instead of the whole store), path word = the digits of levels pm..5 the record carries
+__global__ __launch_bounds__(256) void k_pre_level0(const uint4* __restrict__ recs, int64_t n, int pm,
+                                                    int32_t* __restrict__ pos_node, uint32_t* __restrict__ idx0,
+                                                    uint32_t* __restrict__ path0) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t vp = recs[2 * i + 1].z;
+  const uint32_t d18 = (vp >> 1) & 0x3FFFFu;
+  idx0[i] = (uint32_t)i | 0x80000000u;
+  path0[i] = ((d18 & ((1u << (3 * (6 - pm))) - 1u)) << 14) | (vp & 1u);
+  pos_node[i] = (int32_t)(top_base(pm) + (d18 >> (18 - 3 * pm)));
+}
+
+// k_finalize over the records: the leaf-ordered permutation holds the records' ORIGINAL store indices
+__global__ __launch_bounds__(256) void k_finalize_rec(const int32_t* __restrict__ pos_node,
+                                                      const int32_t* __restrict__ depth,
+                                                      const uint32_t* __restrict__ idx_a,
+                                                      const uint32_t* __restrict__ idx_b,
+                                                      const uint4* __restrict__ recs, int64_t n_alive,
+                                                      uint32_t* __restrict__ ord_idx,
+                                                      double* __restrict__ xyz_ord) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_alive) return;
+  const int d = depth[pos_node[i]];
+  const uint32_t v = ((d & 1) ? idx_b[i] : idx_a[i]) & IDX_MASK;
+  const uint4 a = recs[2 * (size_t)v], b = recs[2 * (size_t)v + 1];
+  ord_idx[i] = b.w & IDX_MASK;
+  uint2* o = reinterpret_cast<uint2*>(xyz_ord + 3 * i);
+  o[0] = uint2{a.x, a.y};
+  o[1] = uint2{a.z, a.w};
+  o[2] = uint2{b.x, b.y};
+}
+
 // scheme-pose point count of every root (only when a pose subset drives the scheme)
 __global__ __launch_bounds__(256) void k_count_scheme(const int32_t* __restrict__ pos_node,
                                                       const uint32_t* __restrict__ idx0,
@@ -530,12 +613,13 @@ __device__ __forceinline__ TileRef locate_tile(const uint32_t* __restrict__ tile
 // digit of a point whose precomputed path is unusable: redo the reference arithmetic against
 // the node's own cube; a point outside the cube of a node that is being split is the
 // reference's IndexError / wrong-child case (octree.py:94-98) -> domain error
-__device__ __forceinline__ uint32_t slow_digit(const double* __restrict__ xyz, uint32_t v,
+// (xs: doubles per point of the coordinate source - 3 for the store, 4 for the 32-byte partition records)
+__device__ __forceinline__ uint32_t slow_digit(const double* __restrict__ xyz, int xs, uint32_t v,
                                                const double* __restrict__ corner, double e,
                                                uint32_t* __restrict__ small) {
   const int64_t i = (int64_t)(v & IDX_MASK);
-  const double ax = xyz[3 * i] - corner[0], ay = xyz[3 * i + 1] - corner[1],
-               az = xyz[3 * i + 2] - corner[2];
+  const double ax = xyz[xs * i] - corner[0], ay = xyz[xs * i + 1] - corner[1],
+               az = xyz[xs * i + 2] - corner[2];
   const double h = e / 2.0;
   const bool ok = (ax >= 0.0) && (ax < e) && (ay >= 0.0) && (ay < e) && (az >= 0.0) && (az < e);
   if (!ok) {
@@ -550,7 +634,7 @@ __device__ __forceinline__ uint32_t slow_digit(const double* __restrict__ xyz, u
 __global__ __launch_bounds__(LV_THREADS) void k_lv_rekey(
     const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
     uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
-    uint32_t* __restrict__ path_io, const double* __restrict__ xyz) {
+    uint32_t* __restrict__ path_io, const double* __restrict__ xyz, int xs) {
   const TileRef tr = locate_tile(tile_base, ns, n_tiles, blockIdx.x);
   const int32_t node = split_nodes[tr.s];
   const uint32_t nstart = nd.start[node], nend = nstart + nd.count[node];
@@ -561,7 +645,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_rekey(
     const uint32_t i = nstart + tr.tl * LV_TILE + r * LV_THREADS + threadIdx.x;
     if (i < nend) {
       const int64_t p = (int64_t)(idx_in[i] & IDX_MASK);
-      path_io[i] = compute_path(xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2], cx, cy, cz, e);
+      path_io[i] = compute_path(xyz[xs * p], xyz[xs * p + 1], xyz[xs * p + 2], cx, cy, cz, e);
     }
   }
 }
@@ -596,7 +680,7 @@ template <bool SCHEME_SUBSET>
 __global__ __launch_bounds__(LV_THREADS) void k_lv_hist(
     const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
     uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
-    const uint32_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
+    const uint32_t* __restrict__ path_in, const double* __restrict__ xyz, int xs, int shift,
     uint32_t* __restrict__ entries, uint32_t* __restrict__ child_sc,
     uint32_t* __restrict__ small) {
   __shared__ uint32_t wc[LV_WAVES][8], wsc[LV_WAVES][8];
@@ -614,7 +698,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_hist(
     if (valid) {
       const uint32_t pw = path_in[i];
       v = idx_in[i];
-      d = (pw & 1u) ? slow_digit(xyz, v, nd.corner + 3 * (int64_t)node, nd.edge[node], small)
+      d = (pw & 1u) ? slow_digit(xyz, xs, v, nd.corner + 3 * (int64_t)node, nd.edge[node], small)
                     : (pw >> shift) & 7u;
     }
     const uint64_t sm = SCHEME_SUBSET ? __ballot(valid && (v >> 31)) : 0ull;
@@ -649,7 +733,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_hist(
 __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
     const int32_t* __restrict__ split_nodes, const uint32_t* __restrict__ tile_base, int ns,
     uint32_t n_tiles, NodePtrs nd, const uint32_t* __restrict__ idx_in,
-    const uint32_t* __restrict__ path_in, const double* __restrict__ xyz, int shift,
+    const uint32_t* __restrict__ path_in, const double* __restrict__ xyz, int xs, int shift,
     const uint32_t* __restrict__ entries_scanned, int32_t child_base,
     uint32_t* __restrict__ idx_out, uint32_t* __restrict__ path_out,
     int32_t* __restrict__ pos_node, uint32_t* __restrict__ small, int64_t K_leaf) {
@@ -678,7 +762,7 @@ __global__ __launch_bounds__(LV_THREADS) void k_lv_scatter(
       pw[r] = path_in[i];
       v[r] = idx_in[i];
       d[r] = (pw[r] & 1u)
-                 ? slow_digit(xyz, v[r], nd.corner + 3 * (int64_t)node, nd.edge[node], small)
+                 ? slow_digit(xyz, xs, v[r], nd.corner + 3 * (int64_t)node, nd.edge[node], small)
                  : (pw[r] >> shift) & 7u;
     }
     rank[r] = wave_stable_rank<3>(d[r], valid, cnt[wave]);
@@ -915,108 +999,6 @@ __global__ __launch_bounds__(256) void k_block_tiles(const int32_t* __restrict__
   }
 }
 
-// k_finalize and the COUNT pass of the block table in one: a workgroup takes one block tile (2048 consecutive
-// positions, eight per thread), gathers the leaf-ordered permutation and coordinates, and - holding node and index
-// of every position anyway - leaves the tile's number of (leaf, pose) block heads behind, so that the block table
-// needs only its fill pass (BASELINE config 4: one 512 MB pass over position -> leaf and the permutation less).
-__global__ __launch_bounds__(256) void k_finalize_tiles(const int32_t* __restrict__ pos_node,
-                                                        const int32_t* __restrict__ depth,
-                                                        const uint32_t* __restrict__ idx_a,
-                                                        const uint32_t* __restrict__ idx_b,
-                                                        const double* __restrict__ xyz,
-                                                        const int64_t* __restrict__ pose_off, int n_poses,
-                                                        int64_t n_alive, uint32_t* __restrict__ ord_idx,
-                                                        double* __restrict__ xyz_ord,
-                                                        uint32_t* __restrict__ tile_cnt) {
-  __shared__ int64_t s_off[BLK_LDS_POSES + 1];
-  __shared__ uint32_t s_w[4];
-  const bool in_lds = n_poses <= BLK_LDS_POSES;
-  if (in_lds)
-    for (int p = threadIdx.x; p <= n_poses; p += 256) s_off[p] = pose_off[p];
-  __syncthreads();
-  auto off_at = [&](int p) { return in_lds ? s_off[p] : pose_off[p]; };
-  auto slot_of = [&](uint32_t idx) {
-    if (n_poses <= 1) return 0;
-    int lo = 0, hi = n_poses;  // off[lo] <= idx < off[hi]
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (off_at(mid) <= (int64_t)idx) lo = mid; else hi = mid;
-    }
-    return lo;
-  };
-  auto index_at = [&](int64_t i, int32_t node) {
-    return ((depth[node] & 1) ? idx_b[i] : idx_a[i]) & IDX_MASK;
-  };
-  const int64_t first = (int64_t)blockIdx.x * BLK_TILE + (int64_t)threadIdx.x * BLK_IPT;
-  int32_t node[BLK_IPT];
-  uint32_t idx[BLK_IPT];
-#pragma unroll
-  for (int q = 0; q < BLK_IPT; ++q) {
-    const int64_t i = first + q;
-    node[q] = i < n_alive ? pos_node[i] : -1;
-  }
-#pragma unroll
-  for (int q = 0; q < BLK_IPT; ++q) {
-    const int64_t i = first + q;
-    idx[q] = i < n_alive ? index_at(i, node[q]) : 0u;
-  }
-  // ---- the gather (k_finalize): permutation and coordinates in leaf order --------------------------------------
-  double px[BLK_IPT], py[BLK_IPT], pz[BLK_IPT];
-#pragma unroll
-  for (int q = 0; q < BLK_IPT; ++q) {
-    const int64_t v = (int64_t)idx[q];
-    const bool live = first + q < n_alive;
-    px[q] = live ? xyz[3 * v] : 0.0;
-    py[q] = live ? xyz[3 * v + 1] : 0.0;
-    pz[q] = live ? xyz[3 * v + 2] : 0.0;
-  }
-  if (first + BLK_IPT <= n_alive) {  // (16-byte aligned: first is a multiple of 8; 192 contiguous bytes of coordinates)
-    uint4* oi = reinterpret_cast<uint4*>(ord_idx + first);
-    oi[0] = uint4{idx[0], idx[1], idx[2], idx[3]};
-    oi[1] = uint4{idx[4], idx[5], idx[6], idx[7]};
-    double2* ox = reinterpret_cast<double2*>(xyz_ord + 3 * first);
-#pragma unroll
-    for (int q = 0; q < BLK_IPT; q += 2) {
-      ox[3 * (q / 2) + 0] = double2{px[q], py[q]};
-      ox[3 * (q / 2) + 1] = double2{pz[q], px[q + 1]};
-      ox[3 * (q / 2) + 2] = double2{py[q + 1], pz[q + 1]};
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < BLK_IPT; ++q) {
-      const int64_t i = first + q;
-      if (i < n_alive) {
-        ord_idx[i] = idx[q];
-        xyz_ord[3 * i] = px[q];
-        xyz_ord[3 * i + 1] = py[q];
-        xyz_ord[3 * i + 2] = pz[q];
-      }
-    }
-  }
-  // ---- block heads of the tile (k_block_tiles<false>) ------------------------------------------------------------
-  int32_t pnode = -1;
-  int pslot = -1;
-  if (first > 0 && first < n_alive) {
-    pnode = pos_node[first - 1];
-    pslot = slot_of(index_at(first - 1, pnode));
-  }
-  uint32_t heads = 0;
-#pragma unroll
-  for (int q = 0; q < BLK_IPT; ++q) {
-    const bool live = first + q < n_alive;
-    int sl = pslot;
-    if (live && (pslot < 0 || (int64_t)idx[q] >= off_at(pslot + 1) || (int64_t)idx[q] < off_at(pslot)))
-      sl = slot_of(idx[q]);
-    if (live && (first + q == 0 || node[q] != pnode || sl != pslot)) heads |= 1u << q;
-    pnode = node[q];
-    pslot = sl;
-  }
-  const uint32_t inc = wave_inclusive_add((uint32_t)__popc(heads));
-  if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = inc;
-  __syncthreads();
-  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
 __global__ __launch_bounds__(256) void k_block_sizes(const uint32_t* __restrict__ blk_start,
                                                      const uint32_t* __restrict__ nb_dev,
                                                      int64_t n_alive,
@@ -1068,7 +1050,7 @@ static int read_small(octl_ctx* ctx, int first, int count, uint32_t* out) {
 
 // (Re)build the (leaf, pose) block table from pos_node / ord_idx.  Asynchronous: the block count
 // is left in small[SM_NBLOCKS]; forest_finish_blocks reads it (one synchronisation).
-int forest_make_blocks(octl_forest* f, bool tiles_counted) {
+int forest_make_blocks(octl_forest* f) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
   const int64_t n = f->n_ord;
@@ -1089,12 +1071,10 @@ int forest_make_blocks(octl_forest* f, bool tiles_counted) {
   OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n * 4));
-  if (!tiles_counted) {  // (k_finalize_tiles has left the heads per tile in f->flags already)
-    hipLaunchKernelGGL(k_block_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
-                       (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
-                       n_poses, n, tile_cnt, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
-    HIP_TRY(ctx, hipGetLastError());
-  }
+  hipLaunchKernelGGL(k_block_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
+                     (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
+                     n_poses, n, tile_cnt, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
+  HIP_TRY(ctx, hipGetLastError());
   OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_cnt, tile_cnt, n_tiles, small + SM_NBLOCKS));
   hipLaunchKernelGGL(k_block_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
                      (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
@@ -1165,6 +1145,10 @@ struct LevelLoop {
   int64_t n_internal;
   int level;
   std::vector<octl_forest::LevelSeg>* segs;
+  // coordinates behind the loop's point indices: the store (3 doubles per point, nullptr = f->xyz) or the 32-byte
+  // records of a prefix partition (4 doubles per point; the indices are record positions then)
+  const double* gx = nullptr;
+  int xs = 3;
 };
 
 static int run_level_loop(LevelLoop& L) {
@@ -1176,6 +1160,7 @@ static int run_level_loop(LevelLoop& L) {
   uint32_t* small = ctx->small.as<uint32_t>();
   uint32_t* flags = nullptr;
   int32_t* pos_node = f->pos_node.as<int32_t>();
+  const double* gx = L.gx ? L.gx : (const double*)f->xyz.as<double>();
   while (L.n_new > 0) {
     // split list of the freshly created nodes
     OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(std::max<int64_t>(L.n_new, L.n_alive) + 8) * 4));
@@ -1250,7 +1235,7 @@ static int run_level_loop(LevelLoop& L) {
         hipLaunchKernelGGL(k_lv_rekey, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                            (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
                            (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
-                           f->pathbuf[src].as<uint32_t>(), (const double*)f->xyz.as<double>());
+                           f->pathbuf[src].as<uint32_t>(), gx, L.xs);
         HIP_TRY(ctx, hipGetLastError());
       }
       {
@@ -1260,14 +1245,14 @@ static int run_level_loop(LevelLoop& L) {
                              (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
                              nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
                              (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
-                             (const double*)f->xyz.as<double>(), shift, entries,
+                             gx, L.xs, shift, entries,
                              f->child_sc.as<uint32_t>(), small);
         else
           hipLaunchKernelGGL(k_lv_hist<false>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                              (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
                              nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
                              (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
-                             (const double*)f->xyz.as<double>(), shift, entries,
+                             gx, L.xs, shift, entries,
                              (uint32_t*)nullptr, small);
         HIP_TRY(ctx, hipGetLastError());
       }
@@ -1282,7 +1267,7 @@ static int run_level_loop(LevelLoop& L) {
                            (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
                            (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
                            (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
-                           (const double*)f->xyz.as<double>(), shift, (const uint32_t*)entries,
+                           gx, L.xs, shift, (const uint32_t*)entries,
                            (int32_t)child_base, f->idxbuf[src ^ 1].as<uint32_t>(),
                            f->pathbuf[src ^ 1].as<uint32_t>(), pos_node, small,
                            (L.all_scheme && !L.keep_scheme && !L.resume && L.K >= 0 && L.level + 1 < L.max_depth)
@@ -1548,6 +1533,23 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   // a fresh single cube with every point alive: one root, the store order is the level-0 order (k_cube_level0)
   const bool cube_fast = f->mode == 1 && N > 0 && n_alive == N && !f->built && f->vkeys.empty() &&
                          !getenv("OCTL_NO_CUBE_FAST");
+  // ... and when it is BIG the store is first partitioned once by the digits of its first pm levels
+  // (bucket_build.hip: forest_prefix_partition): the top pm levels of the tree follow from the partition's
+  // histogram, the level loop starts at level pm and every later gather of coordinates stays inside the ~15 000
+  // records of one depth-pm node.  BASELINE config 4 (64 M points, K = 4096, 5 levels): 4 of the 5 level passes
+  // and the store-wide random gather of k_finalize (169 bytes fetched per 24-byte point) go.
+  int pm = 0;
+  const void* pre_recs = nullptr;
+  const uint32_t* pre_bstart = nullptr;
+  const uint32_t* pre_bad = nullptr;
+  uint32_t pre_stride = 0;
+  // (OCTL_CUBE_PREFIX_MIN: tests run this path on small clouds; OCTL_NO_CUBE_PREFIX: never)
+  const int64_t prefix_min = getenv("OCTL_CUBE_PREFIX_MIN") ? atoll(getenv("OCTL_CUBE_PREFIX_MIN")) : ((int64_t)4 << 20);
+  if (cube_fast && all_scheme && !keep_scheme && K >= 0 && n_alive >= prefix_min && !getenv("OCTL_NO_CUBE_PREFIX")) {
+    for (int c = 4; c >= 2 && !pm; --c)   // every node above depth pm has to split: expect >= 2 K points per depth-pm node
+      if (n_alive >= 2 * std::max<int64_t>(K, 1) * ((int64_t)1 << (3 * c)) && c <= max_depth) pm = c;
+    if (pm) OCTL_TRY(forest_prefix_partition(f, pm, &pre_recs, &pre_bstart, &pre_stride, &pre_bad));
+  }
   if (N > 0 && !cube_fast) {
     OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));
     OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 4));
@@ -1667,7 +1669,29 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   std::vector<int32_t> local2root;
   int64_t V = 0;
   NodePtrs nd;
-  if (fresh) {
+  const int cur_epoch_new = f->epoch + (keep_scheme ? 0 : 1);
+  if (pm) {
+    // the complete top of the tree from the partition's bucket starts; a point outside the cube or a node above
+    // depth pm that does not split (few points, very uneven cloud) sends the build down the plain path
+    OCTL_TRY(nodes_reserve(ctx, nt, top_base(pm + 1)));
+    nd = node_ptrs(nt);
+    hipLaunchKernelGGL(k_top_tree, dim3(grid_for(top_base(pm + 1))), dim3(256), 0, st, pre_bstart, pre_stride, pm,
+                       n_alive, K, f->edge, f->corner[0], f->corner[1], f->corner[2], cur_epoch_new, nd,
+                       small + SM_BK_MISSING);
+    HIP_TRY(ctx, hipGetLastError());
+    uint32_t* fl = static_cast<uint32_t*>(ctx->small_host);
+    HIP_TRY(ctx, hipMemcpyAsync(fl, small + SM_BK_MISSING, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(fl + 1, pre_bad, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (fl[0] || fl[1]) {
+      pm = 0;
+      HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_MISSING, 0, 4, st));
+    }
+  }
+  if (pm) {
+    V = 1;
+    nt.n = top_base(pm + 1);
+  } else if (fresh) {
     V = v_pts;
     OCTL_TRY(nodes_reserve(ctx, nt, std::max<int64_t>(V, 1)));
     nt.n = V;
@@ -1785,7 +1809,10 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       l2r = f->root_up.as<int32_t>();
     }
     KTimer t(ctx, "init_level0");
-    if (cube_fast)
+    if (pm)
+      hipLaunchKernelGGL(k_pre_level0, dim3(grid_for(N)), dim3(256), 0, st, static_cast<const uint4*>(pre_recs), N, pm,
+                         pos_node, f->idxbuf[pm & 1].as<uint32_t>(), f->pathbuf[pm & 1].as<uint32_t>());
+    else if (cube_fast)
       hipLaunchKernelGGL(k_cube_level0, dim3(grid_for(N)), dim3(256), 0, st, (const double*)f->xyz.as<double>(), N,
                          f->edge, f->corner[0], f->corner[1], f->corner[2],
                          (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, scheme_dev,
@@ -1810,6 +1837,15 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   std::vector<octl_forest::LevelSeg> segs{{0, V, 0}};
   LevelLoop L{f, &nt, K, (int)keep_scheme, all_scheme, scheme_dev, old_fc, old_epoch, cur_epoch, max_depth,
               n_alive, false, first_new, n_new, 0, 0, &segs};
+  if (pm) {  // levels 0 .. pm-1 are done: all of their nodes are internal
+    for (int d = 1; d <= pm; ++d) segs.push_back({top_base(d), top_base(d + 1), d});
+    L.first_new = top_base(pm);
+    L.n_new = (int64_t)1 << (3 * pm);
+    L.n_internal = top_base(pm);
+    L.level = pm;
+    L.gx = static_cast<const double*>(pre_recs);
+    L.xs = 4;
+  }
   OCTL_TRY(run_level_loop(L));
   nd = node_ptrs(nt);
   n_internal = L.n_internal;
@@ -1820,17 +1856,23 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx, (size_t)n_alive * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord, (size_t)n_alive * 24));
     {
+      // (a fused gather + block-head count, eight positions per thread, was measured SLOWER on BASELINE config 4:
+      //  2.39 + 0.24 ms against 1.95 + 0.39 ms - eight dependent random gathers per thread hide less latency
+      //  than one per thread at full occupancy)
       KTimer t(ctx, "finalize");
-      // (the gather and the count pass of the block table in one: the heads per tile land in f->flags)
-      const int64_t n_btiles = ceil_div(n_alive, (int64_t)BLK_TILE);
-      OCTL_TRY(devbuf_reserve(ctx, f->flags, (size_t)(n_btiles + 8) * 4));
-      hipLaunchKernelGGL(k_finalize_tiles, dim3((unsigned)n_btiles), dim3(256), 0, st,
-                         (const int32_t*)pos_node, (const int32_t*)nd.depth,
-                         (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
-                         (const uint32_t*)f->idxbuf[1].as<uint32_t>(),
-                         (const double*)f->xyz.as<double>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
-                         n_poses, n_alive, f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
-                         f->flags.as<uint32_t>());
+      if (pm)
+        hipLaunchKernelGGL(k_finalize_rec, dim3(grid_for(n_alive)), dim3(256), 0, st,
+                           (const int32_t*)pos_node, (const int32_t*)nd.depth,
+                           (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
+                           (const uint32_t*)f->idxbuf[1].as<uint32_t>(), static_cast<const uint4*>(pre_recs),
+                           n_alive, f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>());
+      else
+        hipLaunchKernelGGL(k_finalize, dim3(grid_for(n_alive)), dim3(256), 0, st,
+                           (const int32_t*)pos_node, (const int32_t*)nd.depth,
+                           (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
+                           (const uint32_t*)f->idxbuf[1].as<uint32_t>(),
+                           (const double*)f->xyz.as<double>(), n_alive, f->ord_idx.as<uint32_t>(),
+                           f->xyz_ord.as<double>());
       HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -1838,7 +1880,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   int64_t n_blocks = 0;
   const int64_t n_ord_before = f->n_ord;
   f->n_ord = n_alive;
-  OCTL_TRY(forest_make_blocks(f, n_alive > 0));
+  OCTL_TRY(forest_make_blocks(f));
   {
     uint32_t e = 0;
     OCTL_TRY(forest_finish_blocks(f, &e));  // the build's final synchronisation

@@ -73,3 +73,8 @@ struct BucketBuildGeom {  // decoding of the linear voxel keys: lin = ((qx-min0)
 int forest_bucket_build(octl_forest* f, const BucketBuildArgs& a, NodeTable& nt, int* done,
                         std::vector<octl_forest::LevelSeg>* segs, int64_t* n_internal, int* levels,
                         int64_t* n_voxels, int64_t* n_blocks, int64_t* pending, BucketBuildGeom* geom);
+
+// bucket_build.hip: one stable partition of a single cube's store by the child digits of its first pm levels
+// (records of 32 bytes: x, y, z f64 | six digits << 1 | bad | store index + scheme bit)
+int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const uint32_t** bstart, uint32_t* bstride,
+                            const uint32_t** bad_flag);

@@ -155,7 +155,7 @@ int store_compute_bbox(octl_forest* f);
 int store_materialize(octl_forest* f);
 int ransac_check_table(octl_ctx* ctx, const double* hyp, int32_t H, int32_t k);
 // build.hip: (re)build the (leaf, pose) block table from pos_node / ord_idx
-int forest_make_blocks(octl_forest* f, bool tiles_counted = false);
+int forest_make_blocks(octl_forest* f);
 // reads the block count (and the domain-error flag) left on the device: one synchronisation
 int forest_finish_blocks(octl_forest* f, uint32_t* err_out);
 // host copy of the voxel keys (synchronises when stale)

@@ -2460,3 +2460,67 @@ def test_six_digits_at_once_in_a_single_cube(monkeypatch):
                 monkeypatch.delenv("OCTL_NO_EXACT_DIGITS")
         _assert_same_tables(tabs[0], tabs[1])
         assert len(pts) > 65_535 and int(tabs[0][0]["depth"].max()) >= 3
+
+
+# ------------------------------------------------------------------------------------------------
+# a big single cube: the store partitioned once by its first levels, the level loop started below them
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["unit", "offset", "fractional", "negative", "uneven", "outside"])
+def test_single_cube_prefix_partition_equals_the_plain_level_loop(monkeypatch, case):
+    """BASELINE config 4's build path (build.hip: prefix partition + complete top tree + level loop from level pm),
+    forced onto small clouds: node table, block table, permutation and listing order must be those of the plain
+    level loop (itself pinned to the oracle and the reference's golden vectors) - for an integer cube (the exact
+    digit form), a cube at an offset, a fractional and a negative corner (level-by-level digits), an uneven cloud
+    whose top nodes do not all split (the path must step aside), and a point outside the cube (DomainError from
+    the plain path, as before)."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    rng = np.random.default_rng(123)
+    corner, edge = {"unit": ([0.0, 0.0, 0.0], 1.0), "offset": ([4.0, 8.0, 2.0], 2.0),
+                    "fractional": ([0.3, -0.7, 2.25], 1.5), "negative": ([-3.0, -1.0, -2.0], 1.0),
+                    "uneven": ([0.0, 0.0, 0.0], 1.0), "outside": ([0.0, 0.0, 0.0], 1.0)}[case]
+    corner = np.array(corner)
+    n = 300_000
+    pts = corner + rng.random((n, 3)) * edge
+    if case == "uneven":       # nearly everything in one octant: the other depth-1 nodes hold too little to split
+        pts = corner + np.vstack([rng.random((n - 40, 3)) * 0.5, 0.5 + rng.random((40, 3)) * 0.5]) * edge
+    if case == "outside":
+        pts[1234] = corner + np.array([1.5, 0.2, 0.2]) * edge
+    pts = pts[((pts >= corner) & (pts < corner + edge)).all(axis=1) | (case == "outside")]
+    ctx = nat.get_context()
+
+    def build(K, plain):
+        if plain:
+            monkeypatch.setenv("OCTL_NO_CUBE_PREFIX", "1")
+        else:
+            monkeypatch.delenv("OCTL_NO_CUBE_PREFIX", raising=False)
+        f = Forest(1, corner, edge)
+        f.add_pose(pts[: len(pts) // 2])
+        f.add_pose(pts[len(pts) // 2 :])         # two poses: (leaf, pose) blocks need the ORIGINAL indices
+        ctx.set_profiling(True)
+        try:
+            f.subdivide(K)
+            names = set(ctx.timings())
+            t = _tables(f)
+        finally:
+            ctx.set_profiling(False)
+            f.close()
+        return t, names
+
+    monkeypatch.setenv("OCTL_CUBE_PREFIX_MIN", "100000")
+    for K, levels in ((30, 4), (200, 3), (2000, 2)):
+        if case == "outside":
+            for plain in (False, True):
+                with pytest.raises((IndexError, ValueError)):
+                    build(K, plain)
+            continue
+        got, names = build(K, False)
+        want, plain_names = build(K, True)
+        _assert_same_tables(got, want)
+        assert "prefix_scatter" not in plain_names
+        # (300 000 points: >= 2 K points per depth-pm node for pm = 4 / 3 / 2; the uneven cloud makes the path step aside)
+        assert "level_hist" in names
+        if case != "uneven":
+            assert "prefix_scatter" in names and "keygen" not in names
+            assert int(got[0]["depth"].max()) >= levels
