@@ -374,6 +374,8 @@ def build_path(timer_names):
         return "bucket" + (" + level loop for the voxels left behind" if loop else "")
     if general:
         return "general (keygen + radix sort + level loop)" + (" after a bucket attempt" if bucket else "")
+    if "prefix_scatter" in timer_names:
+        return "general (a single cube: prefix partition by the first levels + level loop below them)"
     if loop:
         return "general (a single cube: one fused level-0 pass + level loop)"
     return "incremental" if "inc_place" in timer_names else "unknown"
@@ -1094,18 +1096,19 @@ TIMER_KERNELS = {
     "keygen": ["k_keygen"],
     "linkey": ["k_linkey"],
     "roots": ["k_root_tiles<", "k_make_roots"],
-    "init_level0": ["k_init_level0", "k_count_scheme"],
+    "init_level0": ["k_init_level0", "k_count_scheme", "k_pre_level0", "k_cube_level0", "k_top_tree"],
     "level_prepare": ["k_split_flags", "k_compact_split"],
     "level_hist": ["k_lv_hist<"],
     "level_scatter": ["k_lv_scatter"],
     "level_children": ["k_make_children"],
     "finalize": ["k_finalize"],
     "blocks": ["k_block_tiles<", "k_block_sizes"],
-    "prefix_part": ["k_pre_hist", "k_pre_scatter"],
+    "prefix_hist": ["k_part_hist<false", "k_transpose_u32"],
+    "prefix_scatter": ["k_part_scatter<"],
     "ransac": ["k_ransac<"],
 }
 # the kernel that runs exactly ONCE per step of a workload: dispatch counts are taken relative to it
-PROFILE_REF = {"headline": "k_bucket_totals", "c5shard": "k_bucket_totals", "c4": "k_finalize"}
+PROFILE_REF = {"headline": "k_bucket_totals", "c5shard": "k_bucket_totals", "c4": "k_finalize_rec"}
 
 # DESIGN bytes per point of the streaming kernels of insert + subdivide: what each one has to read and write
 # in THIS pipeline per launch - not SURVEY 8(d)'s algorithmic 24 B/point, which is reported
@@ -1123,12 +1126,13 @@ BUILD_DESIGN_BYTES = {
     "sort_hist": 8,
     "sort_scatter": 12 + 12,
     "roots": 8,
-    "init_level0": 8 + 4 + 8 + 4 + 4 + 8,
+    "init_level0": 32 + 4 + 4 + 4,     # (single cube behind a prefix partition: record tail -> index, path, leaf)
     "level_hist": 8 + 4,
     "level_scatter": 8 + 4 + 8 + 4 + 4,
     "finalize": 4 + 4 + 24 + 4 + 24,
     "blocks": 4 + 4,
-    "prefix_part": 24 + 24 + 32,
+    "prefix_hist": 24,                # a big single cube: histogram over the digits of its first levels
+    "prefix_scatter": 24 + 32,        # ... and the one move of the coordinates into records grouped by them
 }
 
 
