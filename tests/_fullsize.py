@@ -65,14 +65,17 @@ def voxel_points_from_chunks(chunks, chosen_coords, L=1.0):
     return np.concatenate(pts_out), np.concatenate(idx_out)
 
 
-def oracle_check_voxels(f, chunks, n_voxels, K, rng, slot=0):
+def oracle_check_voxels(f, chunks, n_voxels, K, rng, slot=0, ranks=None):
     """>= n_voxels random top-level voxels of a one-pose grid forest: their points rebuilt with the
     recursive oracle (OGrid) - leaf table (corner bits, edge bits) -> original index set and the leaf
     order must be equal."""
     from oracle import octree_np as onp
 
     vox = f.voxels
-    ranks = np.sort(rng.choice(len(vox), size=min(n_voxels, len(vox)), replace=False))
+    if ranks is None:
+        ranks = np.sort(rng.choice(len(vox), size=min(n_voxels, len(vox)), replace=False))
+    else:
+        ranks = np.sort(np.asarray(ranks))
     pts, gidx = voxel_points_from_chunks(chunks, vox[ranks])
     og = onp.OGrid(1)
     og.insert_points(0, pts)

@@ -238,3 +238,51 @@ def test_c4_manager_multi_pose_reduced_vs_oracle_and_full_properties():
     f.subdivide(K // 8, scheme_slots=[0, 5, 9, 33])
     oracle_check_every_leaf(f, poses, K // 8, grid=False, scheme_slots=[0, 5, 9, 33])
     f.close()
+
+
+def test_sparse_scene_10M_every_leaf_against_the_count_oracle():
+    """A scene that is NOT dense in its box (octreelib_amd.synthetic.sparse_scene: a terrain sheet through 256 x 256 x
+    32 voxels + one blob at 20 x the density - the blob's buckets are cut into chunks of whole voxels, the bench's
+    `secondary.sparse_scene`): at the full 10 M points the whole build - every node (corner bits, edge bits, leaf or
+    internal, child order) and the leaf of every point - equals the count-only oracle's, on the bucket path (with its
+    chunked buckets) and on the level-synchronous path; 200 whole voxels of the blob and of the sheet are rebuilt by
+    the recursive oracle (leaf tables and listing order)."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+    from octreelib_amd._engine import Forest
+    from tests._fullsize import oracle_check_every_leaf, oracle_check_voxels
+
+    n, K = 10_000_000, 64
+    pts = synthetic.sparse_scene(n, (256, 256, 32), seed=7)
+    ctx = nat.get_context()
+    f = Forest(0, np.zeros(3), 1.0)
+    f.add_pose(pts)
+    ctx.set_profiling(True)
+    f.subdivide(K)
+    names = set(ctx.timings())
+    ctx.set_profiling(False)
+    assert "bucket_build" in names and "keygen" not in names            # the bucket path took it ...
+    _check_structure(f, n, K)
+    oracle_check_every_leaf(f, [pts], K, grid=True)
+    rng = np.random.default_rng(5)
+    oracle_check_voxels(f, [(0, pts)], 200, K, rng)                      # voxels of the sheet ...
+    per_voxel = np.bincount(f.nodes["voxel"][f.blocks["node"]], weights=f.blocks["size"], minlength=len(f.voxels))
+    dense = np.argsort(per_voxel)[-60:]                                  # ... and the 60 fullest voxels of the blob
+    assert per_voxel[dense].min() > 1000
+    oracle_check_voxels(f, [(0, pts)], 60, K, rng, ranks=dense)
+    tables = (f.nodes, f.blocks, f.perm, f.order)
+    f.close()
+    import os
+
+    os.environ["OCTL_NO_BUCKET_BUILD"] = "1"                             # ... and the level loop agrees bit for bit
+    try:
+        g = Forest(0, np.zeros(3), 1.0)
+        g.add_pose(pts)
+        g.subdivide(K)
+        for a, b in zip(tables[:2], (g.nodes, g.blocks)):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(tables[2], g.perm) and np.array_equal(tables[3], g.order)
+        g.close()
+    finally:
+        del os.environ["OCTL_NO_BUCKET_BUILD"]
