@@ -44,9 +44,24 @@ constexpr int PT_THREADS = 256;
 constexpr int PT_BITS = 12;
 constexpr int PT_BINS = 1 << PT_BITS;            // buckets
 
+// BB_ONE_READ (experiments, -D): the bucket kernel reads every record ONCE - the coordinates stay in registers
+// from the first pass to the output, which goes through an LDS window - instead of the tail first and the whole
+// record again for the output.  It needs 8 instead of 16 items per thread (48 VGPRs of coordinates) and so 512
+// threads per bucket, two workgroups per CU instead of three.
+#ifndef BB_ONE_READ
+#define BB_ONE_READ 1
+#endif
+#if BB_ONE_READ
+constexpr int BB_THREADS = 512;
+constexpr int BB_IPT = 8;
+constexpr int BB_WGS = 4;   // waves per SIMD asked of the compiler (2 workgroups of 8 waves per CU)
+#else
 constexpr int BB_THREADS = 256;
 constexpr int BB_IPT = 16;
+constexpr int BB_WGS = 3;   // (3 workgroups of 4 waves per CU)
+#endif
 constexpr int BB_CAP = BB_THREADS * BB_IPT;      // points per bucket handled in LDS
+static_assert(BB_CAP == 4096, "leaf words, 16-bit item ids and the chunk plan assume 4096 points per piece");
 constexpr int BB_LEVELS = 7;                     // child digits per point (21 bits)
 constexpr uint32_t PATH_MASK = 0x1FFFFFu;
 
@@ -694,8 +709,9 @@ __global__ __launch_bounds__(256) void k_bucket_bounds(const uint4* __restrict__
 // ---------------------------------------------------------------------------------------------
 // helpers of the bucket kernel
 // ---------------------------------------------------------------------------------------------
-// exclusive prefix of one value per thread over the 256-thread block; *total = block sum.
-// scratch: >= 4 words of LDS; two barriers inside.
+// exclusive prefix of one value per thread over the NT-thread block; *total = block sum.
+// scratch: >= NT / 64 words of LDS; two barriers inside.
+template <int NT = 256>
 __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t* total, uint32_t* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t inc = wave_inclusive_add(v);
@@ -703,7 +719,7 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t* total, 
   __syncthreads();
   uint32_t basev = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < BB_THREADS / 64; ++w) {
+  for (int w = 0; w < NT / 64; ++w) {
     const uint32_t s = scratch[w];
     if (w < wave) basev += s;
     tot += s;
@@ -760,7 +776,8 @@ constexpr int BB_BINS = 8192;          // histogram bins per level (nodes of a l
 #endif
 constexpr int BB_SORT_BITS = 9;        // digit of the in-bucket radix sort
 constexpr int BB_SORT_BINS = 1 << BB_SORT_BITS;
-static_assert(BB_SORT_BINS == 2 * BB_THREADS, "two sort digits per thread in the offset scan");
+constexpr int BB_SORT_DPT = BB_SORT_BINS / BB_THREADS;  // sort digits per thread in the offset scan
+static_assert(BB_SORT_DPT * BB_THREADS == BB_SORT_BINS && BB_SORT_DPT >= 1, "whole sort digits per thread");
 constexpr uint32_t NOT_OVER = 0xFFFFFFFFu;
 
 // One chunk of a bucket: n <= BB_CAP points (a run of whole voxels), records part[SRC[i]] (CHUNKED)
@@ -773,7 +790,8 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord, uint32_t* __restrict__ leafinfo,
     uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_node, const uint32_t node_stage, const uint32_t node_room,
     uint32_t* s_bins, uint16_t (*s_slot)[BB_CAP], uint16_t (*s_cnt)[BB_SORT_BINS],
-    uint32_t* s_scr, uint32_t* s_tot, uint32_t* s_base, uint32_t* s_todo, uint32_t* __restrict__ small) {
+    uint32_t* s_scr, uint32_t* s_tot, uint32_t* s_base, uint32_t* s_todo, uint32_t* __restrict__ small,
+    uint32_t* s_idx) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s = P.lp.shift;
   BB_STAMP_INIT;
@@ -808,17 +826,32 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   //      decided: bits 28..30 leaf depth d, bits 0..15 ordinal of the leaf's PARENT among the overfull nodes
   //      of level d - 1 (d = 0: the voxel ordinal again)
   uint32_t pth[BB_IPT], vlv[BB_IPT], stt[BB_IPT];
+#if BB_ONE_READ
+  double cxr[BB_IPT], cyr[BB_IPT], czr[BB_IPT];  // the records' coordinates: read once, held to the output
+#endif
   bool bad_any = false;
 #pragma unroll
   for (int r = 0; r < BB_IPT; ++r) {
     pth[r] = 0;
     vlv[r] = 0;
     stt[r] = 0;
+#if BB_ONE_READ
+    cxr[r] = cyr[r] = czr[r] = 0.0;
+#endif
     if (r < rounds) {
       const int i = wave * per_wave + r * 64 + lane;
       if (i < n) {
         // (16-byte loads: the second half of the record holds voxel, child digits and index)
+#if BB_ONE_READ
+        const uint4* q4 = reinterpret_cast<const uint4*>(part + (CHUNKED ? (int)SRC[i] : i));
+        const uint4 a4 = q4[0], w4 = q4[1];
+        cxr[r] = __longlong_as_double((long long)(((uint64_t)a4.y << 32) | a4.x));
+        cyr[r] = __longlong_as_double((long long)(((uint64_t)a4.w << 32) | a4.z));
+        czr[r] = __longlong_as_double((long long)(((uint64_t)w4.y << 32) | w4.x));
+        s_idx[i] = w4.w;
+#else
         const uint4 w4 = reinterpret_cast<const uint4*>(part + (CHUNKED ? (int)SRC[i] : i))[1];
+#endif
         const uint2 w = uint2{w4.z, w4.w};
         const bool bad = w.x & 1u;
         pth[r] = (((w.x >> 1) & 0x3FFFFu) << 3) | (w.y & 0x80000000u) | (bad ? 0x40000000u : 0u);
@@ -867,7 +900,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       }
     }
     uint32_t tot;
-    uint32_t run = block_excl_add(mine, &tot, s_scr);
+    uint32_t run = block_excl_add<BB_THREADS>(mine, &tot, s_scr);
     for (int q = 0; q < per; ++q) {
       const int d = tid * per + q;
       if (d < nbins0) {
@@ -949,7 +982,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
         if (d < nbl) mine += (int64_t)s_bins[d] > P.K ? 1u : 0u;
       }
       uint32_t tot;
-      uint32_t run = block_excl_add(mine, &tot, s_scr);
+      uint32_t run = block_excl_add<BB_THREADS>(mine, &tot, s_scr);
       const uint32_t* ninfo_up = s_ninfo + 1024 * ((l - 1) & 1);
       uint32_t* ninfo_me = s_ninfo + 1024 * (l & 1);
       for (int q = 0; q < per; ++q) {
@@ -1065,23 +1098,23 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     }
     __syncthreads();
     {
-      // exclusive offsets: digits d = 2 tid, 2 tid + 1 (all waves of a digit one after the other)
-      uint32_t c[2][BB_THREADS / 64], tot = 0;
+      // exclusive offsets: digits d = DPT tid ... DPT tid + DPT - 1 (all waves of a digit one after the other)
+      uint32_t c[BB_SORT_DPT][BB_THREADS / 64], tot = 0;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < BB_SORT_DPT; ++q) {
 #pragma unroll
         for (int w = 0; w < BB_THREADS / 64; ++w) {
-          c[q][w] = s_cnt[w][2 * tid + q];
+          c[q][w] = s_cnt[w][BB_SORT_DPT * tid + q];
           tot += c[q][w];
         }
       }
       uint32_t all;
-      uint32_t run = block_excl_add(tot, &all, s_scr);
+      uint32_t run = block_excl_add<BB_THREADS>(tot, &all, s_scr);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < BB_SORT_DPT; ++q) {
 #pragma unroll
         for (int w = 0; w < BB_THREADS / 64; ++w) {
-          s_cnt[w][2 * tid + q] = (uint16_t)run;
+          s_cnt[w][BB_SORT_DPT * tid + q] = (uint16_t)run;
           run += c[q][w];
         }
       }
@@ -1108,6 +1141,62 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 
   // ---- 5. outputs (coalesced) ------------------------------------------------------------------------------------
   uint32_t nblk = 0;
+#if BB_ONE_READ
+  // item -> final position, in the sort buffer that is free now
+  uint16_t* INV = s_slot[cur ^ 1];
+#pragma unroll
+  for (int r = 0; r < BB_IPT; ++r) {
+    const int f = r * BB_THREADS + tid;
+    if (f < n) INV[RS[f]] = (uint16_t)f;
+  }
+  // leaf words and the permutation in sorted order (index words from LDS: nothing is read from the records again)
+#pragma unroll
+  for (int r = 0; r < BB_IPT; ++r) {
+    const int f = r * BB_THREADS + tid;
+    if (f < n) {
+      const uint32_t it = RS[f];
+      const uint32_t key = KEY[it];
+      const uint32_t pit = f > 0 ? (uint32_t)RS[f - 1] : 0u;
+      const uint32_t pkey = f > 0 ? KEY[pit] : ~key;
+      const bool leaf_head = key != pkey;
+      const bool vox_head = f == 0 || (key >> kshift) != (pkey >> kshift);
+      const uint32_t idx = s_idx[it] & IDX_MASK;
+      bool blk_head = leaf_head;
+      if (!leaf_head && P.n_poses > 1)
+        blk_head = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, s_idx[pit] & IDX_MASK);
+      nblk += blk_head ? 1u : 0u;
+      const size_t o = (size_t)out_base + f;
+      leafinfo[o] = INFO[it] | (vox_head ? LI_VHEAD : 0u) | (blk_head ? LI_BHEAD : 0u);
+      ord_idx[o] = idx;
+    }
+  }
+  __syncthreads();  // KEY / INFO are dead: their 32 KB become the coordinate window; INV is complete
+  {
+    double* XW = reinterpret_cast<double*>(s_bins);
+    constexpr int W = (BB_BINS * 4) / 24;  // positions per window round (1365)
+    for (int w0 = 0; w0 < n; w0 += W) {
+      const int cnt = min(W, n - w0);
+#pragma unroll
+      for (int r = 0; r < BB_IPT; ++r) {
+        if (r < rounds) {
+          const int i = wave * per_wave + r * 64 + lane;
+          if (i < n) {
+            const int f = (int)INV[i] - w0;
+            if ((unsigned)f < (unsigned)cnt) {
+              XW[3 * f] = cxr[r];
+              XW[3 * f + 1] = cyr[r];
+              XW[3 * f + 2] = czr[r];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      double* __restrict__ dst = xyz_ord + 3 * ((size_t)out_base + w0);
+      for (int e = tid; e < 3 * cnt; e += BB_THREADS) dst[e] = XW[e];
+      __syncthreads();
+    }
+  }
+#else
 #pragma unroll BB_OUT_UNROLL
   for (int r = 0; r < BB_IPT; ++r) {
     const int f = r * BB_THREADS + tid;
@@ -1136,6 +1225,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       xyz_ord[3 * o + 2] = z;
     }
   }
+#endif
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) nblk += __shfl_xor(nblk, off);
   if (lane == 0 && nblk) atomicAdd(&s_tot[BK_NBLK], nblk);
@@ -1164,7 +1254,7 @@ struct __attribute__((aligned(16))) ChunkDesc {
 constexpr uint32_t CK_CAP = 1u << 16;  // chunks per build (beyond: the general path)
 
 // normal buckets: at most BB_CAP points
-__global__ __launch_bounds__(BB_THREADS, 3) void k_bucket_build(
+__global__ __launch_bounds__(BB_THREADS, BB_WGS) void k_bucket_build(
     const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
     const GeomDev* __restrict__ G,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
@@ -1178,10 +1268,15 @@ __global__ __launch_bounds__(BB_THREADS, 3) void k_bucket_build(
   __shared__ uint32_t s_base[BK_ROWS];            // totals of the bucket before the current chunk
   __shared__ uint16_t s_slot[2][BB_CAP];          // sort buffers: positions -> item
   __shared__ uint16_t s_cnt[BB_THREADS / 64][BB_SORT_BINS];
-  __shared__ uint32_t s_scr[8];
+  __shared__ uint32_t s_scr[16];
   __shared__ uint32_t s_tot[BK_ROWS];
   __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
   __shared__ uint16_t s_src[1];
+#if BB_ONE_READ
+  __shared__ uint32_t s_idx[BB_CAP];              // index | scheme bit of every item (the records are read once)
+#else
+  uint32_t* s_idx = nullptr;
+#endif
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
   const uint32_t start = bstart[(size_t)b * P.bstride];
@@ -1200,7 +1295,7 @@ __global__ __launch_bounds__(BB_THREADS, 3) void k_bucket_build(
   const PartRec* __restrict__ recs = part + start;
   const uint32_t fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
                                           bk_vox, bk_node, start, (uint32_t)n, s_bins, s_slot, s_cnt, s_scr, s_tot,
-                                          s_base, s_todo, small);
+                                          s_base, s_todo, small, s_idx);
   if (fl) {  // the host runs the general path instead
     if (tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
     if (tid == 0) atomicOr(&small[SM_BK_FLAGS], fl);
@@ -1290,7 +1385,7 @@ __global__ __launch_bounds__(BB_THREADS) void k_bucket_plan(
 }
 
 // one workgroup per chunk (the grid strides over the list: its length is on the device)
-__global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_chunks(
+__global__ __launch_bounds__(BB_THREADS, BB_ONE_READ ? 1 : 2) void k_bucket_chunks(
     const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
     const GeomDev* __restrict__ G, const ChunkDesc* __restrict__ ck_desc, uint32_t* __restrict__ ck_tot,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
@@ -1304,10 +1399,15 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_chunks(
   __shared__ uint32_t s_base[BK_ROWS];
   __shared__ uint16_t s_slot[2][BB_CAP];
   __shared__ uint16_t s_cnt[BB_THREADS / 64][BB_SORT_BINS];
-  __shared__ uint32_t s_scr[8];
+  __shared__ uint32_t s_scr[16];
   __shared__ uint32_t s_tot[BK_ROWS];
   __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
   __shared__ uint16_t s_src[BB_CAP];  // chunk item -> record of the bucket
+#if BB_ONE_READ
+  __shared__ uint32_t s_idx[BB_CAP];
+#else
+  uint32_t* s_idx = nullptr;
+#endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t total = min(small[SM_CK_COUNT], CK_CAP);
   if (small[SM_BK_FLAGS] & BF_OVERFLOW) return;  // (the plan gave up: the general path takes the build)
@@ -1322,7 +1422,7 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_chunks(
     const PartRec* __restrict__ recs = part + start;
     if (tid < BK_ROWS) s_tot[tid] = 0;
     if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
-    if (tid < 8) s_scr[tid] = 0;
+    if (tid < 16) s_scr[tid] = 0;
     __syncthreads();
     uint32_t fl = 0;
     if (cd.big) {
@@ -1380,14 +1480,14 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_chunks(
       }
       if (lane == 0) {
         atomicAdd(&s_tot[BK_NBLK], nblk);
-        atomicAdd(&s_scr[4], nsch);
+        atomicAdd(&s_scr[12], nsch);  // (slots 0..7 are the waves' counts)
       }
       __syncthreads();
       if (tid == 0) {
         const size_t at = 3 * ((size_t)start + cd.cvox);
         bk_vox[at] = lin0 + vl;
         bk_vox[at + 1] = basec | 0x80000000u;
-        bk_vox[at + 2] = s_scr[4];
+        bk_vox[at + 2] = s_scr[12];
         s_tot[BK_NVOX] += 1;
         atomicAdd(&small[SM_BK_TODO], 1u);
       }
@@ -1415,7 +1515,7 @@ __global__ __launch_bounds__(BB_THREADS, 2) void k_bucket_chunks(
       }
       fl = bucket_chunk<true>(recs, s_src, (int)cd.n, start + cd.cofs, start + cd.cvox, lin0, P, pose_off, ord_idx,
                               xyz_ord, leafinfo, bk_vox, bk_node, start + cd.cofs, cd.n, s_bins, s_slot, s_cnt, s_scr,
-                              s_tot, s_base, s_todo, small);
+                              s_tot, s_base, s_todo, small, s_idx);
     }
     if (fl) {
       if (tid == 0) atomicOr(&small[SM_BK_FLAGS], fl);
