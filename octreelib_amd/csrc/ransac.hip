@@ -282,7 +282,7 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #define RS_EARLY_EXIT 1  // skip the later hypothesis groups once one hypothesis holds all points
 #endif
 #ifndef RS_FIRST_GROUPS
-#define RS_FIRST_GROUPS 1  // hypothesis groups (of THREADS) evaluated before the early-exit check
+#define RS_FIRST_GROUPS 0  // hypothesis groups (of THREADS) evaluated before the early-exit check (0: RS_FIRST_HYPS / THREADS)
 #endif
 #ifndef RS_SCHED_BARRIER
 #define RS_SCHED_BARRIER 1
@@ -300,8 +300,20 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #define RS_BIG_THREADS 256  // lanes per workgroup for H > 256 (x RS_BIG_HPL hypotheses per lane)
 #endif
 #define RS_BIG_HPL (1024 / RS_BIG_THREADS)
+#ifndef RS_SMALL_THREADS
+#define RS_SMALL_THREADS 128  // H > 256: blocks with fewer points than this get workgroups of this many lanes (0: no split)
+#endif
+#ifndef RS_SUB
+#define RS_SUB 0  // hypothesis groups per batch of pass 2 (0: three with 8 or more hypotheses per lane, else all in one)
+#endif
+#ifndef RS_FIRST_HYPS
+#define RS_FIRST_HYPS 256  // hypotheses evaluated before the early-exit check (whole groups of THREADS)
+#endif
 #ifndef RS_PER_CU
 #define RS_PER_CU 64
+#endif
+#ifndef RS_SMALL_PER_CU
+#define RS_SMALL_PER_CU 128
 #endif
 #define RS_PRAGMA_(x) _Pragma(#x)
 #define RS_PRAGMA(x) RS_PRAGMA_(x)
@@ -607,6 +619,14 @@ __device__ __forceinline__ void screen_group(const f4* __restrict__ loc, int n, 
 }
 #endif
 
+template <int B, int NB, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  if constexpr (B < NB) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, NB>(f);
+  }
+}
+
 // -DRS_STAMPS: phase clocks of k_ransac (experiments only, like BB_STAMPS in bucket_build.hip).  Wave 0 of every
 // workgroup reads s_memtime at the phase boundaries of every block and keeps the sums in SGPRs; at the end of the
 // kernel they are added to a device array that tools/rs_stamps.py reads through octl_debug_rs_stamps:
@@ -660,8 +680,8 @@ __device__ unsigned long long g_rs_stamps[16];
 template <int THREADS, int HPL, int KT, int ABL, bool FULLH>
 __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ xyz, const BlockDesc* __restrict__ sdesc,
-    const uint32_t* __restrict__ n_sorted_ptr, const double* __restrict__ hyp, int H, int k_rt,
-    double thr, RansacOut out) {
+    const uint32_t* __restrict__ lo_ptr, const uint32_t* __restrict__ hi_ptr, const double* __restrict__ hyp, int H,
+    int k_rt, double thr, RansacOut out) {
   constexpr int KS = KT > 0 ? KT : RS_KMAX;
   constexpr int GW = (KS + 3) / 4;  // packed sample positions: one byte each
   constexpr int W = THREADS / 64;
@@ -676,13 +696,16 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   __shared__ float s_wext[3][W];
   __shared__ uint32_t s_wfast[3][W];
 #endif
-  const int nbs = (int)*n_sorted_ptr;
+  // this launch's part [lo, hi) of the size-sorted list (device-side counts; lo_ptr == nullptr: from the front)
+  const int lo = lo_ptr ? (int)*lo_ptr : 0;
+  const int hi = (int)*hi_ptr;
+  const int nbs = hi - lo;
   // workgroup w owns the CONTIGUOUS chunk [w*C, (w+1)*C) of the size-sorted list: its blocks have
   // (almost always) the same size, so the cached sample positions stay valid, and the chunks with
   // the largest blocks are dispatched first
   const int C = (nbs + (int)gridDim.x - 1) / (int)gridDim.x;
-  int j = (int)blockIdx.x * C;
-  const int j_end = min(nbs, j + C);
+  int j = lo + (int)blockIdx.x * C;
+  const int j_end = min(hi, j + C);
   if (j >= j_end) return;
   BlockDesc cur = sdesc[j];
   BlockDesc nxt = cur;
@@ -708,10 +731,19 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   RS_STAMP_INIT;
   bool any_risk = false;
   uint32_t gpk[HPL][GW];
-  uint32_t risk[HPL];
+  // "risky" draws of the lane's hypotheses (sample_index_cached), KS bits per hypothesis packed into words
+  constexpr int RW = (HPL * KS + 31) / 32;
+  uint32_t riskw[RW];
+#pragma unroll
+  for (int w = 0; w < RW; ++w) riskw[w] = 0;
+  auto risk_of = [&](const int q) -> uint32_t {
+    const int w0 = (q * KS) >> 5, sh = (q * KS) & 31;
+    uint32_t r = riskw[w0] >> sh;
+    if (sh + KS > 32) r |= riskw[w0 + 1] << (32 - sh);
+    return r & ((1u << KS) - 1u);
+  };
 #pragma unroll
   for (int q = 0; q < HPL; ++q) {
-    risk[q] = 0;
 #pragma unroll
     for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
   }
@@ -753,9 +785,11 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       cached_n = n;
       uint32_t risk_any = 0;
 #pragma unroll
+      for (int w = 0; w < RW; ++w) riskw[w] = 0;
+#pragma unroll
       for (int q = 0; q < HPL; ++q) {
         const int t = tx + q * THREADS;
-        risk[q] = 0;
+        uint32_t rq = 0;
 #pragma unroll
         for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
         if (FULLH || t < H) {
@@ -766,11 +800,16 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
               bool risky;
               const int g = sample_index_cached(row[i], n, &risky);
               gpk[q][i >> 2] |= (uint32_t)g << (8 * (i & 3));
-              risk[q] |= risky ? (1u << i) : 0u;
+              rq |= risky ? (1u << i) : 0u;
             }
           }
         }
-        risk_any |= risk[q];
+        {
+          const int w0 = (q * KS) >> 5, sh = (q * KS) & 31;
+          riskw[w0] |= rq << sh;
+          if (sh + KS > 32) riskw[w0 + 1] |= rq >> (32 - sh);
+        }
+        risk_any |= rq;
       }
       // does any lane of this wave hold a draw that needs the block's start (probability 2^-20
       // per draw)?  Otherwise the gathers below skip the per-sample check.
@@ -854,7 +893,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
             sx[i] = sy[i] = sz[i] = 0.0;
             if (i < k) {
               int g = (int)((gpk[q][i >> 2] >> (8 * (i & 3))) & 0xFFu);
-              if (risk[q] & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
+              if (risk_of(q) & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
               sx[i] = lx[g];
               sy[i] = ly[g];
               sz[i] = lz[g];
@@ -934,8 +973,32 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     // groups and scoring them in one loop; the exit removes 10 % of the VALU instructions on the
     // benchmark scene.  Gating the two passes by block size - inside the kernel or as two
     // launches - was slower than the plain two-pass kernel.)
-    constexpr int F = HPL > RS_FIRST_GROUPS ? RS_FIRST_GROUPS : HPL;
+    constexpr int F0 = RS_FIRST_GROUPS > 0 ? RS_FIRST_GROUPS : (RS_FIRST_HYPS >= THREADS ? RS_FIRST_HYPS / THREADS : 1);
+    constexpr int F = HPL > F0 ? F0 : HPL;
+    // The lane's best hypothesis so far - maximum over the lane, then over the wave; lowest hypothesis index among
+    // the tied (cuda_ransac.py:125-146) - is taken over after every batch of groups, so that the planes of a
+    // batch are dead when the next one is fitted (RS_SUB groups per batch of pass 2).
+    // (one 32-bit key: (count + 1) << 10 | 1023 - index; count <= 255, index < 1024 <= H_max; 0 = no hypothesis)
+    static_assert(THREADS * HPL <= 1024, "hypothesis index in 10 bits");
+    uint32_t best = 0;
+    float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
+    auto take = [&](const int q0, const int nh) {
+#pragma unroll
+      for (int q = q0; q < q0 + nh; ++q) {
+        const int t = tx + q * THREADS;
+        if (FULLH || t < H) {
+          const uint32_t key = ((uint32_t)(cnt[q] + 1) << 10) | (uint32_t)(1023 - t);
+          if (key > best) {
+            best = key;
+            wa = fa[q]; wb = fb[q]; wc = fc[q]; wd = fd[q];
+          }
+        }
+      }
+    };
     bool skipped = false;  // pass 2 not evaluated (wave-uniform)
+    // (8 hypotheses per lane make this section 88 KB of straight-line code - 8 plane fits, 3 scoring loops - against
+    //  the 64 KB instruction cache two CUs share; as a rolled loop over batches of two groups, the packed sample
+    //  positions rotating through the slots, it is 16 KB and 5 % SLOWER: 3.76 against 3.57 ms on the same box.)
 #pragma unroll
     for (int q = 0; q < F; ++q) fit(q);
     RS_STAMP(1);
@@ -950,31 +1013,33 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #pragma unroll
       for (int q = 0; q < F; ++q) full = full || ((FULLH || (int)tx + q * THREADS < H) && cnt[q] == n);
       skipped = RS_EARLY_EXIT && __any(full);
+    }
+    take(0, F);
+    if (HPL > F) {
       if (!skipped) {
+        constexpr int REST = HPL > F ? HPL - F : 1;
+        constexpr int SUB0 = RS_SUB > 0 ? RS_SUB : (HPL >= 8 ? 3 : REST);
+        constexpr int SUB = SUB0 < REST ? SUB0 : REST;
+        constexpr int FULL_BATCHES = REST / SUB, TAIL = REST % SUB;
+        static_for<0, FULL_BATCHES>([&](auto bt) {
+          constexpr int q0 = F + decltype(bt)::value * SUB;
 #pragma unroll
-        for (int q = F; q < HPL; ++q) fit(q);
-        RS_STAMP(3);
-        score(std::integral_constant<int, (HPL > F ? HPL - F : 1)>{}, F);
+          for (int q = q0; q < q0 + SUB; ++q) fit(q);
+          if (decltype(bt)::value == FULL_BATCHES - 1 && TAIL == 0) RS_STAMP(3);
+          score(std::integral_constant<int, SUB>{}, q0);
+          take(q0, SUB);
+        });
+        if (TAIL > 0) {
+          constexpr int q0 = F + FULL_BATCHES * SUB;
+#pragma unroll
+          for (int q = q0; q < HPL; ++q) fit(q);
+          RS_STAMP(3);
+          score(std::integral_constant<int, (TAIL > 0 ? TAIL : 1)>{}, q0);
+          take(q0, TAIL);
+        }
         RS_STAMP(4);
       } else {
         RS_COUNT(9, 1);
-      }
-    }
-    // maximum over the lane, then over the wave; lowest hypothesis index among the tied
-    // (cuda_ransac.py:125-146)
-    // (one 32-bit key: (count + 1) << 10 | 1023 - index; count <= 255, index < 1024 <= H_max; 0 = no hypothesis)
-    static_assert(THREADS * HPL <= 1024, "hypothesis index in 10 bits");
-    uint32_t best = 0;
-    float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
-#pragma unroll
-    for (int q = 0; q < HPL; ++q) {
-      const int t = tx + q * THREADS;
-      if ((FULLH || t < H) && (q < F || !skipped)) {
-        const uint32_t key = ((uint32_t)(cnt[q] + 1) << 10) | (uint32_t)(1023 - t);
-        if (key > best) {
-          best = key;
-          wa = fa[q]; wb = fb[q]; wc = fc[q]; wd = fd[q];
-        }
       }
     }
     const uint32_t wbest = wave_max_u32(best);
@@ -1427,18 +1492,37 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   }
   const int cus = octl_ctx_cus(ctx);
   KTimer t(ctx, "ransac");
-#define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU)                                        \
+  // (LO, HI: device words holding the launch's part [lo, hi) of the size-sorted list; LO nullptr = from the front)
+#define OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, LO, HI)                                 \
   do {                                                                                           \
     const unsigned g = (unsigned)std::min<int64_t>(nb, (int64_t)cus * (PER_CU));                 \
     if (H == (THREADS) * (HPL))                                                                  \
       hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, true>), dim3(g), dim3(THREADS), 0, st,  \
-                         xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(counters + RC_SORTED), \
+                         xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
                          hyp_dev, H, k, thr, out);                                                \
     else                                                                                         \
       hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, false>), dim3(g), dim3(THREADS), 0, st, \
-                         xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(counters + RC_SORTED), \
+                         xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
                          hyp_dev, H, k, thr, out);                                                \
   } while (0)
+#define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU) \
+  OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED)
+  // H > 256: a block of n points is worked on by one workgroup, and every wave of it pays the per-block work
+  // (staging, reduction, barrier, the winner's mask) whatever n is.  Blocks with n < RS_SMALL_THREADS - the bulk:
+  // a leaf has at most K points - therefore get workgroups of RS_SMALL_THREADS lanes x 1024 / RS_SMALL_THREADS
+  // hypotheses per lane (two waves per block instead of four: -5 % on the benchmark scene), the others the
+  // RS_BIG_THREADS-lane instance; the size-sorted list is split at the start of size class RS_SMALL_THREADS - 1.
+#if RS_SMALL_THREADS > 0 && RS_SMALL_THREADS < RS_BIG_THREADS
+#define OCTL_RANSAC_SPLIT(KT, ABL)                                                                               \
+  do {                                                                                                           \
+    OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr, counters + RC_START + RS_SMALL_THREADS - 1); \
+    HIP_TRY(ctx, hipGetLastError());                                                                             \
+    OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                     \
+                      counters + RC_START + RS_SMALL_THREADS - 1, counters + RC_SORTED);                         \
+  } while (0)
+#else
+#define OCTL_RANSAC_SPLIT(KT, ABL) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU)
+#endif
   if (any_k) {
     // (nothing was put on the sorted list)
   } else if (H <= 64) {
@@ -1448,15 +1532,17 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   } else {
     // (timing experiments - no fit / no scoring, results meaningless - exist only in builds made with
     //  -DRS_ABLATE=1|2, tools/build_variant.sh; the shipped library has no such switch)
-    if (k == 6) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 6, RS_ABLATE, RS_PER_CU);
+    if (k == 6) OCTL_RANSAC_SPLIT(6, RS_ABLATE);
     // the other small sample sizes also get compile-time k (sample arrays in registers; the generic
     // instantiation indexes them at run time and spills)
-    else if (k == 5) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 5, 0, RS_PER_CU);
-    else if (k == 4) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 4, 0, RS_PER_CU);
-    else if (k == 3) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 3, 0, RS_PER_CU);
+    else if (k == 5) OCTL_RANSAC_SPLIT(5, 0);
+    else if (k == 4) OCTL_RANSAC_SPLIT(4, 0);
+    else if (k == 3) OCTL_RANSAC_SPLIT(3, 0);
     else OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 0, 0, 2);
   }
+#undef OCTL_RANSAC_SPLIT
 #undef OCTL_RANSAC_LAUNCH
+#undef OCTL_RANSAC_RANGE
   HIP_TRY(ctx, hipGetLastError());
   // the (rare) blocks that do not fit the LDS staging; the grid is fixed, the count is on the device
 #define OCTL_RANSAC_BIG(THREADS, HPL, KT)                                                       \
