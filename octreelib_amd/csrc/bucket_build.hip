@@ -60,6 +60,16 @@ constexpr int BB_THREADS = 256;
 constexpr int BB_IPT = 16;
 constexpr int BB_WGS = 3;   // (3 workgroups of 4 waves per CU)
 #endif
+#ifndef BB_LEAF_UNROLL
+#define BB_LEAF_UNROLL 2
+#endif
+#ifndef BB_LOAD_BATCH
+#define BB_LOAD_BATCH 0
+#endif
+#ifndef BB_KEEP_ROUNDS
+#define BB_KEEP_ROUNDS 7
+#endif
+constexpr int BB_KEEP = BB_KEEP_ROUNDS < BB_IPT ? BB_KEEP_ROUNDS : BB_IPT;   // rounds whose coordinates stay in registers (BB_ONE_READ)
 constexpr int BB_CAP = BB_THREADS * BB_IPT;      // points per bucket handled in LDS
 static_assert(BB_CAP == 4096, "leaf words, 16-bit item ids and the chunk plan assume 4096 points per piece");
 constexpr int BB_LEVELS = 7;                     // child digits per point (21 bits)
@@ -827,7 +837,11 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   //      of level d - 1 (d = 0: the voxel ordinal again)
   uint32_t pth[BB_IPT], vlv[BB_IPT], stt[BB_IPT];
 #if BB_ONE_READ
-  double cxr[BB_IPT], cyr[BB_IPT], czr[BB_IPT];  // the records' coordinates: read once, held to the output
+  // the records' coordinates: read once, held to the output - for the first BB_KEEP rounds; a bucket of more
+  // than BB_KEEP * BB_THREADS points (the average bucket holds 60 % of BB_CAP) reads the coordinates of the
+  // rest again at the output, when the pyramid's registers are free (held through, they spill: 132 B of
+  // scratch per lane were +166 MB of reads and +197 MB of writes per 10 M points)
+  double cxr[BB_KEEP], cyr[BB_KEEP], czr[BB_KEEP];
 #endif
   bool bad_any = false;
 #pragma unroll
@@ -836,7 +850,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     vlv[r] = 0;
     stt[r] = 0;
 #if BB_ONE_READ
-    cxr[r] = cyr[r] = czr[r] = 0.0;
+    if (r < BB_KEEP) cxr[r] = cyr[r] = czr[r] = 0.0;
 #endif
     if (r < rounds) {
       const int i = wave * per_wave + r * 64 + lane;
@@ -844,10 +858,13 @@ __device__ __forceinline__ uint32_t bucket_chunk(
         // (16-byte loads: the second half of the record holds voxel, child digits and index)
 #if BB_ONE_READ
         const uint4* q4 = reinterpret_cast<const uint4*>(part + (CHUNKED ? (int)SRC[i] : i));
-        const uint4 a4 = q4[0], w4 = q4[1];
-        cxr[r] = __longlong_as_double((long long)(((uint64_t)a4.y << 32) | a4.x));
-        cyr[r] = __longlong_as_double((long long)(((uint64_t)a4.w << 32) | a4.z));
-        czr[r] = __longlong_as_double((long long)(((uint64_t)w4.y << 32) | w4.x));
+        const uint4 w4 = q4[1];
+        if (r < BB_KEEP) {
+          const uint4 a4 = q4[0];
+          cxr[r] = __longlong_as_double((long long)(((uint64_t)a4.y << 32) | a4.x));
+          cyr[r] = __longlong_as_double((long long)(((uint64_t)a4.w << 32) | a4.z));
+          czr[r] = __longlong_as_double((long long)(((uint64_t)w4.y << 32) | w4.x));
+        }
         s_idx[i] = w4.w;
 #else
         const uint4 w4 = reinterpret_cast<const uint4*>(part + (CHUNKED ? (int)SRC[i] : i))[1];
@@ -860,6 +877,10 @@ __device__ __forceinline__ uint32_t bucket_chunk(
         bad_any = bad_any || bad;
       }
     }
+#if BB_ONE_READ && BB_LOAD_BATCH > 0
+    // whole records in flight are 8 VGPRs per round: the loads go out in batches of BB_LOAD_BATCH rounds
+    if ((r + 1) % BB_LOAD_BATCH == 0 && r + 1 < BB_IPT) __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   BB_STAMP(0);  // records' tails loaded
   // (after the loop: a conditional LDS access between the loads serialises them)
@@ -892,6 +913,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       return P.K >= 0 && (int64_t)(c & 0xFFFFu) > P.K && !((s_todo[d >> 5] >> (d & 31)) & 1u);
     };
     uint32_t mine = 0;  // low half: voxels, high half: overfull voxels
+#pragma unroll 1
     for (int q = 0; q < per; ++q) {
       const int d = tid * per + q;
       if (d < nbins0) {
@@ -901,6 +923,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     }
     uint32_t tot;
     uint32_t run = block_excl_add<BB_THREADS>(mine, &tot, s_scr);
+#pragma unroll 1
     for (int q = 0; q < per; ++q) {
       const int d = tid * per + q;
       if (d < nbins0) {
@@ -977,6 +1000,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
     {
       const int per = (nbl + BB_THREADS - 1) / BB_THREADS;
       uint32_t mine = 0;
+#pragma unroll 1
       for (int q = 0; q < per; ++q) {
         const int d = tid * per + q;
         if (d < nbl) mine += (int64_t)s_bins[d] > P.K ? 1u : 0u;
@@ -985,6 +1009,7 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       uint32_t run = block_excl_add<BB_THREADS>(mine, &tot, s_scr);
       const uint32_t* ninfo_up = s_ninfo + 1024 * ((l - 1) & 1);
       uint32_t* ninfo_me = s_ninfo + 1024 * (l & 1);
+#pragma unroll 1
       for (int q = 0; q < per; ++q) {
         const int d = tid * per + q;
         if (d < nbl) {
@@ -1144,13 +1169,15 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 #if BB_ONE_READ
   // item -> final position, in the sort buffer that is free now
   uint16_t* INV = s_slot[cur ^ 1];
-#pragma unroll
+  // (these two loops touch no per-item register array: rolled or nearly so - BB_LEAF_UNROLL - they leave the
+  //  registers to the coordinates that are held across them)
+#pragma unroll BB_LEAF_UNROLL
   for (int r = 0; r < BB_IPT; ++r) {
     const int f = r * BB_THREADS + tid;
     if (f < n) INV[RS[f]] = (uint16_t)f;
   }
   // leaf words and the permutation in sorted order (index words from LDS: nothing is read from the records again)
-#pragma unroll
+#pragma unroll BB_LEAF_UNROLL
   for (int r = 0; r < BB_IPT; ++r) {
     const int f = r * BB_THREADS + tid;
     if (f < n) {
@@ -1174,6 +1201,25 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   {
     double* XW = reinterpret_cast<double*>(s_bins);
     constexpr int W = (BB_BINS * 4) / 24;  // positions per window round (1365)
+    // (the coordinates of the rounds past BB_KEEP: a full bucket only)
+    constexpr int LATE = BB_IPT > BB_KEEP ? BB_IPT - BB_KEEP : 1;
+    double lxr[LATE], lyr[LATE], lzr[LATE];
+    lxr[0] = lyr[0] = lzr[0] = 0.0;
+#pragma unroll
+    for (int r = BB_KEEP; r < BB_IPT; ++r) {
+      lxr[r - BB_KEEP] = lyr[r - BB_KEEP] = lzr[r - BB_KEEP] = 0.0;
+      if (r < rounds) {
+        const int i = wave * per_wave + r * 64 + lane;
+        if (i < n) {
+          const PartRec* q = part + (CHUNKED ? (int)SRC[i] : i);
+          const uint4 a4 = reinterpret_cast<const uint4*>(q)[0];
+          const uint2 b2 = reinterpret_cast<const uint2*>(q)[2];
+          lxr[r - BB_KEEP] = __longlong_as_double((long long)(((uint64_t)a4.y << 32) | a4.x));
+          lyr[r - BB_KEEP] = __longlong_as_double((long long)(((uint64_t)a4.w << 32) | a4.z));
+          lzr[r - BB_KEEP] = __longlong_as_double((long long)(((uint64_t)b2.y << 32) | b2.x));
+        }
+      }
+    }
     for (int w0 = 0; w0 < n; w0 += W) {
       const int cnt = min(W, n - w0);
 #pragma unroll
@@ -1183,9 +1229,9 @@ __device__ __forceinline__ uint32_t bucket_chunk(
           if (i < n) {
             const int f = (int)INV[i] - w0;
             if ((unsigned)f < (unsigned)cnt) {
-              XW[3 * f] = cxr[r];
-              XW[3 * f + 1] = cyr[r];
-              XW[3 * f + 2] = czr[r];
+              XW[3 * f] = r < BB_KEEP ? cxr[r < BB_KEEP ? r : 0] : lxr[r < BB_KEEP ? 0 : r - BB_KEEP];
+              XW[3 * f + 1] = r < BB_KEEP ? cyr[r < BB_KEEP ? r : 0] : lyr[r < BB_KEEP ? 0 : r - BB_KEEP];
+              XW[3 * f + 2] = r < BB_KEEP ? czr[r < BB_KEEP ? r : 0] : lzr[r < BB_KEEP ? 0 : r - BB_KEEP];
             }
           }
         }
