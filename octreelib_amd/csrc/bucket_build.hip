@@ -1389,23 +1389,42 @@ __global__ __launch_bounds__(BB_THREADS) void k_bucket_plan(
   for (int d = tid; d < nbins0; d += BB_THREADS) s_bins[d] = 0;
   __syncthreads();
   const PartRec* __restrict__ recs = part + start;
-  for (int i = tid; i < n; i += BB_THREADS)
-    atomicAdd(&s_bins[reinterpret_cast<const uint4*>(recs + i)[1].z >> 19], 1u);
+  // (four loads in flight per lane: the bucket is up to 16 times the kernel's threads)
+  for (int i0 = 0; i0 < n; i0 += 4 * BB_THREADS) {
+    uint32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * BB_THREADS + tid;
+      v[u] = i < n ? reinterpret_cast<const uint4*>(recs + i)[1].z >> 19 : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (v[u] != 0xFFFFFFFFu) atomicAdd(&s_bins[v[u]], 1u);
+  }
   __syncthreads();
+  // one lane walks the <= 4096 bins (the cut depends on the running size) - eight bins per LDS round trip - and
+  // leaves the chunks in LDS; the workgroup claims their range in the list and copies them out
+  constexpr int PLAN_MAX = 64;  // (two neighbouring chunks hold more than BB_CAP points and n <= 65535: <= 34 chunks)
+  __shared__ ChunkDesc s_desc[PLAN_MAX];
+  __shared__ uint32_t s_plan[2];  // chunks, base in the list (0xFFFFFFFF: given up)
   if (tid == 0) {
-    // (one lane, <= 4096 bins, two sweeps: count the chunks, claim their range, emit them)
-    auto sweep = [&](ChunkDesc* out) {
-      uint32_t c = 0, size = 0, vox = 0, cum = 0, first = 0, cofs = 0, cvox = 0;
-      auto close_chunk = [&](uint32_t v_end, uint32_t big) {
-        if (out) out[c] = ChunkDesc{b, first, v_end, size, cofs, cvox, big, 0u};
-        ++c;
-        size = 0;
-        first = v_end;
-        cofs = cum;
-        cvox = vox;
-      };
-      for (int d = 0; d < nbins0; ++d) {
-        const uint32_t cnt = s_bins[d];
+    uint32_t c = 0, size = 0, vox = 0, cum = 0, first = 0, cofs = 0, cvox = 0;
+    auto close_chunk = [&](uint32_t v_end, uint32_t big) {
+      if (c < (uint32_t)PLAN_MAX) s_desc[c] = ChunkDesc{b, first, v_end, size, cofs, cvox, big, 0u};
+      ++c;
+      size = 0;
+      first = v_end;
+      cofs = cum;
+      cvox = vox;
+    };
+    for (int d0 = 0; d0 < nbins0; d0 += 8) {
+      uint32_t cn[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cn[u] = d0 + u < nbins0 ? s_bins[d0 + u] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t cnt = cn[u];
+        const int d = d0 + u;
         if (cnt == 0) continue;
         const bool big = cnt > (uint32_t)BB_CAP;  // a single voxel beyond the LDS capacity: one leaf, copied through
         if (size > 0 && (big || size + cnt > (uint32_t)BB_CAP)) close_chunk((uint32_t)d, 0u);
@@ -1414,19 +1433,29 @@ __global__ __launch_bounds__(BB_THREADS) void k_bucket_plan(
         ++vox;
         if (big) close_chunk((uint32_t)d + 1u, (uint32_t)d + 1u);
       }
-      if (size > 0) close_chunk((uint32_t)nbins0, 0u);
-      return c;
-    };
-    const uint32_t nch = sweep(nullptr);
-    const uint32_t base = atomicAdd(&small[SM_CK_COUNT], nch);
-    if (base + nch > CK_CAP) {
+    }
+    if (size > 0) close_chunk((uint32_t)nbins0, 0u);
+    uint32_t base = 0xFFFFFFFFu;
+    if (c <= (uint32_t)PLAN_MAX) {
+      base = atomicAdd(&small[SM_CK_COUNT], c);
+      if (base + c > CK_CAP) base = 0xFFFFFFFFu;
+    }
+    if (base == 0xFFFFFFFFu) {
       ck_of_bucket[b] = uint2{0u, 0u};
       atomicOr(&small[SM_BK_FLAGS], BF_OVERFLOW);
     } else {
-      sweep(ck_desc + base);
-      ck_of_bucket[b] = uint2{base, nch};
+      ck_of_bucket[b] = uint2{base, c};
     }
+    s_plan[0] = c;
+    s_plan[1] = base;
     atomicOr(&small[SM_BK_NOORDER], 1u);  // (a chunked bucket's blocks are ordered by order.hip)
+  }
+  __syncthreads();
+  if (s_plan[1] != 0xFFFFFFFFu) {
+    // (a descriptor is two 16-byte words)
+    const uint4* src = reinterpret_cast<const uint4*>(s_desc);
+    uint4* dst = reinterpret_cast<uint4*>(ck_desc + s_plan[1]);
+    for (uint32_t e = tid; e < 2u * s_plan[0]; e += BB_THREADS) dst[e] = src[e];
   }
 }
 
@@ -1539,24 +1568,44 @@ __global__ __launch_bounds__(BB_THREADS, BB_ONE_READ ? 1 : 2) void k_bucket_chun
       }
       __syncthreads();
     } else {
-      // stable compaction of the chunk's records: SRC[k] = k-th record of the bucket whose voxel is in the chunk
-      uint32_t basec = 0;
-      for (int i0 = 0; i0 < n; i0 += BB_THREADS) {
-        const int i = i0 + tid;
-        uint32_t vl = 0xFFFFFFFFu;
-        if (i < n) vl = reinterpret_cast<const uint4*>(recs + i)[1].z >> 19;
-        const bool sel = i < n && vl >= cd.v_first && vl < cd.v_end;
-        const uint64_t m = __ballot(sel);
-        if (lane == 0) s_scr[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t off = basec, tot = 0;
+      // stable compaction of the chunk's records: SRC[k] = k-th record of the bucket whose voxel is in the chunk.
+      // Every wave takes one contiguous stretch of the bucket and goes over it twice - count, then place behind
+      // the waves in front of it - with ONE barrier in between (a barrier pair per BB_THREADS records, as before
+      // round 4, made the workgroup's ~65 steps over a 33 k-point bucket a chain of barrier latencies).
+      {
+        constexpr int W = BB_THREADS / 64, U = 8;
+        const int seg = (((n + W - 1) / W) + 63) & ~63;
+        const int lo = wave * seg, hi = min(n, lo + seg);
+        auto selected = [&](const int i) {
+          uint32_t vl = 0xFFFFFFFFu;
+          if (i < hi) vl = reinterpret_cast<const uint4*>(recs + i)[1].z >> 19;
+          return i < hi && vl >= cd.v_first && vl < cd.v_end;
+        };
+        uint32_t mine = 0;
+        for (int i0 = lo; i0 < hi; i0 += 64 * U) {
+          bool sel[U];
 #pragma unroll
-        for (int w = 0; w < BB_THREADS / 64; ++w) {
-          if (w < wave) off += s_scr[w];
-          tot += s_scr[w];
+          for (int u = 0; u < U; ++u) sel[u] = selected(i0 + u * 64 + lane);
+#pragma unroll
+          for (int u = 0; u < U; ++u) mine += (uint32_t)__popcll(__ballot(sel[u]));
         }
-        if (sel) s_src[off + (uint32_t)__popcll(m & lanemask_lt())] = (uint16_t)i;
-        basec += tot;
+        if (lane == 0) s_scr[wave] = mine;
+        __syncthreads();
+        uint32_t off = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w)
+          if (w < wave) off += s_scr[w];
+        for (int i0 = lo; i0 < hi; i0 += 64 * U) {
+          bool sel[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) sel[u] = selected(i0 + u * 64 + lane);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const uint64_t m = __ballot(sel[u]);
+            if (sel[u]) s_src[off + (uint32_t)__popcll(m & lanemask_lt())] = (uint16_t)(i0 + u * 64 + lane);
+            off += (uint32_t)__popcll(m);
+          }
+        }
         __syncthreads();
       }
       fl = bucket_chunk<true>(recs, s_src, (int)cd.n, start + cd.cofs, start + cd.cvox, lin0, P, pose_off, ord_idx,
