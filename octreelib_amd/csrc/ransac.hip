@@ -1025,9 +1025,10 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
           constexpr int q0 = F + decltype(bt)::value * SUB;
 #pragma unroll
           for (int q = q0; q < q0 + SUB; ++q) fit(q);
-          if (decltype(bt)::value == FULL_BATCHES - 1 && TAIL == 0) RS_STAMP(3);
+          RS_STAMP(3);
           score(std::integral_constant<int, SUB>{}, q0);
           take(q0, SUB);
+          RS_STAMP(4);
         });
         if (TAIL > 0) {
           constexpr int q0 = F + FULL_BATCHES * SUB;
@@ -1036,8 +1037,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
           RS_STAMP(3);
           score(std::integral_constant<int, (TAIL > 0 ? TAIL : 1)>{}, q0);
           take(q0, TAIL);
+          RS_STAMP(4);
         }
-        RS_STAMP(4);
       } else {
         RS_COUNT(9, 1);
       }

@@ -5,7 +5,7 @@
 # region of BASELINE config 3 and nothing else), so that the per-kernel averages of the tracked files are the
 # headline's own - the secondaries (uniform scene, two streams, Python API ...) launch the same kernels on other
 # inputs and used to be averaged in.
-# 1. full default bench.py run                                   -> profiles/TAG_bench.json
+# 1. (last, see 6.) full default bench.py run                   -> profiles/TAG_bench.json
 # 2. rocprofv3 --kernel-trace --stats of the headline-only run    -> profiles/TAG_kernel_stats.csv
 # 3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters), as MI355X_MICROARCH.md asks
 # 4. the same kernel-stats pass on the uniform scene               -> profiles/TAG_uniform_kernel_stats.csv
@@ -14,13 +14,12 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 HEAD="--no-secondary --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 $HEAD > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_$TAG.err || exit 2
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 $HEAD > /dev/null 2>&1 || exit 3
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 $HEAD > /dev/null 2>&1 || exit 4
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 $HEAD > /dev/null 2>&1 || exit 5
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_uniform -- python3 $R/bench.py --steps 10 --warmup 2 --cloud uniform $HEAD > $R/gpurun_out/prof_${TAG}_uniform_bench.json 2> $R/gpurun_out/prof_${TAG}_uniform.err || exit 6
-cd $R && python3 tools/summarize_profiles.py $TAG gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_sq_$TAG gpurun_out/prof_${TAG}_bench.json && cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
+cd $R && python3 tools/summarize_profiles.py $TAG gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_sq_$TAG gpurun_out/prof_${TAG}_bench.json || exit 6
 cp $(ls gpurun_out/prof_${TAG}_uniform/*/*kernel_stats.csv | head -1) profiles/${TAG}_uniform_kernel_stats.csv
 # 5. the two largest BASELINE configs alone (bench.py --workload c4 / c5shard): kernel stats + FETCH / WRITE passes
 #    -> profiles/TAG_c4_*, profiles/TAG_c5shard_*
@@ -34,5 +33,9 @@ if [ -z "$OCTL_PROFILE_HEADLINE_ONLY" ]; then
   done
   cd $R
 fi
+# 6. the full default bench.py run LAST: its counter figures (roofline.traffic, roofline_build) are read from the
+#    profiles/TAG_* files the passes above have just written
+cd /tmp && python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err || exit 1
+cd $R && cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
 # profiles/ is not writable back from the box: the condensed files are copied to gpurun_out/ too
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/

@@ -9,6 +9,7 @@ import numpy as np
 import bench
 from octreelib_amd import _native as nat
 
+WAVES = 2   # waves per block of the benchmarked instance, k_ransac<128,8,6>
 ctx = nat.Context(0)
 lib = ctx.lib
 lib.octl_debug_rs_stamps.restype = C.c_int
@@ -27,8 +28,8 @@ tm = ctx.timings()
 ctx.set_profiling(False)
 ctx.check(lib.octl_debug_rs_stamps(ctx.handle, out, 0))
 ms = tm["ransac"][0] / tm["ransac"][1]
-names = ["iteration head (prefetch, sample positions)", "plane fits, group 0 (256 hypotheses)", "scoring, group 0",
-         "plane fits, groups 1-3 (768 hypotheses)", "scoring, groups 1-3", "reduction + staging of the next block",
+names = ["iteration head (prefetch, sample positions)", "plane fits, pass 1 (256 hypotheses)", "scoring, pass 1",
+         "plane fits, pass 2 (768 hypotheses)", "scoring, pass 2", "reduction + staging of the next block",
          "barrier", "winner, outputs, final mask"]
 tot = sum(out[i] for i in range(8))
 blocks, skipped, wgs, pts = out[8] / reps, out[9] / reps, out[10] / reps, out[11] / reps
@@ -42,7 +43,7 @@ for i, nm in enumerate(names):
     print("  %-46s %5.1f %%  %6.3f ms  %9.0f clocks per block" % (nm, 100 * share, share * ms, out[i] / reps / blocks))
 fits = blocks * 256 + (blocks - skipped) * 768
 print("  plane fits per launch: %.3e (%.0f wave-fits); clocks per wave-fit: %.1f" % (
-    fits, fits / 64, (out[1] + out[3]) / reps / (fits / 64 / 4)))   # wave 0 executes a quarter of a block's wave-fits
+    fits, fits / 64, (out[1] + out[3]) / reps / (fits / 64 / WAVES)))   # wave 0 executes 1 / WAVES of a block's wave-fits
 res["fits_per_launch"] = fits
 json.dump(res, open("gpurun_out/rs_stamps.json", "w"), indent=1)
 wl.close()
