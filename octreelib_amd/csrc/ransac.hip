@@ -303,6 +303,15 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #ifndef RS_SMALL_THREADS
 #define RS_SMALL_THREADS 128  // H > 256: blocks with fewer points than this get workgroups of this many lanes (0: no split)
 #endif
+#ifndef RS_POS_TABLE
+#define RS_POS_TABLE 1   // H > 256, k <= 6: sample positions from a per-launch table instead of a register cache
+#endif
+#ifndef RS_TINY_THREADS
+#define RS_TINY_THREADS 64  // ... and blocks with fewer points than this get ONE wave x 16 hypotheses per lane (0: off)
+#endif
+#ifndef RS_TINY_PER_CU
+#define RS_TINY_PER_CU 256
+#endif
 #ifndef RS_SUB
 #define RS_SUB 0  // hypothesis groups per batch of pass 2 (0: three with 8 or more hypotheses per lane, else all in one)
 #endif
@@ -677,11 +686,14 @@ __device__ unsigned long long g_rs_stamps[16];
 //   * ONE barrier per block (three rotating point buffers, reduction slots by parity).
 // FULLH: the table has exactly THREADS x HPL hypotheses (the default 1024): every lane owns HPL of them and the
 // `index < H` guards (a compare, an EXEC save / restore and six zero-initialisations per plane fit) fold away.
-template <int THREADS, int HPL, int KT, int ABL, bool FULLH>
+// PT: the sample positions come from the launch's position table (k_pos_table: a function of (block size,
+// hypothesis) alone) instead of being cached in registers while the block size stays the same.
+template <int THREADS, int HPL, int KT, int ABL, bool FULLH, bool PT>
 __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ xyz, const BlockDesc* __restrict__ sdesc,
     const uint32_t* __restrict__ lo_ptr, const uint32_t* __restrict__ hi_ptr, const double* __restrict__ hyp, int H,
-    int k_rt, double thr, RansacOut out) {
+    int k_rt, double thr, RansacOut out, const uint2* __restrict__ pos_tab) {
+  static_assert(!PT || (KT > 0 && KT <= 6), "the position table packs up to six positions and their risk bits");
   constexpr int KS = KT > 0 ? KT : RS_KMAX;
   constexpr int GW = (KS + 3) / 4;  // packed sample positions: one byte each
   constexpr int W = THREADS / 64;
@@ -731,6 +743,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   RS_STAMP_INIT;
   bool any_risk = false;
   uint32_t gpk[HPL][GW];
+  uint32_t rkq[HPL];  // (PT) risky-draw bits of the loaded positions
   // "risky" draws of the lane's hypotheses (sample_index_cached), KS bits per hypothesis packed into words
   constexpr int RW = (HPL * KS + 31) / 32;
   uint32_t riskw[RW];
@@ -744,6 +757,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   };
 #pragma unroll
   for (int q = 0; q < HPL; ++q) {
+    rkq[q] = 0;
 #pragma unroll
     for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
   }
@@ -780,8 +794,19 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ ly = s_pts[buf][1];
     const double* __restrict__ lz = s_pts[buf][2];
 
+    // (PT) positions of hypothesis group q out of the table: 8 bytes per lane, issued a batch ahead of their fits
+    auto load_pos = [&](const int q) {
+      if constexpr (PT) {
+        const int t = tx + q * THREADS;
+        uint2 e = uint2{0u, 0u};
+        if (FULLH || t < H) e = pos_tab[(size_t)n * (size_t)H + t];
+        gpk[q][0] = e.x;
+        if (GW > 1) gpk[q][GW - 1] = e.y & 0xFFFFu;
+        rkq[q] = e.y >> 16;
+      }
+    };
     // sampled positions: recomputed only when the block size changes (wave-uniform branch)
-    if (n != cached_n) {
+    if (!PT && n != cached_n) {
       cached_n = n;
       uint32_t risk_any = 0;
 #pragma unroll
@@ -876,7 +901,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       fa[q] = fb[q] = fc[q] = fd[q] = sto[q] = sdl[q] = 0.f;
       if (FULLH || t < H) {
         double sx[KS], sy[KS], sz[KS];
-        if (!any_risk) {  // wave-uniform: practically always
+        const bool some_risk = PT ? (bool)__any(rkq[q] != 0u) : any_risk;
+        if (!some_risk) {  // wave-uniform: practically always
 #pragma unroll
           for (int i = 0; i < KS; ++i) {
             sx[i] = sy[i] = sz[i] = 0.0;
@@ -893,7 +919,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
             sx[i] = sy[i] = sz[i] = 0.0;
             if (i < k) {
               int g = (int)((gpk[q][i >> 2] >> (8 * (i & 3))) & 0xFFu);
-              if (risk_of(q) & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
+              if ((PT ? rkq[q] : risk_of(q)) & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
               sx[i] = lx[g];
               sy[i] = ly[g];
               sz[i] = lz[g];
@@ -999,9 +1025,19 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     // (8 hypotheses per lane make this section 88 KB of straight-line code - 8 plane fits, 3 scoring loops - against
     //  the 64 KB instruction cache two CUs share; as a rolled loop over batches of two groups, the packed sample
     //  positions rotating through the slots, it is 16 KB and 5 % SLOWER: 3.76 against 3.57 ms on the same box.)
+    constexpr int REST = HPL > F ? HPL - F : 1;
+    constexpr int SUB0 = RS_SUB > 0 ? RS_SUB : (HPL >= 8 ? 3 : REST);
+    constexpr int SUB = SUB0 < REST ? SUB0 : REST;
+    constexpr int FULL_BATCHES = REST / SUB, TAIL = REST % SUB;
+#pragma unroll
+    for (int q = 0; q < F; ++q) load_pos(q);
 #pragma unroll
     for (int q = 0; q < F; ++q) fit(q);
     RS_STAMP(1);
+    if (HPL > F) {  // (PT) the first batch of pass 2 is on its way while pass 1 is scored
+#pragma unroll
+      for (int q = F; q < F + SUB && q < HPL; ++q) load_pos(q);
+    }
     score(std::integral_constant<int, F>{}, 0);
     RS_STAMP(2);
     if (HPL > F) {
@@ -1017,14 +1053,12 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     take(0, F);
     if (HPL > F) {
       if (!skipped) {
-        constexpr int REST = HPL > F ? HPL - F : 1;
-        constexpr int SUB0 = RS_SUB > 0 ? RS_SUB : (HPL >= 8 ? 3 : REST);
-        constexpr int SUB = SUB0 < REST ? SUB0 : REST;
-        constexpr int FULL_BATCHES = REST / SUB, TAIL = REST % SUB;
         static_for<0, FULL_BATCHES>([&](auto bt) {
           constexpr int q0 = F + decltype(bt)::value * SUB;
 #pragma unroll
           for (int q = q0; q < q0 + SUB; ++q) fit(q);
+#pragma unroll
+          for (int q = q0 + SUB; q < q0 + 2 * SUB && q < HPL; ++q) load_pos(q);
           RS_STAMP(3);
           score(std::integral_constant<int, SUB>{}, q0);
           take(q0, SUB);
@@ -1389,6 +1423,25 @@ __global__ __launch_bounds__(256) void k_bin_starts(uint32_t* __restrict__ count
   if (threadIdx.x == 0) counters[RC_SORTED] = s + c[0];
 }
 
+// Sample positions of every hypothesis for every block size that occurs in the launch (k <= 6, sizes up to 255):
+// one 8-byte entry per (size, hypothesis) - positions in bytes 0..5, the risky-draw bits (sample_index_cached) in
+// bits 16..21 of the second word.  k_ransac<..., PT = true> reads its entries a batch ahead of the plane fits.
+__global__ __launch_bounds__(256) void k_pos_table(const double* __restrict__ hyp, int H, int k,
+                                                   const uint32_t* __restrict__ counters, uint2* __restrict__ tab) {
+  const int n = (int)blockIdx.y;
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= H || n < k || counters[RC_BINS + n] == 0u) return;
+  const double* __restrict__ row = hyp + (int64_t)t * k;
+  uint32_t x = 0, y = 0;
+  for (int i = 0; i < k; ++i) {
+    bool risky;
+    const uint32_t g = (uint32_t)sample_index_cached(row[i], n, &risky);
+    if (i < 4) x |= g << (8 * i); else y |= g << (8 * (i - 4));
+    y |= risky ? (0x10000u << i) : 0u;
+  }
+  tab[(size_t)n * (size_t)H + t] = uint2{x, y};
+}
+
 // descriptors -> size-sorted list.  Position inside a size class: rank inside the workgroup (LDS
 // atomics) + ONE global atomic per (workgroup, size) - same-address global atomics serialise.
 // The order inside a size class is arbitrary; blocks are independent, results do not depend on it.
@@ -1465,13 +1518,17 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   const size_t off_s = off_d + (size_t)nb * sizeof(BlockDesc);
   const size_t off_b = off_s + (size_t)nb * sizeof(BlockDesc);
   const size_t off_c = (off_b + (size_t)nb * 4 + 31) & ~(size_t)31;
-  OCTL_TRY(devbuf_reserve(ctx, scratch, off_c + RC_WORDS * 4));
+  // (position table of the H > 256, k <= 6 instances: 256 sizes x H entries of 8 bytes)
+  const bool use_tab = RS_POS_TABLE && !any_k && H > 256 && k >= 3 && k <= 6;
+  const size_t off_t = (off_c + RC_WORDS * 4 + 31) & ~(size_t)31;
+  OCTL_TRY(devbuf_reserve(ctx, scratch, off_t + (use_tab ? (size_t)256 * (size_t)H * sizeof(uint2) : 0)));
   char* base = static_cast<char*>(scratch.p);
   uint32_t* tmp = scratch.as<uint32_t>();
   BlockDesc* desc = reinterpret_cast<BlockDesc*>(base + off_d);
   BlockDesc* sdesc = reinterpret_cast<BlockDesc*>(base + off_s);
   uint32_t* big_list = reinterpret_cast<uint32_t*>(base + off_b);
   uint32_t* counters = reinterpret_cast<uint32_t*>(base + off_c);
+  uint2* pos_tab = use_tab ? reinterpret_cast<uint2*>(base + off_t) : nullptr;
   const int threads = (H <= 64) ? 64 : (H <= 256 ? 256 : RS_BIG_THREADS);
   RansacOut out{mask_dev, plane_dev, count_dev, index_dev};
   {
@@ -1487,6 +1544,11 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(256), 0, st, counters);
     HIP_TRY(ctx, hipGetLastError());
+    if (use_tab) {
+      hipLaunchKernelGGL(k_pos_table, dim3((unsigned)ceil_div(H, 256), 256), dim3(256), 0, st, hyp_dev, (int)H, (int)k,
+                         (const uint32_t*)counters, pos_tab);
+      HIP_TRY(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(k_block_scatter, dim3((unsigned)ceil_div(nb, 256 * BS_PER_THREAD)), dim3(256), 0, st,
                        (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc);
     HIP_TRY(ctx, hipGetLastError());
@@ -1494,32 +1556,46 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   const int cus = octl_ctx_cus(ctx);
   KTimer t(ctx, "ransac");
   // (LO, HI: device words holding the launch's part [lo, hi) of the size-sorted list; LO nullptr = from the front)
-#define OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, LO, HI)                                 \
+#define OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, LO, HI, PT)                             \
   do {                                                                                           \
     const unsigned g = (unsigned)std::min<int64_t>(nb, (int64_t)cus * (PER_CU));                 \
     if (H == (THREADS) * (HPL))                                                                  \
-      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, true>), dim3(g), dim3(THREADS), 0, st,  \
+      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, true, PT>), dim3(g), dim3(THREADS), 0, st, \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
-                         hyp_dev, H, k, thr, out);                                                \
+                         hyp_dev, H, k, thr, out, (const uint2*)pos_tab);                         \
     else                                                                                         \
-      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, false>), dim3(g), dim3(THREADS), 0, st, \
+      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, false, PT>), dim3(g), dim3(THREADS), 0, st, \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
-                         hyp_dev, H, k, thr, out);                                                \
+                         hyp_dev, H, k, thr, out, (const uint2*)pos_tab);                         \
   } while (0)
 #define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU) \
-  OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED)
+  OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED, false)
   // H > 256: a block of n points is worked on by one workgroup, and every wave of it pays the per-block work
   // (staging, reduction, barrier, the winner's mask) whatever n is.  Blocks with n < RS_SMALL_THREADS - the bulk:
   // a leaf has at most K points - therefore get workgroups of RS_SMALL_THREADS lanes x 1024 / RS_SMALL_THREADS
   // hypotheses per lane (two waves per block instead of four: -5 % on the benchmark scene), the others the
   // RS_BIG_THREADS-lane instance; the size-sorted list is split at the start of size class RS_SMALL_THREADS - 1.
+#if RS_POS_TABLE && RS_TINY_THREADS > 0 && RS_TINY_THREADS < RS_SMALL_THREADS
+#define RS_SMALL_END (counters + RC_START + RS_TINY_THREADS - 1)
+#define OCTL_RANSAC_TINY(KT, ABL)                                                                                \
+  do {                                                                                                           \
+    HIP_TRY(ctx, hipGetLastError());                                                                             \
+    OCTL_RANSAC_RANGE(RS_TINY_THREADS, (1024 / RS_TINY_THREADS), KT, ABL, RS_TINY_PER_CU,                        \
+                      counters + RC_START + RS_TINY_THREADS - 1, counters + RC_SORTED, true);                    \
+  } while (0)
+#else
+#define RS_SMALL_END (counters + RC_SORTED)
+#define OCTL_RANSAC_TINY(KT, ABL) do {} while (0)
+#endif
 #if RS_SMALL_THREADS > 0 && RS_SMALL_THREADS < RS_BIG_THREADS
 #define OCTL_RANSAC_SPLIT(KT, ABL)                                                                               \
   do {                                                                                                           \
-    OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr, counters + RC_START + RS_SMALL_THREADS - 1); \
+    OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                                   \
+                      counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0));                          \
     HIP_TRY(ctx, hipGetLastError());                                                                             \
     OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                     \
-                      counters + RC_START + RS_SMALL_THREADS - 1, counters + RC_SORTED);                         \
+                      counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0));      \
+    OCTL_RANSAC_TINY(KT, ABL);                                                                                   \
   } while (0)
 #else
 #define OCTL_RANSAC_SPLIT(KT, ABL) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU)
@@ -1542,6 +1618,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     else OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 0, 0, 2);
   }
 #undef OCTL_RANSAC_SPLIT
+#undef OCTL_RANSAC_TINY
 #undef OCTL_RANSAC_LAUNCH
 #undef OCTL_RANSAC_RANGE
   HIP_TRY(ctx, hipGetLastError());

@@ -585,6 +585,40 @@ def test_ransac_operator_boundary_shapes_vs_oracle(H, k):
     assert np.array_equal(mask, o_mask)
 
 
+@pytest.mark.parametrize("H,k", [(1024, 6), (1000, 6), (1024, 3), (600, 5), (1024, 4), (1024, 9)])
+def test_ransac_blocks_on_both_sides_of_the_128_point_split_vs_oracle(H, k):
+    """With more than 256 hypotheses the size-sorted block list is split on the device: blocks under 128 points go to
+    workgroups of 128 lanes x 8 hypotheses (pass 2 in batches of three groups), blocks of 128 ... 255 points to
+    256 lanes x 4, larger ones to the tiled kernel.  Sizes on and around every boundary, many blocks of each so that
+    every workgroup walks across size changes, exactly planar blocks (the early exit) among them; batches where one
+    of the parts is empty."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(1000 * H + k)
+    edge = np.array([126, 127, 128, 129, 130, 254, 255, 256, 257, k, k + 1, 64, 65, 96, 191, 192], dtype=np.int32)
+    for sizes in (np.concatenate([np.repeat(edge, 9), rng.integers(1, 140, 300).astype(np.int32)]),
+                  rng.integers(128, 256, 60).astype(np.int32),        # nothing for the 128-lane instance
+                  rng.integers(k, 128, 400).astype(np.int32)):        # nothing for the 256-lane instance
+        sizes = sizes.copy()
+        rng.shuffle(sizes)
+        n = int(sizes.sum())
+        cloud = rng.random((n, 3)) * 3.0
+        cloud[:, 2] = 0.4 * cloud[:, 0] - 0.2 * cloud[:, 1] + rng.normal(0, 0.008, n)
+        starts = np.concatenate(([0], np.cumsum(sizes)))
+        for b in range(0, len(sizes), 5):   # exactly planar: some hypothesis of pass 1 holds every point
+            s_, e_ = starts[b], starts[b + 1]
+            cloud[s_:e_, 2] = 0.5 * cloud[s_:e_, 0] + 0.25 * cloud[s_:e_, 1]
+        np.random.seed(H + k)
+        op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=k)
+        mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+        o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.01, details=True)
+        assert np.array_equal(counts, o_count)
+        assert np.array_equal(index, o_index)
+        assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
+        assert np.array_equal(mask, o_mask)
+
+
 @pytest.mark.parametrize("H", [1024, 700, 257, 513])
 def test_ransac_early_exit_keeps_the_lowest_index_winner(H):
     """The kernel skips the hypotheses H >= 256 of a wavefront once one of its first hypotheses
