@@ -553,7 +553,8 @@ __device__ __forceinline__ float wave_max_nonneg_f32(float m) {
 template <int THREADS>
 __device__ __forceinline__ void stage_local(double ox, double oy, double oz, const BlockDesc& d,
                                             double px, double py, double pz, f4* loc,
-                                            float* wext, uint32_t* wfast) {
+                                            float* wext, uint32_t* wfast, float* ext_out = nullptr,
+                                            uint32_t* fast_out = nullptr) {
   float m = 0.f;
   if ((int)threadIdx.x < d.n) {
     const float u = (float)(px - ox), v = (float)(py - oy), w = (float)(pz - oz);
@@ -566,7 +567,10 @@ __device__ __forceinline__ void stage_local(double ox, double oy, double oz, con
   // the range certificate of the plane fit's shortcuts (see RS_BLKFAST): lanes that stage nothing hold +0.0
   const bool inr = coord_in_fast_range(px) && coord_in_fast_range(py) && coord_in_fast_range(pz);
   const bool wave_fast = __all(inr);
-  if ((threadIdx.x & 63) == 0) {
+  if (ext_out) {  // (one wave per block: the two words stay in the wave's registers)
+    *ext_out = m;
+    *fast_out = wave_fast ? 1u : 0u;
+  } else if ((threadIdx.x & 63) == 0) {
     wext[threadIdx.x >> 6] = m;
     wfast[threadIdx.x >> 6] = wave_fast ? 1u : 0u;
   }
@@ -719,6 +723,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
   int j = lo + (int)blockIdx.x * C;
   const int j_end = min(hi, j + C);
   if (j >= j_end) return;
+  float ext_carry = 0.f;       // (W == 1) extent and range certificate of the staged block
+  uint32_t fast_carry = 0;
   BlockDesc cur = sdesc[j];
   BlockDesc nxt = cur;
   if (j + 1 < j_end) nxt = sdesc[j + 1];
@@ -735,7 +741,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     }
 #if RS_SCREEN
     stage_local<THREADS>(xyz[3 * (int64_t)cur.pstart], xyz[3 * (int64_t)cur.pstart + 1],
-                         xyz[3 * (int64_t)cur.pstart + 2], cur, px, py, pz, s_loc[0], s_wext[0], s_wfast[0]);
+                         xyz[3 * (int64_t)cur.pstart + 2], cur, px, py, pz, s_loc[0], s_wext[0], s_wfast[0],
+                         W == 1 ? &ext_carry : nullptr, W == 1 ? &fast_carry : nullptr);
 #endif
   }
   __syncthreads();
@@ -869,12 +876,12 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     // when one of them holds all n points, no hypothesis of a later group can win - their plane
     // fits and scores are skipped.  On the benchmark scene this is one leaf in five.
     const double ox = lx[0], oy = ly[0], oz = lz[0];
-    float extent = s_wext[buf][0];
+    float extent = W == 1 ? ext_carry : s_wext[buf][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) extent = fmaxf(extent, s_wext[buf][w]);
     // every staged coordinate (block + spill point) is +0.0 or in [2^-30, 2^31): the plane fits run without
     // their per-lane range guards (RS_BLKFAST).  Wave-uniform, kept in an SGPR.
-    uint32_t fastw = s_wfast[buf][0];
+    uint32_t fastw = W == 1 ? fast_carry : s_wfast[buf][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) fastw &= s_wfast[buf][w];
     const bool blk_fast = RS_BLKFAST && __builtin_amdgcn_readfirstlane((int)fastw) != 0;
@@ -1078,7 +1085,19 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       }
     }
     const uint32_t wbest = wave_max_u32(best);
-    if (best == wbest && best != 0) {  // exactly one lane: keys are unique
+    float f0, f1, f2, f3;
+    uint32_t gbest;
+    if constexpr (W == 1) {
+      // one wave per block: the winner's plane comes out of its lane's registers, nothing goes through LDS
+      const unsigned long long wl = __ballot(best == wbest && best != 0);  // exactly one lane: keys are unique
+      const int src = wl ? __ffsll((long long)wl) - 1 : 0;
+      gbest = wbest;
+      f0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wa), src));
+      f1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wb), src));
+      f2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wc), src));
+      f3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wd), src));
+      if (!wl) f0 = f1 = f2 = f3 = 0.f;
+    } else if (best == wbest && best != 0) {  // exactly one lane: keys are unique
       const int w = tx >> 6;
       s_wbest[par][w] = best;
       s_wplane[par][w][0] = wa;
@@ -1098,22 +1117,25 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       s_pts[nbuf][2][tx] = rz;
     }
 #if RS_SCREEN
-    if (has_next) stage_local<THREADS>(nox, noy, noz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf], s_wfast[nbuf]);
+    if (has_next)
+      stage_local<THREADS>(nox, noy, noz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf], s_wfast[nbuf],
+                           W == 1 ? &ext_carry : nullptr, W == 1 ? &fast_carry : nullptr);
 #endif
     RS_STAMP(5);
     __syncthreads();
     RS_STAMP(6);
-    uint32_t gbest = s_wbest[par][0];
-    int gw = 0;
+    if constexpr (W > 1) {
+      gbest = s_wbest[par][0];
+      int gw = 0;
 #pragma unroll
-    for (int w = 1; w < W; ++w) {
-      if (s_wbest[par][w] > gbest) {
-        gbest = s_wbest[par][w];
-        gw = w;
+      for (int w = 1; w < W; ++w) {
+        if (s_wbest[par][w] > gbest) {
+          gbest = s_wbest[par][w];
+          gw = w;
+        }
       }
+      f0 = s_wplane[par][gw][0]; f1 = s_wplane[par][gw][1]; f2 = s_wplane[par][gw][2]; f3 = s_wplane[par][gw][3];
     }
-    const float f0 = s_wplane[par][gw][0], f1 = s_wplane[par][gw][1], f2 = s_wplane[par][gw][2],
-                f3 = s_wplane[par][gw][3];
     if (tx == 0) {
       if (out.plane) {
         out.plane[4 * (int64_t)be + 0] = f0; out.plane[4 * (int64_t)be + 1] = f1;

@@ -1,0 +1,16 @@
+#!/bin/bash
+# one wave per block: winner and extent through registers instead of LDS (base) against the commit before (head);
+# phase clocks of the 64 x 16 instance
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd $R
+for V in base head; do
+  if [ $V = base ]; then unset OCTREELIB_AMD_LIB; else export OCTREELIB_AMD_LIB=$R/build/variants/$V.so; fi
+  timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "ransac" -p no:cacheprovider > gpurun_out/b25_tests_$V.log 2>&1
+  echo "$V tests rc=$? $(tail -1 gpurun_out/b25_tests_$V.log)"
+  for rep in 1 2 3; do
+    timeout -k 10 200 python bench.py --no-secondary --no-cpu-baseline > gpurun_out/b25_${V}_$rep.json 2> gpurun_out/b25_${V}_$rep.err
+    python -c "
+import json; d=json.load(open('gpurun_out/b25_${V}_$rep.json')); print('$V', $rep, round(d['ms_per_step'],3), 'ransac', round(d['kernels']['ransac']['ms_per_step'],3))"
+  done
+done
+OCTREELIB_AMD_LIB=$R/build/variants/rs_stamps.so timeout -k 10 300 python tools/rs_stamps.py 2>&1

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction histogram of k_ransac<128,8,6> (the benchmarked instantiation) from the compiler's own
+"""Instruction histogram of k_ransac<64,16,6> (the benchmarked instantiation) from the compiler's own
 assembly: whole kernel, one plane fit (the region up to the first sched_barrier that follows the sampled
 points' LDS gathers) and the screened scoring loop.  usage: tools/ransac_isa.py > profiles/rNN_ransac_isa.txt"""
 import collections, os, re, subprocess, sys, tempfile
@@ -11,7 +11,7 @@ with tempfile.TemporaryDirectory() as d:
                     f"-I{ROOT}/include", "-S", "--cuda-device-only", f"{ROOT}/octreelib_amd/csrc/ransac.hip", "-o", out],
                    check=True, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*k_ransacILi128ELi8ELi6ELi0ELb1E.*:", l))
+start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN.*k_ransacILi64ELi16ELi6ELi0ELb1ELb1E.*:", l))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
 
@@ -34,7 +34,7 @@ def show(title, c):
         print(f"   {k:26s}{v}")
 
 
-show("k_ransac<128,8,6> whole kernel (static)", ops(body))
+show("k_ransac<64,16,6> whole kernel (static)", ops(body))
 # one plane fit: from the first run of f64 adds after LDS gathers to the first sched_barrier
 sb = [i for i, l in enumerate(body) if "sched_barrier" in l]
 # walk back from the barrier over whole basic blocks until the region holds the fit's multiplies

@@ -9,7 +9,7 @@ import numpy as np
 import bench
 from octreelib_amd import _native as nat
 
-WAVES = 2   # waves per block of the benchmarked instance, k_ransac<128,8,6>
+WAVES = 1   # waves per block of the benchmarked instance, k_ransac<64,16,6>
 ctx = nat.Context(0)
 lib = ctx.lib
 lib.octl_debug_rs_stamps.restype = C.c_int
