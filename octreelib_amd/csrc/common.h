@@ -75,8 +75,10 @@ struct octl_ctx {
   // enqueued before it (its destination may still be read), copy_done orders compute behind the copies
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_gate = nullptr;
-  // route.hip: a rank's own part of the all-to-all is a device copy on a stream of its own, next to the RCCL
-  // transfers on the context's stream (self_gate: the send buffers are complete; self_done: the copies are)
+  // The context's SIDE stream (octl_ctx_side_stream): work that may run next to the context's stream between two
+  // events - self_gate: what it reads is complete on the context's stream; self_done: the side work is.
+  // route.hip: a rank's own part of the all-to-all, next to the RCCL transfers; ransac.hip: the instances for the
+  // larger blocks of a split launch, next to the one-wave instance.
   hipStream_t self_stream = nullptr;
   hipEvent_t self_gate = nullptr, self_done = nullptr;
   struct Upload { const char* dst; size_t bytes; hipEvent_t done; };
@@ -163,6 +165,9 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // (uint32) is written there.  n up to 2^31.
 // compute units of the context's device (cached)
 int octl_ctx_cus(octl_ctx* ctx);
+// the side stream and its two events, created on first use; false when they cannot be had (not an error: the
+// caller uses the context's stream)
+bool octl_ctx_side_stream(octl_ctx* ctx);
 int octl_exclusive_scan_u32(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n,
                             uint32_t* total_dev);
 // stable LSD radix sort of (key u64, value u32) pairs on bits [0, key_bits).  keys[0]/vals[0]

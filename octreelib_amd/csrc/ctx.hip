@@ -23,6 +23,25 @@ extern "C" int octl_debug_host_syncs(uint64_t* count) {
   return OCTL_OK;
 }
 
+bool octl_ctx_side_stream(octl_ctx* ctx) {
+  if (ctx->self_stream) return true;
+  hipStream_t st = nullptr;
+  hipEvent_t gate = nullptr, done = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+      hipEventCreateWithFlags(&gate, hipEventDisableTiming) == hipSuccess &&
+      hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) {
+    ctx->self_stream = st;
+    ctx->self_gate = gate;
+    ctx->self_done = done;
+    return true;
+  }
+  if (done) (void)hipEventDestroy(done);
+  if (gate) (void)hipEventDestroy(gate);
+  if (st) (void)hipStreamDestroy(st);
+  (void)hipGetLastError();
+  return false;
+}
+
 int octl_ctx_cus(octl_ctx* ctx) {
   if (ctx->cus <= 0) {
     hipDeviceProp_t prop;

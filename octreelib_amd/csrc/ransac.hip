@@ -309,6 +309,9 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #ifndef RS_TINY_THREADS
 #define RS_TINY_THREADS 64  // ... and blocks with fewer points than this get ONE wave x 16 hypotheses per lane (0: off)
 #endif
+#ifndef RS_SIDE_STREAM
+#define RS_SIDE_STREAM 1  // the instances for the larger blocks of a split launch run on the context's side stream
+#endif
 #ifndef RS_TINY_PER_CU
 #define RS_TINY_PER_CU 256
 #endif
@@ -1577,21 +1580,34 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   }
   const int cus = octl_ctx_cus(ctx);
   KTimer t(ctx, "ransac");
+  // The instances of the split launch work on disjoint parts of the list and write disjoint outputs: the two for
+  // the larger blocks go to the context's side stream, NEXT TO the one-wave instance on the context's stream, which
+  // waits for them at the end (on the benchmark scene the 128-lane instance has the few leaves of exactly 64 points:
+  // 76 us one after the other, nothing beside the main kernel).
+  hipStream_t side = st;
+  bool on_side = false;
+#if RS_SIDE_STREAM
+  if (!any_k && H > 256 && octl_ctx_side_stream(ctx) && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
+      hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
+    side = ctx->self_stream;
+    on_side = true;
+  }
+#endif
   // (LO, HI: device words holding the launch's part [lo, hi) of the size-sorted list; LO nullptr = from the front)
-#define OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, LO, HI, PT)                             \
+#define OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, LO, HI, PT, ST)                         \
   do {                                                                                           \
     const unsigned g = (unsigned)std::min<int64_t>(nb, (int64_t)cus * (PER_CU));                 \
     if (H == (THREADS) * (HPL))                                                                  \
-      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, true, PT>), dim3(g), dim3(THREADS), 0, st, \
+      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, true, PT>), dim3(g), dim3(THREADS), 0, ST, \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
                          hyp_dev, H, k, thr, out, (const uint2*)pos_tab);                         \
     else                                                                                         \
-      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, false, PT>), dim3(g), dim3(THREADS), 0, st, \
+      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, false, PT>), dim3(g), dim3(THREADS), 0, ST, \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
                          hyp_dev, H, k, thr, out, (const uint2*)pos_tab);                         \
   } while (0)
 #define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU) \
-  OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED, false)
+  OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED, false, st)
   // H > 256: a block of n points is worked on by one workgroup, and every wave of it pays the per-block work
   // (staging, reduction, barrier, the winner's mask) whatever n is.  Blocks with n < RS_SMALL_THREADS - the bulk:
   // a leaf has at most K points - therefore get workgroups of RS_SMALL_THREADS lanes x 1024 / RS_SMALL_THREADS
@@ -1603,7 +1619,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   do {                                                                                                           \
     HIP_TRY(ctx, hipGetLastError());                                                                             \
     OCTL_RANSAC_RANGE(RS_TINY_THREADS, (1024 / RS_TINY_THREADS), KT, ABL, RS_TINY_PER_CU,                        \
-                      counters + RC_START + RS_TINY_THREADS - 1, counters + RC_SORTED, true);                    \
+                      counters + RC_START + RS_TINY_THREADS - 1, counters + RC_SORTED, true, st);                \
   } while (0)
 #else
 #define RS_SMALL_END (counters + RC_SORTED)
@@ -1613,10 +1629,10 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 #define OCTL_RANSAC_SPLIT(KT, ABL)                                                                               \
   do {                                                                                                           \
     OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                                   \
-                      counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0));                          \
+                      counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                    \
     HIP_TRY(ctx, hipGetLastError());                                                                             \
     OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                     \
-                      counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0));      \
+                      counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0), side);      \
     OCTL_RANSAC_TINY(KT, ABL);                                                                                   \
   } while (0)
 #else
@@ -1647,7 +1663,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   // the (rare) blocks that do not fit the LDS staging; the grid is fixed, the count is on the device
 #define OCTL_RANSAC_BIG(THREADS, HPL, KT)                                                       \
   hipLaunchKernelGGL((k_ransac_big<THREADS, HPL, KT>), dim3((unsigned)std::min<int64_t>(nb, (int64_t)RS_BIG_PER_CU * cus)), \
-                     dim3(THREADS), 0, st, xyz_dev, (const BlockDesc*)desc,                     \
+                     dim3(THREADS), 0, side, xyz_dev, (const BlockDesc*)desc,                   \
                      (const uint32_t*)big_list, (const uint32_t*)(counters + RC_BIG), hyp_dev,  \
                      H, k, thr, out)
   if (any_k) {
@@ -1663,6 +1679,10 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   }
 #undef OCTL_RANSAC_BIG
   HIP_TRY(ctx, hipGetLastError());
+  if (on_side) {
+    HIP_TRY(ctx, hipEventRecord(ctx->self_done, side));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->self_done, 0));
+  }
   return OCTL_OK;
 }
 

@@ -420,16 +420,8 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
       // of it); alone (one rank) the context's stream takes them.
       hipStream_t cs = st;
       if (use_rccl) {
-        if (!ctx->self_stream) {
-          self_rc = hipStreamCreateWithFlags(&ctx->self_stream, hipStreamNonBlocking);
-          if (self_rc == hipSuccess) self_rc = hipEventCreateWithFlags(&ctx->self_gate, hipEventDisableTiming);
-          if (self_rc == hipSuccess) self_rc = hipEventCreateWithFlags(&ctx->self_done, hipEventDisableTiming);
-          if (self_rc != hipSuccess) {
-            // (a stream that could not be created is not fatal: the context's stream does the copies)
-            ctx->self_stream = nullptr;
-            self_rc = hipSuccess;
-          }
-        }
+        // (a side stream that could not be created is not fatal: the context's stream does the copies)
+        (void)octl_ctx_side_stream(ctx);
         if (ctx->self_stream && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
             hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
           cs = ctx->self_stream;
