@@ -60,6 +60,9 @@ constexpr int BB_THREADS = 256;
 constexpr int BB_IPT = 16;
 constexpr int BB_WGS = 3;   // (3 workgroups of 4 waves per CU)
 #endif
+#ifndef BB_SIDE_STREAM
+#define BB_SIDE_STREAM 1
+#endif
 #ifndef BB_LEAF_UNROLL
 #define BB_LEAF_UNROLL 2
 #endif
@@ -2363,20 +2366,37 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   uint2* ck_of_bucket = reinterpret_cast<uint2*>(static_cast<char*>(f->bk_chunks.p) + ck_off_bkt);
   {
     KTimer t(ctx, "bucket_build");
-    hipLaunchKernelGGL(k_bucket_plan, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp, (const GeomDev*)gdev, ck_desc,
+    // The over-full buckets (plan, then one workgroup per chunk) and the normal ones (k_bucket_build) touch disjoint
+    // buckets, rows of bk_tot and output ranges: the first two kernels go to the context's side stream, NEXT TO
+    // k_bucket_build, and the context's stream waits for them before the totals are scanned (an evenly filled scene
+    // hides two empty launches, a skewed one the chunks' latency: each is ONE workgroup's whole bucket build).
+    hipStream_t side = st;
+    bool on_side = false;
+#if BB_SIDE_STREAM
+    if (octl_ctx_side_stream(ctx) && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
+        hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
+      side = ctx->self_stream;
+      on_side = true;
+    }
+#endif
+    hipLaunchKernelGGL(k_bucket_plan, dim3(nb), dim3(BB_THREADS), 0, side, recs, bstart, bp, (const GeomDev*)gdev, ck_desc,
                        ck_of_bucket, bk_tot, small);
+    HIP_TRY(ctx, hipGetLastError());
+    // one workgroup per chunk; the list's length is on the device, the grid strides over it
+    hipLaunchKernelGGL(k_bucket_chunks, dim3((unsigned)std::min<int64_t>(2 * (int64_t)cus, CK_CAP)), dim3(BB_THREADS), 0, side,
+                       recs, bstart, bp, (const GeomDev*)gdev, (const ChunkDesc*)ck_desc, ck_tot,
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
+                       f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(), bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
                        bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
-    // one workgroup per chunk; the list's length is on the device, the grid strides over it
-    hipLaunchKernelGGL(k_bucket_chunks, dim3((unsigned)std::min<int64_t>(2 * (int64_t)cus, CK_CAP)), dim3(BB_THREADS), 0, st,
-                       recs, bstart, bp, (const GeomDev*)gdev, (const ChunkDesc*)ck_desc, ck_tot,
-                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
-                       f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(), bk_tot, small);
-    HIP_TRY(ctx, hipGetLastError());
+    if (on_side) {
+      HIP_TRY(ctx, hipEventRecord(ctx->self_done, side));
+      HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->self_done, 0));
+    }
   }
   {
     KTimer t(ctx, "bucket_scan");
