@@ -66,9 +66,6 @@ constexpr int BB_WGS = 3;   // (3 workgroups of 4 waves per CU)
 #ifndef BB_LEAF_UNROLL
 #define BB_LEAF_UNROLL 2
 #endif
-#ifndef BB_LOAD_BATCH
-#define BB_LOAD_BATCH 0
-#endif
 #ifndef BB_KEEP_ROUNDS
 #define BB_KEEP_ROUNDS 7
 #endif
@@ -880,10 +877,6 @@ __device__ __forceinline__ uint32_t bucket_chunk(
         bad_any = bad_any || bad;
       }
     }
-#if BB_ONE_READ && BB_LOAD_BATCH > 0
-    // whole records in flight are 8 VGPRs per round: the loads go out in batches of BB_LOAD_BATCH rounds
-    if ((r + 1) % BB_LOAD_BATCH == 0 && r + 1 < BB_IPT) __builtin_amdgcn_sched_barrier(0);
-#endif
   }
   BB_STAMP(0);  // records' tails loaded
   // (after the loop: a conditional LDS access between the loads serialises them)
