@@ -1242,6 +1242,54 @@ def test_voxel_local_build_random_voxels_vs_level_synchronous_build(monkeypatch,
     _assert_same_build(a, b)
 
 
+@pytest.mark.parametrize("per_voxel,K", [(490, 64), (470, 16), (498, 300), (250, 64)])
+def test_bucket_build_nearly_full_buckets_vs_level_synchronous_build(monkeypatch, per_voxel, K):
+    """Evenly filled scenes whose buckets of 8 (or 16) voxels hold 3 600 ... 4 200 points: the bucket kernel keeps
+    the coordinates of its first seven rounds of 512 points in registers and reads the last round again at the
+    output (buckets above 3 584 points), buckets just above 4 096 points go through the chunk plan.  Both must give
+    the level-synchronous build bit for bit."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd._engine import Forest
+
+    # (the host sizes buckets for OCTL_BUCKET_POINTS points on average - 2 560 by default, so that an evenly filled
+    #  scene stays well inside the capacity; 4 000 puts the buckets of this scene around it)
+    monkeypatch.setenv("OCTL_BUCKET_POINTS", "4000")
+    rng = np.random.default_rng(per_voxel + K)
+    dims = (8, 8, 8)
+    parts = []
+    for c in np.argwhere(np.ones(dims)):
+        m = int(rng.integers(per_voxel - 25, per_voxel + 26))
+        parts.append(rng.random((m, 3)) + c)
+    cloud = np.unique(np.vstack(parts), axis=0)
+    rng.shuffle(cloud)
+    ctx = nat.get_context()
+
+    def build():
+        f = Forest(0, np.zeros(3), 1.0)
+        f.add_pose(cloud)
+        ctx.set_profiling(True)
+        f.subdivide(K, None)
+        names = set(ctx.timings())
+        ctx.set_profiling(False)
+        out = ({k: v.copy() for k, v in f.nodes.items()}, {k: v.copy() for k, v in f.blocks.items()},
+               f.perm.copy(), f.xyz.copy(), f.order.copy(), int(f.info.n_levels))
+        f.close()
+        return out, names
+
+    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    a, names_a = build()
+    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    b, names_b = build()
+    assert "bucket_build" in names_a and "level_hist" not in names_a
+    assert "bucket_build" not in names_b
+    assert a[5] == b[5]
+    for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
+        assert np.array_equal(a[0][k], b[0][k]), k
+    for k in a[1]:
+        assert np.array_equal(a[1][k], b[1][k]), k
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_bucket_build_mixed_voxel_populations_vs_level_synchronous_build(monkeypatch, seed):
     """Skewed scenes: most voxels hold a few hundred points, some 600 .. 3000 (more than one wavefront's
