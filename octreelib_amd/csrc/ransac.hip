@@ -318,6 +318,9 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
 #ifndef RS_SUB
 #define RS_SUB 0  // hypothesis groups per batch of pass 2 (0: three with 8 or more hypotheses per lane, else all in one)
 #endif
+#ifndef RS_EXIT_EVERY_BATCH
+#define RS_EXIT_EVERY_BATCH 1  // the early exit is tested after every batch of pass 2 as well
+#endif
 #ifndef RS_FIRST_HYPS
 #define RS_FIRST_HYPS 256  // hypotheses evaluated before the early-exit check (whole groups of THREADS)
 #endif
@@ -1063,18 +1066,28 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     take(0, F);
     if (HPL > F) {
       if (!skipped) {
+        bool done = false;  // (RS_EXIT_EVERY_BATCH) a hypothesis of an earlier batch of this wave holds every point
         static_for<0, FULL_BATCHES>([&](auto bt) {
           constexpr int q0 = F + decltype(bt)::value * SUB;
+          if (!done) {
 #pragma unroll
-          for (int q = q0; q < q0 + SUB; ++q) fit(q);
+            for (int q = q0; q < q0 + SUB; ++q) fit(q);
 #pragma unroll
-          for (int q = q0 + SUB; q < q0 + 2 * SUB && q < HPL; ++q) load_pos(q);
-          RS_STAMP(3);
-          score(std::integral_constant<int, SUB>{}, q0);
-          take(q0, SUB);
-          RS_STAMP(4);
+            for (int q = q0 + SUB; q < q0 + 2 * SUB && q < HPL; ++q) load_pos(q);
+            RS_STAMP(3);
+            score(std::integral_constant<int, SUB>{}, q0);
+            take(q0, SUB);
+            RS_STAMP(4);
+            if (RS_EXIT_EVERY_BATCH && q0 + SUB < HPL) {
+              // the same argument as after pass 1: every later hypothesis of this wave has a higher index
+              bool full = false;
+#pragma unroll
+              for (int q = q0; q < q0 + SUB; ++q) full = full || ((FULLH || (int)tx + q * THREADS < H) && cnt[q] == n);
+              done = __any(full);
+            }
+          }
         });
-        if (TAIL > 0) {
+        if (TAIL > 0 && !done) {
           constexpr int q0 = F + FULL_BATCHES * SUB;
 #pragma unroll
           for (int q = q0; q < HPL; ++q) fit(q);
