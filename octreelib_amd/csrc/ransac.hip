@@ -682,11 +682,12 @@ __device__ unsigned long long g_rs_stamps[16];
 
 // Persistent workgroups over the descriptors of all blocks with k <= n <= THREADS-1 points,
 // SORTED BY SIZE (largest first): workgroup w handles a contiguous chunk of the list
-//   * the grid is oversubscribed (64 workgroups per CU, 4 resident): the chunks with the largest
+//   * the grid is oversubscribed (64 ... 256 workgroups per CU, 4 ... 16 resident): the chunks with the largest
 //     blocks are dispatched first and the dispatcher evens out the rest (no tail);
 //   * consecutive blocks of a workgroup have the same size, so the positions of the sampled
 //     points - a function of (hypothesis, n) only, see sample_index_cached - are computed once
-//     per size and kept packed in registers, together with the hypothesis-table reads;
+//     per size and kept packed in registers (PT = false), or come out of the launch's position table a batch of
+//     hypothesis groups ahead of their plane fits (PT = true: the instances with more than 256 hypotheses);
 //   * while entry e is computed out of one LDS buffer the points of entry e+1 are already in
 //     flight into registers and the descriptor of entry e+2 is being fetched, so the per-block
 //     latency chain (descriptor -> points) is off the critical path;
@@ -1622,10 +1623,12 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 #define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU) \
   OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED, false, st)
   // H > 256: a block of n points is worked on by one workgroup, and every wave of it pays the per-block work
-  // (staging, reduction, barrier, the winner's mask) whatever n is.  Blocks with n < RS_SMALL_THREADS - the bulk:
-  // a leaf has at most K points - therefore get workgroups of RS_SMALL_THREADS lanes x 1024 / RS_SMALL_THREADS
-  // hypotheses per lane (two waves per block instead of four: -5 % on the benchmark scene), the others the
-  // RS_BIG_THREADS-lane instance; the size-sorted list is split at the start of size class RS_SMALL_THREADS - 1.
+  // (staging, reduction, barrier, the winner's mask) whatever n is.  Three instances therefore share the size-sorted
+  // list, split at the device-side starts of size classes RS_SMALL_THREADS - 1 and RS_TINY_THREADS - 1:
+  //   n < RS_TINY_THREADS (64)     ONE wave x 16 hypotheses per lane - the bulk: a leaf has at most K points
+  //   n < RS_SMALL_THREADS (128)   two waves x 8
+  //   n < RS_BIG_THREADS (256)     four waves x 4
+  // (four -> two waves per block: -8 % on the benchmark scene; one wave, which needs the position table: -3 % more).
 #if RS_POS_TABLE && RS_TINY_THREADS > 0 && RS_TINY_THREADS < RS_SMALL_THREADS
 #define RS_SMALL_END (counters + RC_START + RS_TINY_THREADS - 1)
 #define OCTL_RANSAC_TINY(KT, ABL)                                                                                \
