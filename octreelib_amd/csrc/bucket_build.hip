@@ -44,10 +44,12 @@ constexpr int PT_THREADS = 256;
 constexpr int PT_BITS = 12;
 constexpr int PT_BINS = 1 << PT_BITS;            // buckets
 
-// BB_ONE_READ (experiments, -D): the bucket kernel reads every record ONCE - the coordinates stay in registers
-// from the first pass to the output, which goes through an LDS window - instead of the tail first and the whole
-// record again for the output.  It needs 8 instead of 16 items per thread (48 VGPRs of coordinates) and so 512
-// threads per bucket, two workgroups per CU instead of three.
+// BB_ONE_READ (the shipped form; -DBB_ONE_READ=0 builds the round-3 kernel for comparison): the bucket kernel reads
+// every record ONCE - the coordinates stay in registers from the first pass to the output, which goes through an
+// LDS window - instead of the tail first and the whole record again for the output.  It needs 8 instead of 16
+// items per thread (42 VGPRs of coordinates for BB_KEEP_ROUNDS = 7 of the 8 rounds; a bucket fuller than that reads
+// its last round again) and so 512 threads per bucket, two workgroups per CU instead of three.  (The second argument
+// of __launch_bounds__ is WAVES PER SIMD with this compiler, not workgroups per CU: 4 = 2 workgroups of 8 waves.)
 #ifndef BB_ONE_READ
 #define BB_ONE_READ 1
 #endif
