@@ -697,7 +697,7 @@ __device__ unsigned long long g_rs_stamps[16];
 //   * ONE barrier per block (three rotating point buffers, reduction slots by parity).
 // FULLH: the table has exactly THREADS x HPL hypotheses (the default 1024): every lane owns HPL of them and the
 // `index < H` guards (a compare, an EXEC save / restore and six zero-initialisations per plane fit) fold away.
-// PT: the sample positions come from the launch's position table (k_pos_table: a function of (block size,
+// PT: the sample positions come from the launch's position table (pos_table_part, written by k_block_scatter's extra workgroups: a function of (block size,
 // hypothesis) alone) instead of being cached in registers while the block size stays the same.
 template <int THREADS, int HPL, int KT, int ABL, bool FULLH, bool PT>
 __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
@@ -1450,25 +1450,14 @@ __global__ __launch_bounds__(256) void k_block_desc(const int32_t* __restrict__ 
   if (bins[threadIdx.x]) atomicAdd(&counters[RC_BINS + threadIdx.x], bins[threadIdx.x]);
 }
 
-// start of every size class in the sorted list, largest size first
-__global__ __launch_bounds__(256) void k_bin_starts(uint32_t* __restrict__ counters) {
-  __shared__ uint32_t c[256];
-  c[threadIdx.x] = counters[RC_BINS + threadIdx.x];
-  __syncthreads();
-  uint32_t s = 0;
-  for (int m = 255; m > (int)threadIdx.x; --m) s += c[m];
-  counters[RC_START + threadIdx.x] = s;
-  counters[RC_FILL + threadIdx.x] = 0;
-  if (threadIdx.x == 0) counters[RC_SORTED] = s + c[0];
-}
-
 // Sample positions of every hypothesis for every block size that occurs in the launch (k <= 6, sizes up to 255):
 // one 8-byte entry per (size, hypothesis) - positions in bytes 0..5, the risky-draw bits (sample_index_cached) in
 // bits 16..21 of the second word.  k_ransac<..., PT = true> reads its entries a batch ahead of the plane fits.
-__global__ __launch_bounds__(256) void k_pos_table(const double* __restrict__ hyp, int H, int k,
-                                                   const uint32_t* __restrict__ counters, uint2* __restrict__ tab) {
-  const int n = (int)blockIdx.y;
-  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+// (Run by the extra workgroups of k_block_scatter: part `part` of the hypotheses, block size n.)
+__device__ __forceinline__ void pos_table_part(const double* __restrict__ hyp, int H, int k,
+                                               const uint32_t* __restrict__ counters, uint2* __restrict__ tab,
+                                               int n, int part) {
+  const int t = part * 256 + (int)threadIdx.x;
   if (t >= H || n < k || counters[RC_BINS + n] == 0u) return;
   const double* __restrict__ row = hyp + (int64_t)t * k;
   uint32_t x = 0, y = 0;
@@ -1484,14 +1473,34 @@ __global__ __launch_bounds__(256) void k_pos_table(const double* __restrict__ hy
 // descriptors -> size-sorted list.  Position inside a size class: rank inside the workgroup (LDS
 // atomics) + ONE global atomic per (workgroup, size) - same-address global atomics serialise.
 // The order inside a size class is arbitrary; blocks are independent, results do not depend on it.
+// The start of every size class in the list (largest size first) is formed by every workgroup for itself out of
+// the per-size counts - 256 numbers - and published by workgroup 0 for the k_ransac instances (RC_START, RC_SORTED;
+// RC_FILL was zeroed with the other counters by k_block_sizes_in_order): no kernel of its own.  Workgroups
+// [n_scatter, gridDim.x) write the position table (tab != nullptr): no kernel of its own either.
 __global__ __launch_bounds__(256) void k_block_scatter(const BlockDesc* __restrict__ desc, int64_t nb,
                                                        int cap, int k,
                                                        uint32_t* __restrict__ counters,
-                                                       BlockDesc* __restrict__ sdesc) {
+                                                       BlockDesc* __restrict__ sdesc, unsigned n_scatter,
+                                                       const double* __restrict__ hyp, int H,
+                                                       uint2* __restrict__ tab) {
+  if (blockIdx.x >= n_scatter) {
+    const unsigned parts = (unsigned)(H + 255) / 256u;
+    const unsigned id = blockIdx.x - n_scatter;
+    pos_table_part(hyp, H, k, counters, tab, (int)(id / parts), (int)(id % parts));
+    return;
+  }
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t base[256];
+  __shared__ uint32_t c[256];
   cnt[threadIdx.x] = 0;
+  c[threadIdx.x] = counters[RC_BINS + threadIdx.x];
   __syncthreads();
+  uint32_t first = 0;  // start of size class threadIdx.x
+  for (int m = 255; m > (int)threadIdx.x; --m) first += c[m];
+  if (blockIdx.x == 0) {
+    counters[RC_START + threadIdx.x] = first;
+    if (threadIdx.x == 0) counters[RC_SORTED] = first + c[0];
+  }
   constexpr int PER_THREAD = BS_PER_THREAD;
   const int64_t b0 = (int64_t)blockIdx.x * (256 * PER_THREAD);
   int nn[PER_THREAD];
@@ -1510,9 +1519,7 @@ __global__ __launch_bounds__(256) void k_block_scatter(const BlockDesc* __restri
     }
   }
   __syncthreads();
-  if (cnt[threadIdx.x])
-    base[threadIdx.x] = counters[RC_START + threadIdx.x] +
-                        atomicAdd(&counters[RC_FILL + threadIdx.x], cnt[threadIdx.x]);
+  if (cnt[threadIdx.x]) base[threadIdx.x] = first + atomicAdd(&counters[RC_FILL + threadIdx.x], cnt[threadIdx.x]);
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < PER_THREAD; ++r) {
@@ -1581,15 +1588,12 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                        (const uint32_t*)tmp, nb, n_points, any_k ? 0 : threads - 1, (int)k, desc, big_list,
                        counters, out);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(256), 0, st, counters);
-    HIP_TRY(ctx, hipGetLastError());
-    if (use_tab) {
-      hipLaunchKernelGGL(k_pos_table, dim3((unsigned)ceil_div(H, 256), 256), dim3(256), 0, st, hyp_dev, (int)H, (int)k,
-                         (const uint32_t*)counters, pos_tab);
-      HIP_TRY(ctx, hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_block_scatter, dim3((unsigned)ceil_div(nb, 256 * BS_PER_THREAD)), dim3(256), 0, st,
-                       (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc);
+    // (size-class starts and the position table are made by k_block_scatter's own workgroups)
+    const unsigned n_scatter = (unsigned)ceil_div(nb, 256 * BS_PER_THREAD);
+    const unsigned n_table = use_tab ? 256u * (unsigned)ceil_div(H, 256) : 0u;
+    hipLaunchKernelGGL(k_block_scatter, dim3(n_scatter + n_table), dim3(256), 0, st,
+                       (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc, n_scatter, hyp_dev,
+                       (int)H, pos_tab);
     HIP_TRY(ctx, hipGetLastError());
   }
   const int cus = octl_ctx_cus(ctx);
