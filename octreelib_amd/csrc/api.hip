@@ -134,10 +134,10 @@ __global__ __launch_bounds__(256) void k_fill_u8(uint8_t* p, int64_t n, uint8_t 
 
 // ---- apply_mask: stream compaction of the leaf-ordered arrays and of the block table ----------------------
 // kept points per 2048-point tile (the compaction's tile offsets) ...
-__global__ __launch_bounds__(256) void k_mask_tiles(const uint8_t* __restrict__ mask, int64_t n,
-                                                    uint32_t* __restrict__ tilecnt) {
+__device__ __forceinline__ void mask_tile_count(const uint8_t* __restrict__ mask, int64_t n,
+                                                uint32_t* __restrict__ tilecnt, uint32_t tile) {
   __shared__ uint32_t s_w[4];
-  const int64_t i0 = (int64_t)blockIdx.x * 2048 + (int64_t)threadIdx.x * 8;
+  const int64_t i0 = (int64_t)tile * 2048 + (int64_t)threadIdx.x * 8;
   uint32_t c = 0;
   if (i0 + 8 <= n) {
     const uint64_t w = *reinterpret_cast<const uint64_t*>(mask + i0);  // (the mask buffer is 16-byte aligned)
@@ -151,15 +151,21 @@ __global__ __launch_bounds__(256) void k_mask_tiles(const uint8_t* __restrict__ 
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
   __syncthreads();
-  if (threadIdx.x == 0) tilecnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  if (threadIdx.x == 0) tilecnt[tile] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// ... and per (leaf, pose) block: the block table is compacted block-wise, not re-derived from the points
-__global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ mask,
+// ... and per (leaf, pose) block: the block table is compacted block-wise, not re-derived from the points.
+// ONE launch for both counts: workgroups [0, nt) take a tile of 2048 points each, the rest 256 blocks each.
+__global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ mask, int64_t n, uint32_t nt,
+                                                  uint32_t* __restrict__ tilecnt,
                                                   const uint32_t* __restrict__ blk_start,
                                                   const int32_t* __restrict__ blk_size, int64_t nb,
                                                   uint32_t* __restrict__ kept, uint32_t* __restrict__ nonempty) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x < nt) {
+    mask_tile_count(mask, n, tilecnt, blockIdx.x);
+    return;
+  }
+  const int64_t b = (int64_t)(blockIdx.x - nt) * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const uint32_t st = b < nb ? blk_start[b] : 0u;
   const int sz = b < nb ? blk_size[b] : 0;
@@ -453,9 +459,7 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     uint32_t* raw = f->flags.as<uint32_t>();
     uint32_t* scanned = reinterpret_cast<uint32_t*>(static_cast<char*>(f->flags.p) + o_out);
     const uint8_t* mask = f->mask.as<uint8_t>();
-    hipLaunchKernelGGL(k_mask_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, n, raw);
-    HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_blk_kept, dim3(grid_for(nb)), dim3(256), 0, st, mask,
+    hipLaunchKernelGGL(k_blk_kept, dim3((unsigned)nt + grid_for(nb)), dim3(256), 0, st, mask, n, (uint32_t)nt, raw,
                        (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
                        raw + nt, raw + nt + nb);
     HIP_TRY(ctx, hipGetLastError());
@@ -475,9 +479,9 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
                        (const uint32_t*)scanned, (const uint32_t*)(small + 22), nt, nb,
                        (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
                        f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
-                       f->blk_size2.as<int32_t>(), small + 20);
+                       f->blk_size2.as<int32_t>(), static_cast<uint32_t*>(ctx->small_host));
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small + 20, 8, hipMemcpyDeviceToHost, st));
+    // (the two totals are written into the pinned mirror by the kernel itself: no copy in front of the wait)
     HIP_TRY(ctx, hipStreamSynchronize(st));
     uint32_t res[2];
     std::memcpy(res, ctx->small_host, 8);

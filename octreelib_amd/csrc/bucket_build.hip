@@ -1631,8 +1631,11 @@ __global__ __launch_bounds__(BB_THREADS, BB_ONE_READ ? 1 : 2) void k_bucket_chun
 // so the prefix minus the value at the head of row BK_NINT is the first internal node of level l of a
 // bucket in the LEVEL-MAJOR order of the level-synchronous path (all internal nodes of level 0 in voxel
 // order, then level 1, ...); row BK_NBLK minus its head is the first block.  The row heads are the totals.
+// (mirror: the context's pinned host block - the scalars the host waits for are stored there by this kernel, `words`
+//  32-bit words of `small` from its start, so that no copy stands between the kernel and the host's wait)
 __global__ void k_bucket_totals(const uint32_t* __restrict__ scanned, uint32_t nb,
-                                const uint32_t* __restrict__ grand_total, uint32_t* __restrict__ small) {
+                                const uint32_t* __restrict__ grand_total, uint32_t* __restrict__ small,
+                                uint32_t* __restrict__ mirror, int words) {
   const int t = threadIdx.x;
   if (t == 0) small[SM_NVOX] = scanned[(size_t)BK_NINT * nb];
   if (t < BB_LEVELS) {
@@ -1640,6 +1643,9 @@ __global__ void k_bucket_totals(const uint32_t* __restrict__ scanned, uint32_t n
     small[SM_BK_LEVEL + t] = bq - a;
   }
   if (t == 8) small[SM_NBLOCKS] = *grand_total - scanned[(size_t)BK_NBLK * nb];
+  __threadfence();
+  __syncthreads();
+  for (int w = t; w < words; w += (int)blockDim.x) mirror[w] = small[w];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2396,14 +2402,13 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   {
     KTimer t(ctx, "bucket_scan");
     OCTL_TRY(octl_exclusive_scan_u32(ctx, bk_tot, bk_tot, (int64_t)BK_ROWS * nb, small + SM_BK_TOTAL));
+    static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
     hipLaunchKernelGGL(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_tot, nb,
-                       (const uint32_t*)(small + SM_BK_TOTAL), small);
+                       (const uint32_t*)(small + SM_BK_TOTAL), small, static_cast<uint32_t*>(ctx->small_host),
+                       (int)(64 + (gdev ? sizeof(GeomDev) / 4 : 0)));
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t sm[64];
-  static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, small, sizeof(sm) + (gdev ? sizeof(GeomDev) : 0),
-                              hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   std::memcpy(sm, ctx->small_host, sizeof(sm));
   if (hinted2) {
