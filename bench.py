@@ -147,6 +147,10 @@ def parse_args():
     ap.add_argument("--points-per-rank", "--points", dest="points", type=int, default=None,
                     help="default: 125 M at --gpus 8 (BASELINE config 5), else 10 M")
     ap.add_argument("--cloud", choices=["planar", "uniform"], default="planar")
+    ap.add_argument("--clouds", type=int, default=None,
+                    help="distinct clouds resident in HBM that the timed loop rotates over (default: 3 up to 20 M points "
+                         "per GPU - two draws of the scene and one moved by a voxel, which the geometry hint of the "
+                         "previous step does not fit - else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-overlap", action="store_true",
@@ -176,28 +180,60 @@ def parse_args():
 class Workload:
     """One rank's cloud in HBM + the forest it is built into + the step functions."""
 
-    def __init__(self, ctx, rctx, rank, world, n_local, dims, cloud, k_split, route, overlap, shard_of=0):
+    def __init__(self, ctx, rctx, rank, world, n_local, dims, cloud, k_split, route, overlap, shard_of=0,
+                 n_clouds=1):
         self.ctx, self.rctx, self.lib = ctx, rctx, ctx.lib
         self.rank, self.world, self.n_local, self.dims = rank, world, n_local, dims
         self.k_split, self.route, self.overlap = k_split, route, overlap
-        lib = self.lib
-        self.d_xyz = C.c_void_p()
-        ctx.check(lib.octl_dev_alloc(ctx.handle, n_local * 24, C.byref(self.d_xyz)))
+        self.cloud_kind, self.shard_of = cloud, shard_of
         self.host_pts = None
+        # The timed loop ROTATES over `n_clouds` distinct clouds that are all resident in HBM (a SLAM loop never sees
+        # the same scan twice): variant 0 and 1 are different draws of the same scene (same voxel box), variant 2 is
+        # a third draw moved by one voxel along x - its voxel box is not the previous build's, so the geometry hint
+        # the context carries from step to step is REJECTED going into it and again coming out of it.
+        self.d_clouds = [self.make_cloud(v) for v in range(max(1, n_clouds))]
+        self.d_xyz = self.d_clouds[0]
+        self.tick = 0
+        self.rotate = True
+        lib = self.lib
+        self.corner = np.zeros(3)
+        self.fh = C.c_void_p()
+        ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(self.corner), 1.0, C.byref(self.fh)))
+        self.info = nat.BuildInfo()
+        self.e0 = np.zeros(1, dtype=np.int32)
+        self.n_alive = C.c_int64(0)
+        self.n_recv = C.c_int64(n_local)
+        self.send_counts = np.zeros(max(world, 1), dtype=np.int64)   # points this rank sends to every rank, last routing
+        self.slot = C.c_int32(0)
+        np.random.seed(0)
+        self.table = np.ascontiguousarray(np.random.random((H, KPTS)))
+
+    CLOUD_VARIANTS = ["draw 0 of the scene", "draw 1 of the same scene (same voxel box)",
+                      "draw 2 moved by one voxel along x (the voxel box changes: the geometry hint is rejected)"]
+
+    def make_cloud(self, variant):
+        """One cloud of this rank in HBM (generated chunk by chunk on the host, uploaded in order)."""
+        ctx, lib = self.ctx, self.lib
+        rank, n_local, dims, cloud, shard_of = self.rank, self.n_local, self.dims, self.cloud_kind, self.shard_of
+        d_xyz = C.c_void_p()
+        ctx.check(lib.octl_dev_alloc(ctx.handle, n_local * 24, C.byref(d_xyz)))
 
         def gen(job):
             chunk_id, m = job
             stream = rank if n_local <= GEN_CHUNK else rank * 4096 + chunk_id
+            stream += 1_000_000 * variant
             if shard_of > 1:
                 pts = shard_cloud(m, dims, cloud, stream, shard_of)
             elif cloud == "planar":
                 pts = synthetic.planar_cloud(m, dims, seed=1, stream=stream)
             elif cloud == "uniform32":   # BASELINE C2-U / C3-U: default_rng(0).random((n,3)) * 32
-                pts = np.random.default_rng(0).random((m, 3)) * 32.0
+                pts = np.random.default_rng(variant).random((m, 3)) * 32.0
             elif cloud == "sparse":      # a terrain sheet through a 256 x 256 x 32 box + one over-dense blob
                 pts = synthetic.sparse_scene(m, (256, 256, 32), seed=7 + stream)
             else:
                 pts = synthetic.uniform_cloud(m, dims, seed=1000 + stream)
+            if variant == 2:
+                pts[:, 0] += 1.0
             return np.ascontiguousarray(pts)
 
         jobs = [(c, min(GEN_CHUNK, n_local - c * GEN_CHUNK)) for c in range((n_local + GEN_CHUNK - 1) // GEN_CHUNK)]
@@ -211,26 +247,26 @@ class Workload:
 
             with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
                 for pts in pool.map(gen, jobs):
-                    ctx.check(lib.octl_dev_upload(ctx.handle, C.c_void_p(self.d_xyz.value + done * 24), nat.ptr(pts),
+                    ctx.check(lib.octl_dev_upload(ctx.handle, C.c_void_p(d_xyz.value + done * 24), nat.ptr(pts),
                                                   pts.nbytes))
                     done += len(pts)
         else:
             pts = gen(jobs[0])
-            ctx.check(lib.octl_dev_upload(ctx.handle, self.d_xyz, nat.ptr(pts), pts.nbytes))
-            self.host_pts = pts
-        self.corner = np.zeros(3)
-        self.fh = C.c_void_p()
-        ctx.check(lib.octl_forest_create(ctx.handle, 0, nat.ptr(self.corner), 1.0, C.byref(self.fh)))
-        self.info = nat.BuildInfo()
-        self.e0 = np.zeros(1, dtype=np.int32)
-        self.n_alive = C.c_int64(0)
-        self.n_recv = C.c_int64(n_local)
-        self.send_counts = np.zeros(max(world, 1), dtype=np.int64)   # points this rank sends to every rank, last routing
-        self.slot = C.c_int32(0)
-        np.random.seed(0)
-        self.table = np.ascontiguousarray(np.random.random((H, KPTS)))
+            ctx.check(lib.octl_dev_upload(ctx.handle, d_xyz, nat.ptr(pts), pts.nbytes))
+            if variant == 0:
+                self.host_pts = pts
+        return d_xyz
+
+    def next_cloud(self):
+        """The cloud of the next step: the resident clouds in turn."""
+        if self.rotate and len(self.d_clouds) > 1:
+            self.d_xyz = self.d_clouds[self.tick % len(self.d_clouds)]
+        else:
+            self.d_xyz = self.d_clouds[0]
+        self.tick += 1
 
     def route_once(self):
+        self.next_cloud()
         self.rctx.check(self.lib.octl_route_points(self.rctx.handle, self.d_xyz, None, self.n_local,
                                                    self.rank * self.n_local, nat.ptr(self.corner), 1.0,
                                                    C.byref(self.n_recv), nat.ptr(self.send_counts)))
@@ -256,6 +292,7 @@ class Workload:
                 ctx.check(lib.octl_forest_add_pose_routed(self.fh, C.byref(self.slot)))
         else:
             # (read in place: the cloud is resident in HBM, as the contract of the timed region says)
+            self.next_cloud()
             ctx.check(lib.octl_forest_add_pose_adopt(self.fh, self.d_xyz, self.n_local, C.byref(self.slot)))
 
     def step(self):
@@ -358,7 +395,8 @@ class Workload:
 
     def close(self):
         self.lib.octl_forest_destroy(self.fh)
-        self.ctx.check(self.lib.octl_dev_free(self.ctx.handle, self.d_xyz))
+        for d in self.d_clouds:
+            self.ctx.check(self.lib.octl_dev_free(self.ctx.handle, d))
         for d in getattr(self, "dbuf", []):
             self.ctx.check(self.lib.octl_dev_free(self.ctx.handle, d))
         for h in getattr(self, "pin", []):
@@ -454,20 +492,129 @@ def run_c4(ctx, reps=3):
 
 
 def run_no_hint(ctx, wl, timed):
-    """The cross-step state the headline leans on, as a number: the same step with the geometry hint of the
-    context's previous build switched off (OCTL_NO_GEOM_HINT: the voxel box of the adopted cloud then comes from
-    a box pass of its own, 24 B/point more) - what the first scan of a scene, or a scene that moved, pays."""
-    os.environ["OCTL_NO_GEOM_HINT"] = "1"
-    try:
+    """The cross-step state the headline leans on, as a number: the same step on the SAME cloud with and without the
+    geometry hint of the context's previous build (option NO_GEOM_HINT: the voxel box of the adopted cloud then comes
+    from a box pass of its own, 24 B/point more) - what the first scan of a scene pays.  Measured A/B/A/B in one go,
+    each leg with its own per-kernel table and host-synchronisation count, so that the difference can be read off
+    kernel by kernel."""
+    lib = ctx.lib
+
+    def leg(no_hint):
+        ctx.set_option("NO_GEOM_HINT", 1 if no_hint else 0)
         wl.step()
-        ms_full = timed(wl.step) * 1e3
-        ms_build = timed(wl.step_build_only) * 1e3
+        ms_full = timed(wl.step, reps=6) * 1e3
+        ms_build = timed(wl.step_build_only, reps=6) * 1e3
+        c0, c1 = C.c_uint64(0), C.c_uint64(0)
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
+        for _ in range(4):
+            wl.step()
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
+        ctx.sync()
+        ctx.set_profiling(True)
+        for _ in range(3):
+            wl.step()
+        ctx.sync()
+        tm = ctx.timings()
+        ctx.set_profiling(False)
+        return {"ms": ms_full, "insert_subdivide_only_ms": ms_build, "host_syncs_per_step": (c1.value - c0.value) / 4.0,
+                "kernels_ms_per_step": {k: round(v[0] / 3.0, 4) for k, v in sorted(tm.items())}}
+
+    was = wl.rotate
+    wl.rotate = False
+    try:
+        legs = [leg(False), leg(True), leg(False), leg(True)]
     finally:
-        del os.environ["OCTL_NO_GEOM_HINT"]
+        ctx.set_option("NO_GEOM_HINT", 0)
+        wl.rotate = was
     wl.step()
-    return {"ms": ms_full, "Mpoints_per_s": wl.n_local / ms_full / 1e3, "insert_subdivide_only_ms": ms_build,
-            "note": "same step, OCTL_NO_GEOM_HINT=1: no geometry carried over from the previous build of the "
-                    "context (first scan of a scene / a scene whose voxel box changed)"}
+    hint = {k: min(legs[0][k], legs[2][k]) for k in ("ms", "insert_subdivide_only_ms")}
+    nohint = {k: min(legs[1][k], legs[3][k]) for k in ("ms", "insert_subdivide_only_ms")}
+    names = sorted(set(legs[2]["kernels_ms_per_step"]) | set(legs[3]["kernels_ms_per_step"]))
+    delta = {k: round(legs[3]["kernels_ms_per_step"].get(k, 0.0) - legs[2]["kernels_ms_per_step"].get(k, 0.0), 4)
+             for k in names}
+    return {"ms": nohint["ms"], "Mpoints_per_s": wl.n_local / nohint["ms"] / 1e3,
+            "insert_subdivide_only_ms": nohint["insert_subdivide_only_ms"],
+            "with_hint_ms": hint["ms"], "with_hint_insert_subdivide_only_ms": hint["insert_subdivide_only_ms"],
+            "delta_ms": nohint["ms"] - hint["ms"],
+            "delta_insert_subdivide_only_ms": nohint["insert_subdivide_only_ms"] - hint["insert_subdivide_only_ms"],
+            "kernel_delta_ms_per_step": {k: v for k, v in delta.items() if abs(v) >= 0.002},
+            "legs": legs,
+            "note": "same step on ONE cloud, A/B/A/B (hint, no hint, hint, no hint; 6 timed steps per figure, minimum of "
+                    "the two legs): option NO_GEOM_HINT = no geometry carried over from the previous build of the "
+                    "context, the cloud's voxel box comes from a box pass of its own (timer `ingest`) and the "
+                    "geometry from k_bucket_geom; kernel tables from fully instrumented steps"}
+
+
+def run_c1(ctx, reps=5):
+    """BASELINE config 1: a bare Octree over [0,1)^3, 100 k uniform points (default_rng(1234)), insert +
+    subdivide(len > 32); the reference's own answer for exactly this input is 6601 nodes / 5748 leaves.
+    CPU: the NumPy port of the reference's recursion (oracle/octree_np.py), one core.  GPU: the same through the C ABI
+    (octl_forest_create(mode 1) / add_pose / build), cloud handed over from host memory as the reference's caller does."""
+    from oracle import octree_np as onp
+
+    lib = ctx.lib
+    pts = np.ascontiguousarray(np.random.default_rng(1234).random((100_000, 3)))
+    t0 = time.perf_counter()
+    tree = onp.OTree(np.zeros(3), 1.0)
+    tree.insert_points(pts)
+    tree.subdivide(32)
+    cpu_s = time.perf_counter() - t0
+    cpu_nodes, cpu_leaves = int(tree.n_nodes), int(tree.n_leaves)
+    fh = C.c_void_p()
+    ctx.check(lib.octl_forest_create(ctx.handle, 1, nat.ptr(np.zeros(3)), 1.0, C.byref(fh)))
+    info = nat.BuildInfo()
+    d = C.c_void_p()
+    ctx.check(lib.octl_dev_alloc(ctx.handle, pts.nbytes, C.byref(d)))
+    ctx.check(lib.octl_dev_upload(ctx.handle, d, nat.ptr(pts), pts.nbytes))
+    host_ms, dev_ms = [], []
+    for rep in range(reps + 1):
+        ctx.check(lib.octl_forest_clear(fh))
+        ctx.sync()
+        t1 = time.perf_counter()
+        ctx.check(lib.octl_forest_add_pose(fh, nat.ptr(pts), len(pts), None))
+        ctx.check(lib.octl_forest_build(fh, 32, None, 0, 0, 0, C.byref(info)))
+        ctx.sync()
+        host_ms.append((time.perf_counter() - t1) * 1e3)
+    c0, c1 = C.c_uint64(0), C.c_uint64(0)
+    for rep in range(reps + 1):
+        ctx.check(lib.octl_forest_clear(fh))
+        ctx.sync()
+        if rep == reps:
+            ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
+        t1 = time.perf_counter()
+        ctx.check(lib.octl_forest_add_pose_adopt(fh, d, len(pts), None))
+        ctx.check(lib.octl_forest_build(fh, 32, None, 0, 0, 0, C.byref(info)))
+        ctx.sync()
+        dev_ms.append((time.perf_counter() - t1) * 1e3)
+        if rep == reps:
+            ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
+    ctx.set_profiling(True)
+    ctx.check(lib.octl_forest_clear(fh))
+    ctx.check(lib.octl_forest_add_pose_adopt(fh, d, len(pts), None))
+    ctx.check(lib.octl_forest_build(fh, 32, None, 0, 0, 0, C.byref(info)))
+    ctx.sync()
+    tm = ctx.timings()
+    ctx.set_profiling(False)
+    nb = C.c_int64(0)
+    ctx.check(lib.octl_forest_get_blocks(fh, 0, None, None, None, None, C.byref(nb)))
+    out = {
+        "cpu_port_s": cpu_s, "cpu_port_Mpoints_per_s": len(pts) / cpu_s / 1e6, "cpu_cores": 1,
+        "cpu_port_nodes": cpu_nodes, "cpu_port_leaves": cpu_leaves,
+        "gpu_ms_from_host": min(host_ms[1:]), "gpu_ms_device_resident": min(dev_ms[1:]),
+        "gpu_Mpoints_per_s_device_resident": len(pts) / min(dev_ms[1:]) / 1e3,
+        "gpu_nodes": int(info.n_nodes), "gpu_leaves": int(nb.value), "gpu_levels": int(info.n_levels),
+        "reference_known_answer": {"nodes": 6601, "leaves": 5748},
+        "answers_agree": bool(cpu_nodes == 6601 and cpu_leaves == 5748 and int(info.n_nodes) == 6601 and
+                              int(nb.value) == 5748),
+        "host_syncs_last_build": int(c1.value - c0.value) - 1,   # (minus the ctx.sync() of the clock)
+        "path": build_path(set(tm)), "kernels_ms": {k: round(v[0], 4) for k, v in sorted(tm.items())},
+        "note": "BASELINE config 1 (plumbing): Octree(OctreeConfig(), [0,0,0], 1.0).insert_points(default_rng(1234)"
+                ".random((100000,3))) + subdivide([len > 32]) - the reference measured in the build container: 2.08 s "
+                "(SURVEY 6); cpu_port = oracle/octree_np.py on this host, one core; gpu = C ABI, best of 5",
+    }
+    lib.octl_forest_destroy(fh)
+    ctx.check(lib.octl_dev_free(ctx.handle, d))
+    return out
 
 
 def run_c5_shard(ctx, k_split, timed, n_shard=C5_POINTS_PER_RANK, ranks=8, steps=3):
@@ -549,7 +696,7 @@ def main():
     overlap = route and not args.no_overlap
     rctx = nat.Context(local_rank) if overlap else ctx
     if args.route and world == 1:
-        os.environ["OCTL_ROUTE_SELF_SENDRECV"] = "1"
+        rctx.set_option("ROUTE_SELF_SENDRECV", 1)
         buf = (C.c_uint8 * nat.UNIQUE_ID_BYTES)()
         with stdout_to_stderr():
             rctx.check(lib.octl_comm_unique_id(C.cast(buf, C.c_void_p)))
@@ -602,8 +749,10 @@ def main():
         ctx.close()
         return
 
+    n_clouds = args.clouds if args.clouds else (3 if n_local <= 20_000_000 else 1)
+    n_clouds = max(1, min(n_clouds, len(Workload.CLOUD_VARIANTS)))
     wl = Workload(ctx, rctx, rank, world, n_local, dims, args.cloud, args.k_split, route, overlap,
-                  shard_of=args.shard_of if world == 1 else 0)
+                  shard_of=args.shard_of if world == 1 else 0, n_clouds=n_clouds)
 
     # ---- the timed region: W warm-up steps, then exactly K steps between barriers ----------------
     # Inside the timed region only the DOMINANT kernel (RANSAC scoring) is timed with hipEvents on its own
@@ -612,6 +761,7 @@ def main():
     wl.run(args.warmup)
     ctx.set_profiling(2)
     barrier()
+    wl.tick = 0   # (the timed region starts with cloud 0: which cloud got how many steps is known)
     t0 = time.perf_counter()
     wl.run(args.steps)
     barrier()
@@ -643,39 +793,61 @@ def main():
     if world == 1 and not route:
         c0, c1 = C.c_uint64(0), C.c_uint64(0)
         ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
-        wl.run(4)
+        wl.run(2 * n_clouds)
         ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
-        host_syncs = (c1.value - c0.value) / 4.0
+        host_syncs = (c1.value - c0.value) / (2.0 * n_clouds)
 
     # algorithmic flops of the RANSAC launch from the REAL leaf sizes of this rank's build (every line: N = 1,
     # one rank's shard, N > 1 - the fall-back 6 H n ignores the plane fits and made the lines incomparable)
-    wl.insert()
-    wl.build()
-    sizes = wl.leaf_sizes()
-    fit = sizes[sizes >= KPTS].astype(np.int64)
-    leaves_evaluated = int(len(fit))
-    flops = float(H * (20.0 * KPTS * len(fit) + 6.0 * fit.sum()) + 6.0 * fit.sum())
-    del sizes, fit
+    # With rotating clouds: the average over the clouds, weighted by the steps each one got in the timed region.
+    flops, leaves_evaluated, blocks_early_possible = 0.0, 0.0, None
+    per_cloud = []
+    for c in range(n_clouds):
+        share = len(range(c, args.steps, n_clouds)) / float(args.steps)
+        wl.tick = c
+        wl.insert()
+        wl.build()
+        sizes = wl.leaf_sizes()
+        fit = sizes[sizes >= KPTS].astype(np.int64)
+        fl = float(H * (20.0 * KPTS * len(fit) + 6.0 * fit.sum()) + 6.0 * fit.sum())
+        flops += share * fl
+        leaves_evaluated += share * len(fit)
+        per_cloud.append({"cloud": Workload.CLOUD_VARIANTS[c], "steps_in_timed_region": len(range(c, args.steps, n_clouds)),
+                          "leaves": int(len(sizes)), "leaves_evaluated": int(len(fit)), "voxels": int(wl.info.n_voxels)})
+        del sizes, fit
+    leaves_evaluated = int(round(leaves_evaluated))
 
     # ---- secondary figures (outside the timed region) --------------------------------------------
     secondary = {}
     if not args.no_secondary:
         if world == 1 and not route:
-            ms = timed(wl.step_build_only) * 1e3
+            if n_clouds > 1:
+                wl.rotate = False
+                wl.step()
+                ms = timed(wl.step, reps=6) * 1e3
+                wl.rotate = True
+                secondary["same_cloud"] = {
+                    "ms": ms, "Mpoints_per_s": n_local / ms / 1e3,
+                    "note": "the headline's step on ONE cloud, inserted again every step (rounds 1-4 measured this): "
+                            "the geometry hint of the previous build always fits",
+                }
+                wl.step()
+            ms = timed(wl.step_build_only, reps=2 * n_clouds) * 1e3
             secondary["insert_subdivide_only"] = {
                 "ms": ms, "Mpoints_per_s": n_local / ms / 1e3,
                 "hbm_read_roofline_frac": 24.0 * n_local / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "BASELINE config 2: insert + subdivide alone, algorithmic 24 B/point",
+                "note": "BASELINE config 2: insert + subdivide alone (rotating over the resident clouds like the "
+                        "headline), algorithmic 24 B/point",
             }
             # what a build costs when the bucket path does not apply and the level-synchronous path takes it
             # (more than 2^24 voxel keys in the box, a bucket beyond 65 535 points, a vanished voxel of a previous
             # scheme ...): the same cloud, forced down that path
-            os.environ["OCTL_NO_BUCKET_BUILD"] = "1"
+            ctx.set_option("NO_BUCKET_BUILD", 1)
             try:
                 wl.step_build_only()
                 ms_g = timed(wl.step_build_only) * 1e3
             finally:
-                del os.environ["OCTL_NO_BUCKET_BUILD"]
+                ctx.set_option("NO_BUCKET_BUILD", 0)
             secondary["insert_subdivide_general_path"] = {
                 "ms": ms_g, "Mpoints_per_s": n_local / ms_g / 1e3,
                 "note": "insert + subdivide of the same cloud through the level-synchronous path of build.hip (keygen, "
@@ -844,8 +1016,9 @@ def main():
                         "+ 3 % of the points in one blob at 20 x the density; same step as the headline",
             }
             sw.close()
-            secondary["c4_manager"] = run_c4(ctx)
             secondary["no_geometry_hint"] = run_no_hint(ctx, wl, timed)
+            secondary["c1_octree_100k"] = run_c1(ctx)
+            secondary["c4_manager"] = run_c4(ctx)
             secondary["c5_shard"] = run_c5_shard(ctx, args.k_split, timed)
             # two independent step sequences (two contexts = two streams, two forests, two host threads): what
             # a pipeline over consecutive scans gains from overlapping the memory-bound build of one scan with
@@ -1004,6 +1177,10 @@ def main():
                 "nodes": nodes,
                 "levels": levels,
                 "points_after_ransac": n_alive_after,
+                "clouds": per_cloud,
+                "clouds_note": f"the timed loop rotates over {n_clouds} distinct clouds resident in HBM "
+                               "(leaves / nodes / points_after_ransac above: the last step's cloud)"
+                               if n_clouds > 1 else "one resident cloud, inserted again every step",
             },
             "roofline": {
                 "kernel": dom,

@@ -324,6 +324,13 @@ int octl_dev_copy_bandwidth(octl_ctx* ctx, int64_t bytes, int iters, double* byt
  * everything an operation allocates.  Process-wide.                                                     */
 int octl_debug_fail_alloc(int64_t nth, int64_t* seen);
 
+/* Diagnostic switches of a context (tests and A/B runs compare code paths: "NO_BUCKET_BUILD", "BUCKET_POINTS",
+ * "SYNC_GEOM", "NO_GEOM_HINT", "NO_EXACT_DIGITS", "NO_FAST_ORDER", "NO_BUCKET_HISTORY", "NO_CUBE_FAST",
+ * "NO_CUBE_PREFIX", "CUBE_PREFIX_MIN", "NO_INCREMENTAL", "ROUTE_SELF_SENDRECV", "TRACE_BUILD", "SCAN",
+ * "NO_FUSED_TABLES"; an "OCTL_" prefix is accepted).  octl_ctx_create reads OCTL_<NAME> from the environment once;
+ * this call changes a switch of a live context.  0 = the shipped behaviour.  The reference has no counterpart.  */
+int octl_debug_set_option(octl_ctx* ctx, const char* name, int64_t value);
+
 /* ---- test hooks for the device-wide primitives (host in / host out) ----------------------- */
 int octl_debug_exclusive_scan(octl_ctx* ctx, const uint32_t* in, int64_t n, uint32_t* out,
                               uint32_t* total);

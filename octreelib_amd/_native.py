@@ -100,6 +100,7 @@ SIGNATURES = {
     "octl_debug_route_partition": (C.c_int, [_p, _p, _i64, _i64, C.c_double, C.c_int32, _p, _p, _p]),
     "octl_debug_host_syncs": (C.c_int, [C.POINTER(C.c_uint64)]),
     "octl_debug_fail_alloc": (C.c_int, [_i64, _pi64]),
+    "octl_debug_set_option": (C.c_int, [_p, C.c_char_p, _i64]),
     "octl_route_get_gidx": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_comm_allreduce_i64": (C.c_int, [_p, _p, _i32]),
     "octl_dev_alloc": (C.c_int, [_p, _i64, C.POINTER(_p)]),
@@ -191,6 +192,20 @@ class Context:
 
     def sync(self):
         self.check(self.lib.octl_ctx_sync(self.handle))
+
+    def set_option(self, name: str, value=1):
+        """A diagnostic switch of this context (include/octreelib_hip.h: octl_debug_set_option), e.g.
+        set_option("NO_BUCKET_BUILD", 1).  The library reads OCTL_<NAME> from the environment only when a context
+        is created; tests and A/B runs that compare code paths on a live context go through here.  None / False = 0."""
+        v = 0 if value is None or value is False else int(value)
+        self.check(self.lib.octl_debug_set_option(self.handle, name.encode(), v))
+        touched = self.__dict__.setdefault("_options_touched", set())
+        touched.add(name)
+
+    def reset_options(self):
+        for name in list(self.__dict__.get("_options_touched", ())):
+            self.lib.octl_debug_set_option(self.handle, name.encode(), 0)
+        self.__dict__["_options_touched"] = set()
 
     def set_profiling(self, enabled: bool):
         # (True / 1: every timed region; 2: the RANSAC kernel only; False / 0: off)

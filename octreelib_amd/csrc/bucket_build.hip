@@ -2100,20 +2100,20 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   *done = 0;
   const int64_t N = f->n_store, n_alive = f->n_alive;
   // (OCTL_NO_BUCKET_BUILD: tests compare this path with the level-synchronous one)
-  if (n_alive <= 0 || !f->bbox_dev.p || getenv("OCTL_NO_BUCKET_BUILD")) return OCTL_OK;
+  if (n_alive <= 0 || !f->bbox_dev.p || ctx->opt.no_bucket_build) return OCTL_OK;
   // a single cube (bare Octree / OctreeManager) is ONE bucket: beyond what the oversize launch takes it is the
   // level loop's job from the start
   if (f->mode == 1 && n_alive > 65535) return OCTL_OK;
   const int n_poses = (int)f->pose_off.size() - 1;
   // buckets: runs of 2^s consecutive voxel keys, sized for ~2500 points on average (at most 2^24)
   // (OCTL_BUCKET_POINTS: tests force many small buckets - and with them the two-pass partition - on small clouds)
-  const uint64_t target = getenv("OCTL_BUCKET_POINTS") ? std::max(1, atoi(getenv("OCTL_BUCKET_POINTS"))) : 2560;
+  const uint64_t target = ctx->opt.bucket_points > 0 ? (uint64_t)ctx->opt.bucket_points : 2560;
   uint64_t want = 1;
   while (want < ((uint64_t)PT_BINS << PT_BITS) && want * target < (uint64_t)n_alive) want <<= 1;
   // One partition pass (want <= 4096 buckets): the key geometry is formed on the device (k_bucket_geom) and
   // the host does not wait for the bounding box; all 4096 buckets exist then, the ones behind the last
   // voxel key are empty.  (OCTL_SYNC_GEOM: tests run the host-side form on small clouds too.)
-  const bool async_geom = !force_sync && !ctx->geom_sparse && want <= (uint64_t)PT_BINS && !getenv("OCTL_SYNC_GEOM");
+  const bool async_geom = !force_sync && !ctx->geom_sparse && want <= (uint64_t)PT_BINS && !ctx->opt.sync_geom;
   // a cloud taken in place has not been through the box pass: with the geometry of the context's previous
   // single-pass build as a hint the histogram pass finds the box itself (k_part_hist<true>, k_geom_validate);
   // without one the box pass runs now
@@ -2124,8 +2124,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     std::memcpy(&hint, ctx->geom_hint, sizeof(hint));
     const bool usable = ctx->geom_hint_valid && ctx->geom_hint_want == want && hint.lp.mode == f->mode &&
                         hint.lp.L == f->edge && hint.lp.c0x == f->corner[0] && hint.lp.c0y == f->corner[1] &&
-                        hint.lp.c0z == f->corner[2] && !getenv("OCTL_NO_GEOM_HINT") &&
-                        hint.lp.exact_digits == (getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1);
+                        hint.lp.c0z == f->corner[2] && !ctx->opt.no_geom_hint &&
+                        hint.lp.exact_digits == (ctx->opt.no_exact_digits ? 0 : 1);
     hinted = async_geom && usable && !ctx->geom_hint_two_pass;
     hinted2 = !async_geom && !force_sync && usable && ctx->geom_hint_two_pass && f->mode == 0;
     if (!hinted && !hinted2) OCTL_TRY(store_compute_bbox(f));
@@ -2187,7 +2187,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   lp.dshift = s;
   lp.dmask = 0xFFFFFFFFu;
   lp.raw_vp = 0;
-  lp.exact_digits = getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1;
+  lp.exact_digits = ctx->opt.no_exact_digits ? 0 : 1;
   uint32_t* small = ctx->small.as<uint32_t>();
   // supertiles: one round of workgroups (2 per CU) over the cloud, at most 16 tiles each
   const int cus = octl_ctx_cus(ctx);
@@ -2504,7 +2504,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // the listing order of the blocks falls out of the same kernel for the common case: one pose, a fresh
   // scheme (one epoch), nothing left to the level loop, no bucket beyond what the kernel ranks in LDS
   const bool fast_order = n_poses == 1 && !a.old_fc && sm[SM_BK_TODO] == 0 && sm[SM_BK_NOORDER] == 0 &&
-                          !getenv("OCTL_NO_FAST_ORDER");
+                          !ctx->opt.no_fast_order;
   np.order_out = nullptr;
   if (fast_order) {
     OCTL_TRY(devbuf_reserve(ctx, f->fast_order, (size_t)std::max<uint32_t>(sm[SM_NBLOCKS], 1) * 4));
@@ -2582,7 +2582,7 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
   lp.dshift = 0;
   lp.dmask = 0xFFFFFFFFu;
   lp.raw_vp = 0;
-  lp.exact_digits = getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1;
+  lp.exact_digits = ctx->opt.no_exact_digits ? 0 : 1;
   const uint32_t nd = 1u << (3 * pm);
   const int cus = octl_ctx_cus(ctx);
   constexpr int PT_IPT = OCTL_PT_IPT;

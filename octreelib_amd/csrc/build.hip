@@ -31,7 +31,7 @@
 
 // OCTL_TRACE_BUILD=1: host wall time between the phases of forest_build on stderr (diagnostics)
 struct BuildTrace {
-  bool on = getenv("OCTL_TRACE_BUILD") != nullptr;
+  bool on = false;
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
   void mark(const char* what) {
     if (!on) return;
@@ -1348,6 +1348,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   if (max_depth <= 0) max_depth = 63;
   f->fast_order_valid = false;  // (the block table is about to change)
   BuildTrace trace;
+  trace.on = ctx->opt.trace_build != 0;
   uint32_t* small = ctx->small.as<uint32_t>();
 
   bool all_scheme = true;
@@ -1431,7 +1432,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   //         count-driven subdivide over a previous scheme (its internal nodes keep their epochs, its voxels
   //         must all be there again) ----------------------------------------------------------------------------
   const bool fresh0 = !f->built && f->vkeys.empty() && !f->vkeys_stale;
-  const bool over_old = f->built && !getenv("OCTL_NO_BUCKET_HISTORY");
+  const bool over_old = f->built && !ctx->opt.no_bucket_history;
   if (!keep_scheme && (fresh0 || over_old) && n_alive > 0) {
     NodeTable& bt = f->nodes[f->cur ^ 1];
     const int cur_epoch = f->epoch + 1;
@@ -1532,7 +1533,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   OCTL_TRY(forest_ensure_origin(f));
   // a fresh single cube with every point alive: one root, the store order is the level-0 order (k_cube_level0)
   const bool cube_fast = f->mode == 1 && N > 0 && n_alive == N && !f->built && f->vkeys.empty() &&
-                         !getenv("OCTL_NO_CUBE_FAST");
+                         !ctx->opt.no_cube_fast;
   // ... and when it is BIG the store is first partitioned once by the digits of its first pm levels
   // (bucket_build.hip: forest_prefix_partition): the top pm levels of the tree follow from the partition's
   // histogram, the level loop starts at level pm and every later gather of coordinates stays inside the ~15 000
@@ -1544,8 +1545,8 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
   const uint32_t* pre_bad = nullptr;
   uint32_t pre_stride = 0;
   // (OCTL_CUBE_PREFIX_MIN: tests run this path on small clouds; OCTL_NO_CUBE_PREFIX: never)
-  const int64_t prefix_min = getenv("OCTL_CUBE_PREFIX_MIN") ? atoll(getenv("OCTL_CUBE_PREFIX_MIN")) : ((int64_t)4 << 20);
-  if (cube_fast && all_scheme && !keep_scheme && K >= 0 && n_alive >= prefix_min && !getenv("OCTL_NO_CUBE_PREFIX")) {
+  const int64_t prefix_min = ctx->opt.cube_prefix_min > 0 ? ctx->opt.cube_prefix_min : ((int64_t)4 << 20);
+  if (cube_fast && all_scheme && !keep_scheme && K >= 0 && n_alive >= prefix_min && !ctx->opt.no_cube_prefix) {
     for (int c = 4; c >= 2 && !pm; --c)   // every node above depth pm has to split: expect >= 2 K points per depth-pm node
       if (n_alive >= 2 * std::max<int64_t>(K, 1) * ((int64_t)1 << (3 * c)) && c <= max_depth) pm = c;
     if (pm) OCTL_TRY(forest_prefix_partition(f, pm, &pre_recs, &pre_bstart, &pre_stride, &pre_bad));
@@ -1556,7 +1557,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     KTimer t(ctx, "keygen");
     hipLaunchKernelGGL(k_keygen, dim3(grid_for(N)), dim3(256), 0, st, f->xyz.as<double>(),
                        f->alive.as<uint8_t>(), N, f->mode, f->edge, f->corner[0], f->corner[1],
-                       f->corner[2], f->vorg, getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1, f->vkey.as<uint64_t>(),
+                       f->corner[2], f->vorg, ctx->opt.no_exact_digits ? 0 : 1, f->vkey.as<uint64_t>(),
                        f->path.as<uint32_t>(), small);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1816,7 +1817,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       hipLaunchKernelGGL(k_cube_level0, dim3(grid_for(N)), dim3(256), 0, st, (const double*)f->xyz.as<double>(), N,
                          f->edge, f->corner[0], f->corner[1], f->corner[2],
                          (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, scheme_dev,
-                         getenv("OCTL_NO_EXACT_DIGITS") ? 0 : 1, pos_node,
+                         ctx->opt.no_exact_digits ? 0 : 1, pos_node,
                          f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint32_t>());
     else
       hipLaunchKernelGGL(k_init_level0, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted,

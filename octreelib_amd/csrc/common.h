@@ -28,6 +28,15 @@ static inline hipError_t octl_counted_event_sync(hipEvent_t e) {
 #define hipStreamSynchronize(s) octl_counted_stream_sync(s)
 #define hipEventSynchronize(e) octl_counted_event_sync(e)
 
+// Compile-time experiment switches that change RESULTS (ablations, duplicated work) or add instrumentation never
+// belong in a shipped library: they only compile when the variant build script defines OCTL_EXPERIMENTS
+// (tools/build_variant.sh -> build/variants/NAME.so, loaded through OCTREELIB_AMD_LIB; the Makefile never does).
+#if !defined(OCTL_EXPERIMENTS) && \
+    (defined(RS_NO_REDO) || (defined(RS_ABLATE) && RS_ABLATE != 0) || defined(PS_DUP_KEYS) || defined(PS_DUP_STORE) || \
+     defined(RS_STAMPS) || defined(BB_STAMPS))
+#error "RS_NO_REDO / RS_ABLATE / PS_DUP_* / RS_STAMPS / BB_STAMPS are experiments: build them with tools/build_variant.sh (-DOCTL_EXPERIMENTS)"
+#endif
+
 #define OCTL_WAVE 64
 #define OCTL_PINNED_BYTES (256 * 1024)
 
@@ -50,8 +59,32 @@ struct DevBuf {
   }
 };
 
+// Diagnostic switches of a context (tests and A/B runs compare code paths with them).  Read from the environment
+// ONCE, when the context is created (OCTL_<NAME>=value), or set afterwards with octl_debug_set_option; nothing on a
+// build's path calls getenv.  All default to 0 = the shipped behaviour.
+struct OctlOptions {
+  int64_t no_bucket_build = 0;     // OCTL_NO_BUCKET_BUILD: every build through the level-synchronous path
+  int64_t bucket_points = 0;       // OCTL_BUCKET_POINTS: average points per bucket (0: 2560)
+  int64_t sync_geom = 0;           // OCTL_SYNC_GEOM: the host-side form of the key geometry on small clouds too
+  int64_t no_geom_hint = 0;        // OCTL_NO_GEOM_HINT: no geometry carried over from the context's previous build
+  int64_t no_exact_digits = 0;     // OCTL_NO_EXACT_DIGITS: child digits level by level, never six at once
+  int64_t no_fast_order = 0;       // OCTL_NO_FAST_ORDER: the listing order always from order.hip
+  int64_t no_bucket_history = 0;   // OCTL_NO_BUCKET_HISTORY: a subdivide over a previous scheme through the general path
+  int64_t no_cube_fast = 0;        // OCTL_NO_CUBE_FAST: a fresh single cube through key generation
+  int64_t no_cube_prefix = 0;      // OCTL_NO_CUBE_PREFIX: no prefix partition of big single cubes
+  int64_t cube_prefix_min = 0;     // OCTL_CUBE_PREFIX_MIN: points from which a single cube is prefix-partitioned (0: 4 Mi)
+  int64_t no_incremental = 0;      // OCTL_NO_INCREMENTAL: late poses by re-placement of every stored point
+  int64_t route_self_sendrecv = 0; // OCTL_ROUTE_SELF_SENDRECV: a rank's own part through RCCL too (1-rank rehearsal)
+  int64_t trace_build = 0;         // OCTL_TRACE_BUILD: host wall time between the phases of forest_build on stderr
+  int64_t scan_mode = 0;           // OCTL_SCAN: 1 = single-pass scan always, 3 = three-kernel scan always
+  int64_t no_fused_tables = 0;     // OCTL_NO_FUSED_TABLES: the small table chains as separate launches (A/B)
+};
+// name (without the OCTL_ prefix or with it) -> field; nullptr when there is no such switch
+int64_t* octl_option_field(OctlOptions& o, const char* name);
+
 struct octl_ctx {
   int device = 0;
+  OctlOptions opt;
   hipStream_t stream = nullptr;
   std::string err;
   int profiling = 0;  // 0 off, 1 every timed region, 2 the RANSAC kernel only (an event pair costs ~10 us of pipeline)

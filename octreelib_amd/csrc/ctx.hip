@@ -1,5 +1,6 @@
 // Context, error plumbing, device buffers, kernel timers, small device utilities.
 #include <cstdarg>
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -16,6 +17,50 @@ int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 std::atomic<uint64_t> g_octl_host_syncs{0};
+
+namespace {
+struct OptName { const char* name; int64_t OctlOptions::*field; };
+const OptName kOptions[] = {
+    {"NO_BUCKET_BUILD", &OctlOptions::no_bucket_build},     {"BUCKET_POINTS", &OctlOptions::bucket_points},
+    {"SYNC_GEOM", &OctlOptions::sync_geom},                 {"NO_GEOM_HINT", &OctlOptions::no_geom_hint},
+    {"NO_EXACT_DIGITS", &OctlOptions::no_exact_digits},     {"NO_FAST_ORDER", &OctlOptions::no_fast_order},
+    {"NO_BUCKET_HISTORY", &OctlOptions::no_bucket_history}, {"NO_CUBE_FAST", &OctlOptions::no_cube_fast},
+    {"NO_CUBE_PREFIX", &OctlOptions::no_cube_prefix},       {"CUBE_PREFIX_MIN", &OctlOptions::cube_prefix_min},
+    {"NO_INCREMENTAL", &OctlOptions::no_incremental},       {"ROUTE_SELF_SENDRECV", &OctlOptions::route_self_sendrecv},
+    {"TRACE_BUILD", &OctlOptions::trace_build},             {"SCAN", &OctlOptions::scan_mode},
+    {"NO_FUSED_TABLES", &OctlOptions::no_fused_tables},
+};
+}  // namespace
+
+int64_t* octl_option_field(OctlOptions& o, const char* name) {
+  if (!name) return nullptr;
+  if (std::strncmp(name, "OCTL_", 5) == 0) name += 5;
+  for (const OptName& e : kOptions)
+    if (std::strcmp(e.name, name) == 0) return &(o.*(e.field));
+  return nullptr;
+}
+
+// the environment is read HERE and nowhere else on a build's path: once per context
+static void options_from_environment(OctlOptions& o) {
+  char var[64];
+  for (const OptName& e : kOptions) {
+    std::snprintf(var, sizeof(var), "OCTL_%s", e.name);
+    const char* v = getenv(var);
+    if (!v) continue;
+    char* end = nullptr;
+    const long long x = std::strtoll(v, &end, 10);
+    // ("OCTL_SCAN=1pass" / "3pass" read as 1 / 3; a switch that is set to something that is not a number is on)
+    o.*(e.field) = (end != v) ? (int64_t)x : 1;
+  }
+}
+
+extern "C" int octl_debug_set_option(octl_ctx* ctx, const char* name, int64_t value) {
+  if (!ctx) return OCTL_E_INVALID;
+  int64_t* f = octl_option_field(ctx->opt, name);
+  if (!f) return octl_set_error(ctx, OCTL_E_INVALID, "no such option: %s", name ? name : "(null)");
+  *f = value;
+  return OCTL_OK;
+}
 
 extern "C" int octl_debug_host_syncs(uint64_t* count) {
   if (!count) return OCTL_E_INVALID;
@@ -242,6 +287,7 @@ int octl_ctx_create(int device_id, octl_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return OCTL_E_HIP;
   octl_ctx* ctx = new octl_ctx();
   ctx->device = device_id;
+  options_from_environment(ctx->opt);
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return OCTL_E_HIP;

@@ -348,7 +348,7 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
   *done = 0;
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
-  const bool disabled = getenv("OCTL_NO_INCREMENTAL") != nullptr;  // (tests compare the two paths)
+  const bool disabled = ctx->opt.no_incremental != 0;  // (tests compare the two paths)
   const int n_poses = (int)f->pose_off.size() - 1;
   const int64_t first = f->built_store, n_new = f->n_store - f->built_store;
   if (disabled || !f->built || !f->append_only || n_new <= 0 || n_poses <= f->built_poses) return OCTL_OK;

@@ -297,8 +297,8 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   if (R > 1 && !ctx->comm) return octl_set_error(ctx, OCTL_E_STATE, "communicator not initialised");
   // test hook: with a communicator present, push even the local part through RCCL (a 1-rank
   // communicator then exercises AllGather + grouped Send/Recv on a single GPU)
-  const bool use_rccl = ctx->comm && (R > 1 || getenv("OCTL_ROUTE_SELF_SENDRECV") != nullptr);
-  const bool self_rccl = use_rccl && getenv("OCTL_ROUTE_SELF_SENDRECV") != nullptr;
+  const bool use_rccl = ctx->comm && (R > 1 || ctx->opt.route_self_sendrecv != 0);
+  const bool self_rccl = use_rccl && ctx->opt.route_self_sendrecv != 0;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);

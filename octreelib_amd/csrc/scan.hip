@@ -247,8 +247,8 @@ int octl_exclusive_scan_u32(octl_ctx* ctx, const uint32_t* in, uint32_t* out, in
   // pass: one launch instead of three to five.  Point-sized inputs keep the three-kernel version:
   // with thousands of tiles in flight the look-back chain at the start of the grid costs more
   // than the second read of the input (10 M items: 49 vs 37 us - measured).
-  static const char* force = getenv("OCTL_SCAN");  // "1pass" / "3pass": A/B only
-  const bool single = force ? force[0] == '1' : ceil_div(n, SCAN_TILE) <= 1024;
+  // (OCTL_SCAN=1pass / 3pass forces one form: A/B only)
+  const bool single = ctx->opt.scan_mode ? ctx->opt.scan_mode == 1 : ceil_div(n, SCAN_TILE) <= 1024;
   if (!single) return scan_rec(ctx, in, out, n, total_dev, 0);
   return scan_single_pass(ctx, in, out, n, total_dev);
 }

@@ -45,3 +45,11 @@ def assert_same_leaves(got, want, ordered=True):
     assert dict(got) == dict(want)
     if ordered:
         assert [k for k, _ in got] == [k for k, _ in want]
+
+
+def set_option(name, value=1):
+    """A diagnostic switch of the process-wide context (octl_debug_set_option: the library reads its OCTL_* environment
+    only when a context is created).  tests/conftest.py resets every touched switch after each test."""
+    from octreelib_amd import _native as nat
+
+    nat.get_context().set_option(name, value)

@@ -45,3 +45,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_options():
+    """Diagnostic switches a test set on a process-wide context (tests/_util.set_option) do not outlive it."""
+    yield
+    nat = sys.modules.get("octreelib_amd._native")
+    if nat is not None:
+        for ctx in list(nat._default_ctx.values()):
+            ctx.reset_options()

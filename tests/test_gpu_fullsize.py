@@ -10,6 +10,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from tests._util import set_option
+
 pytestmark = pytest.mark.gpu
 
 
@@ -274,7 +276,7 @@ def test_sparse_scene_10M_every_leaf_against_the_count_oracle():
     f.close()
     import os
 
-    os.environ["OCTL_NO_BUCKET_BUILD"] = "1"                             # ... and the level loop agrees bit for bit
+    set_option("NO_BUCKET_BUILD", 1)                             # ... and the level loop agrees bit for bit
     try:
         g = Forest(0, np.zeros(3), 1.0)
         g.add_pose(pts)
@@ -285,4 +287,4 @@ def test_sparse_scene_10M_every_leaf_against_the_count_oracle():
         assert np.array_equal(tables[2], g.perm) and np.array_equal(tables[3], g.order)
         g.close()
     finally:
-        del os.environ["OCTL_NO_BUCKET_BUILD"]
+        set_option("NO_BUCKET_BUILD", 0)

@@ -10,7 +10,7 @@ order, counters; RANSAC inlier counts / winning hypothesis / f32 plane / mask ex
 import numpy as np
 import pytest
 
-from tests._util import assert_same_leaves, canon_from_list, golden_canon, load_golden
+from tests._util import assert_same_leaves, canon_from_list, golden_canon, load_golden, set_option
 
 pytestmark = pytest.mark.gpu
 
@@ -101,9 +101,9 @@ def test_grid_late_poses_golden(monkeypatch, incremental):
     from octreelib_amd.grid import Grid, GridConfig
 
     if incremental:
-        monkeypatch.delenv("OCTL_NO_INCREMENTAL", raising=False)
+        set_option("NO_INCREMENTAL", 0)
     else:
-        monkeypatch.setenv("OCTL_NO_INCREMENTAL", "1")
+        set_option("NO_INCREMENTAL", 1)
     g = load_golden("grid_late_poses.npz")
     grid = Grid(GridConfig(voxel_edge_length=2))
     idx = [index_map(g[f"points{p}"]) for p in range(5)]
@@ -1175,9 +1175,9 @@ def test_voxel_local_build_equals_level_synchronous_build(monkeypatch, scheme):
         f.close()
         return out
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     a = build()
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("NO_BUCKET_BUILD", 1)
     b = build()
     assert a[5] == b[5] and a[5] >= 2
     for k in ("voxel", "depth", "parent", "first_child", "corner", "edge", "epoch"):
@@ -1230,9 +1230,9 @@ def test_voxel_local_build_random_voxels_vs_level_synchronous_build(monkeypatch,
         f.close()
         return out, names
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     a, names_a = build()
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("NO_BUCKET_BUILD", 1)
     b, names_b = build()
     assert "bucket_build" in names_a and "bucket_build" not in names_b
     if not deep and K >= 8:
@@ -1253,7 +1253,7 @@ def test_bucket_build_nearly_full_buckets_vs_level_synchronous_build(monkeypatch
 
     # (the host sizes buckets for OCTL_BUCKET_POINTS points on average - 2 560 by default, so that an evenly filled
     #  scene stays well inside the capacity; 4 000 puts the buckets of this scene around it)
-    monkeypatch.setenv("OCTL_BUCKET_POINTS", "4000")
+    set_option("BUCKET_POINTS", 4000)
     rng = np.random.default_rng(per_voxel + K)
     dims = (8, 8, 8)
     parts = []
@@ -1276,9 +1276,9 @@ def test_bucket_build_nearly_full_buckets_vs_level_synchronous_build(monkeypatch
         f.close()
         return out, names
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     a, names_a = build()
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("NO_BUCKET_BUILD", 1)
     b, names_b = build()
     assert "bucket_build" in names_a and "level_hist" not in names_a
     assert "bucket_build" not in names_b
@@ -1331,9 +1331,9 @@ def test_bucket_build_mixed_voxel_populations_vs_level_synchronous_build(monkeyp
         f.close()
         return out, names
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     a, names_a = build()
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("NO_BUCKET_BUILD", 1)
     b, names_b = build()
     assert "bucket_build" in names_a and "level_hist" not in names_a
     assert "bucket_build" not in names_b
@@ -1378,11 +1378,11 @@ def test_bucket_build_two_pass_partition_vs_level_synchronous_build(monkeypatch,
         f.close()
         return out, names
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
-    monkeypatch.setenv("OCTL_BUCKET_POINTS", "4")
+    set_option("NO_BUCKET_BUILD", 0)
+    set_option("BUCKET_POINTS", 4)
     a, names_a = build()
-    monkeypatch.delenv("OCTL_BUCKET_POINTS")
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("BUCKET_POINTS", 0)
+    set_option("NO_BUCKET_BUILD", 1)
     b, names_b = build()
     assert "bucket_bounds" in names_a and "level_hist" not in names_a   # two passes, whole build
     assert "bucket_build" not in names_b
@@ -1442,9 +1442,9 @@ def test_bucket_build_leaves_huge_and_deep_voxels_to_the_level_loop(monkeypatch,
         f.close()
         return out, t
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     a, ta = build()
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("NO_BUCKET_BUILD", 1)
     b, tb = build()
     assert "bucket_build" in ta and "level_hist" in ta and "keygen" not in ta    # resumed, not redone
     assert "bucket_build" not in tb and "keygen" in tb
@@ -1656,9 +1656,9 @@ def test_incremental_insertion_equals_replacement(monkeypatch):
         f.close()
         return snaps, after, timers
 
-    monkeypatch.delenv("OCTL_NO_INCREMENTAL", raising=False)
+    set_option("NO_INCREMENTAL", 0)
     a, a_after, ta = run()
-    monkeypatch.setenv("OCTL_NO_INCREMENTAL", "1")
+    set_option("NO_INCREMENTAL", 1)
     b, b_after, tb = run()
     # the first run placed only the new points (three insertions, two of them with new voxels), the
     # second re-placed everything
@@ -1714,9 +1714,9 @@ def test_bucket_build_over_a_previous_scheme_equals_level_synchronous_build(monk
         f.close()
         return nodes, listing, counts, vox, names
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_HISTORY", raising=False)
+    set_option("NO_BUCKET_HISTORY", 0)
     a = run()
-    monkeypatch.setenv("OCTL_NO_BUCKET_HISTORY", "1")
+    set_option("NO_BUCKET_HISTORY", 1)
     b = run()
     assert "bucket_build" in a[4] and "bucket_build" not in b[4] and "keygen" in b[4]
     assert ("keygen" in a[4]) == empty_voxel    # the empty voxel: back to the level-synchronous path
@@ -1758,11 +1758,11 @@ def test_bucket_build_integer_edges_vs_level_synchronous_build_and_oracle(monkey
         f.close()
         return out
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     a = build()
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("NO_BUCKET_BUILD", 1)
     b = build()
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     _assert_same_build(a, b)
     # reduced: against the oracle through the drop-in classes
     small = [p[:6000] for p in poses]
@@ -1800,11 +1800,11 @@ def test_bucket_build_far_from_the_origin_vs_level_synchronous_build_and_oracle(
         f.close()
         return out
 
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     a = build()
-    monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+    set_option("NO_BUCKET_BUILD", 1)
     b = build()
-    monkeypatch.delenv("OCTL_NO_BUCKET_BUILD", raising=False)
+    set_option("NO_BUCKET_BUILD", 0)
     _assert_same_build(a, b)
     assert a[5] >= 5
     small = cloud[:8000]
@@ -2019,9 +2019,9 @@ def test_block_order_left_by_the_bucket_build_equals_order_hip(monkeypatch, seed
         f.close()
         return order, blocks, names, depth
 
-    monkeypatch.delenv("OCTL_NO_FAST_ORDER", raising=False)
+    set_option("NO_FAST_ORDER", 0)
     a, ba, na, depth = run()
-    monkeypatch.setenv("OCTL_NO_FAST_ORDER", "1")
+    set_option("NO_FAST_ORDER", 1)
     b, bb, nb_, _ = run()
     for k in ba:
         assert np.array_equal(ba[k], bb[k]), k
@@ -2080,7 +2080,7 @@ def test_adopted_cloud_builds_the_same_forest_with_and_without_a_geometry_hint(m
     K = 48
     dm = (20, 20, 20) if two_pass else (8, 8, 8)
     if two_pass:
-        monkeypatch.setenv("OCTL_BUCKET_POINTS", "16")
+        set_option("BUCKET_POINTS", 16)
     scenes = {
         "base": synthetic.planar_cloud(200_000, dm, seed=1, stream=0),
         "same_box": synthetic.planar_cloud(200_000, dm, seed=1, stream=1),
@@ -2134,7 +2134,7 @@ def test_adopted_cloud_builds_the_same_forest_with_and_without_a_geometry_hint(m
     # must not (the hint held: no "ingest" timer)
     assert used_box_pass[1] is False and used_box_pass[2] is False
     # with the hint disabled every build runs the box pass and still agrees
-    monkeypatch.setenv("OCTL_NO_GEOM_HINT", "1")
+    set_option("NO_GEOM_HINT", 1)
     pts = scenes["same_box"]
     d = _device_cloud(ctx, pts)
     g = Forest(0, np.zeros(3), 1.0)
@@ -2342,7 +2342,7 @@ def test_grid_at_utm_scale_coordinates_vs_oracle(monkeypatch, general_path):
     from oracle import ransac_np as rnp
 
     if general_path:
-        monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+        set_option("NO_BUCKET_BUILD", 1)
     rng = np.random.default_rng(123)
     origin = np.array([5_432_100.0, -4_321_000.0, 1_250_000.0])   # |voxel index| up to 5.4e6 >> 2^20
     poses = [origin + rng.random((6000, 3)) * 5.0, origin + rng.random((4000, 3)) * 5.0 + np.array([3.0, -2.0, 1.0]),
@@ -2500,7 +2500,7 @@ def test_six_digits_at_once_equal_the_level_by_level_form(monkeypatch, L, lo, hi
     from octreelib_amd._engine import Forest
 
     if general_path:
-        monkeypatch.setenv("OCTL_NO_BUCKET_BUILD", "1")
+        set_option("NO_BUCKET_BUILD", 1)
     rng = np.random.default_rng(int(L * 100 + hi))
     pts = _digit_boundary_cloud(rng, 60_000, float(L), lo, hi)
 
@@ -2514,9 +2514,9 @@ def test_six_digits_at_once_equal_the_level_by_level_form(monkeypatch, L, lo, hi
 
     for K in (40, 3):
         fast = tables(K)
-        monkeypatch.setenv("OCTL_NO_EXACT_DIGITS", "1")
+        set_option("NO_EXACT_DIGITS", 1)
         slow = tables(K)
-        monkeypatch.delenv("OCTL_NO_EXACT_DIGITS")
+        set_option("NO_EXACT_DIGITS", 0)
         _assert_same_tables(fast, slow)
         assert int(fast[0]["depth"].max()) >= (2 if K == 40 else 4)
 
@@ -2533,13 +2533,13 @@ def test_six_digits_at_once_in_a_single_cube(monkeypatch):
         tabs = []
         for off in (False, True):
             if off:
-                monkeypatch.setenv("OCTL_NO_EXACT_DIGITS", "1")
+                set_option("NO_EXACT_DIGITS", 1)
             oc = Octree(OctreeConfig(), corner, np.float64(edge))
             oc.insert_points(pts)
             oc.subdivide(crit(50))
             tabs.append(_tables(oc._forest))
             if off:
-                monkeypatch.delenv("OCTL_NO_EXACT_DIGITS")
+                set_option("NO_EXACT_DIGITS", 0)
         _assert_same_tables(tabs[0], tabs[1])
         assert len(pts) > 65_535 and int(tabs[0][0]["depth"].max()) >= 3
 
@@ -2574,9 +2574,9 @@ def test_single_cube_prefix_partition_equals_the_plain_level_loop(monkeypatch, c
 
     def build(K, plain):
         if plain:
-            monkeypatch.setenv("OCTL_NO_CUBE_PREFIX", "1")
+            set_option("NO_CUBE_PREFIX", 1)
         else:
-            monkeypatch.delenv("OCTL_NO_CUBE_PREFIX", raising=False)
+            set_option("NO_CUBE_PREFIX", 0)
         f = Forest(1, corner, edge)
         f.add_pose(pts[: len(pts) // 2])
         f.add_pose(pts[len(pts) // 2 :])         # two poses: (leaf, pose) blocks need the ORIGINAL indices
@@ -2590,7 +2590,7 @@ def test_single_cube_prefix_partition_equals_the_plain_level_loop(monkeypatch, c
             f.close()
         return t, names
 
-    monkeypatch.setenv("OCTL_CUBE_PREFIX_MIN", "100000")
+    set_option("CUBE_PREFIX_MIN", 100000)
     for K, levels in ((30, 4), (200, 3), (2000, 2)):
         if case == "outside":
             for plain in (False, True):

@@ -9,8 +9,11 @@ for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r["Stream_Id"]))
 ev.sort()
-starts = [i for i, e in enumerate(ev) if e[2].startswith("k_part_hist<true, true>")]
-a, b = starts[-3], starts[-2]
+# a step starts with the reset of the forest's voxel box (octl_forest_clear + add_pose_adopt -> k_bbox_reset)
+first = "k_bbox_reset" if any(e[2].startswith("k_bbox_reset") for e in ev) else "k_part_hist<true, true>"
+starts = [i for i, e in enumerate(ev) if e[2].startswith(first)]
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 3   # which step, counted from the end of the trace
+a, b = starts[-back], starts[-back + 1]
 t0 = prev = ev[a][0]
 for s, e, n, st in ev[a:b]:
     print("%8.1f +%7.1f  gap %7.1f  stream %s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3, st, n[:60]))
