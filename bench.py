@@ -1267,11 +1267,11 @@ def profile_traffic(which="headline"):
 TIMER_KERNELS = {
     "ingest": ["k_ingest<"],
     "part_hist": ["k_part_hist<", "k_part_hist_rec", "k_geom_validate"],
-    "part_scan": ["k_transpose_u32"],
+    "part_scan": ["k_transpose_u32", "k_table_scan"],
     "part_scatter": ["k_part_scatter<"],
     "bucket_bounds": ["k_bucket_bounds"],
     "bucket_build": ["k_bucket_build", "k_bucket_plan", "k_bucket_chunks"],
-    "bucket_nodes": ["k_bucket_finish", "k_block_sizes_dev", "k_node_init"],
+    "bucket_nodes": ["k_bucket_finish"],
     "keygen": ["k_keygen"],
     "linkey": ["k_linkey"],
     "roots": ["k_root_tiles<", "k_make_roots"],

@@ -4,6 +4,7 @@
 #include <unordered_map>
 
 #include "forest.h"
+#include "lookback.h"
 #include "ref_arith.h"
 
 namespace {
@@ -191,6 +192,113 @@ __global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ ma
   }
 }
 
+
+// apply_mask's counts, prefix sums and block-table compaction in ONE launch (round 5; before: k_blk_kept, a scan over
+// [tile counts | kept per block | block non-empty], k_blk_compact).  Workgroups [0, nt) take a tile of 2048 positions:
+// kept points of the tile, chained by decoupled look-back into the tile's offset (k_compact_tiles reads it).
+// Workgroups [nt, nt + nbw) take 256 blocks each: kept points and "non-empty" per block, two look-back chains over
+// the block workgroups (kept points in front = the block's new start, non-empty blocks in front = its new id), and
+// the surviving blocks are written straight into the compacted table.  Chains never cross: each has its own status
+// words, and tiles are taken in blockIdx order inside every chain.  totals[0] / totals[1] (pinned host memory):
+// kept points, surviving blocks.  fill_alive: the store's alive flags have never been written (a cloud taken in
+// place): the tile workgroups write 1s over their range - position range = store range while every point is alive.
+__global__ __launch_bounds__(256) void k_mask_scan(
+    const uint8_t* __restrict__ mask, int64_t n, uint32_t nt, uint32_t* __restrict__ tile_off,
+    const uint32_t* __restrict__ blk_start, const int32_t* __restrict__ blk_size, int64_t nb,
+    const int32_t* __restrict__ blk_node, const int32_t* __restrict__ blk_slot, int32_t* __restrict__ blk_node2,
+    int32_t* __restrict__ blk_slot2, uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2,
+    uint64_t* __restrict__ st_tiles, uint64_t* __restrict__ st_kept, uint64_t* __restrict__ st_ids, uint32_t epoch,
+    uint32_t* __restrict__ totals, uint8_t* __restrict__ alive_fill) {
+  __shared__ uint32_t s_w[2][4];
+  __shared__ uint32_t s_excl;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x < nt) {
+    const uint32_t tile = blockIdx.x;
+    const int64_t i0 = (int64_t)tile * 2048 + (int64_t)threadIdx.x * 8;
+    uint32_t c = 0;
+    if (i0 + 8 <= n) {
+      const uint64_t w = *reinterpret_cast<const uint64_t*>(mask + i0);  // (the mask buffer is 16-byte aligned)
+      const uint64_t nz = ((w & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | w;   // bytes that are not zero
+      c = (uint32_t)__popcll(nz & 0x8080808080808080ull);
+      if (alive_fill) *reinterpret_cast<uint64_t*>(alive_fill + i0) = 0x0101010101010101ull;
+    } else {
+      for (int64_t i = i0; i < n; ++i) {
+        c += mask[i] ? 1u : 0u;
+        if (alive_fill) alive_fill[i] = 1;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) s_w[0][wave] = c;
+    __syncthreads();
+    const uint32_t total = (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]);
+    const uint32_t excl = lookback_exclusive(st_tiles, epoch, tile, total, &s_excl);
+    if (threadIdx.x == 0) {
+      tile_off[tile] = excl;
+      if (tile == nt - 1) totals[0] = excl + total;
+    }
+    return;
+  }
+  const uint32_t bw = blockIdx.x - nt;
+  const int64_t b = (int64_t)bw * 256 + threadIdx.x;
+  const uint32_t st = b < nb ? blk_start[b] : 0u;
+  const int sz = b < nb ? blk_size[b] : 0;
+  uint32_t c = 0;
+  if (sz <= 256)
+    for (int i = 0; i < sz; ++i) c += mask[(size_t)st + i] ? 1u : 0u;
+  // large blocks (unsplit voxels, big leaves of a bare octree): the whole wave, one block at a time
+  unsigned long long big = __ballot(sz > 256);
+  while (big) {
+    const int src = __ffsll((long long)big) - 1;
+    big &= big - 1;
+    const uint32_t s0 = (uint32_t)__shfl((int)st, src);
+    const int z = __shfl(sz, src);
+    uint32_t cc = 0;
+    for (int i = lane; i < z; i += 64) cc += mask[(size_t)s0 + i] ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cc += __shfl_xor(cc, off);
+    if (lane == src) c = cc;
+  }
+  // exclusive prefixes inside the workgroup: kept points, non-empty blocks
+  const uint32_t ne = c ? 1u : 0u;
+  uint32_t ic = c, ie = ne;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t tc = __shfl_up(ic, off), te = __shfl_up(ie, off);
+    if (lane >= off) {
+      ic += tc;
+      ie += te;
+    }
+  }
+  if (lane == 63) {
+    s_w[0][wave] = ic;
+    s_w[1][wave] = ie;
+  }
+  __syncthreads();
+  uint32_t pc = ic - c, pe = ie - ne, tot_c = 0, tot_e = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) {
+      pc += s_w[0][w];
+      pe += s_w[1][w];
+    }
+    tot_c += s_w[0][w];
+    tot_e += s_w[1][w];
+  }
+  __syncthreads();   // (s_excl is used by both chains)
+  const uint32_t ex_c = lookback_exclusive(st_kept, epoch, bw, tot_c, &s_excl);
+  __syncthreads();
+  const uint32_t ex_e = lookback_exclusive(st_ids, epoch, bw, tot_e, &s_excl);
+  if (threadIdx.x == 0 && bw == gridDim.x - nt - 1) totals[1] = ex_e + tot_e;
+  if (b < nb && c) {
+    const uint32_t id = ex_e + pe;
+    blk_node2[id] = blk_node[b];
+    blk_slot2[id] = blk_slot[b];
+    blk_start2[id] = ex_c + pc;
+    blk_size2[id] = (int32_t)c;
+  }
+}
+
 // tile-wise stable compaction (8 rows of 256 points per workgroup, ballot ranks); dropped points die in the store
 __global__ __launch_bounds__(256) void k_compact_tiles(
     const uint8_t* __restrict__ mask, const uint32_t* __restrict__ tile_off, int64_t n,
@@ -359,15 +467,31 @@ __global__ __launch_bounds__(256) void k_widen_u32_i64(const uint32_t* __restric
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
-int bbox_reset(octl_forest* f) {
+}  // namespace
+
+int bbox_ensure(octl_forest* f) {
   octl_ctx* ctx = f->ctx;
   // (no page-locked mirror per forest: hipHostMalloc / hipHostFree synchronise the whole device - also the copy
   //  stream's upload of the next scan; the one readback of the box goes through the context's scalar mirror)
-  if (!f->bbox_dev.p) OCTL_TRY(devbuf_reserve(ctx, f->bbox_dev, 32));
+  if (!f->bbox_dev.p) {
+    OCTL_TRY(devbuf_reserve(ctx, f->bbox_dev, 32));
+    f->bbox_stale = true;
+  }
+  if (!f->bbox_stale) return OCTL_OK;
   hipLaunchKernelGGL(k_bbox_reset, dim3(1), dim3(64), 0, ctx->stream, f->bbox_dev.as<int32_t>());
   HIP_TRY(ctx, hipGetLastError());
+  f->bbox_stale = false;
   return OCTL_OK;
 }
+
+int alive_ensure(octl_forest* f) {
+  if (!f->alive_stale) return OCTL_OK;
+  if (f->n_store > 0) HIP_TRY(f->ctx, hipMemsetAsync(f->alive.p, 1, (size_t)f->n_store, f->ctx->stream));
+  f->alive_stale = false;
+  return OCTL_OK;
+}
+
+namespace {
 
 // Device sources are consumed in stream order (no synchronisation: the caller keeps the buffer
 // unchanged until the next synchronising call on the context); host sources are copied before the
@@ -383,9 +507,10 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
   // cloud whose box has not been taken yet is folded in now (the kernel below only adds the new points)
   if (f->store_borrowed) OCTL_TRY(store_materialize(f));
   if (f->bbox_pending) OCTL_TRY(store_compute_bbox(f));
+  OCTL_TRY(alive_ensure(f));   // (the flags of the points in front of the new ones: the buffer may move)
   OCTL_TRY(devbuf_reserve(ctx, f->xyz, (size_t)std::max<int64_t>(total, 1) * 24 + 16, 1));
   OCTL_TRY(devbuf_reserve(ctx, f->alive, (size_t)std::max<int64_t>(total, 1) + 2, 1));
-  if (!f->bbox_dev.p) OCTL_TRY(bbox_reset(f));
+  OCTL_TRY(bbox_ensure(f));
   if (n > 0) {
     hipStream_t st = ctx->stream;
     double* dst = f->xyz.as<double>() + 3 * f->n_store;
@@ -434,8 +559,12 @@ int store_take_in_place(octl_forest* f, int64_t n) {
   if (n >= ((int64_t)1 << 31))
     return octl_set_error(ctx, OCTL_E_INVALID, "more than 2^31-1 points in one forest");
   OCTL_TRY(devbuf_reserve(ctx, f->alive, (size_t)std::max<int64_t>(n, 1) + 2, 0));
-  if (!f->bbox_dev.p) OCTL_TRY(bbox_reset(f));
-  HIP_TRY(ctx, hipMemsetAsync(f->alive.p, 1, (size_t)n, ctx->stream));
+  if (!f->bbox_dev.p) {
+    OCTL_TRY(devbuf_reserve(ctx, f->bbox_dev, 32));
+    f->bbox_stale = true;
+  }
+  // (no launch here: the flags are written when something needs them, the box is reset by whoever fills it)
+  f->alive_stale = true;
   f->bbox_pending = true;
   return OCTL_OK;
 }
@@ -459,11 +588,15 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     uint32_t* raw = f->flags.as<uint32_t>();
     uint32_t* scanned = reinterpret_cast<uint32_t*>(static_cast<char*>(f->flags.p) + o_out);
     const uint8_t* mask = f->mask.as<uint8_t>();
-    hipLaunchKernelGGL(k_blk_kept, dim3((unsigned)nt + grid_for(nb)), dim3(256), 0, st, mask, n, (uint32_t)nt, raw,
-                       (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
-                       raw + nt, raw + nt + nb);
-    HIP_TRY(ctx, hipGetLastError());
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, raw, scanned, n_all, small + 22));
+    const bool fused = !ctx->opt.no_fused_tables;
+    if (!fused) {
+      OCTL_TRY(alive_ensure(f));
+      hipLaunchKernelGGL(k_blk_kept, dim3((unsigned)nt + grid_for(nb)), dim3(256), 0, st, mask, n, (uint32_t)nt, raw,
+                         (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
+                         raw + nt, raw + nt + nb);
+      HIP_TRY(ctx, hipGetLastError());
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, raw, scanned, n_all, small + 22));
+    }
     OCTL_TRY(devbuf_reserve(ctx, f->ord_idx2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord2, (size_t)n * 24));
     // (block buffers keep the capacity convention of forest_make_blocks: one block per point)
@@ -471,16 +604,40 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     OCTL_TRY(devbuf_reserve(ctx, f->blk_slot2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->blk_start2, (size_t)n * 4));
     OCTL_TRY(devbuf_reserve(ctx, f->blk_size2, (size_t)n * 4));
+    if (fused) {
+      // counts + the three prefix sums + the block table's compaction: one launch (k_mask_scan)
+      const int64_t nbw = ceil_div(nb, 256);
+      uint64_t* status = nullptr;
+      uint32_t epoch = 0;
+      OCTL_TRY(octl_scan_status_acquire(ctx, nt + 2 * nbw, &status, &epoch));
+      // (alive flags that were never written - a cloud taken in place - are filled by the tile workgroups)
+      uint8_t* fill = nullptr;
+      if (f->alive_stale && f->n_ord == f->n_store) {
+        fill = f->alive.as<uint8_t>();
+        f->alive_stale = false;
+      } else {
+        OCTL_TRY(alive_ensure(f));
+      }
+      hipLaunchKernelGGL(k_mask_scan, dim3((unsigned)(nt + nbw)), dim3(256), 0, st, mask, n, (uint32_t)nt, scanned,
+                         (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
+                         (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
+                         f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
+                         f->blk_size2.as<int32_t>(), status, status + nt, status + nt + nbw, epoch,
+                         static_cast<uint32_t*>(ctx->small_host), fill);
+      HIP_TRY(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)scanned, n,
                        (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
                        f->ord_idx2.as<uint32_t>(), f->xyz_ord2.as<double>(), f->alive.as<uint8_t>());
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)raw,
-                       (const uint32_t*)scanned, (const uint32_t*)(small + 22), nt, nb,
-                       (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
-                       f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
-                       f->blk_size2.as<int32_t>(), static_cast<uint32_t*>(ctx->small_host));
-    HIP_TRY(ctx, hipGetLastError());
+    if (!fused) {
+      hipLaunchKernelGGL(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)raw,
+                         (const uint32_t*)scanned, (const uint32_t*)(small + 22), nt, nb,
+                         (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
+                         f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
+                         f->blk_size2.as<int32_t>(), static_cast<uint32_t*>(ctx->small_host));
+      HIP_TRY(ctx, hipGetLastError());
+    }
     // (the two totals are written into the pinned mirror by the kernel itself: no copy in front of the wait)
     HIP_TRY(ctx, hipStreamSynchronize(st));
     uint32_t res[2];
@@ -525,7 +682,7 @@ int store_compute_bbox(octl_forest* f) {
   f->bbox_pending = false;
   const int64_t n = f->n_store;
   if (n <= 0) return OCTL_OK;
-  if (!f->bbox_dev.p) OCTL_TRY(bbox_reset(f));
+  OCTL_TRY(bbox_ensure(f));
   KTimer t(ctx, "ingest");
   const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(3 * n / 2, 256 * ING_UNITS));
   double* p = f->xyz.as<double>();
@@ -608,7 +765,8 @@ void octl_forest_destroy(octl_forest* f) {
 
 int octl_forest_clear(octl_forest* f) {
   if (!f) return OCTL_E_INVALID;
-  if (f->bbox_dev.p) OCTL_TRY(bbox_reset(f));  // (stream ordered: no synchronisation needed)
+  f->bbox_stale = true;   // (nothing is launched: whoever fills the box next resets it first)
+  f->alive_stale = false;
   if (f->store_borrowed) {  // back to the forest's own block; the caller's buffer is the caller's again
     f->xyz = f->xyz_own;
     f->xyz_own = DevBuf{};
@@ -956,7 +1114,8 @@ int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* bl
   f->mask_valid = false;
   f->fast_order_valid = false;
   // the voxel box of the new points is not known (rows may have left their cubes): the next build finds it
-  OCTL_TRY(bbox_reset(f));
+  f->bbox_stale = true;
+  f->alive_stale = false;   // (written above)
   f->bbox_pending = total > 0;
   f->displaced_rows = displaced;
   return OCTL_OK;

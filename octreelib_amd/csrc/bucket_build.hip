@@ -34,6 +34,7 @@
 // level-synchronous path of build.hip.
 #include "build_common.h"
 #include "ref_arith.h"
+#include "lookback.h"
 #include "wave_utils.h"
 
 namespace {
@@ -179,9 +180,8 @@ __global__ void k_bucket_geom(const int32_t* __restrict__ bbox, uint64_t want, L
 __global__ void k_geom_set(GeomDev hint, GeomDev* __restrict__ g) {
   if (threadIdx.x == 0) *g = hint;
 }
-__global__ void k_geom_validate(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
-                                GeomDev* __restrict__ g) {
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void geom_validate_body(const int32_t* __restrict__ bbox, uint64_t want,
+                                                   const LinParams& base, GeomDev* __restrict__ g) {
   GeomDev o;
   geom_from_box(bbox, bbox[6] != 0, want, base, o);
   const GeomDev h = *g;
@@ -193,13 +193,17 @@ __global__ void k_geom_validate(const int32_t* __restrict__ bbox, uint64_t want,
   }
   *g = o;
 }
+__global__ void k_geom_validate(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+                                GeomDev* __restrict__ g) {
+  if (threadIdx.x == 0) geom_validate_body(bbox, want, base, g);
+}
 
 // The same for a hinted TWO-pass build (more than 4096 buckets: 125 M points of one rank's shard).  There the host
 // forms the geometry - it needs the bucket count for its tables - from the hint's box instead of waiting for the
 // box pass; the hint stands when every point fell inside its box and the true box asks for the same bucket width.
 // Otherwise the true box is left in the record (valid = 0, GEOM_REHASH) and the host builds again from it.
-__global__ void k_geom_validate2(const int32_t* __restrict__ bbox, uint64_t want, GeomDev* __restrict__ g) {
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void geom_validate2_body(const int32_t* __restrict__ bbox, uint64_t want,
+                                                    GeomDev* __restrict__ g) {
   GeomDev o = *g;
   const bool domain_error = bbox[6] != 0, inside = bbox[7] == 0;
   bool same = false;
@@ -221,6 +225,9 @@ __global__ void k_geom_validate2(const int32_t* __restrict__ bbox, uint64_t want
   o.valid = 0;
   o.reason = domain_error ? GEOM_DOMAIN : (bbox[0] > bbox[3] ? GEOM_EMPTY : GEOM_REHASH);
   *g = o;
+}
+__global__ void k_geom_validate2(const int32_t* __restrict__ bbox, uint64_t want, GeomDev* __restrict__ g) {
+  if (threadIdx.x == 0) geom_validate2_body(bbox, want, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,6 +473,88 @@ __global__ __launch_bounds__(256) void k_transpose_u32(const uint32_t* __restric
   for (uint32_t j = 0; j < 64; j += 4) {
     const uint32_t c = c0 + ty + j, r = r0 + tx;
     if (r < R && c < C) out[(size_t)c * R + r] = tile[tx][ty + j];
+  }
+}
+
+// The partition table in ONE launch (round 5; before: transpose, scan, transpose back - three launches around
+// 25 MB of traffic for 8 MB of counts).  table[supertile][digit] holds counts; wanted is the exclusive prefix in
+// (digit, supertile) order - where supertile st's share of bucket d starts - IN PLACE and in the same layout, the
+// one k_part_scatter reads its row from, plus the start of every bucket (bucket_start[d], bucket_start[nd] = total).
+// A workgroup owns 64 neighbouring digit columns: lane = column, wave w = the w-th quarter of the rows; a row segment
+// is 256 contiguous bytes.  Pass 1 sums the columns, the workgroups' totals are chained by decoupled look-back
+// (<= 64 workgroups), pass 2 walks the rows again (L2) and writes the running offsets.
+// VALIDATE: the workgroup 0 also decides about the HINTED geometry the histogram ran under (what k_geom_validate /
+// k_geom_validate2 did in a launch of their own): nothing in this kernel reads the verdict, the next launch does.
+constexpr int TS_COLS = 64;
+constexpr int TS_THREADS = 512;
+constexpr int TS_WAVES = TS_THREADS / 64;
+constexpr int TS_UNROLL = 8;             // rows in flight per lane
+constexpr uint32_t TS_MAX_ROWS = 2048;   // beyond: the three-launch form (a workgroup would walk its rows for too long)
+__global__ __launch_bounds__(TS_THREADS) void k_table_scan(uint32_t* __restrict__ table, uint32_t nst, uint32_t nd,
+                                                          uint32_t* __restrict__ bucket_start,
+                                                          uint64_t* __restrict__ status, uint32_t epoch, int validate,
+                                                          const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+                                                          GeomDev* __restrict__ g) {
+  __shared__ uint32_t s_w[TS_WAVES][TS_COLS];   // column sums per slice of the rows
+  __shared__ uint32_t s_col[TS_COLS];           // exclusive prefix over the workgroup's columns
+  __shared__ uint32_t s_tot, s_excl;
+  if (validate && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (validate == 1) geom_validate_body(bbox, want, base, g); else geom_validate2_body(bbox, want, g);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t d = blockIdx.x * TS_COLS + lane;
+  const bool col = d < nd;
+  const uint32_t per = (nst + TS_WAVES - 1) / TS_WAVES;
+  const uint32_t r0 = min(nst, (uint32_t)wave * per), r1 = min(nst, r0 + per);
+  uint32_t sum = 0;
+  if (col) {
+    uint32_t r = r0;
+    for (; r + TS_UNROLL <= r1; r += TS_UNROLL) {
+      const uint32_t* p0 = table + (size_t)r * nd + d;
+      uint32_t v[TS_UNROLL];
+#pragma unroll
+      for (int u = 0; u < TS_UNROLL; ++u) v[u] = p0[(size_t)u * nd];
+#pragma unroll
+      for (int u = 0; u < TS_UNROLL; ++u) sum += v[u];
+    }
+    for (; r < r1; ++r) sum += table[(size_t)r * nd + d];
+  }
+  s_w[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < TS_WAVES; ++w) t += s_w[w][lane];
+    const uint32_t inc = wave_inclusive_add(t);
+    s_col[lane] = inc - t;
+    if (lane == 63) s_tot = inc;
+  }
+  __syncthreads();
+  const uint32_t total = s_tot;
+  const uint32_t excl = lookback_exclusive(status, epoch, blockIdx.x, total, &s_excl);
+  if (!col) return;
+  uint32_t run = excl + s_col[lane];
+  if (wave == 0) {
+    bucket_start[d] = run;
+    if (d == nd - 1) bucket_start[nd] = excl + total;
+  }
+  for (int w = 0; w < wave; ++w) run += s_w[w][lane];   // the slices in front of this one inside the column
+  uint32_t r = r0;
+  for (; r + TS_UNROLL <= r1; r += TS_UNROLL) {
+    uint32_t* p0 = table + (size_t)r * nd + d;
+    uint32_t v[TS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < TS_UNROLL; ++u) v[u] = p0[(size_t)u * nd];
+#pragma unroll
+    for (int u = 0; u < TS_UNROLL; ++u) {
+      p0[(size_t)u * nd] = run;
+      run += v[u];
+    }
+  }
+  for (; r < r1; ++r) {
+    const uint32_t a = table[(size_t)r * nd + d];
+    table[(size_t)r * nd + d] = run;
+    run += a;
   }
 }
 
@@ -1648,6 +1737,63 @@ __global__ void k_bucket_totals(const uint32_t* __restrict__ scanned, uint32_t n
   for (int w = t; w < words; w += (int)blockDim.x) mirror[w] = small[w];
 }
 
+// The scan over the per-bucket totals and k_bucket_totals in ONE launch (round 5): a single-pass look-back scan
+// (2048 entries per workgroup) whose LAST workgroup to finish - a ticket in the scalar block, zeroed with it at the
+// start of the build - forms the totals and copies the scalar block to the pinned mirror.  The table is 36 K entries
+// for 4096 buckets: the device-scope fence in front of the ticket costs nothing here (it did on the 8 MB partition
+// table).
+constexpr int BT_THREADS = 256, BT_IPT = 8, BT_TILE = BT_THREADS * BT_IPT;
+__global__ __launch_bounds__(BT_THREADS) void k_bucket_scan_totals(uint32_t* __restrict__ tot, uint32_t n, uint32_t nb,
+                                                                  uint64_t* __restrict__ status, uint32_t epoch,
+                                                                  uint32_t* __restrict__ small,
+                                                                  uint32_t* __restrict__ mirror, int words) {
+  __shared__ uint32_t s_wave[BT_THREADS / 64];
+  __shared__ uint32_t s_excl, s_last;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t i0 = tile * BT_TILE + threadIdx.x * BT_IPT;
+  uint32_t x[BT_IPT];
+#pragma unroll
+  for (int j = 0; j < BT_IPT; ++j) x[j] = (i0 + j < n) ? tot[i0 + j] : 0u;
+  uint32_t sum = 0;
+#pragma unroll
+  for (int j = 0; j < BT_IPT; ++j) sum += x[j];
+  const uint32_t inc = wave_inclusive_add(sum);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t pre = inc - sum, total = 0;
+#pragma unroll
+  for (int w = 0; w < BT_THREADS / 64; ++w) {
+    if (w < wave) pre += s_wave[w];
+    total += s_wave[w];
+  }
+  const uint32_t excl = lookback_exclusive(status, epoch, tile, total, &s_excl);
+  pre += excl;
+#pragma unroll
+  for (int j = 0; j < BT_IPT; ++j) {
+    if (i0 + j < n) tot[i0 + j] = pre;
+    pre += x[j];
+  }
+  if (tile == gridDim.x - 1 && threadIdx.x == 0) small[SM_BK_TOTAL] = excl + total;
+  // ---- the last workgroup to get here forms the totals ----------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&small[SM_BK_TICKET], 1u) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  auto rd = [&](size_t i) { return __hip_atomic_load(&tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const uint32_t grand = __hip_atomic_load(&small[SM_BK_TOTAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int t = threadIdx.x;
+  if (t == 0) small[SM_NVOX] = rd((size_t)BK_NINT * nb);
+  if (t < BB_LEVELS) small[SM_BK_LEVEL + t] = rd((size_t)(BK_NINT + t + 1) * nb) - rd((size_t)(BK_NINT + t) * nb);
+  if (t == 8) small[SM_NBLOCKS] = grand - rd((size_t)BK_NBLK * nb);
+  __threadfence();
+  __syncthreads();
+  for (int w = t; w < words; w += BT_THREADS)
+    mirror[w] = __hip_atomic_load(&small[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---------------------------------------------------------------------------------------------
 // scheme nodes, position -> leaf, block table: one wavefront per bucket
 // ---------------------------------------------------------------------------------------------
@@ -1682,22 +1828,6 @@ struct NodeParams {
 //            first_child / epoch and its eight children (octree.py:177-191)
 //   blocks   the leafinfo words in storage order: (leaf, pose) block table, and position -> leaf when
 //            the level loop of build.hip is going to resume
-// first_child = -1 (leaf), epoch = 0 for every node of the table (four per thread)
-__global__ __launch_bounds__(256) void k_node_init(int32_t* __restrict__ first_child, int32_t* __restrict__ epoch,
-                                                   int64_t n) {
-  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  // (the node arrays are 16-byte aligned and have room for whole groups of four: nodes_reserve rounds up)
-  if (i + 4 <= n) {
-    *reinterpret_cast<int4*>(first_child + i) = make_int4(-1, -1, -1, -1);
-    *reinterpret_cast<int4*>(epoch + i) = make_int4(0, 0, 0, 0);
-  } else {
-    for (int64_t j = i; j < n; ++j) {
-      first_child[j] = -1;
-      epoch[j] = 0;
-    }
-  }
-}
-
 // packed key (forest.h) of the voxel with linear key lin; root of that voxel in the previous scheme or -1
 __device__ __forceinline__ int32_t old_root_of(const NodeParams& P, uint32_t lin) {
   int64_t qx = 0, qy = 0, qz = 0;
@@ -1752,8 +1882,10 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     const ChunkDesc* __restrict__ ck_desc, const uint32_t* __restrict__ ck_tot, const uint2* __restrict__ ck_of_bucket,
     int32_t* __restrict__ pos_node, uint64_t* __restrict__ vlin,
     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot, uint32_t* __restrict__ blk_start,
-    uint32_t* small) {
+    int32_t* __restrict__ blk_size, uint32_t* small) {
   __shared__ uint32_t s_scr[8];
+  __shared__ unsigned long long s_bal[BB_CAP / 64];   // block-head ballots of the piece, position order
+  __shared__ uint32_t s_hp[256];                      // head positions of one round (pieces beyond BB_CAP)
   // the reference's listing order of the bucket's blocks (P.order_out): preorder keys of its internal nodes,
   // (level, ordinal) -> voxel << 16 | preorder rank, block keys
   __shared__ unsigned long long s_rk[FO_MAX];
@@ -1850,6 +1982,8 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       nd.depth[v] = 0;
       nd.voxel[v] = v;
       nd.parent[v] = -1;
+      nd.first_child[v] = -1;  // (a leaf until the sweep over the internal nodes says otherwise - behind a barrier)
+      nd.epoch[v] = 0;
       nd.old_id[v] = P.old_fc ? old_root_of(P, lin) : -1;
       nd.edge[v] = P.lp.L;
       nd.corner[3 * (int64_t)v] = c0x;
@@ -1891,21 +2025,6 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       e = h;
     }
     const double h = e / 2.0;
-    if (c == 0) {
-      nd.first_child[xid] = cb;
-      int32_t ep = P.cur_epoch;
-      if (P.old_fc) {
-        // the same node (voxel, path) of the previous scheme: internal there -> it keeps its epoch
-        // (k_make_children of build.hip: epoch = old_epoch[old id] when the old node had children)
-        int32_t o = old_root_of(P, bk_vox[3 * ((size_t)vox_stage + vord)]);
-        for (int t = 0; t < l && o >= 0; ++t) {
-          const int32_t ofc = P.old_fc[o];
-          o = ofc >= 0 ? ofc + (int32_t)((prefix >> (3 * (l - 1 - t))) & 7u) : -1;
-        }
-        if (o >= 0 && P.old_fc[o] >= 0) ep = P.old_epoch[o];
-      }
-      nd.epoch[xid] = ep;
-    }
     const int64_t ch = (int64_t)cb + c;
     nd.start[ch] = 0;  // ranges are only meaningful inside the level-synchronous path
     nd.count[ch] = 0;
@@ -1913,11 +2032,39 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     nd.depth[ch] = l + 1;
     nd.voxel[ch] = v;
     nd.parent[ch] = xid;
+    nd.first_child[ch] = -1;  // (k_node_init's job until round 5: every node is written by exactly one owner here)
+    nd.epoch[ch] = 0;
     nd.old_id[ch] = -1;
     nd.edge[ch] = h;
     nd.corner[3 * ch + 0] = cx + ((c & 4) ? h : 0.0);
     nd.corner[3 * ch + 1] = cy + ((c & 2) ? h : 0.0);
     nd.corner[3 * ch + 2] = cz + ((c & 1) ? h : 0.0);
+  }
+  // the internal nodes themselves: first_child / epoch, one thread per record, behind the defaults written above
+  // (a node's defaults come from its parent's lanes or the roots' sweep - other threads of this workgroup)
+  __syncthreads();
+  for (uint32_t j = (uint32_t)tid; j < nrec; j += 256) {
+    const size_t r = 3 * ((size_t)node_stage + j);
+    const uint32_t info = bk_node[r], w1 = bk_node[r + 1], up = bk_node[r + 2];
+    const int l = (int)(w1 >> 28);
+    const uint32_t own = w1 & 0xFFFFu, vord = info >> 18, prefix = info & 0x3FFFFu;
+    const int32_t v = (int32_t)(vbase + vord);
+    const int32_t cb = (int32_t)(V + 8 * (int64_t)(lvl_first(l) + own));
+    const int32_t xid =
+        l == 0 ? v : (int32_t)(V + 8 * (int64_t)(lvl_first(l - 1) + up)) + (int32_t)(prefix & 7u);
+    nd.first_child[xid] = cb;
+    int32_t ep = P.cur_epoch;
+    if (P.old_fc) {
+      // the same node (voxel, path) of the previous scheme: internal there -> it keeps its epoch
+      // (k_make_children of build.hip: epoch = old_epoch[old id] when the old node had children)
+      int32_t o = old_root_of(P, bk_vox[3 * ((size_t)vox_stage + vord)]);
+      for (int t = 0; t < l && o >= 0; ++t) {
+        const int32_t ofc = P.old_fc[o];
+        o = ofc >= 0 ? ofc + (int32_t)((prefix >> (3 * (l - 1 - t))) & 7u) : -1;
+      }
+      if (o >= 0 && P.old_fc[o] >= 0) ep = P.old_epoch[o];
+    }
+    nd.epoch[xid] = ep;
   }
 
   // ---- preorder ranks of the internal nodes (for the block order) -------------------------------------------
@@ -1961,7 +2108,9 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   BB_STAMP(6);  // finish: preorder ranks
   // ---- (leaf, pose) blocks, position -> leaf ------------------------------------------------------------------
   uint32_t brun = 0;
-  auto emit = [&](int f, uint32_t li, bool bhead, uint32_t blk_index) {
+  // (size: points of the block that starts at f = distance to the next head, or to the end of the piece; ~0u: the
+  //  caller fills it in later - pieces beyond BB_CAP)
+  auto emit = [&](int f, uint32_t li, bool bhead, uint32_t blk_index, uint32_t size) {
     const uint32_t dep = (li >> LC_DEPTH) & 7u, ob = li & 0xFFFFu;
     const int32_t leaf =
         dep == 0 ? (int32_t)(vbase + ob)
@@ -1983,6 +2132,7 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       blk_node[bo] = leaf;
       blk_slot[bo] = P.n_poses > 1 ? find_slot_dev(pose_off, P.n_poses, ord_idx[(size_t)start + f]) : 0;
       blk_start[bo] = start + (uint32_t)f;
+      if (size != ~0u) blk_size[bo] = (int32_t)size;
     }
   };
   if (n <= BB_CAP) {
@@ -2001,7 +2151,10 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     for (int r = 0; r < FR; ++r) {
       const uint64_t bal = __ballot((li[r] & LI_BHEAD) != 0u);   // (positions behind n hold 0)
       rk[r] = (uint32_t)__popcll(bal & lt);
-      if (lane == 0) s_hc[r * 4 + wave] = (uint32_t)__popcll(bal);
+      if (lane == 0) {
+        s_hc[r * 4 + wave] = (uint32_t)__popcll(bal);
+        s_bal[r * 4 + wave] = bal;
+      }
     }
     __syncthreads();
     if (tid < 64) {   // exclusive prefix over the FR x 4 counts (position order: round, wave)
@@ -2020,19 +2173,40 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     for (int r = 0; r < FR; ++r) {
       const int f = r * 256 + tid;
       const bool bhead = (li[r] & LI_BHEAD) != 0u;
-      if (f < n && (bhead || P.write_pos)) emit(f, li[r], bhead, s_hc[r * 4 + wave] + rk[r]);
+      uint32_t size = 0;
+      if (bhead) {
+        // the next head: later in this wave's ballot, or the first one of a following ballot; none = end of the piece
+        int q = r * 4 + wave;
+        unsigned long long rest = s_bal[q] & ~lt & ~(1ull << lane);
+        while (rest == 0ull && ++q < FR * 4) rest = s_bal[q];
+        const int next = rest ? q * 64 + (__ffsll((long long)rest) - 1) : n;
+        size = (uint32_t)(next - f);
+      }
+      if (f < n && (bhead || P.write_pos)) emit(f, li[r], bhead, s_hc[r * 4 + wave] + rk[r], size);
     }
     brun = s_hc[64];
   } else {
+    // (a piece beyond BB_CAP: an unsplit voxel, round by round; a block's size is known when the next head shows up)
+    uint32_t open_blk = ~0u, open_pos = 0;   // the last head so far: its block still waits for its size (uniform)
     for (int f0 = 0; f0 < n; f0 += 256) {
       const int f = f0 + tid;
       const uint32_t li = f < n ? leafinfo[(size_t)start + f] : 0u;
       const bool bhead = f < n && (li & LI_BHEAD);
       uint32_t tot;
       const uint32_t pre = block_excl_add(bhead ? 1u : 0u, &tot, s_scr);
-      if (f < n && (bhead || P.write_pos)) emit(f, li, bhead, brun + pre);
+      if (bhead) s_hp[pre] = (uint32_t)f;
+      if (f < n && (bhead || P.write_pos)) emit(f, li, bhead, brun + pre, ~0u);
+      __syncthreads();
+      if (tot > 0) {
+        if (bhead && pre + 1 < tot) blk_size[bbase + brun + pre] = (int32_t)(s_hp[pre + 1] - (uint32_t)f);
+        if (tid == 0 && open_blk != ~0u) blk_size[bbase + open_blk] = (int32_t)(s_hp[0] - open_pos);
+        open_blk = brun + tot - 1;
+        open_pos = s_hp[tot - 1];
+      }
+      __syncthreads();
       brun += tot;
     }
+    if (tid == 0 && open_blk != ~0u) blk_size[bbase + open_blk] = (int32_t)((uint32_t)n - open_pos);
   }
   BB_STAMP(7);  // finish: blocks
   if (want_order) {
@@ -2056,17 +2230,6 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
   for (int l = 0; l < BB_LEVELS; ++l) pre_lvl[l] += lvl_cnt[l];
   __syncthreads();
   }  // pieces
-}
-
-__global__ __launch_bounds__(256) void k_block_sizes_dev(const uint32_t* __restrict__ blk_start,
-                                                         const uint32_t* __restrict__ nb_dev,
-                                                         uint32_t n_alive, int32_t* __restrict__ blk_size) {
-  const int64_t nb = (int64_t)*nb_dev;
-  for (int64_t bq = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; bq < nb;
-       bq += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t e = (bq + 1 < nb) ? blk_start[bq + 1] : n_alive;
-    blk_size[bq] = (int32_t)(e - blk_start[bq]);
-  }
 }
 
 int ceil_log2_u64(uint64_t v) {
@@ -2131,6 +2294,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     if (!hinted && !hinted2) OCTL_TRY(store_compute_bbox(f));
   }
   // every stored point is alive (nothing was removed since the poses were added): the flags are not read
+  if (f->n_alive != f->n_store) OCTL_TRY(alive_ensure(f));
   const uint8_t* alive_p = f->n_alive == f->n_store ? nullptr : f->alive.as<uint8_t>();
   int bb[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ny = 1, nz = 1;
@@ -2220,7 +2384,10 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)n_alive * sizeof(PartRec)));
   if (two_pass) OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[1], (size_t)n_alive * sizeof(PartRec)));
   // [supertile][digit] table | the same digit-major (scanned: the buckets' starts) | bucket bounds (two passes)
-  const size_t tab_elems = (std::max((size_t)nd_a * nst_a, (size_t)nd_b * nst_b) + 15) & ~(size_t)15;
+  const size_t tab_elems = (std::max((size_t)nd_a * nst_a, (size_t)nd_b * nst_b) + 1 + 15) & ~(size_t)15;
+  // the partition table's transposes + scan as ONE launch (k_table_scan), the hint's validation inside it
+  const bool fused_a = !ctx->opt.no_fused_tables && nst_a <= TS_MAX_ROWS;
+  const bool fused_b = !ctx->opt.no_fused_tables && two_pass && nst_b <= TS_MAX_ROWS;
   OCTL_TRY(devbuf_reserve(ctx, f->bk_table, (2 * tab_elems + (two_pass ? nb + 1 : 0) + 16) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, ((size_t)BK_ROWS * nb + 8) * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 12));
@@ -2249,7 +2416,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   if (async_geom) {
     gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
     if (hinted) {
-      hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, hint, gdev);
+      // (normally in place already: k_build_begin copied it with the scalar block)
+      if (!ctx->geom_hint_staged) hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, hint, gdev);
     } else {
       LinParams base = lp;
       base.dshift = s;
@@ -2268,6 +2436,16 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, g2, gdev);
     HIP_TRY(ctx, hipGetLastError());
   }
+  auto table_scan = [&](uint32_t nst, uint32_t nd, uint32_t* bucket_start, int validate) {
+    const unsigned g = (nd + TS_COLS - 1) / TS_COLS;
+    uint64_t* status = nullptr;
+    uint32_t epoch = 0;
+    OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
+    hipLaunchKernelGGL(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, bucket_start, status, epoch,
+                       validate, (const int32_t*)f->bbox_dev.as<int32_t>(), want, lp, gdev);
+    HIP_TRY(ctx, hipGetLastError());
+    return (int)OCTL_OK;
+  };
   {
     KTimer t(ctx, "part_hist");
     if (hinted || hinted2) {
@@ -2277,7 +2455,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                          f->bbox_dev.as<int32_t>());
       HIP_TRY(ctx, hipGetLastError());
       f->bbox_pending = false;  // (the box is on the device now, whatever becomes of the hint)
-      if (hinted)
+      if (fused_a) {
+        // (k_table_scan validates the hint on its way)
+      } else if (hinted)
         hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
                            lp, gdev);
       else
@@ -2293,9 +2473,13 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   }
   {
     KTimer t(ctx, "part_scan");
-    HIP_TRY(ctx, transpose(table, nst_a, nd_a, table_dm));
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd_a * nst_a, nullptr));
-    HIP_TRY(ctx, transpose(table_dm, nd_a, nst_a, table));
+    if (fused_a) {
+      OCTL_TRY(table_scan(nst_a, nd_a, table_dm, hinted ? 1 : (hinted2 ? 2 : 0)));
+    } else {
+      HIP_TRY(ctx, transpose(table, nst_a, nd_a, table_dm));
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd_a * nst_a, nullptr));
+      HIP_TRY(ctx, transpose(table_dm, nd_a, nst_a, table));
+    }
   }
   {
     KTimer t(ctx, "part_scatter");
@@ -2309,7 +2493,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   }
   const PartRec* recs = f->part_xyz[0].as<PartRec>();
   const uint32_t* bstart = table_dm;
-  uint32_t bstride = nst_a;
+  uint32_t bstride = fused_a ? 1u : nst_a;   // (k_table_scan leaves the buckets' starts as a plain array)
   if (two_pass) {
     // second (more significant) digit over the records of the first pass, then the bucket bounds
     lp.dshift = s + bits_a;
@@ -2324,9 +2508,13 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     }
     {
       KTimer t(ctx, "part_scan");
-      HIP_TRY(ctx, transpose(table, nst_b, nd_b, table_dm));
-      OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd_b * nst_b, nullptr));
-      HIP_TRY(ctx, transpose(table_dm, nd_b, nst_b, table));
+      if (fused_b) {
+        OCTL_TRY(table_scan(nst_b, nd_b, table_dm, 0));
+      } else {
+        HIP_TRY(ctx, transpose(table, nst_b, nd_b, table_dm));
+        OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd_b * nst_b, nullptr));
+        HIP_TRY(ctx, transpose(table_dm, nd_b, nst_b, table));
+      }
     }
     {
       KTimer t(ctx, "part_scatter");
@@ -2401,11 +2589,22 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   }
   {
     KTimer t(ctx, "bucket_scan");
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, bk_tot, bk_tot, (int64_t)BK_ROWS * nb, small + SM_BK_TOTAL));
     static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
-    hipLaunchKernelGGL(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_tot, nb,
-                       (const uint32_t*)(small + SM_BK_TOTAL), small, static_cast<uint32_t*>(ctx->small_host),
-                       (int)(64 + (gdev ? sizeof(GeomDev) / 4 : 0)));
+    const int mirror_words = (int)(64 + (gdev ? sizeof(GeomDev) / 4 : 0));
+    if (!ctx->opt.no_fused_tables) {
+      const uint32_t n_tot = (uint32_t)BK_ROWS * nb;
+      const unsigned g = (n_tot + BT_TILE - 1) / BT_TILE;
+      uint64_t* status = nullptr;
+      uint32_t epoch = 0;
+      OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
+      hipLaunchKernelGGL(k_bucket_scan_totals, dim3(g), dim3(BT_THREADS), 0, st, bk_tot, n_tot, nb, status, epoch, small,
+                         static_cast<uint32_t*>(ctx->small_host), mirror_words);
+    } else {
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, bk_tot, bk_tot, (int64_t)BK_ROWS * nb, small + SM_BK_TOTAL));
+      hipLaunchKernelGGL(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_tot, nb,
+                         (const uint32_t*)(small + SM_BK_TOTAL), small, static_cast<uint32_t*>(ctx->small_host),
+                         mirror_words);
+    }
     HIP_TRY(ctx, hipGetLastError());
   }
   uint32_t sm[64];
@@ -2483,9 +2682,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   OCTL_TRY(nodes_reserve(ctx, nt, total));
   OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
   NodePtrs nd = node_ptrs(nt);
-  hipLaunchKernelGGL(k_node_init, dim3((unsigned)ceil_div(ceil_div(total, 4), 256)), dim3(256), 0, st,
-                     nd.first_child, nd.epoch, total);
-  HIP_TRY(ctx, hipGetLastError());
+  // (first_child = -1 / epoch = 0 of every node: written by k_bucket_finish with the node's other fields)
   NodeParams np;
   np.lp = lp;
   np.bstride = bstride;
@@ -2519,12 +2716,10 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), (const ChunkDesc*)ck_desc, (const uint32_t*)ck_tot,
                        (const uint2*)ck_of_bucket, f->pos_node.as<int32_t>(),
                        f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
-                       f->blk_start.as<uint32_t>(), small);
+                       f->blk_start.as<uint32_t>(), f->blk_size.as<int32_t>(), small);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_block_sizes_dev, dim3(1024), dim3(256), 0, st,
-                       (const uint32_t*)f->blk_start.as<uint32_t>(), (const uint32_t*)(small + SM_NBLOCKS),
-                       (uint32_t)n_alive, f->blk_size.as<int32_t>());
-    HIP_TRY(ctx, hipGetLastError());
+    // (block sizes: written by k_bucket_finish itself since round 5 - a block ends where the next head of its piece
+    //  is, or with the piece)
   }
   if (a.old_vcode && a.old_voxels > 0) {
     // a voxel of the previous scheme that has lost all its points keeps its (empty) octree in the reference:

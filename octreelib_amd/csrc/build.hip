@@ -1151,6 +1151,21 @@ struct LevelLoop {
   int xs = 3;
 };
 
+// The first launch of a build (round 5: was the scalar block's copy, k_geom_set and - from octl_forest_clear -
+// k_bbox_reset, three launches): the 32 scalars out of the pinned block, the geometry hint of the context's previous
+// build behind them when the build may run under it (bucket_build.hip decides; staging it costs nothing), and the
+// reset of the forest's voxel box when the build is going to fill it (a cloud taken in place).
+__global__ void k_build_begin(const uint32_t* __restrict__ src, uint32_t* __restrict__ small, int hint_words,
+                              int32_t* __restrict__ bbox) {
+  const int t = threadIdx.x;
+  if (t < 32) small[t] = src[t];
+  if (t >= 32 && t - 32 < hint_words) small[SM_GEOM + t - 32] = src[SM_GEOM + t - 32];
+  if (bbox && t >= 120 && t < 128) {
+    const int a = t - 120;
+    bbox[a] = a < 3 ? (1 << 30) : (a < 6 ? -(1 << 30) : 0);
+  }
+}
+
 static int run_level_loop(LevelLoop& L) {
   octl_forest* f = L.f;
   octl_ctx* ctx = f->ctx;
@@ -1363,8 +1378,25 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     bb[0] = bb[1] = bb[2] = 1 << 30;
     bb[3] = bb[4] = bb[5] = -(1 << 30);
     std::memcpy(ctx->small_host, init, sizeof(init));
-    // (a kernel copy, not a DMA: see octl_copy_from_pinned)
-    OCTL_TRY(octl_copy_from_pinned(ctx, small, ctx->small_host, sizeof(init)));
+    // the hint of the previous build rides along when this build may run under it (a cloud taken in place whose
+    // box is still to be found: bucket_build.hip decides and, if it does, finds the record in place)
+    int hint_words = 0;
+    ctx->geom_hint_staged = false;
+    if (f->bbox_pending && !keep_scheme && ctx->geom_hint_valid && !ctx->geom_hint_two_pass && !ctx->opt.no_geom_hint) {
+      static_assert(sizeof(ctx->geom_hint) == 192, "hint words");
+      std::memcpy(static_cast<char*>(ctx->small_host) + SM_GEOM * 4, ctx->geom_hint, sizeof(ctx->geom_hint));
+      hint_words = (int)(sizeof(ctx->geom_hint) / 4);
+      ctx->geom_hint_staged = true;
+    }
+    int32_t* box = nullptr;
+    if (f->bbox_pending && f->bbox_stale && f->bbox_dev.p) {
+      box = f->bbox_dev.as<int32_t>();
+      f->bbox_stale = false;
+    }
+    // (a kernel copy out of page-locked memory, not a DMA: see octl_copy_from_pinned)
+    hipLaunchKernelGGL(k_build_begin, dim3(1), dim3(128), 0, st, static_cast<const uint32_t*>(ctx->small_host), small,
+                       hint_words, box);
+    HIP_TRY(ctx, hipGetLastError());
   }
 
   // ---- pose offsets / scheme mask on the device ----------------------------------------------
@@ -1552,6 +1584,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     if (pm) OCTL_TRY(forest_prefix_partition(f, pm, &pre_recs, &pre_bstart, &pre_stride, &pre_bad));
   }
   if (N > 0 && !cube_fast) {
+    OCTL_TRY(alive_ensure(f));
     OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));
     OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 4));
     KTimer t(ctx, "keygen");

@@ -128,6 +128,7 @@ struct octl_ctx {
   // box in the same pass (bucket_build.hip: hinted geometry); opaque here
   unsigned char geom_hint[192] = {0};
   bool geom_hint_valid = false;
+  bool geom_hint_staged = false;  // forest_build's first launch has put the hint into the scalar block already
   uint64_t geom_hint_want = 0;
   bool geom_hint_two_pass = false;  // the hint is the geometry of a TWO-pass build (> 4096 buckets, host-side form)
   // the last build found a sparse scene (more than 4096 buckets): the next one skips the single-pass attempt
@@ -136,6 +137,10 @@ struct octl_ctx {
   // cuda_ransac.py:39-41, and a loop over scans hands the same one over for every scan - to a fresh forest each
   // time): kept per CONTEXT so that it is uploaded once
   DevBuf hyp_dev;
+  // launch counters of ransac.hip's preparation: two sets used alternately (a launch zeroes the next one's)
+  DevBuf rs_counters;
+  int rs_parity = 0;
+  bool rs_counters_dirty = false;
   std::vector<double> hyp_host;
   // RCCL (route.hip)
   void* comm = nullptr;
@@ -203,6 +208,8 @@ int octl_ctx_cus(octl_ctx* ctx);
 bool octl_ctx_side_stream(octl_ctx* ctx);
 int octl_exclusive_scan_u32(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n,
                             uint32_t* total_dev);
+// status words + a fresh epoch for one look-back chain of up to `tiles` workgroups (lookback.h)
+int octl_scan_status_acquire(octl_ctx* ctx, int64_t tiles, uint64_t** status, uint32_t* epoch);
 // stable LSD radix sort of (key u64, value u32) pairs on bits [0, key_bits).  keys[0]/vals[0]
 // hold the input; keys[1]/vals[1] are ping-pong space of the same size.  *result (0 or 1)
 // tells which pair of buffers holds the sorted output.

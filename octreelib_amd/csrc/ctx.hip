@@ -328,6 +328,7 @@ void octl_ctx_destroy(octl_ctx* ctx) {
   ctx->user_blocks.clear();
   for (auto& b : ctx->scan_tmp) devbuf_free(b);
   devbuf_free(ctx->hyp_dev);
+  devbuf_free(ctx->rs_counters);
   devbuf_free(ctx->scan_status);
   devbuf_free(ctx->small);
   devbuf_free(ctx->routed_xyz);

@@ -70,6 +70,12 @@ struct octl_forest {
   // voxel bounding box of every point added since the last clear, kept by the ingest kernel
   // (api.hip): int32 x 8 = {min x,y,z, max x,y,z, domain-error flag, point outside a hinted box}
   DevBuf bbox_dev;
+  // octl_forest_clear does not launch anything: the box on the device is STALE until something resets it - the next
+  // ingest / box pass (bbox_ensure), or the first kernel of a build that finds the box itself (k_build_begin)
+  bool bbox_stale = true;
+  // the alive flags of a cloud taken in place (adopted, routed) are not written until something needs them
+  // (alive_ensure: a second pose, a re-placement; apply_mask fills them in its first kernel): every point is alive
+  bool alive_stale = false;
 
   // scheme of the last build
   NodeTable nodes[2];
@@ -152,6 +158,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 int store_adopt(octl_forest* f, DevBuf& src, int64_t n, bool* adopted);
 // api.hip: fold the whole store into bbox_dev (clears bbox_pending); copy a borrowed store into the forest's own block
 int store_compute_bbox(octl_forest* f);
+// api.hip: the box on the device is valid (reset if octl_forest_clear left it stale) / the alive flags are written
+int bbox_ensure(octl_forest* f);
+int alive_ensure(octl_forest* f);
 int store_materialize(octl_forest* f);
 int ransac_check_table(octl_ctx* ctx, const double* hyp, int32_t H, int32_t k);
 // build.hip: (re)build the (leaf, pose) block table from pos_node / ord_idx

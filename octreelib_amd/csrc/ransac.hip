@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "forest.h"
+#include "lookback.h"
 
 namespace {
 
@@ -1450,6 +1451,93 @@ __global__ __launch_bounds__(256) void k_block_desc(const int32_t* __restrict__ 
   if (bins[threadIdx.x]) atomicAdd(&counters[RC_BINS + threadIdx.x], bins[threadIdx.x]);
 }
 
+
+// Sizes in batch order, their prefix sums (the blocks' virtual starts, cuda_ransac.py:64-66) and the descriptors in
+// ONE launch (round 5; before: k_block_sizes_in_order, a scan, k_block_desc): a workgroup takes 2048 consecutive batch
+// entries, eight per thread, and the workgroups' totals are chained by decoupled look-back.  The launch counters it
+// adds to were zeroed by the PREVIOUS launch's k_block_scatter (two sets per context, used alternately).
+constexpr int BP_PER_THREAD = 8;
+__global__ __launch_bounds__(256) void k_block_prepare(const int32_t* __restrict__ order,
+                                                       const uint32_t* __restrict__ start,
+                                                       const int32_t* __restrict__ size, int64_t nb, int64_t n_points,
+                                                       int cap, int k, BlockDesc* __restrict__ desc,
+                                                       uint32_t* __restrict__ big_list, uint32_t* __restrict__ counters,
+                                                       RansacOut out, uint64_t* __restrict__ status, uint32_t epoch) {
+  __shared__ uint32_t bins[256];
+  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_excl;
+  bins[threadIdx.x] = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BP_PER_THREAD;
+  int32_t phys[BP_PER_THREAD + 1];
+  int32_t nn[BP_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r <= BP_PER_THREAD; ++r) {
+    const int64_t b = b0 + r;
+    phys[r] = b < nb ? (order ? order[b] : (int32_t)b) : -1;
+  }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int r = 0; r < BP_PER_THREAD; ++r) {
+    nn[r] = phys[r] >= 0 ? size[phys[r]] : 0;
+    sum += (uint32_t)nn[r];
+  }
+  uint32_t inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t pre = inc - sum, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) pre += s_wave[w];
+    total += s_wave[w];
+  }
+  pre += lookback_exclusive(status, epoch, blockIdx.x, total, &s_excl);
+#pragma unroll
+  for (int r = 0; r < BP_PER_THREAD; ++r) {
+    const int64_t b = b0 + r;
+    if (phys[r] < 0) break;
+    BlockDesc d;
+    d.pstart = start[phys[r]];
+    d.n = nn[r];
+    d.vstart = (int64_t)pre;
+    pre += (uint32_t)nn[r];
+    uint32_t sp = d.n > 0 ? d.pstart + (uint32_t)d.n - 1u : d.pstart;
+    if (phys[r + 1] >= 0) {
+      sp = start[phys[r + 1]];
+    } else if (!order) {
+      // stand-alone operator: the cloud may continue past the last block (cuda_ransac.py:43-81)
+      const int64_t e = (int64_t)d.pstart + d.n;
+      if (e < n_points) sp = (uint32_t)e;
+    }
+    d.pspill = sp;
+    d.pad[0] = 0;
+    d.pad[1] = (uint32_t)b;  // batch entry: index of the per-block outputs
+    d.pad[2] = 0;
+    desc[b] = d;
+    if (d.n < k) {
+      // finished right here: the reference's kernel returns at once, the mask stays False (cuda_ransac.py:96-97)
+      for (int i = 0; i < d.n; ++i) out.mask[(int64_t)d.pstart + i] = 0;
+      if (out.plane) {
+        out.plane[4 * b + 0] = 0.f; out.plane[4 * b + 1] = 0.f;
+        out.plane[4 * b + 2] = 0.f; out.plane[4 * b + 3] = 0.f;
+      }
+      if (out.count) out.count[b] = 0;
+      if (out.index) out.index[b] = -1;
+    } else if (d.n > cap) {
+      big_list[atomicAdd(&counters[RC_BIG], 1u)] = (uint32_t)b;
+    } else {
+      atomicAdd(&bins[d.n], 1u);
+    }
+  }
+  __syncthreads();
+  if (bins[threadIdx.x]) atomicAdd(&counters[RC_BINS + threadIdx.x], bins[threadIdx.x]);
+}
+
 // Sample positions of every hypothesis for every block size that occurs in the launch (k <= 6, sizes up to 255):
 // one 8-byte entry per (size, hypothesis) - positions in bytes 0..5, the risky-draw bits (sample_index_cached) in
 // bits 16..21 of the second word.  k_ransac<..., PT = true> reads its entries a batch ahead of the plane fits.
@@ -1482,7 +1570,10 @@ __global__ __launch_bounds__(256) void k_block_scatter(const BlockDesc* __restri
                                                        uint32_t* __restrict__ counters,
                                                        BlockDesc* __restrict__ sdesc, unsigned n_scatter,
                                                        const double* __restrict__ hyp, int H,
-                                                       uint2* __restrict__ tab) {
+                                                       uint2* __restrict__ tab, uint32_t* __restrict__ next_counters) {
+  // (the counter set of the context's NEXT launch: its previous users finished before this launch started)
+  if (next_counters && blockIdx.x == gridDim.x - 1)
+    for (int w = threadIdx.x; w < RC_WORDS; w += blockDim.x) next_counters[w] = 0;
   if (blockIdx.x >= n_scatter) {
     const unsigned parts = (unsigned)(H + 255) / 256u;
     const unsigned id = blockIdx.x - n_scatter;
@@ -1574,27 +1665,54 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   BlockDesc* sdesc = reinterpret_cast<BlockDesc*>(base + off_s);
   uint32_t* big_list = reinterpret_cast<uint32_t*>(base + off_b);
   uint32_t* counters = reinterpret_cast<uint32_t*>(base + off_c);
+  // fused preparation: the launch counters live in the CONTEXT, two sets used alternately - a launch's
+  // k_block_scatter zeroes the set of the next one, so that no launch starts with a clearing kernel
+  const bool fused = !ctx->opt.no_fused_tables;
+  uint32_t* next_counters = nullptr;
+  if (fused) {
+    if (!ctx->rs_counters.p || ctx->rs_counters_dirty) {
+      // (first launch of the context, or a launch that failed between its two preparation kernels)
+      OCTL_TRY(devbuf_reserve(ctx, ctx->rs_counters, (size_t)2 * RC_WORDS * 4));
+      HIP_TRY(ctx, hipMemsetAsync(ctx->rs_counters.p, 0, (size_t)2 * RC_WORDS * 4, st));
+      ctx->rs_parity = 0;
+    }
+    counters = ctx->rs_counters.as<uint32_t>() + (size_t)ctx->rs_parity * RC_WORDS;
+    next_counters = ctx->rs_counters.as<uint32_t>() + (size_t)(ctx->rs_parity ^ 1) * RC_WORDS;
+    ctx->rs_parity ^= 1;
+    ctx->rs_counters_dirty = true;   // until this launch's k_block_scatter (which zeroes the other set) is enqueued
+  }
   uint2* pos_tab = use_tab ? reinterpret_cast<uint2*>(base + off_t) : nullptr;
   const int threads = (H <= 64) ? 64 : (H <= 256 ? 256 : RS_BIG_THREADS);
   RansacOut out{mask_dev, plane_dev, count_dev, index_dev};
   {
     KTimer t(ctx, "ransac_prepare");
-    const unsigned g = (unsigned)ceil_div(nb, 256);
-    hipLaunchKernelGGL(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp, counters);
-    HIP_TRY(ctx, hipGetLastError());
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, tmp, tmp, nb, nullptr));
-    hipLaunchKernelGGL(k_block_desc, dim3((unsigned)ceil_div(nb, 256 * BD_PER_THREAD)), dim3(256), 0, st, order_dev,
-                       blk_start, blk_size,
-                       (const uint32_t*)tmp, nb, n_points, any_k ? 0 : threads - 1, (int)k, desc, big_list,
-                       counters, out);
-    HIP_TRY(ctx, hipGetLastError());
+    if (fused) {
+      const unsigned g = (unsigned)ceil_div(nb, 256 * BP_PER_THREAD);
+      uint64_t* status = nullptr;
+      uint32_t epoch = 0;
+      OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
+      hipLaunchKernelGGL(k_block_prepare, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size, nb, n_points,
+                         any_k ? 0 : threads - 1, (int)k, desc, big_list, counters, out, status, epoch);
+      HIP_TRY(ctx, hipGetLastError());
+    } else {
+      const unsigned g = (unsigned)ceil_div(nb, 256);
+      hipLaunchKernelGGL(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp, counters);
+      HIP_TRY(ctx, hipGetLastError());
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, tmp, tmp, nb, nullptr));
+      hipLaunchKernelGGL(k_block_desc, dim3((unsigned)ceil_div(nb, 256 * BD_PER_THREAD)), dim3(256), 0, st, order_dev,
+                         blk_start, blk_size,
+                         (const uint32_t*)tmp, nb, n_points, any_k ? 0 : threads - 1, (int)k, desc, big_list,
+                         counters, out);
+      HIP_TRY(ctx, hipGetLastError());
+    }
     // (size-class starts and the position table are made by k_block_scatter's own workgroups)
     const unsigned n_scatter = (unsigned)ceil_div(nb, 256 * BS_PER_THREAD);
     const unsigned n_table = use_tab ? 256u * (unsigned)ceil_div(H, 256) : 0u;
     hipLaunchKernelGGL(k_block_scatter, dim3(n_scatter + n_table), dim3(256), 0, st,
                        (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc, n_scatter, hyp_dev,
-                       (int)H, pos_tab);
+                       (int)H, pos_tab, next_counters);
     HIP_TRY(ctx, hipGetLastError());
+    ctx->rs_counters_dirty = false;
   }
   const int cus = octl_ctx_cus(ctx);
   KTimer t(ctx, "ransac");

@@ -12,9 +12,11 @@
 //     the epoch makes words of earlier scans read as "not yet published": no reset launch.
 // Point-sized inputs use the three-kernel version (reduce / recurse / down-sweep), see
 // octl_exclusive_scan_u32.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
+#include "lookback.h"
 
 namespace {
 
@@ -114,12 +116,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_down(const uint32_t* in, 
   }
 }
 
-constexpr uint32_t ST_AGGREGATE = 1, ST_PREFIX = 2;
-
-__device__ __forceinline__ uint64_t st_pack(uint32_t epoch, uint32_t flag, uint32_t value) {
-  return ((uint64_t)((epoch << 2) | flag) << 32) | value;
-}
-
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(
     const uint32_t* in, uint32_t* out, int64_t n, uint64_t* __restrict__ status, uint32_t epoch,
     uint32_t* total_out) {
@@ -134,45 +130,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(
   for (int j = 0; j < SCAN_IPT; ++j) s += x[j];
   uint32_t total;
   uint32_t pre = block_exclusive_scan(s, &total, lds);
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&status[tile], st_pack(epoch, tile == 0 ? ST_PREFIX : ST_AGGREGATE, total),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t excl = 0;
-  if (tile > 0) {
-    if (threadIdx.x < 64) {
-      const int lane = threadIdx.x;
-      int64_t look = (int64_t)tile - 1;  // highest predecessor not yet accounted for
-      for (;;) {
-        const int64_t t = look - lane;   // lanes past tile 0 see "prefix 0"
-        uint32_t flag = ST_PREFIX, value = 0;
-        if (t >= 0) {
-          for (;;) {
-            const uint64_t w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t hi = (uint32_t)(w >> 32);
-            flag = hi & 3u;
-            value = (uint32_t)w;
-            if ((hi >> 2) == epoch && flag != 0) break;
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        const unsigned long long has_prefix = __ballot(flag == ST_PREFIX);
-        const int first = __ffsll((long long)has_prefix) - 1;  // >= 0: lanes past tile 0 report a prefix
-        uint32_t c = (has_prefix == 0 || lane <= first) ? value : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-        excl += c;
-        if (has_prefix) break;
-        look -= 64;
-      }
-      if (lane == 0) {
-        s_excl = excl;
-        __hip_atomic_store(&status[tile], st_pack(epoch, ST_PREFIX, excl + total), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    __syncthreads();
-    excl = s_excl;
-  }
+  const uint32_t excl = lookback_exclusive(status, epoch, tile, total, &s_excl);
   if (total_out && threadIdx.x == 0 && tile == gridDim.x - 1) *total_out = excl + total;
   pre += excl;
   const int64_t i0 = base + (int64_t)threadIdx.x * SCAN_IPT;
@@ -197,15 +155,11 @@ int scan_single_pass(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n
                      uint32_t* total_dev) {
   const int64_t nb = ceil_div(n, SCAN_TILE);
   if (nb >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_INVALID, "scan: input too large");
-  const size_t need = (size_t)nb * 8;  // status u64[nb]
-  if (ctx->scan_status.cap < need || ctx->scan_epoch >= (1u << 30) - 1) {
-    if (ctx->scan_status.cap < need) OCTL_TRY(devbuf_reserve(ctx, ctx->scan_status, need + need / 2));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->scan_status.p, 0, ctx->scan_status.cap, ctx->stream));
-    ctx->scan_epoch = 0;
-  }
-  const uint32_t epoch = ++ctx->scan_epoch;  // 0 = "never published"
+  uint64_t* status = nullptr;
+  uint32_t epoch = 0;
+  OCTL_TRY(octl_scan_status_acquire(ctx, nb, &status, &epoch));
   hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in,
-                     out, n, ctx->scan_status.as<uint64_t>(), epoch, total_dev);
+                     out, n, status, epoch, total_dev);
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
 }
@@ -233,6 +187,21 @@ int scan_rec(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n, uint32
 }
 
 }  // namespace
+
+// Status words for ONE look-back chain of up to `tiles` tiles (scan.hip's own kernel and the fused table kernels of
+// bucket_build.hip / ransac.hip / api.hip that carry a look-back of their own): a fresh epoch of the context's status
+// array - words of earlier chains read as "not yet published", so nothing is reset between launches.
+int octl_scan_status_acquire(octl_ctx* ctx, int64_t tiles, uint64_t** status, uint32_t* epoch) {
+  const size_t need = (size_t)std::max<int64_t>(tiles, 1) * 8;  // status u64[tiles]
+  if (ctx->scan_status.cap < need || ctx->scan_epoch >= (1u << 30) - 1) {
+    if (ctx->scan_status.cap < need) OCTL_TRY(devbuf_reserve(ctx, ctx->scan_status, need + need / 2));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->scan_status.p, 0, ctx->scan_status.cap, ctx->stream));
+    ctx->scan_epoch = 0;
+  }
+  *epoch = ++ctx->scan_epoch;  // 0 = "never published"
+  *status = ctx->scan_status.as<uint64_t>();
+  return OCTL_OK;
+}
 
 int octl_exclusive_scan_u32(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n,
                             uint32_t* total_dev) {

@@ -9,8 +9,8 @@ for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r["Stream_Id"]))
 ev.sort()
-# a step starts with the reset of the forest's voxel box (octl_forest_clear + add_pose_adopt -> k_bbox_reset)
-first = "k_bbox_reset" if any(e[2].startswith("k_bbox_reset") for e in ev) else "k_part_hist<true, true>"
+# a step starts with the first launch of its build (k_build_begin; before round 5: the reset of the forest's voxel box)
+first = next((k for k in ("k_build_begin", "k_bbox_reset") if any(e[2].startswith(k) for e in ev)), "k_part_hist<true, true>")
 starts = [i for i, e in enumerate(ev) if e[2].startswith(first)]
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 3   # which step, counted from the end of the trace
 a, b = starts[-back], starts[-back + 1]
