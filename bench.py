@@ -170,6 +170,9 @@ def parse_args():
     ap.add_argument("--workload", choices=["headline", "c4", "c5shard"], default="headline",
                     help="profiling only (tools/profile_round.sh): run ONE secondary workload alone and print its "
                          "JSON - c4 = BASELINE config 4, c5shard = one rank's 125 M-point shard of config 5")
+    ap.add_argument("--plan", action="store_true",
+                    help="print what `--gpus N` (default 8) is going to need - host RAM, HBM, generation and run time "
+                         "against the driver's 600 s - and exit; touches no GPU and starts no rank")
     ap.add_argument("--shard-of", type=int, default=0, metavar="R",
                     help="one GPU: generate only the points rank 0 of R would own after routing (a "
                          "rank's shard of the R-rank scene, e.g. --shard-of 8 --points-per-rank 125000000 "
@@ -651,8 +654,60 @@ def run_c5_shard(ctx, k_split, timed, n_shard=C5_POINTS_PER_RANK, ranks=8, steps
     return out
 
 
+def plan(args):
+    """What the N-GPU run is going to need, from the sizes of the run alone (no GPU is touched, no rank started):
+    printed as one JSON object on stdout."""
+    world = args.gpus if args.gpus > 1 else 8
+    strong = args.scaling == "strong"
+    if strong:
+        n_local = (args.points if args.points else 10_000_000) // world
+    else:
+        n_local = args.points if args.points else (C5_POINTS_PER_RANK if world == 8 else 10_000_000)
+    n_clouds = args.clouds if args.clouds else (3 if n_local <= 20_000_000 else 1)
+    cloud_gb = n_local * 24 / 1e9
+    # device bytes per point of one rank's step (routed store + global indices 32, send buffers 32, partition records
+    # 32 per pass - two passes above 10.5 M points -, bucket staging 28, leaf-ordered arrays + block table 48, their
+    # compaction targets 44, mask 1, RANSAC descriptors ~8) + the resident clouds
+    two_pass = n_local > 10_500_000
+    per_point = 32 + 32 + (64 if two_pass else 32) + 28 + 48 + 44 + 1 + 8
+    hbm_gb = n_local * per_point / 1e9 + n_clouds * cloud_gb
+    chunks = max(1, (n_local + GEN_CHUNK - 1) // GEN_CHUNK)
+    chunk_gb = min(n_local, GEN_CHUNK) * 24 / 1e9
+    threads = min(6, os.cpu_count() or 1)
+    # a generator thread holds ~4 arrays of its chunk's size while it works; finished chunks wait for their upload
+    host_gb_rank = chunk_gb * (4 * threads + min(chunks, 2 * threads))
+    gen_s_per_cloud = 0.9 * chunks / max(1, min(threads, (os.cpu_count() or 1) // max(1, world)))   # ~0.9 s per 10 M-point chunk and thread
+    ms_step = 4.5 * n_local / 1e7 * (1.0 if n_local <= 10_500_000 else 1.0)   # ~4.5 ms per 10 M points (RANSAC bound)
+    timed_s = (args.steps + args.warmup + 12) * ms_step / 1e3
+    secondaries_s = 0.0 if args.no_secondary else 24 * 4.5e-3 + 2 * (0.9 + 1.0)   # 10 M / rank + strong series: two more clouds
+    import_s, comm_s = 90.0, 20.0
+    wall = import_s + comm_s + n_clouds * gen_s_per_cloud + timed_s + secondaries_s
+    out = {
+        "plan_for": f"python bench.py --gpus {world} --steps {args.steps} --warmup {args.warmup}"
+                    + (" --scaling strong" if strong else ""),
+        "ranks": world, "points_per_rank": n_local, "total_points": n_local * world, "resident_clouds_per_rank": n_clouds,
+        "host": {"cpu_count_here": os.cpu_count(), "generator_threads_per_rank": threads,
+                 "ram_GB_per_rank_peak_estimate": round(host_gb_rank, 1),
+                 "ram_GB_all_ranks_peak_estimate": round(host_gb_rank * world, 1)},
+        "device": {"hbm_GB_per_rank_estimate": round(hbm_gb, 1), "hbm_GB_available": 288,
+                   "bytes_per_point_estimate": per_point},
+        "exchange": {"bytes_per_point": 32, "GB_sent_to_peers_per_rank_and_step": round(n_local * 32 * (world - 1) / world / 1e9, 2),
+                     "MB_per_peer_message": round(n_local * 32 / world / 1e6, 1)},
+        "seconds": {"import_torch_and_library_first_time": import_s, "communicator_and_first_collective": comm_s,
+                    "host_generation": round(n_clouds * gen_s_per_cloud, 1), "timed_region_and_instrumented_passes": round(timed_s, 1),
+                    "secondary_series": round(secondaries_s, 1), "wall_estimate": round(wall, 1), "driver_budget": 600},
+        "fits_driver_budget": bool(wall < 600),
+        "note": "estimates from the run's sizes and the rates measured on one-GPU boxes in rounds 3-5 (generation "
+                "~0.9 s per 10 M-point chunk and thread, ~4.5 ms of step per 10 M points); no GPU was touched",
+    }
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.plan:
+        plan(args)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
 
@@ -1089,6 +1144,46 @@ def main():
 
     # ---- N > 1: what the exchange moved and how even the shards are (max / mean points per rank) ----
     exchange = None
+    topology = None
+    if dist is not None or args.route:
+        # what the COMMUNICATOR and the devices say about the run (not the launcher's environment)
+        cnt, urank, ver = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        rctx.check(lib.octl_comm_info(rctx.handle, C.byref(cnt), C.byref(urank), C.byref(ver)))
+        bus = C.create_string_buffer(32)
+        uu = (C.c_uint8 * 16)()
+        ncu = C.c_int32(0)
+        ctx.check(lib.octl_device_identity(ctx.handle, bus, C.cast(uu, C.c_void_p), C.byref(ncu)))
+        me = {"launcher_rank": rank, "rccl_user_rank": int(urank.value), "rccl_ranks": int(cnt.value),
+              "rccl_version": int(ver.value), "pci_bus_id": bus.value.decode(), "device_uuid": bytes(uu).hex(),
+              "compute_units": int(ncu.value), "host": socket.gethostname(),
+              "sent_to_rank_last_step": [int(v) for v in wl.send_counts[:world]]}
+        allt = [me]
+        if dist is not None:
+            allt = [None] * world
+            dist.all_gather_object(allt, me)
+        devices = {(t["host"], t["pci_bus_id"], t["device_uuid"]) for t in allt}
+        rehearsal = os.environ.get("OCTL_BENCH_DEVICE") is not None or world == 1
+        topology = {
+            "rccl_ranks": allt[0]["rccl_ranks"], "rccl_version": allt[0]["rccl_version"],
+            "launcher_world_size": world, "ranks": [{k: v for k, v in t.items() if k != "sent_to_rank_last_step"} for t in allt],
+            "distinct_devices": len(devices),
+            "one_device_per_rank": bool(len(devices) == world),
+            "rank_order_agrees": bool(all(t["rccl_user_rank"] in (-1, t["launcher_rank"]) for t in allt)),
+            "alltoall_bytes_rank_to_peer_last_step": [[32 * v for v in t["sent_to_rank_last_step"]] for t in allt],
+            "rehearsal_on_one_device": bool(rehearsal and world > 1),
+        }
+        bad = []
+        if any(t["rccl_ranks"] not in (-1, world) for t in allt):
+            bad.append(f"the communicator has {allt[0]['rccl_ranks']} ranks, the launcher started {world}")
+        if not topology["rank_order_agrees"]:
+            bad.append("a rank's number in the communicator differs from the launcher's")
+        if len(devices) != world and not rehearsal:
+            bad.append(f"{world} ranks share {len(devices)} devices")
+        if bad:
+            if rank == 0:
+                print("bench.py: the run is not what the line would claim: " + "; ".join(bad), file=sys.stderr)
+                print(json.dumps({"error": bad, "topology": topology}), file=sys.stderr)
+            sys.exit(3)
     if dist is not None:
         mine = {"n_recv": int(wl.n_recv.value),
                 "sent_to_peers": int(wl.send_counts.sum() - wl.send_counts[rank]),
@@ -1224,6 +1319,9 @@ def main():
                             "fully instrumented for a few steps behind the timed region (an event pair costs "
                             "~10 us of pipeline, a dozen per step would be 2 % of the step)",
         }
+        if topology is not None:
+            out["rccl_ranks"] = topology["rccl_ranks"]
+            out["topology"] = topology
         if exchange is not None:
             out["imbalance"] = exchange["imbalance_max_over_mean"]
             out["exchange"] = exchange

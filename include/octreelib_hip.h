@@ -324,6 +324,13 @@ int octl_dev_copy_bandwidth(octl_ctx* ctx, int64_t bytes, int iters, double* byt
  * everything an operation allocates.  Process-wide.                                                     */
 int octl_debug_fail_alloc(int64_t nth, int64_t* seen);
 
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclGetVersion; -1 where the collective
+ * library does not export the query), and the device behind a context (PCI bus id as "dddd:bb:dd.f", the 16-byte
+ * UUID of its properties, its compute units): a multi-GPU run prints these so that its line proves what ran where.
+ * The reference has no counterpart (no distributed code).                                            */
+int octl_comm_info(octl_ctx* ctx, int32_t* n_ranks, int32_t* user_rank, int32_t* version);
+int octl_device_identity(octl_ctx* ctx, char pci_bus_id[32], uint8_t uuid[16], int32_t* cus);
+
 /* Diagnostic switches of a context (tests and A/B runs compare code paths: "NO_BUCKET_BUILD", "BUCKET_POINTS",
  * "SYNC_GEOM", "NO_GEOM_HINT", "NO_EXACT_DIGITS", "NO_FAST_ORDER", "NO_BUCKET_HISTORY", "NO_CUBE_FAST",
  * "NO_CUBE_PREFIX", "CUBE_PREFIX_MIN", "NO_INCREMENTAL", "ROUTE_SELF_SENDRECV", "TRACE_BUILD", "SCAN",

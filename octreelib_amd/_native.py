@@ -94,6 +94,8 @@ SIGNATURES = {
     "octl_comm_unique_id": (C.c_int, [_p]),
     "octl_comm_init": (C.c_int, [_p, _i32, _i32, _p]),
     "octl_comm_destroy": (C.c_int, [_p]),
+    "octl_comm_info": (C.c_int, [_p, _pi32, _pi32, _pi32]),
+    "octl_device_identity": (C.c_int, [_p, C.c_char_p, _p, _pi32]),
     "octl_route_points": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _f64, _pi64, _p]),
     "octl_forest_add_pose_routed": (C.c_int, [_p, _pi32]),
     "octl_forest_add_pose_routed_from": (C.c_int, [_p, _p, _pi32]),

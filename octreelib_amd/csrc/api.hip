@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_mask_scan(
     const int32_t* __restrict__ blk_node, const int32_t* __restrict__ blk_slot, int32_t* __restrict__ blk_node2,
     int32_t* __restrict__ blk_slot2, uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2,
     uint64_t* __restrict__ st_tiles, uint64_t* __restrict__ st_kept, uint64_t* __restrict__ st_ids, uint32_t epoch,
-    uint32_t* __restrict__ totals, uint8_t* __restrict__ alive_fill) {
+    uint32_t* __restrict__ mirror, uint32_t seq, uint8_t* __restrict__ alive_fill) {
   __shared__ uint32_t s_w[2][4];
   __shared__ uint32_t s_excl;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256) void k_mask_scan(
     const uint32_t excl = lookback_exclusive(st_tiles, epoch, tile, total, &s_excl);
     if (threadIdx.x == 0) {
       tile_off[tile] = excl;
-      if (tile == nt - 1) totals[0] = excl + total;
+      if (tile == nt - 1) {
+        mirror[MIRROR_MASK_TOTALS] = excl + total;
+        mirror_publish(mirror, MIRROR_FLAG_MASK0, seq);
+      }
     }
     return;
   }
@@ -289,7 +292,10 @@ __global__ __launch_bounds__(256) void k_mask_scan(
   const uint32_t ex_c = lookback_exclusive(st_kept, epoch, bw, tot_c, &s_excl);
   __syncthreads();
   const uint32_t ex_e = lookback_exclusive(st_ids, epoch, bw, tot_e, &s_excl);
-  if (threadIdx.x == 0 && bw == gridDim.x - nt - 1) totals[1] = ex_e + tot_e;
+  if (threadIdx.x == 0 && bw == gridDim.x - nt - 1) {
+    mirror[MIRROR_MASK_TOTALS + 1] = ex_e + tot_e;
+    mirror_publish(mirror, MIRROR_FLAG_MASK1, seq);
+  }
   if (b < nb && c) {
     const uint32_t id = ex_e + pe;
     blk_node2[id] = blk_node[b];
@@ -373,12 +379,15 @@ __global__ __launch_bounds__(256) void k_blk_compact(
     const uint32_t* __restrict__ raw, const uint32_t* __restrict__ scanned, const uint32_t* __restrict__ grand_total,
     int64_t nt, int64_t nb, const int32_t* __restrict__ blk_node,
     const int32_t* __restrict__ blk_slot, int32_t* __restrict__ blk_node2, int32_t* __restrict__ blk_slot2,
-    uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2, uint32_t* __restrict__ totals) {
+    uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2, uint32_t* __restrict__ mirror,
+    uint32_t seq) {
   const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t base_kept = scanned[nt], base_id = scanned[nt + nb];
   if (b == 0) {
-    totals[0] = base_id - base_kept;      // kept points
-    totals[1] = *grand_total - base_id;   // non-empty blocks
+    mirror[MIRROR_MASK_TOTALS] = base_id - base_kept;          // kept points
+    mirror[MIRROR_MASK_TOTALS + 1] = *grand_total - base_id;   // non-empty blocks
+    mirror_publish(mirror, MIRROR_FLAG_MASK0, seq);
+    mirror_publish(mirror, MIRROR_FLAG_MASK1, seq);
   }
   if (b >= nb) return;
   const uint32_t c = raw[nt + b];
@@ -588,7 +597,10 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     uint32_t* raw = f->flags.as<uint32_t>();
     uint32_t* scanned = reinterpret_cast<uint32_t*>(static_cast<char*>(f->flags.p) + o_out);
     const uint8_t* mask = f->mask.as<uint8_t>();
-    const bool fused = !ctx->opt.no_fused_tables;
+    // the fused form chains its workgroups by look-back: beyond ~1000 of them the chain costs more than the
+    // separate scan (10 M points: 65 us against 35)
+    const bool fused = !ctx->opt.no_fused_tables && nt + 2 * ceil_div(nb, 256) <= 1024;
+    const uint32_t wait_seq = octl_wait_next_seq(ctx);
     if (!fused) {
       OCTL_TRY(alive_ensure(f));
       hipLaunchKernelGGL(k_blk_kept, dim3((unsigned)nt + grid_for(nb)), dim3(256), 0, st, mask, n, (uint32_t)nt, raw,
@@ -623,7 +635,7 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
                          (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
                          f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
                          f->blk_size2.as<int32_t>(), status, status + nt, status + nt + nbw, epoch,
-                         static_cast<uint32_t*>(ctx->small_host), fill);
+                         static_cast<uint32_t*>(ctx->small_host), wait_seq, fill);
       HIP_TRY(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)scanned, n,
@@ -635,13 +647,16 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
                          (const uint32_t*)scanned, (const uint32_t*)(small + 22), nt, nb,
                          (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
                          f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
-                         f->blk_size2.as<int32_t>(), static_cast<uint32_t*>(ctx->small_host));
+                         f->blk_size2.as<int32_t>(), static_cast<uint32_t*>(ctx->small_host), wait_seq);
       HIP_TRY(ctx, hipGetLastError());
     }
-    // (the two totals are written into the pinned mirror by the kernel itself: no copy in front of the wait)
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // (the two totals and their flags are written into the pinned mirror by the kernels themselves: the host polls
+    //  for them - the compaction of the points may still be running when this returns, everything behind it is
+    //  ordered by the stream)
+    const int flags[2] = {MIRROR_FLAG_MASK0, MIRROR_FLAG_MASK1};
+    OCTL_TRY(octl_wait_mirror_flags(ctx, flags, 2, wait_seq, 200 + n / 20000));
     uint32_t res[2];
-    std::memcpy(res, ctx->small_host, 8);
+    std::memcpy(res, static_cast<uint32_t*>(ctx->small_host) + MIRROR_MASK_TOTALS, 8);
     std::swap(f->ord_idx, f->ord_idx2);
     std::swap(f->xyz_ord, f->xyz_ord2);
     std::swap(f->blk_node, f->blk_node2);
@@ -765,6 +780,7 @@ void octl_forest_destroy(octl_forest* f) {
 
 int octl_forest_clear(octl_forest* f) {
   if (!f) return OCTL_E_INVALID;
+  f->max_block_hint = INT64_MAX;
   f->bbox_stale = true;   // (nothing is launched: whoever fills the box next resets it first)
   f->alive_stale = false;
   if (f->store_borrowed) {  // back to the forest's own block; the caller's buffer is the caller's again
@@ -1114,6 +1130,7 @@ int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* bl
   f->mask_valid = false;
   f->fast_order_valid = false;
   // the voxel box of the new points is not known (rows may have left their cubes): the next build finds it
+  f->max_block_hint = INT64_MAX;
   f->bbox_stale = true;
   f->alive_stale = false;   // (written above)
   f->bbox_pending = total > 0;
@@ -1342,7 +1359,7 @@ int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
   OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
                          f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>(), nb,
                          f->rs_hyp.as<double>(), H, k, threshold, f->mask.as<uint8_t>(), plane_d,
-                         count_d, index_d, nullptr, f->rs_scratch));
+                         count_d, index_d, nullptr, f->rs_scratch, f->max_block_hint));
   if (plane) HIP_TRY(ctx, hipMemcpyAsync(plane, plane_d, (size_t)nb * 16, hipMemcpyDeviceToHost, st));
   if (best_count) HIP_TRY(ctx, hipMemcpyAsync(best_count, count_d, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
   if (best_index) HIP_TRY(ctx, hipMemcpyAsync(best_index, index_d, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
@@ -1474,11 +1491,13 @@ int octl_ransac_evaluate(octl_ctx* ctx, const double* point_cloud, int64_t M,
     if (best_count_out) EV_TRY(devbuf_reserve(ctx, count, (size_t)B * 4));
     if (best_index_out) EV_TRY(devbuf_reserve(ctx, index, (size_t)B * 4));
     EV_HIP(hipStreamSynchronize(st));
+    int64_t max_size = 0;   // (the caller's block sizes are host data: the largest one is known)
+    for (int64_t b = 0; b < B; ++b) max_size = std::max<int64_t>(max_size, block_sizes[b]);
     EV_TRY(ransac_launch(ctx, xyz.as<double>(), M, starts_d.as<uint32_t>(), sizes.as<int32_t>(),
                          nullptr, B, hyp.as<double>(), H, k, threshold, mask.as<uint8_t>(),
                          planes_out ? plane.as<float>() : nullptr,
                          best_count_out ? count.as<int32_t>() : nullptr,
-                         best_index_out ? index.as<int32_t>() : nullptr, nullptr, scratch));
+                         best_index_out ? index.as<int32_t>() : nullptr, nullptr, scratch, max_size));
     if (planes_out) EV_HIP(hipMemcpyAsync(planes_out, plane.p, (size_t)B * 16, hipMemcpyDeviceToHost, st));
     if (best_count_out) EV_HIP(hipMemcpyAsync(best_count_out, count.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     if (best_index_out) EV_HIP(hipMemcpyAsync(best_index_out, index.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));

@@ -144,8 +144,10 @@ __device__ __forceinline__ void geom_from_box(const int32_t* bb, bool domain_err
       while (lw < 64 && (1ull << lw) < want) ++lw;
       int s = lr - lw;
       s = s < 0 ? 0 : (s > 12 ? 12 : s);
-      if (((R - 1) >> s) + 1 > (uint64_t)(1u << 12)) {
-        o.reason = GEOM_RETRY;  // a sparse scene: more than 4096 buckets, two passes
+      // (the host sizes its tables for max(64, want) buckets - at most 4096 - see bucket_build_impl)
+      const uint64_t cap = want < 64 ? 64 : (want > (uint64_t)(1u << 12) ? (uint64_t)(1u << 12) : want);
+      if (((R - 1) >> s) + 1 > cap) {
+        o.reason = GEOM_RETRY;  // a sparse scene: more buckets than the single pass has room for
       } else {
         o.lp.minx = o.bb[0];
         o.lp.miny = o.bb[1];
@@ -1392,7 +1394,7 @@ __global__ __launch_bounds__(BB_THREADS, BB_WGS) void k_bucket_build(
     const GeomDev* __restrict__ G,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
     uint32_t* __restrict__ leafinfo, uint32_t* __restrict__ bk_vox, uint32_t* __restrict__ bk_node,
-    uint32_t* __restrict__ bk_tot, uint32_t* __restrict__ small) {
+    uint32_t* __restrict__ bk_tot, uint32_t* __restrict__ small, int chunks_later) {
   if (G) {
     if (!G->valid) return;
     P.lp = G->lp;
@@ -1415,7 +1417,13 @@ __global__ __launch_bounds__(BB_THREADS, BB_WGS) void k_bucket_build(
   const uint32_t start = bstart[(size_t)b * P.bstride];
   const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   const int n = (int)(end - start);
-  if (n > BB_CAP) return;  // k_bucket_plan / k_bucket_chunks
+  if (n > BB_CAP) {
+    // k_bucket_plan / k_bucket_chunks: running beside this kernel already, or (chunks_later) launched by the host
+    // when the totals tell it that there are such buckets - their rows are zero until the chunks add to them
+    if (chunks_later && tid < BK_ROWS) bk_tot[(size_t)tid * P.nb + b] = 0u;
+    if (tid == 0) atomicAdd(&small[SM_BK_OVERFULL], 1u);
+    return;
+  }
   if (tid < BK_ROWS) s_tot[tid] = 0;
   if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
   if (n == 0) {
@@ -1724,7 +1732,7 @@ __global__ __launch_bounds__(BB_THREADS, BB_ONE_READ ? 1 : 2) void k_bucket_chun
 //  32-bit words of `small` from its start, so that no copy stands between the kernel and the host's wait)
 __global__ void k_bucket_totals(const uint32_t* __restrict__ scanned, uint32_t nb,
                                 const uint32_t* __restrict__ grand_total, uint32_t* __restrict__ small,
-                                uint32_t* __restrict__ mirror, int words) {
+                                uint32_t* __restrict__ mirror, int words, uint32_t seq) {
   const int t = threadIdx.x;
   if (t == 0) small[SM_NVOX] = scanned[(size_t)BK_NINT * nb];
   if (t < BB_LEVELS) {
@@ -1735,6 +1743,9 @@ __global__ void k_bucket_totals(const uint32_t* __restrict__ scanned, uint32_t n
   __threadfence();
   __syncthreads();
   for (int w = t; w < words; w += (int)blockDim.x) mirror[w] = small[w];
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) mirror_publish(mirror, MIRROR_FLAG_BUILD, seq);
 }
 
 // The scan over the per-bucket totals and k_bucket_totals in ONE launch (round 5): a single-pass look-back scan
@@ -1743,17 +1754,18 @@ __global__ void k_bucket_totals(const uint32_t* __restrict__ scanned, uint32_t n
 // for 4096 buckets: the device-scope fence in front of the ticket costs nothing here (it did on the 8 MB partition
 // table).
 constexpr int BT_THREADS = 256, BT_IPT = 8, BT_TILE = BT_THREADS * BT_IPT;
-__global__ __launch_bounds__(BT_THREADS) void k_bucket_scan_totals(uint32_t* __restrict__ tot, uint32_t n, uint32_t nb,
+__global__ __launch_bounds__(BT_THREADS) void k_bucket_scan_totals(const uint32_t* __restrict__ raw,
+                                                                  uint32_t* __restrict__ tot, uint32_t n, uint32_t nb,
                                                                   uint64_t* __restrict__ status, uint32_t epoch,
                                                                   uint32_t* __restrict__ small,
-                                                                  uint32_t* __restrict__ mirror, int words) {
+                                                                  uint32_t* __restrict__ mirror, int words, uint32_t seq) {
   __shared__ uint32_t s_wave[BT_THREADS / 64];
   __shared__ uint32_t s_excl, s_last;
   const uint32_t tile = blockIdx.x;
   const uint32_t i0 = tile * BT_TILE + threadIdx.x * BT_IPT;
   uint32_t x[BT_IPT];
 #pragma unroll
-  for (int j = 0; j < BT_IPT; ++j) x[j] = (i0 + j < n) ? tot[i0 + j] : 0u;
+  for (int j = 0; j < BT_IPT; ++j) x[j] = (i0 + j < n) ? raw[i0 + j] : 0u;
   uint32_t sum = 0;
 #pragma unroll
   for (int j = 0; j < BT_IPT; ++j) sum += x[j];
@@ -1781,6 +1793,9 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_scan_totals(uint32_t* __r
   if (threadIdx.x == 0) s_last = (atomicAdd(&small[SM_BK_TICKET], 1u) == gridDim.x - 1) ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
+  // (the ticket is ready for the next launch: a build whose hinted geometry is rejected runs this kernel twice
+  //  between two resets of the scalar block)
+  if (threadIdx.x == 0) small[SM_BK_TICKET] = 0u;
   __threadfence();
   auto rd = [&](size_t i) { return __hip_atomic_load(&tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const uint32_t grand = __hip_atomic_load(&small[SM_BK_TOTAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1792,6 +1807,9 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_scan_totals(uint32_t* __r
   __syncthreads();
   for (int w = t; w < words; w += BT_THREADS)
     mirror[w] = __hip_atomic_load(&small[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence_system();
+  __syncthreads();
+  if (t == 0) mirror_publish(mirror, MIRROR_FLAG_BUILD, seq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2261,6 +2279,16 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
   *done = 0;
+  // (a rejected hint and a sparse scene make this function call itself, at most twice in a row by design: anything
+  //  deeper is a bug that would otherwise end as a stack overflow)
+  struct Depth {
+    int& d;
+    explicit Depth(int& x) : d(x) { ++d; }
+    ~Depth() { --d; }
+  };
+  static thread_local int retry_depth = 0;
+  Depth guard(retry_depth);
+  if (retry_depth > 4) return octl_set_error(ctx, OCTL_E_STATE, "bucket build: the geometry retries do not terminate");
   const int64_t N = f->n_store, n_alive = f->n_alive;
   // (OCTL_NO_BUCKET_BUILD: tests compare this path with the level-synchronous one)
   if (n_alive <= 0 || !f->bbox_dev.p || ctx->opt.no_bucket_build) return OCTL_OK;
@@ -2299,7 +2327,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   int bb[6] = {0, 0, 0, 0, 0, 0};
   uint64_t ny = 1, nz = 1;
   int s = 0;
-  uint32_t nb = (uint32_t)PT_BINS;
+  // (single pass with the geometry formed on the device: tables and grids for max(64, want) buckets - geom_from_box
+  //  holds the geometry to that - instead of always 4096: a 100 k-point scan has 64)
+  uint32_t nb = async_geom ? (uint32_t)std::max<uint64_t>(64, want) : (uint32_t)PT_BINS;
   bool two_pass = false;
   if (!async_geom) {
     if (hinted2) {
@@ -2389,7 +2419,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   const bool fused_a = !ctx->opt.no_fused_tables && nst_a <= TS_MAX_ROWS;
   const bool fused_b = !ctx->opt.no_fused_tables && two_pass && nst_b <= TS_MAX_ROWS;
   OCTL_TRY(devbuf_reserve(ctx, f->bk_table, (2 * tab_elems + (two_pass ? nb + 1 : 0) + 16) * 4));
-  OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, ((size_t)BK_ROWS * nb + 8) * 4));
+  // per-bucket totals: raw | scanned (apart: buckets beyond 4096 points add theirs later, and the scan runs again)
+  const size_t tot_elems = (((size_t)BK_ROWS * nb + 8) + 15) & ~(size_t)15;
+  OCTL_TRY(devbuf_reserve(ctx, f->bk_tot, 2 * tot_elems * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_vox, (size_t)n_alive * 12));
   OCTL_TRY(devbuf_reserve(ctx, f->bk_node, (size_t)n_alive * 12));
   OCTL_TRY(devbuf_reserve(ctx, f->leafinfo, (size_t)n_alive * 4));
@@ -2546,6 +2578,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   bp.n_poses = n_poses;
   bp.all_scheme = a.scheme_dev ? 0 : 1;
   uint32_t* bk_tot = f->bk_tot.as<uint32_t>();
+  uint32_t* bk_scan = bk_tot + tot_elems;
   // chunk plan of the buckets with more than BB_CAP points: [descriptors CK_CAP | totals CK_CAP x BK_ROWS | range per bucket]
   const size_t ck_off_tot = (size_t)CK_CAP * sizeof(ChunkDesc);
   const size_t ck_off_bkt = ck_off_tot + (size_t)CK_CAP * BK_ROWS * 4;
@@ -2553,63 +2586,78 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   ChunkDesc* ck_desc = reinterpret_cast<ChunkDesc*>(f->bk_chunks.p);
   uint32_t* ck_tot = reinterpret_cast<uint32_t*>(static_cast<char*>(f->bk_chunks.p) + ck_off_tot);
   uint2* ck_of_bucket = reinterpret_cast<uint2*>(static_cast<char*>(f->bk_chunks.p) + ck_off_bkt);
+  // The over-full buckets (plan, then one workgroup per chunk) and the normal ones (k_bucket_build) touch disjoint
+  // buckets, rows of bk_tot and output ranges.  An even scene has none of the former: k_bucket_build counts them
+  // (SM_BK_OVERFULL) and the host launches the two chunk kernels only when the totals say that there are some - then
+  // the totals are scanned again (round 5; before: two empty launches per build).  A context whose PREVIOUS build had
+  // such buckets (a skewed scene, scan after scan) launches them right away on its side stream, NEXT TO
+  // k_bucket_build, as round 4 did: a chunk is one workgroup's whole bucket build, worth hiding.
+  const bool chunks_beside = ctx->had_chunks;
+  auto launch_chunks = [&](hipStream_t on) {
+    hipLaunchKernelGGL(k_bucket_plan, dim3(nb), dim3(BB_THREADS), 0, on, recs, bstart, bp, (const GeomDev*)gdev, ck_desc,
+                       ck_of_bucket, bk_tot, small);
+    HIP_TRY(ctx, hipGetLastError());
+    // one workgroup per chunk; the list's length is on the device, the grid strides over it
+    hipLaunchKernelGGL(k_bucket_chunks, dim3((unsigned)std::min<int64_t>(2 * (int64_t)cus, CK_CAP)), dim3(BB_THREADS), 0, on,
+                       recs, bstart, bp, (const GeomDev*)gdev, (const ChunkDesc*)ck_desc, ck_tot,
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
+                       f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(), bk_tot, small);
+    HIP_TRY(ctx, hipGetLastError());
+    return (int)OCTL_OK;
+  };
   {
     KTimer t(ctx, "bucket_build");
-    // The over-full buckets (plan, then one workgroup per chunk) and the normal ones (k_bucket_build) touch disjoint
-    // buckets, rows of bk_tot and output ranges: the first two kernels go to the context's side stream, NEXT TO
-    // k_bucket_build, and the context's stream waits for them before the totals are scanned (an evenly filled scene
-    // hides two empty launches, a skewed one the chunks' latency: each is ONE workgroup's whole bucket build).
     hipStream_t side = st;
     bool on_side = false;
 #if BB_SIDE_STREAM
-    if (octl_ctx_side_stream(ctx) && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
+    if (chunks_beside && octl_ctx_side_stream(ctx) && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
         hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
       side = ctx->self_stream;
       on_side = true;
     }
 #endif
-    hipLaunchKernelGGL(k_bucket_plan, dim3(nb), dim3(BB_THREADS), 0, side, recs, bstart, bp, (const GeomDev*)gdev, ck_desc,
-                       ck_of_bucket, bk_tot, small);
-    HIP_TRY(ctx, hipGetLastError());
-    // one workgroup per chunk; the list's length is on the device, the grid strides over it
-    hipLaunchKernelGGL(k_bucket_chunks, dim3((unsigned)std::min<int64_t>(2 * (int64_t)cus, CK_CAP)), dim3(BB_THREADS), 0, side,
-                       recs, bstart, bp, (const GeomDev*)gdev, (const ChunkDesc*)ck_desc, ck_tot,
-                       (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
-                       f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(), bk_tot, small);
-    HIP_TRY(ctx, hipGetLastError());
+    if (chunks_beside) OCTL_TRY(launch_chunks(side));
     hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
-                       bk_tot, small);
+                       bk_tot, small, chunks_beside ? 0 : 1);
     HIP_TRY(ctx, hipGetLastError());
     if (on_side) {
       HIP_TRY(ctx, hipEventRecord(ctx->self_done, side));
       HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->self_done, 0));
     }
   }
-  {
-    KTimer t(ctx, "bucket_scan");
-    static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
-    const int mirror_words = (int)(64 + (gdev ? sizeof(GeomDev) / 4 : 0));
-    if (!ctx->opt.no_fused_tables) {
-      const uint32_t n_tot = (uint32_t)BK_ROWS * nb;
-      const unsigned g = (n_tot + BT_TILE - 1) / BT_TILE;
-      uint64_t* status = nullptr;
-      uint32_t epoch = 0;
-      OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
-      hipLaunchKernelGGL(k_bucket_scan_totals, dim3(g), dim3(BT_THREADS), 0, st, bk_tot, n_tot, nb, status, epoch, small,
-                         static_cast<uint32_t*>(ctx->small_host), mirror_words);
-    } else {
-      OCTL_TRY(octl_exclusive_scan_u32(ctx, bk_tot, bk_tot, (int64_t)BK_ROWS * nb, small + SM_BK_TOTAL));
-      hipLaunchKernelGGL(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_tot, nb,
-                         (const uint32_t*)(small + SM_BK_TOTAL), small, static_cast<uint32_t*>(ctx->small_host),
-                         mirror_words);
-    }
-    HIP_TRY(ctx, hipGetLastError());
-  }
+  static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
+  const int mirror_words = (int)(64 + (gdev ? sizeof(GeomDev) / 4 : 0));
   uint32_t sm[64];
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  std::memcpy(sm, ctx->small_host, sizeof(sm));
+  // raw totals -> scanned totals + the build's scalars in the pinned mirror; the host polls for them
+  auto scan_totals = [&]() {
+    const uint32_t wait_seq = octl_wait_next_seq(ctx);
+    {
+      KTimer t(ctx, "bucket_scan");
+      if (!ctx->opt.no_fused_tables) {
+        const uint32_t n_tot = (uint32_t)BK_ROWS * nb;
+        const unsigned g = (n_tot + BT_TILE - 1) / BT_TILE;
+        uint64_t* status = nullptr;
+        uint32_t epoch = 0;
+        OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
+        hipLaunchKernelGGL(k_bucket_scan_totals, dim3(g), dim3(BT_THREADS), 0, st, (const uint32_t*)bk_tot, bk_scan, n_tot,
+                           nb, status, epoch, small, static_cast<uint32_t*>(ctx->small_host), mirror_words, wait_seq);
+      } else {
+        OCTL_TRY(octl_exclusive_scan_u32(ctx, bk_tot, bk_scan, (int64_t)BK_ROWS * nb, small + SM_BK_TOTAL));
+        hipLaunchKernelGGL(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_scan, nb,
+                           (const uint32_t*)(small + SM_BK_TOTAL), small, static_cast<uint32_t*>(ctx->small_host),
+                           mirror_words, wait_seq);
+      }
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    // (the totals kernel writes the scalars and then its flag into the pinned mirror)
+    const int flag = MIRROR_FLAG_BUILD;
+    OCTL_TRY(octl_wait_mirror_flags(ctx, &flag, 1, wait_seq, 200 + n_alive / 20000));
+    std::memcpy(sm, ctx->small_host, sizeof(sm));
+    return (int)OCTL_OK;
+  };
+  OCTL_TRY(scan_totals());
   if (hinted2) {
     GeomDev g;
     std::memcpy(&g, static_cast<char*>(ctx->small_host) + SM_GEOM * 4, sizeof(g));
@@ -2665,6 +2713,16 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // the packed voxel keys of everything that follows (k_bucket_finish's walk over the previous scheme, the
   // incremental insertion, the host's voxel list) are relative to the origin this fixes on the first build
   if (f->mode == 0) OCTL_TRY(forest_fix_origin(f, bb));
+  // buckets beyond 4096 points that nobody has built yet: plan + chunks now, then the totals once more
+  const bool overfull = sm[SM_BK_OVERFULL] > 0;
+  if (overfull && !chunks_beside && !sm[SM_BK_FLAGS]) {
+    {
+      KTimer t(ctx, "bucket_build");
+      OCTL_TRY(launch_chunks(st));
+    }
+    OCTL_TRY(scan_totals());
+  }
+  ctx->had_chunks = overfull;
   if (sm[SM_BK_FLAGS]) return OCTL_OK;  // some bucket / voxel does not fit: the caller runs the general path
   const int64_t V = sm[SM_NVOX];
   int64_t n_int = 0;
@@ -2710,11 +2768,11 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   {
     KTimer t(ctx, "bucket_nodes");
     hipLaunchKernelGGL(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd, np, bstart,
-                       (const uint32_t*)f->bk_tot.as<uint32_t>(), (const uint32_t*)(small + SM_BK_TOTAL),
+                       (const uint32_t*)bk_scan, (const uint32_t*)(small + SM_BK_TOTAL),
                        (const uint32_t*)f->leafinfo.as<uint32_t>(), (const uint32_t*)f->ord_idx.as<uint32_t>(),
                        (const uint32_t*)f->bk_vox.as<uint32_t>(), (const uint32_t*)f->bk_node.as<uint32_t>(),
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), (const ChunkDesc*)ck_desc, (const uint32_t*)ck_tot,
-                       (const uint2*)ck_of_bucket, f->pos_node.as<int32_t>(),
+                       (const uint2*)((overfull || chunks_beside) ? ck_of_bucket : nullptr), f->pos_node.as<int32_t>(),
                        f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
                        f->blk_start.as<uint32_t>(), f->blk_size.as<int32_t>(), small);
     HIP_TRY(ctx, hipGetLastError());

@@ -1362,6 +1362,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
                           "there and raises IndexError when such a leaf is subdivided (octree.py:94-98)");
   if (max_depth <= 0) max_depth = 63;
   f->fast_order_valid = false;  // (the block table is about to change)
+  f->max_block_hint = INT64_MAX;
   BuildTrace trace;
   trace.on = ctx->opt.trace_build != 0;
   uint32_t* small = ctx->small.as<uint32_t>();
@@ -1544,6 +1545,9 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       f->store_dirty = false;
       f->vcode_valid = false;
       f->fast_order_valid = geom.order_done && pending == 0;
+      // (count-driven from ALL poses: a leaf holds at most K points; what the level loop finished for the voxels left
+      //  behind obeys the same rule)
+      if (all_scheme && K >= 0) f->max_block_hint = K;
       f->built_store = f->n_store;
       f->built_poses = n_poses;
       f->append_only = true;

@@ -20,6 +20,7 @@ enum {
   SM_BK_TOTAL = 26,     // bucket build: grand total of the scanned bucket table
   SM_BK_TODO = 27,      // bucket build: voxels left as one leaf for the level loop of build.hip
   SM_BK_MISSING = 28,
+  SM_BK_OVERFULL = 18,  // bucket build: buckets with more than 4096 points (they are built in chunks of whole voxels)
   SM_BK_TICKET = 17,    // bucket build: workgroups of k_bucket_scan_totals that have finished (the last one forms the totals)
   SM_CK_COUNT = 29,     // bucket build: chunks of the buckets with more than 4096 points (k_bucket_plan)   // bucket build over a previous scheme: voxels of that scheme without points now
   SM_BK_LEVEL = 40,     // bucket build: internal nodes per level (7 words)

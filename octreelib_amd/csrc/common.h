@@ -78,6 +78,7 @@ struct OctlOptions {
   int64_t trace_build = 0;         // OCTL_TRACE_BUILD: host wall time between the phases of forest_build on stderr
   int64_t scan_mode = 0;           // OCTL_SCAN: 1 = single-pass scan always, 3 = three-kernel scan always
   int64_t no_fused_tables = 0;     // OCTL_NO_FUSED_TABLES: the small table chains as separate launches (A/B)
+  int64_t no_spin_wait = 0;        // OCTL_NO_SPIN_WAIT: every host wait is a hipStreamSynchronize (A/B)
 };
 // name (without the OCTL_ prefix or with it) -> field; nullptr when there is no such switch
 int64_t* octl_option_field(OctlOptions& o, const char* name);
@@ -133,6 +134,9 @@ struct octl_ctx {
   bool geom_hint_two_pass = false;  // the hint is the geometry of a TWO-pass build (> 4096 buckets, host-side form)
   // the last build found a sparse scene (more than 4096 buckets): the next one skips the single-pass attempt
   bool geom_sparse = false;
+  // the last bucket build had buckets beyond 4096 points (a skewed scene): the next one launches the chunk kernels
+  // beside k_bucket_build right away instead of learning about them from the totals (two launches an even scene saves)
+  bool had_chunks = false;
   // the hypothesis table of the last octl_forest_ransac_all on this context (CudaRansac draws it once per object,
   // cuda_ransac.py:39-41, and a loop over scans hands the same one over for every scan - to a fresh forest each
   // time): kept per CONTEXT so that it is uploaded once
@@ -140,6 +144,7 @@ struct octl_ctx {
   // launch counters of ransac.hip's preparation: two sets used alternately (a launch zeroes the next one's)
   DevBuf rs_counters;
   int rs_parity = 0;
+  uint32_t wait_seq = 0;   // sequence numbers of the mirror flags (octl_wait_mirror_flags)
   bool rs_counters_dirty = false;
   std::vector<double> hyp_host;
   // RCCL (route.hip)
@@ -153,6 +158,21 @@ struct octl_ctx {
 };
 
 int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...);
+// Host waits for a few scalars, not for the stream: the kernel that produces them writes them into the pinned mirror
+// (ctx->small_host) and then the launch's sequence number into flag word(s) of that mirror; the host polls the flags
+// for up to budget_us and only then falls back to hipStreamSynchronize.  (A stream synchronisation returns 15-25 us
+// after the kernel has finished - interrupt, wake-up - which is a tenth of a 100 k-point scan.)  Counted as a host
+// wait like a synchronisation.  Words of the mirror: MIRROR_FLAG_BUILD (bucket totals), MIRROR_FLAG_MASK0/1
+// (apply_mask: kept points, surviving blocks), MIRROR_MASK_TOTALS (the two totals themselves).
+enum { MIRROR_MASK_TOTALS = 992, MIRROR_FLAG_BUILD = 1000, MIRROR_FLAG_MASK0 = 1001, MIRROR_FLAG_MASK1 = 1002 };
+uint32_t octl_wait_next_seq(octl_ctx* ctx);
+int octl_wait_mirror_flags(octl_ctx* ctx, const int* words, int n_words, uint32_t seq, int64_t budget_us);
+// device side: publish `seq` behind everything this thread (and, through the barriers in front of the call, its
+// workgroup) has written to the mirror
+__device__ __forceinline__ void mirror_publish(uint32_t* mirror, int word, uint32_t seq) {
+  __threadfence_system();
+  __hip_atomic_store(&mirror[word], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // the compute stream waits (on the device, no host wait) for the uploads enqueued so far whose destination
 // overlaps [p, p + bytes); p == nullptr: for all of them
 int ctx_wait_uploads(octl_ctx* ctx, const void* p = nullptr, size_t bytes = 0);

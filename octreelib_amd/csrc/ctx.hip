@@ -1,4 +1,5 @@
 // Context, error plumbing, device buffers, kernel timers, small device utilities.
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 
@@ -28,7 +29,7 @@ const OptName kOptions[] = {
     {"NO_CUBE_PREFIX", &OctlOptions::no_cube_prefix},       {"CUBE_PREFIX_MIN", &OctlOptions::cube_prefix_min},
     {"NO_INCREMENTAL", &OctlOptions::no_incremental},       {"ROUTE_SELF_SENDRECV", &OctlOptions::route_self_sendrecv},
     {"TRACE_BUILD", &OctlOptions::trace_build},             {"SCAN", &OctlOptions::scan_mode},
-    {"NO_FUSED_TABLES", &OctlOptions::no_fused_tables},
+    {"NO_FUSED_TABLES", &OctlOptions::no_fused_tables},     {"NO_SPIN_WAIT", &OctlOptions::no_spin_wait},
 };
 }  // namespace
 
@@ -65,6 +66,40 @@ extern "C" int octl_debug_set_option(octl_ctx* ctx, const char* name, int64_t va
 extern "C" int octl_debug_host_syncs(uint64_t* count) {
   if (!count) return OCTL_E_INVALID;
   *count = g_octl_host_syncs.load(std::memory_order_relaxed);
+  return OCTL_OK;
+}
+
+uint32_t octl_wait_next_seq(octl_ctx* ctx) {
+  if (++ctx->wait_seq == 0) ++ctx->wait_seq;
+  return ctx->wait_seq;
+}
+
+int octl_wait_mirror_flags(octl_ctx* ctx, const int* words, int n_words, uint32_t seq, int64_t budget_us) {
+  volatile uint32_t* m = static_cast<volatile uint32_t*>(ctx->small_host);
+  auto all_there = [&]() {
+    for (int i = 0; i < n_words; ++i)
+      if (m[words[i]] != seq) return false;
+    return true;
+  };
+  if (!ctx->opt.no_spin_wait && budget_us > 0) {
+    g_octl_host_syncs.fetch_add(1, std::memory_order_relaxed);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int spin = 0; spin < 64; ++spin) {
+        if (all_there()) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          return OCTL_OK;
+        }
+        __builtin_ia32_pause();
+      }
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget_us)
+        break;
+    }
+    g_octl_host_syncs.fetch_sub(1, std::memory_order_relaxed);  // (the synchronisation below counts itself)
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!all_there())
+    return octl_set_error(ctx, OCTL_E_HIP, "a kernel did not publish its results (mirror flag %d)", words[0]);
   return OCTL_OK;
 }
 

@@ -111,6 +111,10 @@ struct octl_forest {
   DevBuf blk_eval;   // u8 [n_blocks] block was evaluated since the last apply_mask
   bool mask_valid = false;
 
+  // an upper bound of the points a block can hold, when the host knows one (a count-driven build from all poses
+  // leaves at most K points per leaf, and masks / filters only remove points): the RANSAC launch skips the instances
+  // for block sizes that cannot occur.  INT64_MAX: unknown (late poses, installed schemes, replaced contents ...)
+  int64_t max_block_hint = INT64_MAX;
   DevBuf rs_scratch, rs_order, rs_hyp, rs_plane, rs_count, rs_index;  // ransac staging
   // the blocks in the reference's listing order as the bucket build left them (one pose, one epoch):
   // forest_reference_order takes this instead of computing it; any change of the blocks invalidates it
@@ -151,7 +155,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                   const uint32_t* blk_start, const int32_t* blk_size, const int32_t* order_dev,
                   int64_t nb, const double* hyp_dev, int32_t H, int32_t k, double thr,
                   uint8_t* mask_dev, float* plane_dev, int32_t* count_dev, int32_t* index_dev,
-                  uint8_t* evaluated_dev, DevBuf& scratch);
+                  uint8_t* evaluated_dev, DevBuf& scratch, int64_t max_block = INT64_MAX);
 // the hypothesis table must hold draws from [0, 1) (np.random.random, cuda_ransac.py:39-41): anything
 // else would index outside the block in the sampling arithmetic (cuda_ransac.py:103-107)
 // api.hip: an empty store takes over a library-owned device buffer (swap) instead of copying it

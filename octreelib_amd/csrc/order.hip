@@ -411,7 +411,7 @@ static int ransac_all_impl(octl_forest* f, int32_t poses_per_batch, const int32_
     OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
                            f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>(), f->n_blocks,
                            ctx->hyp_dev.as<double>(), H, k, threshold, f->mask.as<uint8_t>(), nullptr,
-                           nullptr, nullptr, nullptr, f->rs_scratch));
+                           nullptr, nullptr, nullptr, f->rs_scratch, f->max_block_hint));
     return OCTL_OK;
   }
   // one evaluate() per batch of poses_per_batch consecutive poses (grid.py:149-157,194)
@@ -423,7 +423,7 @@ static int ransac_all_impl(octl_forest* f, int32_t poses_per_batch, const int32_
       OCTL_TRY(ransac_launch(ctx, f->xyz_ord.as<double>(), f->n_ord, f->blk_start.as<uint32_t>(),
                              f->blk_size.as<int32_t>(), f->rs_order.as<int32_t>() + off, nbatch,
                              ctx->hyp_dev.as<double>(), H, k, threshold, f->mask.as<uint8_t>(),
-                             nullptr, nullptr, nullptr, nullptr, f->rs_scratch));
+                             nullptr, nullptr, nullptr, nullptr, f->rs_scratch, f->max_block_hint));
     off += nbatch;
   }
   return OCTL_OK;

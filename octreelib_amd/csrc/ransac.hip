@@ -1640,7 +1640,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                   const uint32_t* blk_start, const int32_t* blk_size, const int32_t* order_dev,
                   int64_t nb, const double* hyp_dev, int32_t H, int32_t k, double thr,
                   uint8_t* mask_dev, float* plane_dev, int32_t* count_dev, int32_t* index_dev,
-                  uint8_t* evaluated_dev, DevBuf& scratch) {
+                  uint8_t* evaluated_dev, DevBuf& scratch, int64_t max_block) {
   (void)evaluated_dev;
   if (nb <= 0) return OCTL_OK;
   if (H < 1 || H > 1024) return octl_set_error(ctx, OCTL_E_INVALID, "H must be in [1, 1024]");
@@ -1723,7 +1723,11 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   hipStream_t side = st;
   bool on_side = false;
 #if RS_SIDE_STREAM
-  if (!any_k && H > 256 && octl_ctx_side_stream(ctx) && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
+  // (max_block: no block of the launch holds more points - the instances for larger blocks are not launched at all)
+  const bool need_small = max_block >= RS_TINY_THREADS, need_mid = max_block >= RS_SMALL_THREADS,
+             need_big = any_k || max_block >= threads;
+  if (!any_k && H > 256 && (need_small || need_big) && octl_ctx_side_stream(ctx) &&
+      hipEventRecord(ctx->self_gate, st) == hipSuccess &&
       hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
     side = ctx->self_stream;
     on_side = true;
@@ -1766,11 +1770,13 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 #if RS_SMALL_THREADS > 0 && RS_SMALL_THREADS < RS_BIG_THREADS
 #define OCTL_RANSAC_SPLIT(KT, ABL)                                                                               \
   do {                                                                                                           \
-    OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                                   \
-                      counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                    \
+    if (need_mid)                                                                                                \
+      OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                                 \
+                        counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                  \
     HIP_TRY(ctx, hipGetLastError());                                                                             \
-    OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                     \
-                      counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0), side);      \
+    if (need_small)                                                                                              \
+      OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                   \
+                        counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0), side);    \
     OCTL_RANSAC_TINY(KT, ABL);                                                                                   \
   } while (0)
 #else
@@ -1804,7 +1810,9 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
                      dim3(THREADS), 0, side, xyz_dev, (const BlockDesc*)desc,                   \
                      (const uint32_t*)big_list, (const uint32_t*)(counters + RC_BIG), hyp_dev,  \
                      H, k, thr, out)
-  if (any_k) {
+  if (!need_big) {
+    // (no block of the launch can be that large)
+  } else if (any_k) {
     if (H <= 64) OCTL_RANSAC_BIG(64, 1, -1);
     else if (H <= 256) OCTL_RANSAC_BIG(256, 1, -1);
     else OCTL_RANSAC_BIG(RS_BIG_THREADS, RS_BIG_HPL, -1);

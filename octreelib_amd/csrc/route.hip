@@ -33,6 +33,10 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // optional (octl_comm_info: what the communicator itself says about the run)
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 
 RcclApi g_rccl;
@@ -63,6 +67,9 @@ const char* rccl_load() {
   RCCL_SYM(GroupEnd, "ncclGroupEnd")
   RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RCCL_SYM
+  g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(h, "ncclCommCount"));
+  g_rccl.CommUserRank = reinterpret_cast<decltype(g_rccl.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
+  g_rccl.GetVersion = reinterpret_cast<decltype(g_rccl.GetVersion)>(dlsym(h, "ncclGetVersion"));
   g_rccl.handle = h;
   return nullptr;
 }
@@ -269,6 +276,46 @@ int octl_comm_init(octl_ctx* ctx, int32_t n_ranks, int32_t rank,
   ctx->comm = comm;
   ctx->n_ranks = n_ranks;
   ctx->rank = rank;
+  return OCTL_OK;
+}
+
+// What the COMMUNICATOR says about the run (not the launcher's environment): ranks in it, this context's rank in it,
+// the collective library's version code; -1 where the library does not export the query.
+int octl_comm_info(octl_ctx* ctx, int32_t* n_ranks, int32_t* user_rank, int32_t* version) {
+  if (!ctx) return OCTL_E_INVALID;
+  if (!ctx->comm) return octl_set_error(ctx, OCTL_E_STATE, "communicator not initialised");
+  ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+  int v = -1;
+  if (n_ranks) {
+    v = -1;
+    if (g_rccl.CommCount) NCCL_TRY(ctx, g_rccl.CommCount(comm, &v));
+    *n_ranks = v;
+  }
+  if (user_rank) {
+    v = -1;
+    if (g_rccl.CommUserRank) NCCL_TRY(ctx, g_rccl.CommUserRank(comm, &v));
+    *user_rank = v;
+  }
+  if (version) {
+    v = -1;
+    if (g_rccl.GetVersion) NCCL_TRY(ctx, g_rccl.GetVersion(&v));
+    *version = v;
+  }
+  return OCTL_OK;
+}
+
+// The device behind a context: PCI bus id ("0000:05:00.0") and the 16-byte UUID of its properties - what a
+// multi-GPU run gathers to show that its ranks sit on DISTINCT devices.
+int octl_device_identity(octl_ctx* ctx, char pci_bus_id[32], uint8_t uuid[16], int32_t* cus) {
+  if (!ctx) return OCTL_E_INVALID;
+  if (pci_bus_id) {
+    pci_bus_id[0] = 0;
+    HIP_TRY(ctx, hipDeviceGetPCIBusId(pci_bus_id, 32, ctx->device));
+  }
+  hipDeviceProp_t prop;
+  HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (uuid) std::memcpy(uuid, prop.uuid.bytes, 16);
+  if (cus) *cus = prop.multiProcessorCount;
   return OCTL_OK;
 }
 

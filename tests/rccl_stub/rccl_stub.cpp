@@ -210,6 +210,26 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int n_ranks, ncclUniqueId id, in
   return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+  const Comm* c = reinterpret_cast<const Comm*>(comm);
+  if (!c || !count) return ncclInvalidArgument;
+  *count = c->n_ranks;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank) {
+  const Comm* c = reinterpret_cast<const Comm*>(comm);
+  if (!c || !rank) return ncclInvalidArgument;
+  *rank = c->rank;
+  return ncclSuccess;
+}
+
+ncclResult_t ncclGetVersion(int* version) {
+  if (!version) return ncclInvalidArgument;
+  *version = 0;   // (the stand-in, not a release of RCCL)
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm* c = reinterpret_cast<Comm*>(comm);
   if (!c) return ncclSuccess;
