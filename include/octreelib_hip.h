@@ -193,6 +193,14 @@ int octl_forest_internal_per_voxel(octl_forest* f, int64_t cap, int32_t* counts,
 int octl_forest_get_perm(octl_forest* f, int64_t cap, int64_t* perm, int64_t* n);
 /* Leaf-ordered coordinates (n,3) f64 for storage positions [start, start+count).           */
 int octl_forest_get_points(octl_forest* f, int64_t start, int64_t count, double* xyz);
+/* The rows of the blocks block_ids[0..m) (host array), concatenated in THAT order: one device gather and one
+ * download instead of a host loop over the blocks.  *n_points = rows of the selection; rows are written only when
+ * xyz != NULL and cap >= *n_points (call with xyz = NULL for the size).  Replaces the concatenation loops of
+ * Grid.get_points / OctreeManager.get_points / Octree.get_points (grid.py:234-242, octree_manager.py:121-130,
+ * octree.py:55-65,252-254), whose order - managers in creation order, leaves in cached order - the caller encodes
+ * in block_ids.                                                                                                */
+int octl_forest_gather_blocks(octl_forest* f, const int32_t* block_ids, int64_t m, int64_t cap, double* xyz,
+                              int64_t* n_points);
 
 /* ---- RANSAC on the forest (device resident) ------------------------------------------- */
 

@@ -470,6 +470,31 @@ class Forest:
             self._xyz = a
         return self._xyz
 
+    def gather_blocks(self, block_ids) -> np.ndarray:
+        """Rows of the given blocks, concatenated in the given order: ONE device gather and one download
+        (octl_forest_gather_blocks) - what the reference's get_points loops concatenate leaf by leaf
+        (grid.py:234-242, octree_manager.py:121-130, octree.py:55-65).  A host copy of the whole ordered cloud that
+        is there already is sliced instead."""
+        ids = np.ascontiguousarray(block_ids, dtype=np.int32)
+        if len(ids) == 0:
+            return np.empty((0, 3), dtype=float)
+        blk = self.blocks
+        if self._xyz is not None:
+            starts = blk["start"][ids].astype(np.int64)
+            sizes = blk["size"][ids].astype(np.int64)
+            offs = np.cumsum(sizes) - sizes
+            idx = np.repeat(starts - offs, sizes) + np.arange(int(sizes.sum()), dtype=np.int64)
+            return self._xyz[idx]
+        self.ensure_built()
+        n = int(blk["size"][ids].sum())
+        out = np.empty((n, 3), dtype=np.float64)
+        got = C.c_int64(0)
+        self.ctx.check(self.lib.octl_forest_gather_blocks(self.handle, nat.ptr(ids), len(ids), n, nat.ptr(out),
+                                                          C.byref(got)))
+        if got.value != n:
+            raise RuntimeError(f"gather_blocks: {got.value} rows on the device, {n} in the host's block table")
+        return out
+
     @property
     def perm(self) -> np.ndarray:
         """perm[i] = index (in the concatenation of all pose clouds, slot order) of the point at

@@ -79,6 +79,7 @@ SIGNATURES = {
     "octl_forest_internal_per_voxel": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_forest_get_perm": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_forest_get_points": (C.c_int, [_p, _i64, _i64, _p]),
+    "octl_forest_gather_blocks": (C.c_int, [_p, _p, _i64, _i64, _p, _pi64]),
     "octl_forest_ransac": (C.c_int, [_p, _p, _i64, _p, _i32, _i32, _f64, _p, _p, _p]),
     "octl_forest_reference_order": (C.c_int, [_p, _p, _i32, _i64, _p, _pi64]),
     "octl_forest_ransac_all": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i32, _f64]),

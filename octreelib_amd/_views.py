@@ -87,12 +87,22 @@ def leaf_views(forest, slot: int, non_empty: bool = True) -> List[LeafView]:
     order = all_leaves_order(forest, slot)
     xyz = forest.xyz
     ids = forest.slot_blocks(slot)
-    by_node = {int(n): (int(s), int(z)) for n, s, z in zip(blk["node"][ids], blk["start"][ids], blk["size"][ids])}
-    out = []
-    for n in order.tolist():
-        s, z = by_node.get(n, (0, 0))
-        out.append(LeafView(_node_corner(forest, n), nd["edge"][n], xyz, s, z, n))
-    return out
+    # the pose's block of every listed leaf (none: an empty leaf) by one sorted search, not a dictionary per call
+    starts = np.zeros(len(order), dtype=np.int64)
+    sizes = np.zeros(len(order), dtype=np.int64)
+    if len(ids) and len(order):
+        bn = blk["node"][ids]
+        by = np.argsort(bn, kind="stable")
+        sbn = bn[by]
+        pos = np.minimum(np.searchsorted(sbn, order), len(sbn) - 1)
+        hit = sbn[pos] == order
+        src = ids[by][pos]
+        starts[hit] = blk["start"][src][hit]
+        sizes[hit] = blk["size"][src][hit]
+    starts, sizes = starts.tolist(), sizes.tolist()
+    corners = _node_corners(forest, order)
+    return [LeafView(c, e, xyz, s, z, n)
+            for c, e, s, z, n in zip(corners, nd["edge"][order], starts, sizes, order.tolist())]
 
 
 def preorder_rank(nd) -> np.ndarray:

@@ -476,6 +476,27 @@ __global__ __launch_bounds__(256) void k_widen_u32_i64(const uint32_t* __restric
 
 inline unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
 
+// octl_forest_gather_blocks: sizes of the selected blocks, then one wavefront per block copies its rows to where the
+// prefix sum of the sizes puts them
+__global__ __launch_bounds__(256) void k_gather_sizes(const int32_t* __restrict__ ids, int64_t m,
+                                                      const int32_t* __restrict__ blk_size, uint32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) out[i] = (uint32_t)blk_size[ids[i]];
+}
+__global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ ids, int64_t m,
+                                                     const uint32_t* __restrict__ blk_start,
+                                                     const int32_t* __restrict__ blk_size,
+                                                     const uint32_t* __restrict__ offs, const double* __restrict__ xyz,
+                                                     double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= m) return;
+  const int32_t b = ids[i];
+  const double* src = xyz + 3 * (size_t)blk_start[b];
+  double* dst = out + 3 * (size_t)offs[i];
+  const int n3 = 3 * blk_size[b];
+  for (int j = threadIdx.x & 63; j < n3; j += 64) dst[j] = src[j];
+}
+
 }  // namespace
 
 int bbox_ensure(octl_forest* f) {
@@ -1317,6 +1338,45 @@ int octl_forest_get_points(octl_forest* f, int64_t start, int64_t count, double*
   HIP_TRY(ctx, hipMemcpyAsync(xyz, f->xyz_ord.as<double>() + 3 * start, (size_t)count * 24,
                               hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return OCTL_OK;
+}
+
+int octl_forest_gather_blocks(octl_forest* f, const int32_t* block_ids, int64_t m, int64_t cap, double* xyz,
+                              int64_t* n_points) {
+  if (!f || !n_points || m < 0 || (m > 0 && !block_ids)) return OCTL_E_INVALID;
+  octl_ctx* ctx = f->ctx;
+  if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
+  *n_points = 0;
+  if (m == 0) return OCTL_OK;
+  for (int64_t i = 0; i < m; ++i)
+    if (block_ids[i] < 0 || block_ids[i] >= f->n_blocks) return octl_set_error(ctx, OCTL_E_INVALID, "bad block id");
+  hipStream_t st = ctx->stream;
+  // scratch (f->hist): [ids i32 m | sizes -> offsets u32 m + 1 | total]
+  const size_t o_sz = (((size_t)m * 4) + 15) & ~(size_t)15;
+  const size_t o_tot = o_sz + ((((size_t)m + 1) * 4) + 15) / 16 * 16;
+  OCTL_TRY(devbuf_reserve(ctx, f->hist, o_tot + 16));
+  char* base = static_cast<char*>(f->hist.p);
+  int32_t* ids_d = reinterpret_cast<int32_t*>(base);
+  uint32_t* offs = reinterpret_cast<uint32_t*>(base + o_sz);
+  uint32_t* total = reinterpret_cast<uint32_t*>(base + o_tot);
+  HIP_TRY(ctx, hipMemcpyAsync(ids_d, block_ids, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_gather_sizes, dim3(grid_for(m)), dim3(256), 0, st, (const int32_t*)ids_d, m,
+                     (const int32_t*)f->blk_size.as<int32_t>(), offs);
+  HIP_TRY(ctx, hipGetLastError());
+  OCTL_TRY(octl_exclusive_scan_u32(ctx, offs, offs, m, total));
+  uint32_t tot_h = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&tot_h, total, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));  // (also: the pageable id list is the caller's again)
+  *n_points = tot_h;
+  if (tot_h == 0 || !xyz || cap < (int64_t)tot_h) return OCTL_OK;  // (size query, or nothing to copy)
+  // the gathered rows go through the compaction target of apply_mask (free between calls)
+  OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord2, (size_t)tot_h * 24));
+  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)ceil_div(m, 4)), dim3(256), 0, st, (const int32_t*)ids_d, m,
+                     (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(),
+                     (const uint32_t*)offs, (const double*)f->xyz_ord.as<double>(), f->xyz_ord2.as<double>());
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(xyz, f->xyz_ord2.p, (size_t)tot_h * 24, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
   return OCTL_OK;
 }
 

@@ -97,11 +97,12 @@ class Grid(GridBase):
         if len(sel) == 0:
             return np.empty((0, 3), dtype=float)
         vox_rank = f.nodes["voxel"][blk["node"][sel]]
-        creation = f.creation_ranks(f.voxels)
-        order = np.lexsort((blk["start"][sel], creation[vox_rank]))
-        xyz = f.xyz
-        starts, sizes = blk["start"][sel][order], blk["size"][sel][order]
-        return np.vstack([xyz[s : s + z] for s, z in zip(starts.tolist(), sizes.tolist())])
+        creation = f.creation_ranks(f.voxels)[vox_rank]
+        # managers in creation order, storage order inside one (= the DFS order of octree.get_points); a grid whose
+        # voxels were created in voxel order - one pose, or poses over the same voxels - is in that order already
+        if len(sel) > 1 and np.any(creation[1:] < creation[:-1]):
+            sel = sel[np.lexsort((blk["start"][sel], creation))]
+        return f.gather_blocks(sel)
 
     # grid.py:260-267
     def filter(self, filtering_criteria: List[Callable]):

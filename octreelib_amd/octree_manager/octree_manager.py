@@ -103,9 +103,7 @@ class OctreeManager(VoxelBase):
         # octree.get_points(): DFS order of the leaves = storage order
         blk = f.blocks
         sel = np.nonzero(blk["slot"] == self._slots[pose_number])[0]
-        xyz = f.xyz
-        parts = [xyz[s : s + z] for s, z in zip(blk["start"][sel].tolist(), blk["size"][sel].tolist())]
-        return np.vstack(parts) if parts else np.empty((0, 3), dtype=float)
+        return f.gather_blocks(sel)
 
     def n_points(self, pose_number: Optional[int] = None) -> int:
         if self._plug is not None:

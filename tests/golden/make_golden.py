@@ -651,7 +651,45 @@ def gen_ransac_unique():
               threshold=np.float64(0.01), seed=np.int64(seed), mask=mask, ref_plane=plane, ref_max_inliers=count)
 
 
+# --------------------------------------------------------------------------------------
+# Grid.get_points / OctreeManager.get_points: the ORDER of the rows (grid.py:234-242 walks all managers in the
+# order they were first created, octree.py:55-65 the leaves depth first).  Inside a leaf the reference's order is an
+# artefact of its unstable argsort, so the fixture records, for every row, the original index and the leaf (as the
+# position in get_leaf_points' list) it came from: the sequence of leaves is what an implementation must reproduce.
+# --------------------------------------------------------------------------------------
+def gen_grid_get_points():
+    rng = np.random.default_rng(77)
+    # pose 0 creates voxels in one order, pose 1 - inserted second - adds new voxels in front of and between them
+    poses = [rng.random((6000, 3)) * np.array([3.0, 2.0, 2.0]) + np.array([2.0, 0.0, 0.0]),
+             rng.random((5000, 3)) * np.array([6.0, 3.0, 2.0]) - np.array([1.0, 1.0, 0.0])]
+    g = Grid(GridConfig(voxel_edge_length=1))
+    out = {"L": np.float64(1), "n_poses": np.int64(2)}
+    for p, pts in enumerate(poses):
+        g.insert_points(p, pts)
+        out[f"points{p}"] = pts
+    for stage, K in (("pre", None), ("k40", 40)):
+        if K is not None:
+            g.subdivide(crit(K))
+        for p, pts in enumerate(poses):
+            index = _index_of(pts)
+            leaves = g.get_leaf_points(p)
+            leaf_of = {}
+            for li, v in enumerate(leaves):
+                q = np.ascontiguousarray(v.get_points(), dtype=np.float64)
+                for i in range(len(q)):
+                    leaf_of[index[q[i].tobytes()]] = li
+            rows = np.ascontiguousarray(g.get_points(p), dtype=np.float64)
+            idx = np.array([index[rows[i].tobytes()] for i in range(len(rows))], dtype=np.int64)
+            out[f"{stage}_p{p}_rows_idx"] = idx
+            out[f"{stage}_p{p}_rows_leaf"] = np.array([leaf_of[i] for i in idx], dtype=np.int64)
+            c, e, s, i = _leaf_table(leaves, index)
+            out[f"{stage}_p{p}_corners"], out[f"{stage}_p{p}_edges"] = c, e
+            out[f"{stage}_p{p}_sizes"], out[f"{stage}_p{p}_idx"] = s, i
+    _save("grid_get_points.npz", **out)
+
+
 GENERATORS = {
+    "grid_get_points": gen_grid_get_points,
     "octree": gen_octree,
     "grid": gen_grid,
     "manager": gen_manager,

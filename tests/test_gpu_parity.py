@@ -1451,6 +1451,51 @@ def test_bucket_build_leaves_huge_and_deep_voxels_to_the_level_loop(monkeypatch,
     _assert_same_build(a, b)
 
 
+@pytest.mark.parametrize("host_copy", [False, True])
+def test_grid_get_points_row_order_golden(host_copy):
+    """Grid.get_points against the reference's own row order (tests/golden/grid_get_points.npz, generated by the
+    reference: two poses whose voxels are created in different orders, before and after a subdivide): the SEQUENCE of
+    leaves along the rows must be the reference's (managers in creation order, grid.py:234-242, leaves depth first,
+    octree.py:55-65) and every leaf must contribute its rows - inside a leaf the reference's order is an artefact of
+    an unstable argsort.  host_copy: with the whole ordered cloud already on the host the rows are sliced there,
+    otherwise they come from one device gather (octl_forest_gather_blocks)."""
+    from octreelib_amd.grid import Grid, GridConfig
+
+    gold = load_golden("grid_get_points.npz")
+    poses = [gold["points0"], gold["points1"]]
+    grid = Grid(GridConfig(voxel_edge_length=1))
+    for p, pts in enumerate(poses):
+        grid.insert_points(p, pts)
+
+    def runs(a):
+        a = np.asarray(a)
+        return a[np.concatenate(([True], a[1:] != a[:-1]))]
+
+    for stage, K in (("pre", None), ("k40", 40)):
+        if K is not None:
+            grid.subdivide(crit(K))
+        for p, pts in enumerate(poses):
+            index = {pts[i].tobytes(): i for i in range(len(pts))}
+            f = grid._forest
+            if host_copy:
+                f.xyz          # (fetches and keeps the ordered cloud)
+            else:
+                f._xyz = None
+            rows = np.ascontiguousarray(grid.get_points(p))
+            assert (f._xyz is not None) == host_copy
+            idx = np.array([index[rows[i].tobytes()] for i in range(len(rows))], dtype=np.int64)
+            # every row once
+            assert np.array_equal(np.sort(idx), np.sort(gold[f"{stage}_p{p}_rows_idx"]))
+            # leaf of every original index, from the reference's leaf table (leaf = position in get_leaf_points' list)
+            sizes = gold[f"{stage}_p{p}_sizes"]
+            leaf_of = np.empty(len(pts), dtype=np.int64)
+            leaf_of[gold[f"{stage}_p{p}_idx"]] = np.repeat(np.arange(len(sizes)), sizes)
+            want_seq = runs(gold[f"{stage}_p{p}_rows_leaf"])
+            got_seq = runs(leaf_of[idx])
+            assert np.array_equal(got_seq, want_seq)
+            assert len(np.unique(got_seq)) == len(got_seq)          # a leaf's rows are contiguous
+
+
 def test_grid_get_points_follows_voxel_creation_order():
     """Grid.get_points walks ALL managers in the order they were first created (the dict order of
     Grid.__octrees, grid.py:56,100-109,240-242), not in lexicographic voxel order: a voxel first
