@@ -844,13 +844,16 @@ def main():
 
     # host <-> device round trips of one step (library-internal synchronisations, counted by the library;
     # a few extra steps outside the timed region, profiling off)
-    host_syncs = None
+    host_syncs = launches = None
     if world == 1 and not route:
-        c0, c1 = C.c_uint64(0), C.c_uint64(0)
+        c0, c1, l0, l1 = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
+        ctx.check(lib.octl_debug_launches(C.byref(l0)))
         wl.run(2 * n_clouds)
         ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
+        ctx.check(lib.octl_debug_launches(C.byref(l1)))
         host_syncs = (c1.value - c0.value) / (2.0 * n_clouds)
+        launches = (l1.value - l0.value) / (2.0 * n_clouds)
 
     # algorithmic flops of the RANSAC launch from the REAL leaf sizes of this rank's build (every line: N = 1,
     # one rank's shard, N > 1 - the fall-back 6 H n ignores the plane fits and made the lines incomparable)
@@ -1251,6 +1254,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "host_syncs_per_step": host_syncs,
+            "launches_per_step": launches,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -1303,9 +1307,13 @@ def main():
                 "frac_no_fma": (valu_tflops / (FP64_VALU_PEAK_TFLOPS / 2)) if valu_tflops else None,
                 "algorithmic_flops_per_launch": flops,
                 "leaves_evaluated": leaves_evaluated,
-                "note": "algorithmic f64 flops per leaf with n >= k points: H*(20k + 6n) + 6n (plane fits, "
-                        "scoring, final mask); parity mode issues separate mul/add (no FMA contraction), so "
-                        "the attainable ceiling is peak/2",
+                "executed": valu_executed(ransac_ms) if (world == 1 and n_local == 10_000_000 and
+                                                          args.cloud == "planar" and not args.shard_of) else None,
+                "note": "ALGORITHMIC-EQUIVALENT f64 flops per leaf with n >= k points: H*(20k + 6n) + 6n (plane fits, "
+                        "scoring, final mask) over the kernel's time - it counts work the kernel never executes (a "
+                        "fifth of the blocks leave after 256 of the 1024 hypotheses) and the f32 screen's scoring as "
+                        "f64: it is not a utilisation of the machine.  `executed` is: instruction counts by type from "
+                        "the tracked profile against the issue ceiling at the measured clock",
             },
             "roofline_build": roofline_build,
             "pipeline_hbm": {
@@ -1343,12 +1351,76 @@ def main():
 
 # tracked rocprofv3 --pmc profiles of the three measured workloads (tools/profile_round.sh): per-launch HBM bytes by
 # kernel.  They are read beside the live timings, never measured by the run that prints the line.
-PROFILE_TRAFFIC = "profiles/r04_hbm_traffic.json"
+def _tracked(name):
+    """profiles/r05_<name> when this round's profile run has written it, else round 4's."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for tag in ("r05", "r04"):
+        p = f"profiles/{tag}_{name}"
+        if os.path.exists(os.path.join(here, p)):
+            return p
+    return f"profiles/r05_{name}"
+
+
+PROFILE_TRAFFIC = _tracked("hbm_traffic.json")
 PROFILE_FILES = {
     "headline": PROFILE_TRAFFIC,
-    "c4": "profiles/r04_c4_hbm_traffic.json",
-    "c5shard": "profiles/r04_c5shard_hbm_traffic.json",
+    "c4": _tracked("c4_hbm_traffic.json"),
+    "c5shard": _tracked("c5shard_hbm_traffic.json"),
 }
+
+
+def tracked_json(name):
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), _tracked(name))) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
+def valu_executed(ransac_ms_live):
+    """What k_ransac EXECUTES (the tracked --pmc pass of this command over the VALU instruction types, the SQ pass for
+    the clock, the counting variant of the library for exits and recounts) - beside roofline_valu's algorithmic
+    figure, which counts flops the kernel never executes (blocks that leave early) and counts the f32 screen's work as
+    f64.  Per launch = all k_ransac instances of one step."""
+    mix, sq, cnt = tracked_json("valu_mix.json"), tracked_json("sq_counters.json"), tracked_json("ransac_counts.json")
+    if not mix or not sq:
+        return None
+    rows = {k: v for k, v in mix["kernels"].items() if k.startswith("k_ransac")}
+    main = max(rows, key=lambda k: rows[k]["duration_us"]) if rows else None
+    if main is None or main not in sq["kernels"]:
+        return None
+    tot = {t: sum(r.get(t, 0.0) for r in rows.values()) for t in
+           ("add_f64", "mul_f64", "fma_f64", "trans_f64", "add_f32", "mul_f32", "fma_f32", "int32")}
+    t_s = rows[main]["duration_us"] * 1e-6
+    clock = sq["kernels"][main]["effective_clock_GHz"]
+    all_valu = sq["kernels"][main]["wave_valu_instructions"]
+    f64 = tot["add_f64"] + tot["mul_f64"] + tot["fma_f64"] + tot["trans_f64"]
+    f32 = tot["add_f32"] + tot["mul_f32"] + tot["fma_f32"]
+    issue_ceiling = 1024 * clock * 1e9 / 4.0          # wave instructions per second: 1024 SIMDs, 4 cycles each
+    out = {
+        "profile": _tracked("valu_mix.json"), "kernel": main, "launch_ms_profiled": rows[main]["duration_us"] / 1e3,
+        "launch_ms_live": ransac_ms_live, "effective_clock_GHz": clock,
+        "wave_instructions_per_launch": {"f64": f64, "f32": f32, "int32": tot["int32"], "all_valu": all_valu, **tot},
+        "f64_TFLOPs_executed": (64 * (tot["add_f64"] + tot["mul_f64"] + tot["trans_f64"]) + 128 * tot["fma_f64"]) / t_s / 1e12,
+        "f32_TFLOPs_executed": (64 * (tot["add_f32"] + tot["mul_f32"]) + 128 * tot["fma_f32"]) / t_s / 1e12,
+        "valu_issue_fraction_at_measured_clock": all_valu / t_s / issue_ceiling,
+        "f64_share_of_valu_instructions": f64 / all_valu if all_valu else None,
+        "f32_share_of_valu_instructions": f32 / all_valu if all_valu else None,
+        "note": "wave-level instruction counts of the tracked profile (all k_ransac instances of a step); issue "
+                "ceiling = 1024 SIMDs x clock / 4 cycles per wave instruction at the clock the SQ pass measured "
+                "(power-limited: 2.4 GHz nominal)",
+    }
+    if cnt:
+        out.update({
+            "fraction_blocks_leaving_after_256_hypotheses": cnt["fraction_blocks_leaving_after_pass_1"],
+            "fraction_plane_fits_executed": cnt["fraction_plane_fits_executed"],
+            "fraction_pairs_scored_by_f32_screen": cnt["fraction_pairs_scored"],
+            "fraction_hypotheses_recounted_in_f64": cnt["fraction_hypotheses_recounted"],
+            "counts_profile": _tracked("ransac_counts.json"),
+        })
+    return out
+
+
 
 
 def profile_traffic(which="headline"):
@@ -1385,7 +1457,8 @@ TIMER_KERNELS = {
     "ransac": ["k_ransac<"],
 }
 # the kernel that runs exactly ONCE per step of a workload: dispatch counts are taken relative to it
-PROFILE_REF = {"headline": "k_bucket_totals", "c5shard": "k_bucket_totals", "c4": "k_finalize_rec"}
+PROFILE_REF = {"headline": ("k_bucket_scan_totals", "k_bucket_totals"), "c5shard": ("k_bucket_scan_totals", "k_bucket_totals"),
+               "c4": ("k_finalize_rec",)}
 
 # DESIGN bytes per point of the streaming kernels of insert + subdivide: what each one has to read and write
 # in THIS pipeline per launch - not SURVEY 8(d)'s algorithmic 24 B/point, which is reported
@@ -1432,7 +1505,7 @@ def kernel_table(kern, n_points, which):
     move in this pipeline (all its launches of a step); (3) the bytes the PMC counters saw, from the tracked profile
     of the same workload (null when there is none)."""
     counters = profile_traffic(which)
-    ref = PROFILE_REF[which]
+    ref = next((r for r in PROFILE_REF[which] if counters and r in counters), PROFILE_REF[which][0])
     out = {}
     for k, v in kern.items():
         if k not in BUILD_DESIGN_BYTES or v["ms_per_step"] <= 0:

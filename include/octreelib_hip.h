@@ -292,6 +292,9 @@ int octl_route_get_gidx(octl_ctx* ctx, int64_t cap, int64_t* gidx, int64_t* n);
 /* Number of times the library has made the host wait for the device (stream / event synchronisations)
  * since it was loaded: bench.py reports the round trips per step from it.                        */
 int octl_debug_host_syncs(uint64_t* count);
+/* Kernel launches + asynchronous fills enqueued by the library so far (process-wide), the companion of
+ * octl_debug_host_syncs: bench.py reports launches per step.                                          */
+int octl_debug_launches(uint64_t* count);
 
 /* Test hook: the communicator-independent half of octl_route_points for ANY number of ranks -
  * destination of every point (host cloud in), per-destination counts [n_ranks], and the packed

@@ -27,14 +27,24 @@ static inline hipError_t octl_counted_event_sync(hipEvent_t e) {
 }
 #define hipStreamSynchronize(s) octl_counted_stream_sync(s)
 #define hipEventSynchronize(e) octl_counted_event_sync(e)
+// ... and every kernel launch and asynchronous fill (a fill is a kernel of the runtime's): octl_debug_launches -
+// launches per step is the other figure a small scan lives by
+extern std::atomic<uint64_t> g_octl_launches;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                   \
+  do {                                                                        \
+    g_octl_launches.fetch_add(1, std::memory_order_relaxed);                  \
+    hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                    \
+  } while (0)
+#define hipMemsetAsync(...) (g_octl_launches.fetch_add(1, std::memory_order_relaxed), hipMemsetAsync(__VA_ARGS__))
 
 // Compile-time experiment switches that change RESULTS (ablations, duplicated work) or add instrumentation never
 // belong in a shipped library: they only compile when the variant build script defines OCTL_EXPERIMENTS
 // (tools/build_variant.sh -> build/variants/NAME.so, loaded through OCTREELIB_AMD_LIB; the Makefile never does).
 #if !defined(OCTL_EXPERIMENTS) && \
     (defined(RS_NO_REDO) || (defined(RS_ABLATE) && RS_ABLATE != 0) || defined(PS_DUP_KEYS) || defined(PS_DUP_STORE) || \
-     defined(RS_STAMPS) || defined(BB_STAMPS))
-#error "RS_NO_REDO / RS_ABLATE / PS_DUP_* / RS_STAMPS / BB_STAMPS are experiments: build them with tools/build_variant.sh (-DOCTL_EXPERIMENTS)"
+     defined(RS_STAMPS) || defined(RS_COUNTS) || defined(BB_STAMPS))
+#error "RS_NO_REDO / RS_ABLATE / PS_DUP_* / RS_STAMPS / RS_COUNTS / BB_STAMPS are experiments: build them with tools/build_variant.sh (-DOCTL_EXPERIMENTS)"
 #endif
 
 #define OCTL_WAVE 64

@@ -63,6 +63,14 @@ extern "C" int octl_debug_set_option(octl_ctx* ctx, const char* name, int64_t va
   return OCTL_OK;
 }
 
+std::atomic<uint64_t> g_octl_launches{0};
+
+extern "C" int octl_debug_launches(uint64_t* count) {
+  if (!count) return OCTL_E_INVALID;
+  *count = g_octl_launches.load(std::memory_order_relaxed);
+  return OCTL_OK;
+}
+
 extern "C" int octl_debug_host_syncs(uint64_t* count) {
   if (!count) return OCTL_E_INVALID;
   *count = g_octl_host_syncs.load(std::memory_order_relaxed);

@@ -656,9 +656,14 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 //   [5] reduction over the lane / wave + staging of the next block   [6] the block's barrier
 //   [7] winner, outputs, final mask
 //   [8] blocks  [9] blocks that skipped pass 2  [10] workgroups  [11] sum of block sizes
-#ifdef RS_STAMPS
+//   [12] hypothesis groups of pass 2 skipped by the exit after a later batch   [13] hypotheses recounted exactly
+//   [14] hypothesis groups scored (wave 0's: x 64 lanes = hypotheses)   [15] sum over the scored groups of the block size
+// -DRS_COUNTS: the counts [8..15] alone, no clocks (the clocks' accumulators make the 16-hypothesis instance spill):
+// what the kernel EXECUTES of what the algorithm asks for (tools/rs_counts.py -> profiles/rNN_ransac_counts.json).
+#if defined(RS_STAMPS) || defined(RS_COUNTS)
 __device__ unsigned long long g_rs_stamps[16];
-#define RS_STAMP_INIT unsigned long long _rs_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+#ifdef RS_STAMPS
+#define RS_STAMP_INIT unsigned long long _rs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
                       unsigned long long _rs_t0 = __builtin_readcyclecounter()
 #define RS_STAMP(k)                                                   \
   do {                                                                \
@@ -666,12 +671,16 @@ __device__ unsigned long long g_rs_stamps[16];
     _rs_acc[k] += _t - _rs_t0;                                        \
     _rs_t0 = _t;                                                      \
   } while (0)
+#else
+#define RS_STAMP_INIT unsigned long long _rs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define RS_STAMP(k) do {} while (0)
+#endif
 #define RS_COUNT(k, v) _rs_acc[k] += (unsigned long long)(v)
 #define RS_STAMP_FLUSH                                                                  \
   do {                                                                                  \
     if (threadIdx.x == 0) {                                                             \
       _rs_acc[10] += 1;                                                                 \
-      for (int _k = 0; _k < 12; ++_k) atomicAdd(&g_rs_stamps[_k], _rs_acc[_k]);         \
+      for (int _k = 0; _k < 16; ++_k) atomicAdd(&g_rs_stamps[_k], _rs_acc[_k]);         \
     }                                                                                   \
   } while (0)
 #else
@@ -973,6 +982,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       constexpr int NH = decltype(nh_tag)::value;
       if (ABL == 1) return;  // ablation: no scoring
       float margin[NH];
+      RS_COUNT(14, NH);
+      RS_COUNT(15, NH * n);
       screen_group<NH>(loc, n, fa + q0, fb + q0, fc + q0, sto + q0, nthr2, cnt + q0, margin);
       // a hypothesis whose smallest |e| does not clear its bound is recounted exactly (per
       // hypothesis: a recount costs the whole wave 8 n instructions, and by the bound some lane
@@ -991,6 +1002,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
         // that holds up the lane's wave - and behind it the workgroup's barrier - for ~n LDS
         // round trips: measured 7 % of the kernel although only 2 % of the checks recount.
         unsigned long long todo = __ballot(redo);
+        RS_COUNT(13, __popcll(todo));
         while (todo) {
           const int src = __ffsll((long long)todo) - 1;
           todo &= todo - 1;
@@ -1087,6 +1099,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
               for (int q = q0; q < q0 + SUB; ++q) full = full || ((FULLH || (int)tx + q * THREADS < H) && cnt[q] == n);
               done = __any(full);
             }
+          } else {
+            RS_COUNT(12, SUB);
           }
         });
         if (TAIL > 0 && !done) {
@@ -1097,6 +1111,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
           score(std::integral_constant<int, (TAIL > 0 ? TAIL : 1)>{}, q0);
           take(q0, TAIL);
           RS_STAMP(4);
+        } else if (TAIL > 0) {
+          RS_COUNT(12, TAIL);
         }
       } else {
         RS_COUNT(9, 1);
@@ -1918,7 +1934,7 @@ static int debug_plane_arith(octl_ctx* ctx, const double* num3, const double* de
   return rc == OCTL_OK ? OCTL_OK : octl_set_error(ctx, rc, "octl_debug_plane_arith failed");
 }
 
-#ifdef RS_STAMPS
+#if defined(RS_STAMPS) || defined(RS_COUNTS)
 extern "C" int octl_debug_rs_stamps(octl_ctx* ctx, unsigned long long out[16], int reset) {
   if (!ctx || !out) return OCTL_E_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

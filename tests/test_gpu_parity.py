@@ -2651,3 +2651,103 @@ def test_single_cube_prefix_partition_equals_the_plain_level_loop(monkeypatch, c
         if case != "uneven":
             assert "prefix_scatter" in names and "keygen" not in names
             assert int(got[0]["depth"].max()) >= levels
+
+
+def _step_tables(pts_list, K, adopt_ctx=None, H=256):
+    """insert (one pose per cloud) + subdivide + RANSAC + apply_mask through the engine; the tables before and after
+    the mask."""
+    from octreelib_amd._engine import Forest
+
+    f = Forest(0, np.zeros(3), 1.0)
+    bufs = []
+    for pts in pts_list:
+        if adopt_ctx is not None and not bufs:
+            d = _device_cloud(adopt_ctx, pts)
+            bufs.append(d)
+            f.add_pose_device(d, len(pts), adopt=True)
+        else:
+            f.add_pose(pts)
+    f.subdivide(K)
+    before = _tables(f)
+    np.random.seed(0)
+    table = np.random.random((H, 6))
+    f.ransac_all(10, table, 0.01)
+    f.apply_device_mask()
+    after = (({k: v.copy() for k, v in f.blocks.items()}), f.perm.copy(), f.xyz.copy())
+    f.close()
+    for d in bufs:
+        adopt_ctx.check(adopt_ctx.lib.octl_dev_free(adopt_ctx.handle, d))
+    return before, after
+
+
+def _assert_same_step(a, b, canonical=False):
+    if canonical:
+        # (bucket path + level loop for the voxels it left behind numbers those voxels' nodes behind the others;
+        #  the level-synchronous path numbers everything level-major: compare independent of the numbering)
+        na, ba = _canon_build(a[0])
+        nb, bb = _canon_build(b[0])
+        assert na == nb and ba == bb
+        for x, y in zip(a[0][2:], b[0][2:]):
+            assert np.array_equal(x, y)
+    else:
+        _assert_same_tables(a[0], b[0])
+    assert a[1][0].keys() == b[1][0].keys()
+    for k in a[1][0]:
+        assert np.array_equal(a[1][0][k], b[1][0][k]), k
+    assert np.array_equal(a[1][1], b[1][1]) and np.array_equal(a[1][2], b[1][2])
+
+
+@pytest.mark.parametrize("scene", ["even", "tiny", "skewed", "two_poses", "two_pass"])
+def test_round5_launch_trimming_changes_no_result(scene):
+    """Round 5 took launches out of the step - the partition table in one kernel (k_table_scan), the bucket totals'
+    scan with a last-workgroup epilogue, RANSAC preparation and apply_mask as look-back kernels, chunk kernels and
+    RANSAC instances only when needed, host waits that poll the pinned mirror.  Every one of them has a switch back to
+    the round-4 form (octl_debug_set_option): the results must not depend on any of them - scheme, blocks, order,
+    permutation before the mask; blocks, permutation and coordinates after it."""
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+
+    ctx = nat.get_context()
+    K = 40
+    if scene == "even":
+        clouds = [synthetic.planar_cloud(150_000, (6, 6, 6), seed=1, stream=3)]
+    elif scene == "tiny":
+        clouds = [synthetic.planar_cloud(900, (2, 2, 2), seed=1, stream=3)]
+    elif scene == "skewed":   # buckets beyond 4096 points: the chunk kernels
+        clouds = [synthetic.sparse_scene(200_000, (24, 24, 8), seed=5, cluster_fraction=0.3, cluster_density=60.0)]
+    elif scene == "two_poses":
+        clouds = [synthetic.planar_cloud(60_000, (5, 5, 5), seed=1, stream=1),
+                  synthetic.planar_cloud(50_000, (5, 5, 5), seed=1, stream=2)]
+    else:
+        clouds = [synthetic.planar_cloud(120_000, (16, 16, 16), seed=1, stream=4)]
+        set_option("BUCKET_POINTS", 16)   # > 4096 buckets: the two-pass partition
+    adopt = ctx if scene != "two_poses" else None
+    want = _step_tables(clouds, K, adopt)
+    again = _step_tables(clouds, K, adopt)          # (second build of the context: hinted geometry, chunk history)
+    _assert_same_step(want, again)
+    for opt in ("NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_GEOM_HINT", "NO_BUCKET_BUILD"):
+        set_option(opt, 1)
+        got = _step_tables(clouds, K, adopt)
+        set_option(opt, 0)
+        _assert_same_step(want, got, canonical=(opt == "NO_BUCKET_BUILD"))
+        _assert_same_step(want, _step_tables(clouds, K, adopt))   # ... and back
+
+
+def test_small_scans_through_the_bucket_path_equal_the_level_loop():
+    """A scan of a few points up to a LiDAR sweep: the single-pass tables are sized by the bucket count the cloud asks
+    for (64 ... 4096 buckets), whatever that is the bucket path must build the level loop's tables."""
+    from octreelib_amd import synthetic
+    from octreelib_amd._engine import Forest
+
+    for n in (1, 2, 7, 63, 64, 65, 200, 3000, 30_000, 100_000, 300_000):
+        pts = synthetic.planar_cloud(n, (7, 7, 7), seed=1, stream=n)
+        tabs = []
+        for general in (0, 1):
+            set_option("NO_BUCKET_BUILD", general)
+            f = Forest(0, np.zeros(3), 1.0)
+            f.add_pose(pts)
+            f.subdivide(20)
+            tabs.append(_tables(f))
+            f.close()
+        set_option("NO_BUCKET_BUILD", 0)
+        _assert_same_tables(tabs[0], tabs[1])

@@ -10,7 +10,7 @@
 # 3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters), as MI355X_MICROARCH.md asks
 # 4. the same kernel-stats pass on the uniform scene               -> profiles/TAG_uniform_kernel_stats.csv
 # then tools/summarize_profiles.py condenses them into profiles/TAG_*.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$PWD}
 HEAD="--no-secondary --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
@@ -18,8 +18,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 $HEAD > /dev/null 2>&1 || exit 3
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 $HEAD > /dev/null 2>&1 || exit 4
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 $HEAD > /dev/null 2>&1 || exit 5
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 --output-format csv -d $R/gpurun_out/pmc_valu_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 $HEAD > /dev/null 2>&1 || exit 5
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_uniform -- python3 $R/bench.py --steps 10 --warmup 2 --cloud uniform $HEAD > $R/gpurun_out/prof_${TAG}_uniform_bench.json 2> $R/gpurun_out/prof_${TAG}_uniform.err || exit 6
-cd $R && python3 tools/summarize_profiles.py $TAG gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_sq_$TAG gpurun_out/prof_${TAG}_bench.json || exit 6
+cd $R && python3 tools/summarize_profiles.py $TAG gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/pmc_sq_$TAG gpurun_out/prof_${TAG}_bench.json "bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline: the headline scene only, 10 M planar points, three resident clouds in turn" gpurun_out/pmc_valu_$TAG || exit 6
+python3 tools/probes/step_timeline.py gpurun_out/prof_$TAG planar 4 > profiles/${TAG}_step_timeline.txt 2>&1
+# what k_ransac executes of what the algorithm asks for: the counting variant of the library (tools/build_variant.sh)
+if [ -f build/variants/rs_counts.so ]; then
+  OCTREELIB_AMD_LIB=$R/build/variants/rs_counts.so python3 tools/rs_counts.py > gpurun_out/rs_counts.log 2>&1 && cp gpurun_out/rs_counts.json profiles/${TAG}_ransac_counts.json
+fi
 cp $(ls gpurun_out/prof_${TAG}_uniform/*/*kernel_stats.csv | head -1) profiles/${TAG}_uniform_kernel_stats.csv
 # 5. the two largest BASELINE configs alone (bench.py --workload c4 / c5shard): kernel stats + FETCH / WRITE passes
 #    -> profiles/TAG_c4_*, profiles/TAG_c5shard_*

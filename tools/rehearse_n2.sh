@@ -24,6 +24,15 @@ total = sum(ex["points_received_per_rank"])
 assert total == (2000000 if "$MODE" == "weak" else 2000000 // $N) * $N, total
 if "$MODE" == "weak":
     assert "strong_scaling_10M_total" in d["secondary"]
+# what the communicator and the devices say (the stand-in answers ncclCommCount / ncclCommUserRank / ncclGetVersion)
+tp = d["topology"]
+assert d["rccl_ranks"] == tp["rccl_ranks"] == $N == tp["launcher_world_size"], tp
+assert [r["rccl_user_rank"] for r in tp["ranks"]] == list(range($N)) == [r["launcher_rank"] for r in tp["ranks"]]
+assert tp["rank_order_agrees"] and tp["rehearsal_on_one_device"] and tp["distinct_devices"] == 1   # (every rank on device 0 here)
+assert all(len(r["device_uuid"]) == 32 and r["pci_bus_id"] for r in tp["ranks"])
+m = tp["alltoall_bytes_rank_to_peer_last_step"]
+assert len(m) == $N and all(len(row) == $N for row in m)
+assert [sum(row) - row[i] for i, row in enumerate(m)] == ex["bytes_sent_to_peers_per_rank"], (m, ex["bytes_sent_to_peers_per_rank"])
 print("$MODE", d["n_gpus"], "ranks", round(d["ms_per_step"], 2), "ms/step", round(d["value"]), d["unit"],
       "| imbalance", round(d["imbalance"], 4), "| all-to-all ms", round(ex["alltoall_ms_per_step_max_over_ranks"], 3),
       "| bytes sent", ex["bytes_sent_to_peers_per_rank"], "| leaves evaluated", d["roofline_valu"]["leaves_evaluated"])

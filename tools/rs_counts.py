@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""What k_ransac EXECUTES of what the algorithm asks for (a library built with -DRS_COUNTS, see csrc/ransac.hip):
+   tools/build_variant.sh rs_counts "-DRS_COUNTS" && OCTREELIB_AMD_LIB=build/variants/rs_counts.so python tools/rs_counts.py
+Counts per launch of the benchmarked instance (one wave per block): blocks, blocks that leave after pass 1 (256
+hypotheses) or after a later batch, plane fits executed of the 1024 per block the reference runs, (point, hypothesis)
+pairs scored by the f32 screen, hypotheses recounted in f64.  -> gpurun_out/rs_counts.json (kept as
+profiles/rNN_ransac_counts.json; bench.py's roofline_valu.executed reads it)."""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from octreelib_amd import _native as nat
+
+ctx = nat.Context(0)
+lib = ctx.lib
+lib.octl_debug_rs_stamps.restype = C.c_int
+lib.octl_debug_rs_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+wl = bench.Workload(ctx, ctx, 0, 1, 10_000_000, (32, 32, 32), "planar", 64, False, False, n_clouds=3)
+for _ in range(3):
+    wl.step()
+out = (C.c_ulonglong * 16)()
+ctx.check(lib.octl_debug_rs_stamps(ctx.handle, out, 1))
+reps = 6
+for _ in range(reps):
+    wl.step()
+ctx.sync()
+ctx.check(lib.octl_debug_rs_stamps(ctx.handle, out, 0))
+v = [out[i] / reps for i in range(16)]
+blocks, skipped1, pts = v[8], v[9], v[11]
+H, F, HPL, LANES = 1024, 256, 16, 64
+groups_total = blocks * HPL                       # hypothesis groups of 64 the reference's 1024 threads amount to
+groups_skipped = skipped1 * (HPL - F // LANES) + v[12]
+groups_scored = v[14]
+res = {
+    "instance": "k_ransac<64,16,6,0,true,true> (blocks of 6..63 points; the 64-point leaves run in k_ransac<128,8,...> "
+                "and are not counted here)",
+    "blocks_per_launch": blocks, "mean_block_size": pts / blocks,
+    "blocks_leaving_after_pass_1": skipped1, "fraction_blocks_leaving_after_pass_1": skipped1 / blocks,
+    "hypothesis_groups_skipped_by_later_exits": v[12],
+    "plane_fits_asked": blocks * H, "plane_fits_executed": groups_scored * LANES,
+    "fraction_plane_fits_executed": groups_scored / groups_total,
+    "pairs_asked": pts * H, "pairs_screened_f32": v[15] * LANES,
+    "fraction_pairs_scored": v[15] * LANES / (pts * H),
+    "hypotheses_recounted_f64": v[13], "fraction_hypotheses_recounted": v[13] / (groups_scored * LANES),
+    "pairs_recounted_f64_estimate": v[13] * (pts / blocks),
+    "check_groups": {"scored_plus_skipped": groups_scored + groups_skipped, "total": groups_total},
+    "note": "average per launch over %d steps of the rotating headline workload; wave 0 of every workgroup counts "
+            "(the instance runs one wave per block, so wave 0 is the block)" % reps,
+}
+print(json.dumps(res, indent=1))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/rs_counts.json", "w"), indent=1)
+wl.close()

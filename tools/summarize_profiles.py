@@ -83,6 +83,23 @@ def main():
     json.dump({"_note": "SQ counters per launch (sum over XCDs); SQ_* cycle counters are quad-cycles; "
                         "valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8)",
                "kernels": rows}, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
+    # instruction mix of the VALU (a fourth --pmc pass, optional 8th argument): wave-level instructions per launch by
+    # type - what the RANSAC kernel EXECUTES, to hold against the algorithmic flop count of SURVEY 8(d)
+    if len(sys.argv) > 8 and sys.argv[8] != "-":
+        mix_c, mix_d = counters(sys.argv[8]), durations(sys.argv[8])
+        mix = {}
+        for k, c in mix_c.items():
+            if not any(n.startswith("SQ_INSTS_VALU_") for n in c) or k not in mix_d:
+                continue
+            mix[k] = {"duration_us": mix_d[k] / 1e3, "dispatches": c.get("_dispatches", 0)}
+            mix[k].update({n[len("SQ_INSTS_VALU_"):].lower(): v for n, v in c.items() if n.startswith("SQ_INSTS_VALU_")})
+        json.dump({"_note": "wave-level VALU instructions per launch by type (rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 "
+                            "MUL_F64 FMA_F64 TRANS_F64 ADD_F32 MUL_F32 FMA_F32 INT32, one pass; sum over XCDs); one "
+                            "wave instruction = 64 lane operations, an FMA = 2 flops per lane",
+                   "kernels": mix}, open(f"profiles/{tag}_valu_mix.json", "w"), indent=1)
+        for k in sorted(mix):
+            if k.startswith("k_ransac<"):
+                print(k, json.dumps(mix[k]))
     for k in sorted(set(rows) | set(out["kernels"])):
         if not re.match(r"k_(ransac<|ingest|part_|bucket_|compact_tiles|transpose)", k):
             continue
