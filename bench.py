@@ -1396,19 +1396,24 @@ def valu_executed(ransac_ms_live):
     all_valu = sq["kernels"][main]["wave_valu_instructions"]
     f64 = tot["add_f64"] + tot["mul_f64"] + tot["fma_f64"] + tot["trans_f64"]
     f32 = tot["add_f32"] + tot["mul_f32"] + tot["fma_f32"]
-    issue_ceiling = 1024 * clock * 1e9 / 4.0          # wave instructions per second: 1024 SIMDs, 4 cycles each
+    sq_t_s = sq["kernels"][main]["duration_us"] * 1e-6
+    simd_cycles = 1024 * clock * 1e9 * sq_t_s          # SIMD cycles of the SQ pass's launch (1024 SIMDs)
     out = {
         "profile": _tracked("valu_mix.json"), "kernel": main, "launch_ms_profiled": rows[main]["duration_us"] / 1e3,
         "launch_ms_live": ransac_ms_live, "effective_clock_GHz": clock,
         "wave_instructions_per_launch": {"f64": f64, "f32": f32, "int32": tot["int32"], "all_valu": all_valu, **tot},
         "f64_TFLOPs_executed": (64 * (tot["add_f64"] + tot["mul_f64"] + tot["trans_f64"]) + 128 * tot["fma_f64"]) / t_s / 1e12,
         "f32_TFLOPs_executed": (64 * (tot["add_f32"] + tot["mul_f32"]) + 128 * tot["fma_f32"]) / t_s / 1e12,
-        "valu_issue_fraction_at_measured_clock": all_valu / t_s / issue_ceiling,
+        "valu_busy_fraction": sq["kernels"][main]["valu_busy_fraction"],
+        "simd_cycles_per_valu_wave_instruction": simd_cycles / all_valu if all_valu else None,
+        "f64_issue_cycles_share": (4.0 * f64 / simd_cycles) if simd_cycles else None,
         "f64_share_of_valu_instructions": f64 / all_valu if all_valu else None,
         "f32_share_of_valu_instructions": f32 / all_valu if all_valu else None,
         "note": "wave-level instruction counts of the tracked profile (all k_ransac instances of a step); issue "
-                "ceiling = 1024 SIMDs x clock / 4 cycles per wave instruction at the clock the SQ pass measured "
-                "(power-limited: 2.4 GHz nominal)",
+                "MEASURED, not assumed: simd_cycles_per_valu_wave_instruction = 1024 SIMDs x the clock x the time of the SQ "
+                "pass's launch / its VALU wave instructions, at valu_busy ~ 1 (a 64-lane f64 instruction issues over 4 "
+                "cycles: f64_issue_cycles_share of all SIMD cycles; the rest of the stream - f32 screen, integer, moves - "
+                "averages less than 4).  The clock is power-limited (2.4 GHz nominal)",
     }
     if cnt:
         out.update({
@@ -1457,7 +1462,9 @@ TIMER_KERNELS = {
     "ransac": ["k_ransac<"],
 }
 # the kernel that runs exactly ONCE per step of a workload: dispatch counts are taken relative to it
-PROFILE_REF = {"headline": ("k_bucket_scan_totals", "k_bucket_totals"), "c5shard": ("k_bucket_scan_totals", "k_bucket_totals"),
+# (k_bucket_finish: a build whose hinted geometry is rejected launches the partition kernels and the totals twice,
+#  the finish once; round-4 profiles: k_bucket_totals)
+PROFILE_REF = {"headline": ("k_bucket_finish", "k_bucket_totals"), "c5shard": ("k_bucket_finish", "k_bucket_totals"),
                "c4": ("k_finalize_rec",)}
 
 # DESIGN bytes per point of the streaming kernels of insert + subdivide: what each one has to read and write

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void k_fill_u8(uint8_t* p, int64_t n, uint8_t 
 // ---- apply_mask: stream compaction of the leaf-ordered arrays and of the block table ----------------------
 // kept points per 2048-point tile (the compaction's tile offsets) ...
 __device__ __forceinline__ void mask_tile_count(const uint8_t* __restrict__ mask, int64_t n,
-                                                uint32_t* __restrict__ tilecnt, uint32_t tile) {
+                                                uint32_t* __restrict__ tilecnt, uint32_t tile,
+                                                uint8_t* __restrict__ alive_fill) {
   __shared__ uint32_t s_w[4];
   const int64_t i0 = (int64_t)tile * 2048 + (int64_t)threadIdx.x * 8;
   uint32_t c = 0;
@@ -145,8 +146,13 @@ __device__ __forceinline__ void mask_tile_count(const uint8_t* __restrict__ mask
     // bytes that are not zero
     const uint64_t nz = ((w & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | w;
     c = (uint32_t)__popcll(nz & 0x8080808080808080ull);
+    // (alive flags that were never written - a cloud taken in place: position range = store range)
+    if (alive_fill) *reinterpret_cast<uint64_t*>(alive_fill + i0) = 0x0101010101010101ull;
   } else {
-    for (int64_t i = i0; i < n; ++i) c += mask[i] ? 1u : 0u;
+    for (int64_t i = i0; i < n; ++i) {
+      c += mask[i] ? 1u : 0u;
+      if (alive_fill) alive_fill[i] = 1;
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
@@ -161,9 +167,10 @@ __global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ ma
                                                   uint32_t* __restrict__ tilecnt,
                                                   const uint32_t* __restrict__ blk_start,
                                                   const int32_t* __restrict__ blk_size, int64_t nb,
-                                                  uint32_t* __restrict__ kept, uint32_t* __restrict__ nonempty) {
+                                                  uint32_t* __restrict__ kept, uint32_t* __restrict__ nonempty,
+                                                  uint8_t* __restrict__ alive_fill) {
   if (blockIdx.x < nt) {
-    mask_tile_count(mask, n, tilecnt, blockIdx.x);
+    mask_tile_count(mask, n, tilecnt, blockIdx.x, alive_fill);
     return;
   }
   const int64_t b = (int64_t)(blockIdx.x - nt) * blockDim.x + threadIdx.x;
@@ -622,11 +629,19 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     // separate scan (10 M points: 65 us against 35)
     const bool fused = !ctx->opt.no_fused_tables && nt + 2 * ceil_div(nb, 256) <= 1024;
     const uint32_t wait_seq = octl_wait_next_seq(ctx);
-    if (!fused) {
+    // (alive flags that were never written - a cloud taken in place - are filled by the tile workgroups of the
+    //  first kernel: k_compact_tiles, a later launch, then clears the dropped points')
+    uint8_t* fill = nullptr;
+    if (f->alive_stale && f->n_ord == f->n_store) {
+      fill = f->alive.as<uint8_t>();
+      f->alive_stale = false;
+    } else {
       OCTL_TRY(alive_ensure(f));
+    }
+    if (!fused) {
       hipLaunchKernelGGL(k_blk_kept, dim3((unsigned)nt + grid_for(nb)), dim3(256), 0, st, mask, n, (uint32_t)nt, raw,
                          (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
-                         raw + nt, raw + nt + nb);
+                         raw + nt, raw + nt + nb, fill);
       HIP_TRY(ctx, hipGetLastError());
       OCTL_TRY(octl_exclusive_scan_u32(ctx, raw, scanned, n_all, small + 22));
     }
@@ -643,14 +658,6 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
       uint64_t* status = nullptr;
       uint32_t epoch = 0;
       OCTL_TRY(octl_scan_status_acquire(ctx, nt + 2 * nbw, &status, &epoch));
-      // (alive flags that were never written - a cloud taken in place - are filled by the tile workgroups)
-      uint8_t* fill = nullptr;
-      if (f->alive_stale && f->n_ord == f->n_store) {
-        fill = f->alive.as<uint8_t>();
-        f->alive_stale = false;
-      } else {
-        OCTL_TRY(alive_ensure(f));
-      }
       hipLaunchKernelGGL(k_mask_scan, dim3((unsigned)(nt + nbw)), dim3(256), 0, st, mask, n, (uint32_t)nt, scanned,
                          (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
                          (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
