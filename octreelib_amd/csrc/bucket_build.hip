@@ -1896,7 +1896,10 @@ __global__ __launch_bounds__(256) void k_old_voxels_missing(const uint64_t* __re
   if (!found) atomicAdd(missing, 1u);
 }
 
-__global__ __launch_bounds__(256) void k_bucket_finish(
+#ifndef BF_WAVES
+#define BF_WAVES 8   // waves per SIMD asked of the compiler for k_bucket_finish: 64 VGPRs, 16 B of scratch per lane (A/B on one box: 4 waves at 128 VGPRs 0.109 ms, 5: 0.121, 6: 0.104, 8: 0.092 - the kernel is latency bound)
+#endif
+__global__ __launch_bounds__(256, BF_WAVES) void k_bucket_finish(
     NodePtrs nd, NodeParams P, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bk_base,
     const uint32_t* __restrict__ grand_total, const uint32_t* __restrict__ leafinfo,
     const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bk_vox,
@@ -2163,19 +2166,23 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
     constexpr int FR = BB_CAP / 256;
     const int wave = tid >> 6, lane = tid & 63;
     const uint64_t lt = lanemask_lt();
-    uint32_t li[FR], rk[FR];
+    // (the words are held only as far as the ballots: the emitting pass below finds its heads in the ballots and
+    //  loads a head's word again - an L2 hit for one lane in ~17 - instead of keeping 16 words and 16 ranks per lane
+    //  through it: 128 -> fewer VGPRs, more buckets in flight per CU; the kernel is latency bound)
+    {
+      uint32_t li[FR];
 #pragma unroll
-    for (int r = 0; r < FR; ++r) {
-      const int f = r * 256 + tid;
-      li[r] = f < n ? leafinfo[(size_t)start + f] : 0u;
-    }
+      for (int r = 0; r < FR; ++r) {
+        const int f = r * 256 + tid;
+        li[r] = f < n ? leafinfo[(size_t)start + f] : 0u;
+      }
 #pragma unroll
-    for (int r = 0; r < FR; ++r) {
-      const uint64_t bal = __ballot((li[r] & LI_BHEAD) != 0u);   // (positions behind n hold 0)
-      rk[r] = (uint32_t)__popcll(bal & lt);
-      if (lane == 0) {
-        s_hc[r * 4 + wave] = (uint32_t)__popcll(bal);
-        s_bal[r * 4 + wave] = bal;
+      for (int r = 0; r < FR; ++r) {
+        const uint64_t bal = __ballot((li[r] & LI_BHEAD) != 0u);   // (positions behind n hold 0)
+        if (lane == 0) {
+          s_hc[r * 4 + wave] = (uint32_t)__popcll(bal);
+          s_bal[r * 4 + wave] = bal;
+        }
       }
     }
     __syncthreads();
@@ -2191,20 +2198,23 @@ __global__ __launch_bounds__(256) void k_bucket_finish(
       if (tid == 63) s_hc[64] = inc;
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll 2
     for (int r = 0; r < FR; ++r) {
       const int f = r * 256 + tid;
-      const bool bhead = (li[r] & LI_BHEAD) != 0u;
+      if (r * 256 >= n) break;
+      const unsigned long long bal = s_bal[r * 4 + wave];
+      const bool bhead = ((bal >> lane) & 1ull) != 0ull;
       uint32_t size = 0;
       if (bhead) {
         // the next head: later in this wave's ballot, or the first one of a following ballot; none = end of the piece
         int q = r * 4 + wave;
-        unsigned long long rest = s_bal[q] & ~lt & ~(1ull << lane);
+        unsigned long long rest = bal & ~lt & ~(1ull << lane);
         while (rest == 0ull && ++q < FR * 4) rest = s_bal[q];
         const int next = rest ? q * 64 + (__ffsll((long long)rest) - 1) : n;
         size = (uint32_t)(next - f);
       }
-      if (f < n && (bhead || P.write_pos)) emit(f, li[r], bhead, s_hc[r * 4 + wave] + rk[r], size);
+      if (f < n && (bhead || P.write_pos))
+        emit(f, leafinfo[(size_t)start + f], bhead, s_hc[r * 4 + wave] + (uint32_t)__popcll(bal & lt), size);
     }
     brun = s_hc[64];
   } else {
