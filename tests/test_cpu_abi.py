@@ -179,3 +179,27 @@ def test_bench_gpus_n_starts_its_own_ranks_or_says_why_not():
                          text=True, timeout=300, env=env)
     assert out.returncode == 2
     assert "needs 2 GPUs" in out.stderr and out.stdout.strip() == ""
+
+
+def test_bench_plan_touches_no_gpu_and_fits_the_drivers_budget():
+    """`bench.py --gpus 8 --plan`: what the 8-rank run of BASELINE config 5 needs, printed as one JSON object without
+    starting a rank or touching a GPU (it must run in the build container)."""
+    import json
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plan"], capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["ranks"] == 8 and d["points_per_rank"] == 125_000_000 and d["total_points"] == 10 ** 9
+    assert d["device"]["hbm_GB_per_rank_estimate"] < d["device"]["hbm_GB_available"]
+    assert d["exchange"]["bytes_per_point"] == 32 and d["exchange"]["MB_per_peer_message"] == 500.0
+    assert d["seconds"]["wall_estimate"] < d["seconds"]["driver_budget"] == 600 and d["fits_driver_budget"] is True
+    # the strong-scaling series divides the N = 1 cloud
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plan", "--scaling", "strong"],
+                         capture_output=True, text=True, timeout=120)
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["ranks"] == 4 and d["points_per_rank"] == 2_500_000 and d["resident_clouds_per_rank"] == 3

@@ -239,3 +239,38 @@ def test_blocks_outside_the_range_certificate_keep_the_guards():
         assert np.array_equal(index, o_index)
         assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
         assert np.array_equal(mask, o_mask)
+
+
+def test_context_switches_counters_and_device_identity():
+    """Round-5 additions to the C ABI: diagnostic switches of a live context (octl_debug_set_option - the library
+    reads its OCTL_* environment only when a context is created), the launch counter beside the host-wait counter,
+    the identity of the device behind a context, and the communicator query without a communicator."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+    from octreelib_amd._engine import Forest
+
+    ctx = nat.get_context()
+    lib = ctx.lib
+    with pytest.raises(ValueError, match="no such option"):
+        ctx.set_option("NO_SUCH_SWITCH", 1)
+    ctx.set_option("OCTL_NO_SPIN_WAIT", 1)      # (the prefix is accepted)
+    ctx.set_option("NO_SPIN_WAIT", 0)
+    l0, l1, s0, s1 = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    ctx.check(lib.octl_debug_launches(C.byref(l0)))
+    ctx.check(lib.octl_debug_host_syncs(C.byref(s0)))
+    f = Forest(0, np.zeros(3), 1.0)
+    f.add_pose(synthetic.planar_cloud(20_000, (3, 3, 3), seed=1, stream=9))
+    f.subdivide(32)
+    f.close()
+    ctx.check(lib.octl_debug_launches(C.byref(l1)))
+    ctx.check(lib.octl_debug_host_syncs(C.byref(s1)))
+    assert 5 <= l1.value - l0.value <= 40 and 1 <= s1.value - s0.value <= 12
+    bus = C.create_string_buffer(32)
+    uu = (C.c_uint8 * 16)()
+    cus = C.c_int32(0)
+    ctx.check(lib.octl_device_identity(ctx.handle, bus, C.cast(uu, C.c_void_p), C.byref(cus)))
+    assert len(bus.value.decode().split(":")) == 3 and cus.value >= 64 and any(bytes(uu))
+    n = C.c_int32(0)
+    assert lib.octl_comm_info(ctx.handle, C.byref(n), None, None) == nat.OCTL_E_STATE   # no communicator on this context
