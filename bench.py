@@ -548,6 +548,38 @@ def run_no_hint(ctx, wl, timed):
                     "geometry from k_bucket_geom; kernel tables from fully instrumented steps"}
 
 
+def run_small_scan(ctx, k_split, timed, n=100_000, steps=60):
+    """The same step on one LiDAR sweep's worth of points (BASELINE config 1's size, 7^3 voxels of the planar scene):
+    bound by launches and host waits, not by bytes - both are counted by the library."""
+    lib = ctx.lib
+    side = max(2, int(round((n / 305.0) ** (1.0 / 3.0))))
+    out = {"points": n, "scene": f"{side}^3 voxels of 1 m, planar"}
+    for name, n_clouds in (("one_cloud", 1), ("rotating_3_clouds", 3)):
+        w = Workload(ctx, ctx, 0, 1, n, (side, side, side), "planar", k_split, False, False, n_clouds=n_clouds)
+        w.run(6)
+        ms = timed(w.step, reps=steps) * 1e3
+        c0, c1, l0, l1 = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
+        ctx.check(lib.octl_debug_launches(C.byref(l0)))
+        w.run(6)
+        ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
+        ctx.check(lib.octl_debug_launches(C.byref(l1)))
+        ctx.sync()
+        ctx.set_profiling(True)
+        w.run(6)
+        ctx.sync()
+        tm = ctx.timings()
+        ctx.set_profiling(False)
+        out[name] = {"ms": ms, "Mpoints_per_s": n / ms / 1e3, "launches_per_step": (l1.value - l0.value) / 6.0,
+                     "host_waits_per_step": (c1.value - c0.value) / 6.0, "leaves": int(w.info.n_blocks),
+                     "kernels_ms_per_step_instrumented": {k: round(v[0] / 6.0, 4) for k, v in sorted(tm.items())}}
+        w.close()
+    out["note"] = ("insert + subdivide(len>%d) + RANSAC(H=1024) + apply_mask of a %d-point scan, %d timed steps; host "
+                   "waits poll a flag in the pinned mirror (octl_wait_mirror_flags) and are counted like "
+                   "synchronisations; round 4: 0.25 ms, 30 launches" % (k_split, n, steps))
+    return out
+
+
 def run_c1(ctx, reps=5):
     """BASELINE config 1: a bare Octree over [0,1)^3, 100 k uniform points (default_rng(1234)), insert +
     subdivide(len > 32); the reference's own answer for exactly this input is 6601 nodes / 5748 leaves.
@@ -1076,6 +1108,7 @@ def main():
             sw.close()
             secondary["no_geometry_hint"] = run_no_hint(ctx, wl, timed)
             secondary["c1_octree_100k"] = run_c1(ctx)
+            secondary["small_scan_100k"] = run_small_scan(ctx, args.k_split, timed)
             secondary["c4_manager"] = run_c4(ctx)
             secondary["c5_shard"] = run_c5_shard(ctx, args.k_split, timed)
             # two independent step sequences (two contexts = two streams, two forests, two host threads): what

@@ -21,5 +21,7 @@ for fn, seeds in cases:
             print("FAILED", fn.__name__, seed); traceback.print_exc()
         finally:
             mp.undo()
+            from octreelib_amd import _native as nat
+            nat.get_context().reset_options()   # (the tests switch code paths with Context.set_option)
     print(fn.__name__, "done", flush=True)
 print("failures:", bad)

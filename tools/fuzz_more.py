@@ -9,4 +9,6 @@ for seed in range(lo, hi):
     except Exception:
         bad += 1
         print("FAILED seed", seed); traceback.print_exc()
+    if seed % 10 == 0:
+        print("seed", seed, flush=True)
 print("done, failures:", bad)
