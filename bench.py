@@ -167,7 +167,7 @@ def parse_args():
                     help="N > 1: weak = --points-per-rank points on every rank, the scene grows with N (default); "
                          "strong = the N = 1 workload (10 M points over 32^3 voxels, or --points-per-rank as the TOTAL) "
                          "divided among the ranks, SURVEY 8(d)")
-    ap.add_argument("--workload", choices=["headline", "c4", "c5shard"], default="headline",
+    ap.add_argument("--workload", choices=["headline", "c4", "c5shard", "small"], default="headline",
                     help="profiling only (tools/profile_round.sh): run ONE secondary workload alone and print its "
                          "JSON - c4 = BASELINE config 4, c5shard = one rank's 125 M-point shard of config 5")
     ap.add_argument("--plan", action="store_true",
@@ -830,8 +830,12 @@ def main():
     if args.workload != "headline":
         if world != 1:
             sys.exit("--workload c4 / c5shard are one-GPU profiling runs")
-        res = run_c4(ctx, reps=max(3, args.steps)) if args.workload == "c4" else \
-            run_c5_shard(ctx, args.k_split, timed, steps=max(3, args.steps))
+        if args.workload == "small":   # (secondary.small_scan_100k alone)
+            res = run_small_scan(ctx, args.k_split, timed, n=args.points or 100_000)
+        elif args.workload == "c4":
+            res = run_c4(ctx, reps=max(3, args.steps))
+        else:
+            res = run_c5_shard(ctx, args.k_split, timed, steps=max(3, args.steps))
         print(json.dumps({"workload": args.workload, **res}))
         ctx.close()
         return
