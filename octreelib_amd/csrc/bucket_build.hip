@@ -2861,12 +2861,13 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
   const int st_tiles = (int)std::min<int64_t>(16, std::max<int64_t>(1, ceil_div(ceil_div(N, tile), (int64_t)cus * OCTL_PT_WGS)));
   const uint32_t nst = (uint32_t)ceil_div(N, (int64_t)st_tiles * tile);
   OCTL_TRY(devbuf_reserve(ctx, f->part_xyz[0], (size_t)N * sizeof(PartRec)));
-  const size_t tab_elems = (((size_t)nd * nst) + 15) & ~(size_t)15;
+  const size_t tab_elems = (((size_t)nd * nst) + 1 + 15) & ~(size_t)15;
   OCTL_TRY(devbuf_reserve(ctx, f->bk_table, (2 * tab_elems + 16) * 4));
   uint32_t* table = f->bk_table.as<uint32_t>();
   uint32_t* table_dm = table + tab_elems;
   uint32_t* flag = table + 2 * tab_elems;
   HIP_TRY(ctx, hipMemsetAsync(flag, 0, 4, st));
+  const bool fused = !ctx->opt.no_fused_tables && nst <= TS_MAX_ROWS;   // (the table in one launch: k_table_scan)
   auto transpose = [&](const uint32_t* in, uint32_t R, uint32_t Cc, uint32_t* out) {
     hipLaunchKernelGGL(k_transpose_u32, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, R, Cc, out);
     return hipGetLastError();
@@ -2878,9 +2879,19 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
                        N, lp, (const GeomDev*)nullptr, nst, nd, (int64_t)st_tiles * tile, table,
                        reinterpret_cast<int32_t*>(flag));
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, transpose(table, nst, nd, table_dm));
-    OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd * nst, nullptr));
-    HIP_TRY(ctx, transpose(table_dm, nd, nst, table));
+    if (fused) {
+      const unsigned g = (nd + TS_COLS - 1) / TS_COLS;
+      uint64_t* status = nullptr;
+      uint32_t epoch = 0;
+      OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
+      hipLaunchKernelGGL(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, table_dm, status, epoch, 0,
+                         (const int32_t*)nullptr, (uint64_t)0, lp, (GeomDev*)nullptr);
+      HIP_TRY(ctx, hipGetLastError());
+    } else {
+      HIP_TRY(ctx, transpose(table, nst, nd, table_dm));
+      OCTL_TRY(octl_exclusive_scan_u32(ctx, table_dm, table_dm, (int64_t)nd * nst, nullptr));
+      HIP_TRY(ctx, transpose(table_dm, nd, nst, table));
+    }
   }
   {
     KTimer t(ctx, "prefix_scatter");
@@ -2893,7 +2904,7 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
   }
   *recs_out = f->part_xyz[0].p;
   *bstart = table_dm;
-  *bstride = nst;
+  *bstride = fused ? 1u : nst;   // (k_table_scan leaves the buckets' starts as a plain array)
   *bad_flag = flag;
   return OCTL_OK;
 }
