@@ -1447,11 +1447,19 @@ def valu_executed(ransac_ms_live):
         "f64_share_of_valu_instructions": f64 / all_valu if all_valu else None,
         "f32_share_of_valu_instructions": f32 / all_valu if all_valu else None,
         "note": "wave-level instruction counts of the tracked profile (all k_ransac instances of a step); issue "
-                "MEASURED, not assumed: simd_cycles_per_valu_wave_instruction = 1024 SIMDs x the clock x the time of the SQ "
-                "pass's launch / its VALU wave instructions, at valu_busy ~ 1 (a 64-lane f64 instruction issues over 4 "
-                "cycles: f64_issue_cycles_share of all SIMD cycles; the rest of the stream - f32 screen, integer, moves - "
-                "averages less than 4).  The clock is power-limited (2.4 GHz nominal)",
+                "effective_clock_GHz (GRBM_GUI_ACTIVE / 8 / time, the SQ pass) under-reads this kernel - with it VALU busy "
+                "exceeds 1 and an instruction would cost 3.5 cycles; the kernel's own clock (in_kernel_clock_GHz: s_memtime "
+                "over s_memrealtime in the counting build) is near nominal, and valu_issue_time = all VALU wave "
+                "instructions x 4 cycles / 1024 SIMDs / that clock reproduces the launch time: the kernel is VALU-ISSUE "
+                "bound, every instruction of any type costs the same four cycles, the chip is not throttling",
     }
+    if cnt and cnt.get("in_kernel_clock_GHz"):
+        # the kernel's OWN clock (s_memtime over s_memrealtime inside the counting build): with it the launch time
+        # follows from the instruction count alone - 4 cycles per 64-lane VALU instruction of any type
+        ck = cnt["in_kernel_clock_GHz"]
+        t_issue = 4.0 * all_valu / 1024.0 / (ck * 1e9)
+        out.update({"in_kernel_clock_GHz": ck, "valu_issue_time_ms_at_in_kernel_clock": t_issue * 1e3,
+                    "valu_issue_time_over_live_launch_time": t_issue * 1e3 / ransac_ms_live if ransac_ms_live else None})
     if cnt:
         out.update({
             "fraction_blocks_leaving_after_256_hypotheses": cnt["fraction_blocks_leaving_after_pass_1"],

@@ -672,13 +672,27 @@ __device__ unsigned long long g_rs_stamps[16];
     _rs_t0 = _t;                                                      \
   } while (0)
 #else
-#define RS_STAMP_INIT unsigned long long _rs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+// (RS_COUNTS: slots [0] / [1] carry the kernel's own clock instead - s_memtime ticks at the shader clock,
+//  s_memrealtime at 100 MHz: their ratio over a workgroup's life is the clock the chip held under this kernel's load,
+//  MI355X_MICROARCH.md "DVFS give-back" (6))
+#define RS_STAMP_INIT unsigned long long _rs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+                      const unsigned long long _rs_m0 = __builtin_amdgcn_s_memtime(),                      \
+                                               _rs_r0 = __builtin_amdgcn_s_memrealtime()
 #define RS_STAMP(k) do {} while (0)
+#define RS_CLOCK_FLUSH                                                  \
+  do {                                                                  \
+    _rs_acc[0] = __builtin_amdgcn_s_memtime() - _rs_m0;                 \
+    _rs_acc[1] = __builtin_amdgcn_s_memrealtime() - _rs_r0;             \
+  } while (0)
+#endif
+#ifndef RS_CLOCK_FLUSH
+#define RS_CLOCK_FLUSH do {} while (0)
 #endif
 #define RS_COUNT(k, v) _rs_acc[k] += (unsigned long long)(v)
 #define RS_STAMP_FLUSH                                                                  \
   do {                                                                                  \
     if (threadIdx.x == 0) {                                                             \
+      RS_CLOCK_FLUSH;                                                                   \
       _rs_acc[10] += 1;                                                                 \
       for (int _k = 0; _k < 16; ++_k) atomicAdd(&g_rs_stamps[_k], _rs_acc[_k]);         \
     }                                                                                   \

@@ -31,6 +31,8 @@ groups_total = blocks * HPL                       # hypothesis groups of 64 the 
 groups_skipped = skipped1 * (HPL - F // LANES) + v[12]
 groups_scored = v[14]
 res = {
+    # the kernel's own clock: shader-clock ticks over 100 MHz ticks, summed over the workgroups' lives
+    "in_kernel_clock_GHz": (v[0] / v[1]) * 0.1 if v[1] else None,
     "instance": "k_ransac<64,16,6,0,true,true> (blocks of 6..63 points; the 64-point leaves run in k_ransac<128,8,...> "
                 "and are not counted here)",
     "blocks_per_launch": blocks, "mean_block_size": pts / blocks,
