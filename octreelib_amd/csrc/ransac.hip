@@ -508,8 +508,10 @@ __device__ __forceinline__ void ransac_block_global(const BlockDesc& d, int be,
 // Helpers of the screened scoring loop, as inline asm on purpose: the loop's instruction mix is
 // the whole point.  Plain v_fma_f32: left to itself hipcc SLP-packs neighbouring hypotheses into
 // v_pk_fma_f32, which measured SLOWER than two scalar FMAs on gfx950 (both as compiler output
-// and hand-packed with op_sel broadcasts: 5.56 vs 5.47 ms), and adds canonicalising v_max
-// around fminf.
+// and hand-packed with op_sel broadcasts: 5.56 vs 5.47 ms in round 2; again in round 5 on the
+// VALU-issue-bound kernel: 120 v_pk_fma_f32 for 240 v_fma_f32, same moves, 119 VGPRs - 3.60 vs
+// 3.52 ms, although tools/probes/pkfma_probe.hip has the packed form at 5.2 cycles against
+// 2 x 3.5 in isolation), and adds canonicalising v_max around fminf.
 typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float fma32(float a, float b, float c) {
   float r;
