@@ -573,6 +573,20 @@ def run_small_scan(ctx, k_split, timed, n=100_000, steps=60):
         out[name] = {"ms": ms, "Mpoints_per_s": n / ms / 1e3, "launches_per_step": (l1.value - l0.value) / 6.0,
                      "host_waits_per_step": (c1.value - c0.value) / 6.0, "leaves": int(w.info.n_blocks),
                      "kernels_ms_per_step_instrumented": {k: round(v[0] / 6.0, 4) for k, v in sorted(tm.items())}}
+        if n_clouds == 1:
+            # A/B/A: k_bucket_finish only behind the host's look at the totals (the round-5 form before the speculative
+            # launch)
+            ctx.set_option("NO_SPEC_FINISH", 1)
+            try:
+                w.run(6)
+                ms_plain = timed(w.step, reps=steps) * 1e3
+            finally:
+                ctx.set_option("NO_SPEC_FINISH", 0)
+            w.run(6)
+            ms_again = timed(w.step, reps=steps) * 1e3
+            out[name]["ms"] = min(ms, ms_again)
+            out[name]["Mpoints_per_s"] = n / out[name]["ms"] / 1e3
+            out[name]["ms_without_speculative_finish"] = ms_plain
         w.close()
     out["note"] = ("insert + subdivide(len>%d) + RANSAC(H=1024) + apply_mask of a %d-point scan, %d timed steps; host "
                    "waits poll a flag in the pinned mirror (octl_wait_mirror_flags) and are counted like "
@@ -880,16 +894,23 @@ def main():
 
     # host <-> device round trips of one step (library-internal synchronisations, counted by the library;
     # a few extra steps outside the timed region, profiling off)
-    host_syncs = launches = None
+    host_syncs = launches = spec_finish = None
     if world == 1 and not route:
         c0, c1, l0, l1 = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        h0, h1, m0, m1 = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         ctx.check(lib.octl_debug_host_syncs(C.byref(c0)))
         ctx.check(lib.octl_debug_launches(C.byref(l0)))
+        ctx.check(lib.octl_debug_spec_finish(C.byref(h0), C.byref(m0)))
         wl.run(2 * n_clouds)
         ctx.check(lib.octl_debug_host_syncs(C.byref(c1)))
         ctx.check(lib.octl_debug_launches(C.byref(l1)))
+        ctx.check(lib.octl_debug_spec_finish(C.byref(h1), C.byref(m1)))
         host_syncs = (c1.value - c0.value) / (2.0 * n_clouds)
         launches = (l1.value - l0.value) / (2.0 * n_clouds)
+        # k_bucket_finish enqueued before the host has seen the build's totals (the wait runs beside it): launches
+        # that did the work / that the host had to repeat, per step
+        spec_finish = {"held_per_step": (h1.value - h0.value) / (2.0 * n_clouds),
+                       "missed_per_step": (m1.value - m0.value) / (2.0 * n_clouds)}
 
     # algorithmic flops of the RANSAC launch from the REAL leaf sizes of this rank's build (every line: N = 1,
     # one rank's shard, N > 1 - the fall-back 6 H n ignores the plane fits and made the lines incomparable)
@@ -1292,6 +1313,7 @@ def main():
             "ms_per_step": ms_per_step,
             "host_syncs_per_step": host_syncs,
             "launches_per_step": launches,
+            "speculative_finish": spec_finish,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,

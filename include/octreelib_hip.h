@@ -295,6 +295,10 @@ int octl_debug_host_syncs(uint64_t* count);
 /* Kernel launches + asynchronous fills enqueued by the library so far (process-wide), the companion of
  * octl_debug_host_syncs: bench.py reports launches per step.                                          */
 int octl_debug_launches(uint64_t* count);
+/* Speculative launches of the bucket build's last kernel (k_bucket_finish enqueued before the host has seen the
+ * build's totals, its tables sized from the context's previous build) that did the work / that the host had to
+ * repeat the ordinary way (process-wide).  No reference counterpart: the reference has no device queue.        */
+int octl_debug_spec_finish(uint64_t* held, uint64_t* missed);
 
 /* Test hook: the communicator-independent half of octl_route_points for ANY number of ranks -
  * destination of every point (host cloud in), per-destination counts [n_ranks], and the packed

@@ -1844,6 +1844,15 @@ struct NodeParams {
   const uint64_t* old_vcode;
   int64_t old_voxels;
   VoxOrg org;  // voxel origin of the packed keys (old_vcode)
+  // Speculative launch (round 5): the kernel is enqueued BEFORE the host has seen the build's totals, so that the
+  // host's wait for them runs beside it instead of in front of it.  What the host would have decided from the totals
+  // is decided here from the same device words, identically for every workgroup: the geometry record is valid, nothing
+  // was left to the level loop / the general path / order.hip, no bucket needs the chunk kernels that have not run,
+  // and the tables the host sized from the context's previous build are large enough.  If not, every workgroup
+  // returns at once and the host - which checks the same words in the mirror - launches again the ordinary way.
+  const GeomDev* spec_geom;  // nullptr: an ordinary launch (lp above is final); else lp is read from this record
+  int spec_chunks;           // the chunk kernels ran beside the bucket kernel
+  int64_t vox_cap, blk_cap;  // capacity of vlin / order_out (entries)
 };
 
 // One workgroup per bucket, three independent sweeps (nothing is a serial chain any more: the bucket
@@ -1925,6 +1934,15 @@ __global__ __launch_bounds__(256, BF_WAVES) void k_bucket_finish(
   __shared__ uint32_t s_hc[65];            // block heads per (round, wave) of the piece, then their exclusive prefix | total
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
+  const bool spec = P.spec_geom != nullptr;
+  if (spec) {
+    // (kernel-uniform; the words are final: k_bucket_scan_totals is in front of this launch)
+    if (!P.spec_geom->valid) return;
+    if (small[SM_BK_FLAGS] | small[SM_BK_TODO] | small[SM_BK_NOORDER]) return;
+    if (!P.spec_chunks && small[SM_BK_OVERFULL]) return;
+    if ((int64_t)small[SM_NVOX] > P.vox_cap || (int64_t)small[SM_NBLOCKS] > P.blk_cap) return;
+    P.lp = P.spec_geom->lp;
+  }
   const uint32_t bucket_start = bstart[(size_t)b * P.bstride];
   const uint32_t bucket_end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   if (bucket_end == bucket_start) return;
@@ -1932,7 +1950,7 @@ __global__ __launch_bounds__(256, BF_WAVES) void k_bucket_finish(
   const int64_t V = (int64_t)head_int;                     // total of row BK_NVOX
   const int64_t n_int = (int64_t)(head_blk - head_int);    // total of the level rows
   if (V + 8 * n_int > P.node_cap) {
-    if (tid == 0) atomicOr(&small[SM_BK_FLAGS], 0x100u);  // the host grows the table and launches again
+    if (tid == 0 && !spec) atomicOr(&small[SM_BK_FLAGS], 0x100u);  // the host grows the table and launches again
     return;
   }
   // entries of the scanned table: row r, bucket b; the entry behind the last one of the table is the total
@@ -2648,8 +2666,73 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   static_assert(SM_GEOM == 64, "the geometry record is read back together with the 64 scalars in front of it");
   const int mirror_words = (int)(64 + (gdev ? sizeof(GeomDev) / 4 : 0));
   uint32_t sm[64];
+  // k_bucket_finish, launched the ordinary way (behind the host's look at the totals) or speculatively (in front of
+  // it: NodeParams::spec_geom)
+  NodePtrs nd_launch;
+  auto launch_finish = [&](const NodeParams& np, bool with_chunk_map) {
+    KTimer t(ctx, "bucket_nodes");
+    hipLaunchKernelGGL(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd_launch, np, bstart,
+                       (const uint32_t*)bk_scan, (const uint32_t*)(small + SM_BK_TOTAL),
+                       (const uint32_t*)f->leafinfo.as<uint32_t>(), (const uint32_t*)f->ord_idx.as<uint32_t>(),
+                       (const uint32_t*)f->bk_vox.as<uint32_t>(), (const uint32_t*)f->bk_node.as<uint32_t>(),
+                       (const int64_t*)f->pose_off_dev.as<int64_t>(), (const ChunkDesc*)ck_desc, (const uint32_t*)ck_tot,
+                       (const uint2*)(with_chunk_map ? ck_of_bucket : nullptr), f->pos_node.as<int32_t>(),
+                       f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
+                       f->blk_start.as<uint32_t>(), f->blk_size.as<int32_t>(), small);
+    return hipGetLastError();
+  };
+  NodeParams np;
+  std::memset(&np, 0, sizeof(np));
+  np.lp = lp;
+  np.bstride = bstride;
+  np.nb = nb;
+  np.n_alive = (uint32_t)n_alive;
+  np.n_poses = n_poses;
+  np.all_scheme = bp.all_scheme;
+  np.cur_epoch = a.cur_epoch;
+  np.old_fc = a.old_fc;
+  np.old_epoch = a.old_epoch;
+  np.old_vcode = a.old_vcode;
+  np.old_voxels = a.old_voxels;
+  // Speculative k_bucket_finish (see NodeParams): a fresh scheme under a geometry record on the device and tables sized from the context's previous bucket build (ctx->spec_*: 25 % above what that one
+  // needed).  OCTL_NO_SPEC_FINISH: never.
+  bool spec_launched = false;
+  int64_t spec_node_cap = 0, spec_vox_cap = 0, spec_blk_cap = 0;
+  const bool spec_order = n_poses == 1 && !ctx->opt.no_fast_order;
+  // (the voxel origin is only read against a previous scheme: NodeParams::org)
+  const bool spec_want = async_geom && gdev && !a.old_fc && !a.old_vcode && ctx->spec_nodes > 0 &&
+                         !ctx->opt.no_spec_finish;
+  auto spec_finish = [&]() {
+    // (a table that held the previous build is taken as it is - growing a live buffer waits for the stream, and the
+    //  kernel checks the real capacities anyway; one that did not is sized 25 % above that build)
+    // (the previous build's counts, in proportion to the points: a scan ten times larger is not given tables that
+    //  the ordinary launch would have to grow right away)
+    const double scale = (double)n_alive / (double)std::max<int64_t>(ctx->spec_points, 1);
+    auto expect = [&](int64_t prev) { return (int64_t)std::ceil((double)prev * scale); };
+    const int64_t e_nodes = expect(ctx->spec_nodes), e_vox = expect(ctx->spec_vox), e_blocks = expect(ctx->spec_blocks);
+    if (nt.cap < e_nodes) OCTL_TRY(nodes_reserve(ctx, nt, e_nodes + e_nodes / 4 + 64));
+    if (f->vlin_dev.cap < (size_t)e_vox * 8) OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)(e_vox + e_vox / 4 + 64) * 8));
+    if (spec_order && f->fast_order.cap < (size_t)e_blocks * 4)
+      OCTL_TRY(devbuf_reserve(ctx, f->fast_order, (size_t)(e_blocks + e_blocks / 4 + 64) * 4));
+    spec_node_cap = nt.cap;
+    spec_vox_cap = (int64_t)(f->vlin_dev.cap / 8);
+    spec_blk_cap = spec_order ? (int64_t)(f->fast_order.cap / 4) : ((int64_t)1 << 40);
+    nd_launch = node_ptrs(nt);
+    NodeParams sp = np;
+    sp.node_cap = spec_node_cap;
+    sp.write_pos = 0;
+    sp.order_out = spec_order ? f->fast_order.as<int32_t>() : nullptr;
+    sp.org = f->vorg;
+    sp.spec_geom = gdev;
+    sp.spec_chunks = chunks_beside ? 1 : 0;
+    sp.vox_cap = spec_vox_cap;
+    sp.blk_cap = spec_blk_cap;
+    HIP_TRY(ctx, launch_finish(sp, chunks_beside));
+    spec_launched = true;
+    return (int)OCTL_OK;
+  };
   // raw totals -> scanned totals + the build's scalars in the pinned mirror; the host polls for them
-  auto scan_totals = [&]() {
+  auto scan_totals = [&](bool with_spec) {
     const uint32_t wait_seq = octl_wait_next_seq(ctx);
     {
       KTimer t(ctx, "bucket_scan");
@@ -2669,13 +2752,14 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       }
       HIP_TRY(ctx, hipGetLastError());
     }
+    if (with_spec) OCTL_TRY(spec_finish());
     // (the totals kernel writes the scalars and then its flag into the pinned mirror)
     const int flag = MIRROR_FLAG_BUILD;
     OCTL_TRY(octl_wait_mirror_flags(ctx, &flag, 1, wait_seq, 200 + n_alive / 20000));
     std::memcpy(sm, ctx->small_host, sizeof(sm));
     return (int)OCTL_OK;
   };
-  OCTL_TRY(scan_totals());
+  OCTL_TRY(scan_totals(spec_want));
   if (hinted2) {
     GeomDev g;
     std::memcpy(&g, static_cast<char*>(ctx->small_host) + SM_GEOM * 4, sizeof(g));
@@ -2738,7 +2822,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       KTimer t(ctx, "bucket_build");
       OCTL_TRY(launch_chunks(st));
     }
-    OCTL_TRY(scan_totals());
+    OCTL_TRY(scan_totals(false));
   }
   ctx->had_chunks = overfull;
   if (sm[SM_BK_FLAGS]) return OCTL_OK;  // some bucket / voxel does not fit: the caller runs the general path
@@ -2755,45 +2839,35 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   if (depth > a.max_depth) return octl_set_error(ctx, OCTL_E_DEPTH, "maximum depth %d exceeded", a.max_depth);
   const int64_t total = V + 8 * n_int;
   if (total >= ((int64_t)1 << 31)) return octl_set_error(ctx, OCTL_E_NOMEM, "more than 2^31 scheme nodes");
-  OCTL_TRY(nodes_reserve(ctx, nt, total));
-  OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
-  NodePtrs nd = node_ptrs(nt);
-  // (first_child = -1 / epoch = 0 of every node: written by k_bucket_finish with the node's other fields)
-  NodeParams np;
-  np.lp = lp;
-  np.bstride = bstride;
-  np.nb = nb;
-  np.n_alive = (uint32_t)n_alive;
-  np.n_poses = n_poses;
-  np.all_scheme = bp.all_scheme;
-  np.cur_epoch = a.cur_epoch;
-  np.node_cap = nt.cap;
-  np.write_pos = sm[SM_BK_TODO] > 0;
-  np.old_fc = a.old_fc;
-  np.old_epoch = a.old_epoch;
-  np.old_vcode = a.old_vcode;
-  np.old_voxels = a.old_voxels;
-  np.org = f->vorg;
   // the listing order of the blocks falls out of the same kernel for the common case: one pose, a fresh
   // scheme (one epoch), nothing left to the level loop, no bucket beyond what the kernel ranks in LDS
   const bool fast_order = n_poses == 1 && !a.old_fc && sm[SM_BK_TODO] == 0 && sm[SM_BK_NOORDER] == 0 &&
                           !ctx->opt.no_fast_order;
-  np.order_out = nullptr;
-  if (fast_order) {
-    OCTL_TRY(devbuf_reserve(ctx, f->fast_order, (size_t)std::max<uint32_t>(sm[SM_NBLOCKS], 1) * 4));
-    np.order_out = f->fast_order.as<int32_t>();
-  }
-  {
-    KTimer t(ctx, "bucket_nodes");
-    hipLaunchKernelGGL(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd, np, bstart,
-                       (const uint32_t*)bk_scan, (const uint32_t*)(small + SM_BK_TOTAL),
-                       (const uint32_t*)f->leafinfo.as<uint32_t>(), (const uint32_t*)f->ord_idx.as<uint32_t>(),
-                       (const uint32_t*)f->bk_vox.as<uint32_t>(), (const uint32_t*)f->bk_node.as<uint32_t>(),
-                       (const int64_t*)f->pose_off_dev.as<int64_t>(), (const ChunkDesc*)ck_desc, (const uint32_t*)ck_tot,
-                       (const uint2*)((overfull || chunks_beside) ? ck_of_bucket : nullptr), f->pos_node.as<int32_t>(),
-                       f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
-                       f->blk_start.as<uint32_t>(), f->blk_size.as<int32_t>(), small);
-    HIP_TRY(ctx, hipGetLastError());
+  // the speculative launch did the work iff the words it looked at on the device - the same ones as in `sm` - passed
+  // (the geometry record is valid here: the invalid cases have returned above)
+  const bool spec_held = spec_launched && sm[SM_BK_TODO] == 0 && sm[SM_BK_NOORDER] == 0 &&
+                         (chunks_beside || !overfull) && V <= spec_vox_cap && (int64_t)sm[SM_NBLOCKS] <= spec_blk_cap &&
+                         total <= spec_node_cap;
+  ctx->spec_points = n_alive;
+  ctx->spec_nodes = total;
+  ctx->spec_vox = V;
+  ctx->spec_blocks = sm[SM_NBLOCKS];
+  if (spec_launched) (spec_held ? g_octl_spec_held : g_octl_spec_missed).fetch_add(1, std::memory_order_relaxed);
+  if (!spec_held) {
+    OCTL_TRY(nodes_reserve(ctx, nt, total));
+    OCTL_TRY(devbuf_reserve(ctx, f->vlin_dev, (size_t)std::max<int64_t>(V, 1) * 8));
+    nd_launch = node_ptrs(nt);
+    // (first_child = -1 / epoch = 0 of every node: written by k_bucket_finish with the node's other fields)
+    np.lp = lp;
+    np.node_cap = nt.cap;
+    np.write_pos = sm[SM_BK_TODO] > 0;
+    np.org = f->vorg;
+    np.order_out = nullptr;
+    if (fast_order) {
+      OCTL_TRY(devbuf_reserve(ctx, f->fast_order, (size_t)std::max<uint32_t>(sm[SM_NBLOCKS], 1) * 4));
+      np.order_out = f->fast_order.as<int32_t>();
+    }
+    HIP_TRY(ctx, launch_finish(np, overfull || chunks_beside));
     // (block sizes: written by k_bucket_finish itself since round 5 - a block ends where the next head of its piece
     //  is, or with the piece)
   }

@@ -30,6 +30,8 @@ static inline hipError_t octl_counted_event_sync(hipEvent_t e) {
 // ... and every kernel launch and asynchronous fill (a fill is a kernel of the runtime's): octl_debug_launches -
 // launches per step is the other figure a small scan lives by
 extern std::atomic<uint64_t> g_octl_launches;
+// speculative launches of k_bucket_finish that did the work / that the host had to repeat (octl_debug_spec_finish)
+extern std::atomic<uint64_t> g_octl_spec_held, g_octl_spec_missed;
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, ...)                                   \
   do {                                                                        \
@@ -89,6 +91,8 @@ struct OctlOptions {
   int64_t scan_mode = 0;           // OCTL_SCAN: 1 = single-pass scan always, 3 = three-kernel scan always
   int64_t no_fused_tables = 0;     // OCTL_NO_FUSED_TABLES: the small table chains as separate launches (A/B)
   int64_t no_spin_wait = 0;        // OCTL_NO_SPIN_WAIT: every host wait is a hipStreamSynchronize (A/B)
+  int64_t ransac_waves = 0;        // OCTL_RANSAC_WAVES: waves per block of the H > 256 RANSAC instances (0: the library's policy; 1, 2, 4)
+  int64_t no_spec_finish = 0;      // OCTL_NO_SPEC_FINISH: k_bucket_finish only behind the host's look at the totals (A/B)
 };
 // name (without the OCTL_ prefix or with it) -> field; nullptr when there is no such switch
 int64_t* octl_option_field(OctlOptions& o, const char* name);
@@ -147,6 +151,9 @@ struct octl_ctx {
   // the last bucket build had buckets beyond 4096 points (a skewed scene): the next one launches the chunk kernels
   // beside k_bucket_build right away instead of learning about them from the totals (two launches an even scene saves)
   bool had_chunks = false;
+  // node / voxel / block counts of the context's previous bucket build: the tables of a speculative k_bucket_finish
+  // are sized from them (0: no bucket build yet)
+  int64_t spec_points = 0, spec_nodes = 0, spec_vox = 0, spec_blocks = 0;
   // the hypothesis table of the last octl_forest_ransac_all on this context (CudaRansac draws it once per object,
   // cuda_ransac.py:39-41, and a loop over scans hands the same one over for every scan - to a fresh forest each
   // time): kept per CONTEXT so that it is uploaded once

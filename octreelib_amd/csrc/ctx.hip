@@ -30,6 +30,7 @@ const OptName kOptions[] = {
     {"NO_INCREMENTAL", &OctlOptions::no_incremental},       {"ROUTE_SELF_SENDRECV", &OctlOptions::route_self_sendrecv},
     {"TRACE_BUILD", &OctlOptions::trace_build},             {"SCAN", &OctlOptions::scan_mode},
     {"NO_FUSED_TABLES", &OctlOptions::no_fused_tables},     {"NO_SPIN_WAIT", &OctlOptions::no_spin_wait},
+    {"NO_SPEC_FINISH", &OctlOptions::no_spec_finish},       {"RANSAC_WAVES", &OctlOptions::ransac_waves},
 };
 }  // namespace
 
@@ -68,6 +69,15 @@ std::atomic<uint64_t> g_octl_launches{0};
 extern "C" int octl_debug_launches(uint64_t* count) {
   if (!count) return OCTL_E_INVALID;
   *count = g_octl_launches.load(std::memory_order_relaxed);
+  return OCTL_OK;
+}
+
+std::atomic<uint64_t> g_octl_spec_held{0}, g_octl_spec_missed{0};
+
+extern "C" int octl_debug_spec_finish(uint64_t* held, uint64_t* missed) {
+  if (!held || !missed) return OCTL_E_INVALID;
+  *held = g_octl_spec_held.load(std::memory_order_relaxed);
+  *missed = g_octl_spec_missed.load(std::memory_order_relaxed);
   return OCTL_OK;
 }
 

@@ -1754,6 +1754,19 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   // 76 us one after the other, nothing beside the main kernel).
   hipStream_t side = st;
   bool on_side = false;
+  // waves per block of the H > 256 instances: 1 / 2 / 4 by size class (0), or every block under 128 points on two
+  // waves (2), every block under 256 on four (4) - see the launch policy below.  OCTL_RANSAC_WAVES forces one.
+  int waves_per_block = (int)ctx->opt.ransac_waves;
+  if (waves_per_block == 0 && !any_k && H > 256) {
+    // Launch policy.  One wave per block is the cheapest form per block (no cross-wave reduction, no barrier) and wins
+    // when there are many blocks per wave slot; a launch with few blocks is bound by the LATENCY of a block and by
+    // how evenly the blocks fall on the SIMDs: two or four waves per block shorten both.  Measured on dense planar
+    // scans (one cloud, whole step): 1 140 blocks 0.160 / 0.144 / 0.139 ms with 1 / 2 / 4 waves, 5 269 blocks 0.191 /
+    // 0.182 / 0.182, 16 644 blocks 0.266 / 0.262 / 0.272, 54 432 blocks 0.544 / 0.556 / 0.575.
+    const int64_t slots = (int64_t)cus * 16;   // resident one-wave workgroups
+    if (nb * 2 <= slots) waves_per_block = 4;
+    else if (nb <= 6 * slots) waves_per_block = 2;
+  }
 #if RS_SIDE_STREAM
   // (max_block: no block of the launch holds more points - the instances for larger blocks are not launched at all)
   const bool need_small = max_block >= RS_TINY_THREADS, need_mid = max_block >= RS_SMALL_THREADS,
@@ -1802,14 +1815,26 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
 #if RS_SMALL_THREADS > 0 && RS_SMALL_THREADS < RS_BIG_THREADS
 #define OCTL_RANSAC_SPLIT(KT, ABL)                                                                               \
   do {                                                                                                           \
-    if (need_mid)                                                                                                \
-      OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                                 \
-                        counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                  \
-    HIP_TRY(ctx, hipGetLastError());                                                                             \
-    if (need_small)                                                                                              \
+    if (waves_per_block == 4) {                                                                                  \
+      OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr, counters + RC_SORTED,           \
+                        (RS_POS_TABLE != 0), st);                                                                \
+    } else if (waves_per_block == 2) {                                                                           \
+      if (need_mid)                                                                                              \
+        OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                               \
+                          counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                \
+      HIP_TRY(ctx, hipGetLastError());                                                                           \
       OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                   \
-                        counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0), side);    \
-    OCTL_RANSAC_TINY(KT, ABL);                                                                                   \
+                        counters + RC_START + RS_SMALL_THREADS - 1, counters + RC_SORTED, (RS_POS_TABLE != 0), st); \
+    } else {                                                                                                     \
+      if (need_mid)                                                                                              \
+        OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                               \
+                          counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                \
+      HIP_TRY(ctx, hipGetLastError());                                                                           \
+      if (need_small)                                                                                            \
+        OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                 \
+                          counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0), side);  \
+      OCTL_RANSAC_TINY(KT, ABL);                                                                                 \
+    }                                                                                                            \
   } while (0)
 #else
 #define OCTL_RANSAC_SPLIT(KT, ABL) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU)

@@ -611,12 +611,17 @@ def test_ransac_blocks_on_both_sides_of_the_128_point_split_vs_oracle(H, k):
             cloud[s_:e_, 2] = 0.5 * cloud[s_:e_, 0] + 0.25 * cloud[s_:e_, 1]
         np.random.seed(H + k)
         op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=k)
-        mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
         o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.01, details=True)
-        assert np.array_equal(counts, o_count)
-        assert np.array_equal(index, o_index)
-        assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
-        assert np.array_equal(mask, o_mask)
+        # (RANSAC_WAVES: the launch policy's choice for a launch of this many blocks, then every block on the instance
+        #  its size class names / under 128 points on two waves / under 256 on four - ransac.hip: ransac_launch)
+        for waves in (0, 1, 2, 4):
+            set_option("RANSAC_WAVES", waves)
+            mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+            assert np.array_equal(counts, o_count), waves
+            assert np.array_equal(index, o_index), waves
+            assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32)), waves
+            assert np.array_equal(mask, o_mask), waves
+        set_option("RANSAC_WAVES", 0)
 
 
 @pytest.mark.parametrize("H", [1024, 700, 257, 513])
@@ -641,14 +646,17 @@ def test_ransac_early_exit_keeps_the_lowest_index_winner(H):
         cloud[starts[b], 2] += 0.5
     np.random.seed(H)
     op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=6)
-    mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
     o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.01, details=True)
     full = o_count == sizes
     assert 0.1 < full.mean() < 0.95          # the exit is exercised and so is the full evaluation
-    assert np.array_equal(counts, o_count)
-    assert np.array_equal(index, o_index)
-    assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32))
-    assert np.array_equal(mask, o_mask)
+    for waves in (0, 1, 2, 4):               # (one, two, four waves per block: ransac_launch's policy and each form forced)
+        set_option("RANSAC_WAVES", waves)
+        mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+        assert np.array_equal(counts, o_count), waves
+        assert np.array_equal(index, o_index), waves
+        assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32)), waves
+        assert np.array_equal(mask, o_mask), waves
+    set_option("RANSAC_WAVES", 0)
 
 
 @pytest.mark.parametrize("H", [1024, 256, 64])
@@ -2727,7 +2735,7 @@ def test_round5_launch_trimming_changes_no_result(scene):
     want = _step_tables(clouds, K, adopt)
     again = _step_tables(clouds, K, adopt)          # (second build of the context: hinted geometry, chunk history)
     _assert_same_step(want, again)
-    for opt in ("NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_GEOM_HINT", "NO_BUCKET_BUILD"):
+    for opt in ("NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_SPEC_FINISH", "NO_GEOM_HINT", "NO_BUCKET_BUILD"):
         set_option(opt, 1)
         got = _step_tables(clouds, K, adopt)
         set_option(opt, 0)
@@ -2753,3 +2761,57 @@ def test_small_scans_through_the_bucket_path_equal_the_level_loop():
             f.close()
         set_option("NO_BUCKET_BUILD", 0)
         _assert_same_tables(tabs[0], tabs[1])
+
+
+@pytest.mark.gpu
+def test_speculative_bucket_finish_holds_on_a_repeated_scan_and_misses_safely():
+    """Round 5: from a context's second bucket build on, k_bucket_finish is enqueued BEFORE the host has seen the build's
+    totals (tables sized from the previous build; the kernel checks on the device what the host checks in the mirror).
+    A repeated scan must be served by the speculative launch; a scan that outgrows the previous one's tables, or leaves
+    work to other paths, must be caught by the check and built the ordinary way - same scheme either way."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+
+    ctx = nat.get_context()
+    lib = ctx.lib
+
+    def counters():
+        h, m = C.c_uint64(0), C.c_uint64(0)
+        ctx.check(lib.octl_debug_spec_finish(C.byref(h), C.byref(m)))
+        return h.value, m.value
+
+    small = synthetic.planar_cloud(40_000, (4, 4, 4), seed=3, stream=1)
+    again = synthetic.planar_cloud(40_000, (4, 4, 4), seed=3, stream=2)
+    big = synthetic.planar_cloud(400_000, (8, 8, 8), seed=3, stream=3)        # ten times the points, nodes and blocks
+    spread = synthetic.planar_cloud(40_000, (14, 14, 14), seed=3, stream=4)   # the small scan's points in 43 x the voxels
+    skew = synthetic.sparse_scene(200_000, (24, 24, 8), seed=5, cluster_fraction=0.3, cluster_density=60.0)
+    K = 24
+    want = {}
+    set_option("NO_SPEC_FINISH", 1)
+    for name, c in (("small", small), ("again", again), ("big", big), ("spread", spread), ("skew", skew)):
+        want[name] = _step_tables([c], K, ctx)
+    set_option("NO_SPEC_FINISH", 0)
+    _step_tables([small], K, ctx)                    # (whatever ran before: the context's sizes are this scan's now)
+    h0, m0 = counters()
+    got = _step_tables([again], K, ctx)
+    h1, m1 = counters()
+    assert (h1 - h0, m1 - m0) == (1, 0), (h1 - h0, m1 - m0)
+    _assert_same_step(want["again"], got)
+    got = _step_tables([big], K, ctx)                # (tables in proportion to the points: may hold, may miss)
+    h2, m2 = counters()
+    assert (h2 - h1) + (m2 - m1) >= 1
+    _assert_same_step(want["big"], got)
+    _step_tables([small], K, ctx)
+    h2, m2 = counters()
+    got = _step_tables([spread], K, ctx)             # outgrows the tables sized from the small scan: caught on the device
+    h3, m3 = counters()
+    assert h3 - h2 == 0 and m3 - m2 >= 1, (h3 - h2, m3 - m2)
+    _assert_same_step(want["spread"], got)
+    got = _step_tables([skew], K, ctx)               # buckets beyond 4096 points (chunk kernels), a new voxel box
+    _assert_same_step(want["skew"], got)
+    got = _step_tables([skew], K, ctx)
+    _assert_same_step(want["skew"], got)
+    got = _step_tables([small], K, ctx)              # and back
+    _assert_same_step(want["small"], got)
