@@ -1771,7 +1771,10 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   // (max_block: no block of the launch holds more points - the instances for larger blocks are not launched at all)
   const bool need_small = max_block >= RS_TINY_THREADS, need_mid = max_block >= RS_SMALL_THREADS,
              need_big = any_k || max_block >= threads;
-  if (!any_k && H > 256 && (need_small || need_big) && octl_ctx_side_stream(ctx) &&
+  // (the side stream is gated in and out with events: only when one of the instances below will go there)
+  const bool side_work = waves_per_block == 4 ? need_big
+                         : (waves_per_block == 2 ? (need_mid || need_big) : (need_small || need_mid || need_big));
+  if (!any_k && H > 256 && side_work && octl_ctx_side_stream(ctx) &&
       hipEventRecord(ctx->self_gate, st) == hipSuccess &&
       hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
     side = ctx->self_stream;
