@@ -318,8 +318,10 @@ constexpr int PH_THREADS = 1024;
 // box are not counted (the flag bbox[7] invalidates the pass), the true box is reduced on the way.
 // (Round 5, measured: this pass takes 70 us for 10 M points and the plain one 40 - NOT because of what it does per
 //  point: without the box, without the domain test, without the inside test, with the loads two pairs ahead in three
-//  fixed register sets it stays at 69-73 us.  It reads the cloud COLD at 3.5 TB/s; the plain pass only ever runs behind
-//  the box pass, which has just pulled the 240 MB into the memory-side cache.)
+//  fixed register sets it stays at 69-73 us.  It is the step's first reader and pays for the write-back of the dirty
+//  lines the previous kernels left in the memory-side cache: tools/probes/stream_probe.hip reads a cold cloud with this
+//  kernel's skeleton in 46 us behind clean reads and in 106 us behind 768 MB of writes.  The plain pass runs behind the
+//  box pass, which has paid that bill.)
 template <bool BBOX, bool LONE>
 __global__ __launch_bounds__(PH_THREADS) void k_part_hist(const double* __restrict__ xyz,
                                                           const uint8_t* __restrict__ alive, int64_t N,
