@@ -1370,7 +1370,7 @@ def main():
                                                           args.cloud == "planar" and not args.shard_of) else None,
                 "note": "ALGORITHMIC-EQUIVALENT f64 flops per leaf with n >= k points: H*(20k + 6n) + 6n (plane fits, "
                         "scoring, final mask) over the kernel's time - it counts work the kernel never executes (a "
-                        "fifth of the blocks leave after 256 of the 1024 hypotheses) and the f32 screen's scoring as "
+                        "fifth of the blocks leave after the first 64 of the 1024 hypotheses) and the f32 screen's scoring as "
                         "f64: it is not a utilisation of the machine.  `executed` is: instruction counts by type from "
                         "the tracked profile against the issue ceiling at the measured clock",
             },
@@ -1484,7 +1484,7 @@ def valu_executed(ransac_ms_live):
                     "valu_issue_time_over_live_launch_time": t_issue * 1e3 / ransac_ms_live if ransac_ms_live else None})
     if cnt:
         out.update({
-            "fraction_blocks_leaving_after_256_hypotheses": cnt["fraction_blocks_leaving_after_pass_1"],
+            "fraction_blocks_leaving_after_the_first_64_hypotheses": cnt["fraction_blocks_leaving_after_pass_1"],
             "fraction_plane_fits_executed": cnt["fraction_plane_fits_executed"],
             "fraction_pairs_scored_by_f32_screen": cnt["fraction_pairs_scored"],
             "fraction_hypotheses_recounted_in_f64": cnt["fraction_hypotheses_recounted"],

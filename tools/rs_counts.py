@@ -26,7 +26,7 @@ ctx.sync()
 ctx.check(lib.octl_debug_rs_stamps(ctx.handle, out, 0))
 v = [out[i] / reps for i in range(16)]
 blocks, skipped1, pts = v[8], v[9], v[11]
-H, F, HPL, LANES = 1024, 256, 16, 64
+H, F, HPL, LANES = 1024, 64, 16, 64   # (F: hypotheses in front of the first exit check, RS_FIRST_GROUPS x 64)
 groups_total = blocks * HPL                       # hypothesis groups of 64 the reference's 1024 threads amount to
 groups_skipped = skipped1 * (HPL - F // LANES) + v[12]
 groups_scored = v[14]
