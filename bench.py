@@ -212,7 +212,8 @@ class Workload:
         self.table = np.ascontiguousarray(np.random.random((H, KPTS)))
 
     CLOUD_VARIANTS = ["draw 0 of the scene", "draw 1 of the same scene (same voxel box)",
-                      "draw 2 moved by one voxel along x (the voxel box changes: the geometry hint is rejected)"]
+                      "draw 2 moved by one voxel along x (the voxel box changes: a geometry hint of the other draws is rejected, "
+                      "and the context stops hinting while the box keeps changing)"]
 
     def make_cloud(self, variant):
         """One cloud of this rank in HBM (generated chunk by chunk on the host, uploaded in order)."""

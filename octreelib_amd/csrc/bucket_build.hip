@@ -2355,7 +2355,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                         hint.lp.L == f->edge && hint.lp.c0x == f->corner[0] && hint.lp.c0y == f->corner[1] &&
                         hint.lp.c0z == f->corner[2] && !ctx->opt.no_geom_hint &&
                         hint.lp.exact_digits == (ctx->opt.no_exact_digits ? 0 : 1);
-    hinted = async_geom && usable && !ctx->geom_hint_two_pass;
+    // (a hint was rejected lately: see geom_hint_cooldown below - the box pass is cheaper than another wasted attempt)
+    hinted = async_geom && usable && !ctx->geom_hint_two_pass && ctx->geom_hint_cooldown == 0;
     hinted2 = !async_geom && !force_sync && usable && ctx->geom_hint_two_pass && f->mode == 0;
     if (!hinted && !hinted2) OCTL_TRY(store_compute_bbox(f));
   }
@@ -2797,11 +2798,25 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                               "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
                               OCTL_VOX_ABS_LIMIT);
       if (g.reason == GEOM_EMPTY) return OCTL_OK;
-      // the hinted geometry did not hold: the box is on the device now, the build runs again from it
-      if (g.reason == GEOM_REHASH)
+      // the hinted geometry did not hold: the box is on the device now, the build runs again from it.  Hints are
+      // suspended until the scene has stood still for two scans: a rejected attempt costs a histogram pass, the
+      // launches behind it and a round trip - more than the box pass a build without a hint starts with.
+      if (g.reason == GEOM_REHASH) {
+        if (!ctx->opt.no_hint_cooldown) ctx->geom_hint_cooldown = 2;
         return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, false);
+      }
       // not a single-pass case after all (a sparse scene): the host-side form decides
       return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
+    }
+    // (suspended hints: would the previous build's geometry have held for this cloud?  Two scans in a row that say
+    //  yes end the suspension, one that says no starts it again)
+    if (ctx->geom_hint_cooldown > 0 && !hinted) {
+      GeomDev prev;
+      std::memcpy(&prev, ctx->geom_hint, sizeof(prev));
+      bool held = ctx->geom_hint_valid && !ctx->geom_hint_two_pass && ctx->geom_hint_want == want &&
+                  prev.lp.shift == g.lp.shift;
+      for (int ax = 0; ax < 3 && held; ++ax) held = g.bb[ax] >= prev.bb[ax] && g.bb[3 + ax] <= prev.bb[3 + ax];
+      ctx->geom_hint_cooldown = held ? ctx->geom_hint_cooldown - 1 : 2;
     }
     // the geometry of this build is the next build's hint
     static_assert(sizeof(GeomDev) <= sizeof(ctx->geom_hint), "hint storage");

@@ -2735,7 +2735,7 @@ def test_round5_launch_trimming_changes_no_result(scene):
     want = _step_tables(clouds, K, adopt)
     again = _step_tables(clouds, K, adopt)          # (second build of the context: hinted geometry, chunk history)
     _assert_same_step(want, again)
-    for opt in ("NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_SPEC_FINISH", "NO_GEOM_HINT", "NO_BUCKET_BUILD"):
+    for opt in ("NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_SPEC_FINISH", "NO_HINT_COOLDOWN", "NO_GEOM_HINT", "NO_BUCKET_BUILD"):
         set_option(opt, 1)
         got = _step_tables(clouds, K, adopt)
         set_option(opt, 0)
@@ -2815,3 +2815,59 @@ def test_speculative_bucket_finish_holds_on_a_repeated_scan_and_misses_safely():
     _assert_same_step(want["skew"], got)
     got = _step_tables([small], K, ctx)              # and back
     _assert_same_step(want["small"], got)
+
+
+@pytest.mark.gpu
+def test_a_rejected_geometry_hint_suspends_hinting_until_the_scene_stands_still():
+    """Round 5: a build whose hinted geometry is rejected costs a wasted attempt; after one, the context's builds start
+    with the box pass again until two scans in a row would have fitted the previous scan's geometry.  Counted by the
+    launches of a build (a rejected attempt launches the partition kernels twice); the results never depend on it."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+
+    ctx = nat.get_context()
+    lib = ctx.lib
+    a = synthetic.planar_cloud(60_000, (5, 5, 5), seed=4, stream=1)
+    a2 = synthetic.planar_cloud(60_000, (5, 5, 5), seed=4, stream=2)
+    c = a + np.array([1.0, 0.0, 0.0])       # the same scene one voxel further: the box of `a` does not hold it
+    K = 32
+
+    def launches_of(pts):
+        l0, l1 = C.c_uint64(0), C.c_uint64(0)
+        ctx.check(lib.octl_debug_launches(C.byref(l0)))
+        got = _step_tables([pts], K, ctx)
+        ctx.check(lib.octl_debug_launches(C.byref(l1)))
+        return l1.value - l0.value, got
+
+    want = {}
+    set_option("NO_GEOM_HINT", 1)
+    for name, pts in (("a", a), ("a2", a2), ("c", c)):
+        want[name] = _step_tables([pts], K, ctx)
+    set_option("NO_GEOM_HINT", 0)
+    _step_tables([a], K, ctx)
+    _step_tables([a2], K, ctx)
+    _step_tables([a], K, ctx)                 # (standing still: whatever ran before, hints are in use now)
+    base, got = launches_of(a2)               # a build under a hint that holds
+    _assert_same_step(want["a2"], got)
+    rej, got = launches_of(c)                 # rejected: the attempt's launches come on top
+    _assert_same_step(want["c"], got)
+    assert rej > base + 3, (base, rej)
+    seq = []
+    for name, pts in (("a", a), ("c", c), ("a2", a2), ("c", c)):     # the box keeps moving: no hint is tried
+        n, got = launches_of(pts)
+        _assert_same_step(want[name], got)
+        seq.append(n)
+    assert max(seq) < rej, (base, rej, seq)
+    for name, pts in (("a", a), ("a2", a2), ("a", a)):              # two scans that would have fitted: hints again
+        n, got = launches_of(pts)
+        _assert_same_step(want[name], got)
+    n, got = launches_of(a2)
+    _assert_same_step(want["a2"], got)
+    assert n == base, (base, n)
+    set_option("NO_HINT_COOLDOWN", 1)         # the form before: every moved box costs an attempt
+    launches_of(c)
+    n, got = launches_of(a)
+    _assert_same_step(want["a"], got)
+    assert n >= rej, (rej, n)
