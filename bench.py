@@ -17,10 +17,12 @@ points to their owners inside the step (weak scaling).  Points per rank: 125 M a
 config 5, 10^9 points over [0,128)^3 - otherwise 10 M (`--points-per-rank` overrides; at N = 8 the
 10 M/rank point of the weak-scaling series is measured as well and reported under `secondary`).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant
-kernel, live hipEvent timings), `roofline_build` (dominant streaming kernel of insert+subdivide)
+Prints ONE JSON line of under 8 KB on rank 0's stdout (contract in the task description) with `roofline`
+(dominant kernel, live hipEvent timings), `roofline_build` (dominant streaming kernel of insert+subdivide)
 and `cpu_baseline` (the NumPy port of the reference's algorithm, timed on this box's host on a
-bounded sample of the same workload).
+bounded sample of the same workload).  The full result - secondaries, per-kernel tables, notes, the
+N > 1 topology and exchange blocks - goes to bench_detail.json beside this script and to stderr
+(`compact_line` / `emit` below).
 """
 
 import argparse
@@ -173,6 +175,9 @@ def parse_args():
     ap.add_argument("--plan", action="store_true",
                     help="print what `--gpus N` (default 8) is going to need - host RAM, HBM, generation and run time "
                          "against the driver's 600 s - and exit; touches no GPU and starts no rank")
+    ap.add_argument("--detail", default=None, metavar="PATH",
+                    help="where the full result goes (default: bench_detail.json beside this script); stdout carries "
+                         "one bounded line only")
     ap.add_argument("--shard-of", type=int, default=0, metavar="R",
                     help="one GPU: generate only the points rank 0 of R would own after routing (a "
                          "rank's shard of the R-rank scene, e.g. --shard-of 8 --points-per-rank 125000000 "
@@ -1397,7 +1402,7 @@ def main():
             out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only (the other ranks would wait)
             out["cpu_baseline"] = cpu_baseline(scene_dims(1, False), wl.table)
-        print(json.dumps(out))
+        emit(out, args.detail)
 
     wl.close()
     if route:
@@ -1409,16 +1414,84 @@ def main():
     ctx.close()
 
 
+# ---- what goes on stdout ------------------------------------------------------------------------------------------
+# The driver parses ONE line of stdout.  Round 5's line had grown to 24 KB (17 secondary blocks, two per-kernel tables,
+# notes) and was not parsed: the record of that round is empty.  The line is now a fixed selection of the full result,
+# bounded in size; everything else goes to bench_detail.json beside this script and to stderr.
+LINE_LIMIT = 8192
+DETAIL_FILE = "bench_detail.json"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _r(x, digits=6):
+    """Floats of the line to six significant digits (the detail file keeps them all)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def compact_line(full):
+    """The driver's line from the full result: the contract's keys, `roofline`, `cpu_baseline`, and the few figures the
+    review reads beside them.  No notes, no per-kernel tables, no secondaries (bench_detail.json has them)."""
+    cfg = full.get("config") or {}
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                        "scaling", "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(cfg, ("workload", "points_per_gpu", "K", "hypotheses", "leaves"))
+    line["roofline"] = _pick(full.get("roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                    "launch_ms"))
+    rv = full.get("roofline_valu")
+    if rv:
+        line["roofline_valu"] = _pick(rv, ("achieved", "peak", "unit", "frac", "frac_no_fma"))
+    rb = full.get("roofline_build")
+    if rb:
+        line["roofline_build"] = _pick(rb, ("kernel", "frac", "counter_frac"))
+        wb = rb.get("whole_build") or {}
+        line["roofline_build"]["whole_build"] = _pick(wb, ("section8d_frac", "counter_bytes_per_point"))
+    if full.get("cpu_baseline"):
+        line["cpu_baseline"] = _pick(full["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+    line.update(_pick(full, ("launches_per_step", "host_syncs_per_step")))
+    if full.get("n_gpus", 1) > 1 or "rccl_ranks" in full:
+        line.update(_pick(full, ("rccl_ranks", "imbalance")))
+    line["detail"] = DETAIL_FILE
+    line = _r(line)
+    text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, f"bench line is {len(text)} bytes (limit {LINE_LIMIT}): the driver would not parse it"
+    assert "\n" not in text
+    return text
+
+
+def emit(full, detail_path=None):
+    """Full result -> bench_detail.json (+ stderr); the bounded line -> stdout, the only thing printed there."""
+    text = compact_line(full)
+    path = detail_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), DETAIL_FILE)
+    try:
+        with open(path, "w") as fh:
+            json.dump(full, fh, indent=1)
+            fh.write("\n")
+    except OSError as e:   # (a read-only tree must not cost the run its line)
+        print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    print("bench.py detail: " + json.dumps(full), file=sys.stderr)
+    sys.stderr.flush()
+    print(text, flush=True)
+
+
 # tracked rocprofv3 --pmc profiles of the three measured workloads (tools/profile_round.sh): per-launch HBM bytes by
 # kernel.  They are read beside the live timings, never measured by the run that prints the line.
 def _tracked(name):
-    """profiles/r05_<name> when this round's profile run has written it, else round 4's."""
+    """profiles/r06_<name> when this round's profile run has written it, else the latest earlier one."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for tag in ("r05", "r04"):
+    for tag in ("r06", "r05", "r04"):
         p = f"profiles/{tag}_{name}"
         if os.path.exists(os.path.join(here, p)):
             return p
-    return f"profiles/r05_{name}"
+    return f"profiles/r06_{name}"
 
 
 PROFILE_TRAFFIC = _tracked("hbm_traffic.json")

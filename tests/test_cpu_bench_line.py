@@ -1,0 +1,82 @@
+"""bench.py prints ONE bounded line: round 5's 24 KB line was not parsed by the driver and the round went
+unmeasured.  The line is a fixed selection of the full result (`bench.compact_line`); this test feeds it round 5's
+full result (profiles/r05_bench.json, the canned table) and an N = 8 shaped one and checks size and keys."""
+
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def canned():
+    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as fh:
+        return json.load(fh)
+
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_line_is_bounded_and_complete():
+    import bench
+
+    full = canned()
+    assert len(json.dumps(full)) > 20000          # the thing that did not parse
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT == 8192
+    assert "\n" not in text
+    line = json.loads(text)
+    for k in CONTRACT:
+        assert k in line, k
+    assert set(line["config"]) == {"workload", "points_per_gpu", "K", "hypotheses", "leaves"}
+    assert set(line["roofline"]) == {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms"}
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["unit"] == "GB/s"
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-6
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    assert set(line["roofline_valu"]) == {"achieved", "peak", "unit", "frac", "frac_no_fma"}
+    assert set(line["roofline_build"]) == {"kernel", "frac", "counter_frac", "whole_build"}
+    assert set(line["roofline_build"]["whole_build"]) == {"section8d_frac", "counter_bytes_per_point"}
+    assert "launches_per_step" in line and "host_syncs_per_step" in line
+    for k in ("secondary", "kernels", "topology", "exchange"):
+        assert k not in line
+    # the numbers are the full result's, to six digits
+    assert abs(line["value"] / full["value"] - 1) < 1e-5
+    assert abs(line["ms_per_step"] / full["ms_per_step"] - 1) < 1e-5
+
+
+def test_line_of_an_eight_rank_run_is_bounded():
+    import bench
+
+    full = canned()
+    full["n_gpus"] = 8
+    full.pop("cpu_baseline")
+    ranks = [{"launcher_rank": r, "rccl_user_rank": r, "rccl_ranks": 8, "rccl_version": 22203,
+              "pci_bus_id": f"0000:{r:02x}:00.0", "device_uuid": "ab" * 16, "compute_units": 256, "host": "h" * 40}
+             for r in range(8)]
+    full["rccl_ranks"] = 8
+    full["imbalance"] = 1.0123456789
+    full["topology"] = {"rccl_ranks": 8, "ranks": ranks,
+                        "alltoall_bytes_rank_to_peer_last_step": [[500_000_000] * 8 for _ in range(8)]}
+    full["exchange"] = {"points_received_per_rank": [125_000_000] * 8, "note": "x" * 400}
+    text = bench.compact_line(full)
+    assert len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    assert line["rccl_ranks"] == 8 and abs(line["imbalance"] - 1.01235) < 1e-9
+    assert "cpu_baseline" not in line and "topology" not in line
+
+
+def test_emit_writes_detail_and_one_stdout_line(tmp_path, capsys):
+    import bench
+
+    full = canned()
+    path = str(tmp_path / "detail.json")
+    bench.emit(full, path)
+    cap = capsys.readouterr()
+    lines = [ln for ln in cap.out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < bench.LINE_LIMIT
+    json.loads(lines[0])
+    with open(path) as fh:
+        assert json.load(fh)["secondary"].keys() == full["secondary"].keys()
+    assert "bench.py detail: " in cap.err
