@@ -347,10 +347,13 @@ int octl_comm_info(octl_ctx* ctx, int32_t* n_ranks, int32_t* user_rank, int32_t*
 int octl_device_identity(octl_ctx* ctx, char pci_bus_id[32], uint8_t uuid[16], int32_t* cus);
 
 /* Diagnostic switches of a context (tests and A/B runs compare code paths: "NO_BUCKET_BUILD", "BUCKET_POINTS",
- * "SYNC_GEOM", "NO_GEOM_HINT", "NO_EXACT_DIGITS", "NO_FAST_ORDER", "NO_BUCKET_HISTORY", "NO_CUBE_FAST",
+ * "SYNC_GEOM", "NO_GEOM_HINT", "GEOM_MARGIN", "NO_EXACT_DIGITS", "NO_FAST_ORDER", "NO_BUCKET_HISTORY", "NO_CUBE_FAST",
  * "NO_CUBE_PREFIX", "CUBE_PREFIX_MIN", "NO_INCREMENTAL", "ROUTE_SELF_SENDRECV", "TRACE_BUILD", "SCAN",
- * "NO_FUSED_TABLES"; an "OCTL_" prefix is accepted).  octl_ctx_create reads OCTL_<NAME> from the environment once;
- * this call changes a switch of a live context.  0 = the shipped behaviour.  The reference has no counterpart.  */
+ * "NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_SPEC_FINISH", "RANSAC_WAVES"; an "OCTL_" prefix is accepted; the table in
+ * INTEGRATION.md says what each one does).  octl_ctx_create reads OCTL_<NAME> from the environment ONCE, as a
+ * number: OCTL_X=0 is OFF (rounds 1-4 tested only for the variable's presence), a value that is not a number is 1,
+ * and setting the environment after the context exists has no effect - this call changes a switch of a live
+ * context.  0 = the shipped behaviour.  The reference has no counterpart.                                     */
 int octl_debug_set_option(octl_ctx* ctx, const char* name, int64_t value);
 
 /* ---- test hooks for the device-wide primitives (host in / host out) ----------------------- */

@@ -94,18 +94,32 @@ struct LinParams {
   int pm;            // mode 2: levels of the key (the "voxels" of the partition are the cube's depth-pm nodes)
   double L;          // voxel edge
   double c0x, c0y, c0z;  // cube corner (mode 1)
-  int minx, miny, minz;  // voxel bounding box
+  int minx, miny, minz;  // origin of the linear keys: the voxel box the geometry was formed for, PADDED (see geom_from_box)
   uint32_t ny, nz;
-  int shift;         // bucket = lin >> shift
+  int shift;         // bits of a voxel's position inside its bucket (width <= 1 << shift); two passes: bucket = lin >> shift
   // digit of the current partition pass: (lin >> dshift) & dmask.  One pass: the bucket itself.  More
   // than 4096 buckets: two stable passes, the low 12 bits of the bucket first, then the rest.
   int dshift;
   uint32_t dmask;
   int raw_vp;        // 1: this pass is not the last one, records carry the full linear key
   int exact_digits;  // 0: child digits always level by level (OCTL_NO_EXACT_DIGITS, tests)
+  // A single pass whose geometry was formed by geom_from_box: bucket = lin / width for ANY width <= 4096 (round 6:
+  // the box is padded by a margin so that a scene drifting by a voxel keeps its geometry, and a padded box's key
+  // count is no power of two times the bucket count).  winv = fl(1 / width) and whalf = winv / 2:
+  // trunc(fma(lin, winv, whalf)) = floor((lin + 0.5) / width) = floor(lin / width) exactly for lin < 2^24 - the true
+  // value is at least 0.5 / width >= 2^-13 away from an integer, the rounding errors are below 2^-27.
+  // winv == 0: the shift form (host-formed geometries: two passes, single cubes, OCTL_SYNC_GEOM).
+  uint32_t width;
+  double winv, whalf;
 };
+__device__ __forceinline__ uint32_t bucket_of(const LinParams& lp, uint32_t lin) {
+  return lp.winv != 0.0 ? (uint32_t)fma((double)lin, lp.winv, lp.whalf) : lin >> lp.shift;
+}
+__device__ __forceinline__ uint32_t bucket_lin0(const LinParams& lp, uint32_t b) {
+  return lp.winv != 0.0 ? b * lp.width : b << lp.shift;
+}
 __device__ __forceinline__ uint32_t digit_of(const LinParams& lp, uint32_t lin) {
-  return (lin >> lp.dshift) & lp.dmask;
+  return lp.winv != 0.0 ? (uint32_t)fma((double)lin, lp.winv, lp.whalf) : (lin >> lp.dshift) & lp.dmask;
 }
 
 // The geometry of the linear voxel keys, formed ON THE DEVICE from the bounding box the ingest kernel
@@ -113,7 +127,8 @@ __device__ __forceinline__ uint32_t digit_of(const LinParams& lp, uint32_t lin) 
 // built without the host ever waiting for the box; it reads this record together with the bucket totals.
 struct GeomDev {
   LinParams lp;
-  int32_t bb[6];
+  int32_t bb[6];    // the box of the linear keys: the true box padded by the margin
+  int32_t tb[6];    // the TRUE voxel box of the cloud this build partitioned (the next build's hint is formed from it)
   uint32_t valid;   // 1: the kernels run; 0: they return at once, and the host acts on `reason`
   uint32_t reason;  // 1 a point outside the voxel domain, 2 nothing alive, 3 not a single-pass case,
                     // 4 the hinted geometry did not hold (the box is known now: build again)
@@ -121,32 +136,74 @@ struct GeomDev {
 enum { GEOM_DOMAIN = 1, GEOM_EMPTY = 2, GEOM_RETRY = 3, GEOM_REHASH = 4 };
 static_assert(sizeof(GeomDev) <= 192, "GeomDev lives in the scalar block");
 
-// geometry of the box bb for `want` buckets (valid = 1), or the reason why this is not a single-pass case
-__device__ __forceinline__ void geom_from_box(const int32_t* bb, bool domain_error, uint64_t want,
+// what a build asks of the geometry (host -> kernels that form or validate one)
+struct GeomAsk {
+  uint64_t want;      // buckets wanted (a power of two, n_alive / target rounded up)
+  int64_t n_alive;
+  uint32_t target;    // points per bucket aimed at
+  int32_t margin;     // voxels of slack on every side of the true box
+};
+
+__host__ __device__ inline int geom_ceil_log2(uint64_t v) {
+  int b = 0;
+  while (b < 64 && ((uint64_t)1 << b) < v) ++b;
+  return b;
+}
+// buckets a single pass has tables for: twice what the points ask for - the padded box's empty keys take buckets
+// too, and a bucket must not grow past what one workgroup holds because of them - at least 64, at most 4096
+__host__ __device__ inline uint64_t geom_bucket_cap(uint64_t want) {
+  const uint64_t c = 2 * want;
+  return c < 64 ? 64 : (c > (uint64_t)(1u << 12) ? (uint64_t)(1u << 12) : c);
+}
+// the true box widened by the margin on every side (indices stay far inside int32: |q| <= 2^30, margin <= 64)
+__host__ __device__ inline void geom_pad_box(const int32_t* tb, int margin, int32_t* pb) {
+  for (int a = 0; a < 3; ++a) {
+    pb[a] = tb[a] - margin;
+    pb[3 + a] = tb[3 + a] + margin;
+  }
+}
+
+// Geometry of a single pass for the cloud whose TRUE voxel box is tb (valid = 1), or the reason why this is not a
+// single-pass case.  Round 6: the keys are linearised over the box PADDED by ask.margin voxels on every side and a
+// bucket is a run of `width` consecutive keys for any width (not a power of two), so that
+//   * a geometry is a function of the true box alone - the same on the host (the next build's hint) and on the
+//     device (k_bucket_geom, the validation of a hint);
+//   * a scene whose box drifts by up to `margin` voxels between two scans fits the geometry of the previous scan:
+//     the hinted histogram pass finds the true box on its way and no scan pays a box pass of its own
+//     (grid.py:72-90 rebuckets from scratch on every call - there is no state to carry; here the state is a hint
+//     that the build verifies);
+//   * the width follows the points: about ask.target points per bucket of a box that is full, and never more
+//     buckets than the tables hold (geom_bucket_cap).
+__host__ __device__ inline void geom_from_box(const int32_t* tb, bool domain_error, const GeomAsk& ask,
                                               const LinParams& base, GeomDev& o) {
   o.lp = base;
-  for (int a = 0; a < 6; ++a) o.bb[a] = bb[a];
+  for (int a = 0; a < 6; ++a) o.tb[a] = o.bb[a] = tb[a];
   o.valid = 0;
   o.reason = 0;
   if (domain_error) {
     o.reason = GEOM_DOMAIN;
-  } else if (o.bb[0] > o.bb[3]) {
+  } else if (tb[0] > tb[3]) {
     o.reason = GEOM_EMPTY;
   } else {
-    const uint64_t nx = (uint64_t)(o.bb[3] - o.bb[0] + 1), ny = (uint64_t)(o.bb[4] - o.bb[1] + 1),
-                   nz = (uint64_t)(o.bb[5] - o.bb[2] + 1);
+    geom_pad_box(tb, ask.margin, o.bb);
+    const uint64_t nx = (uint64_t)((int64_t)o.bb[3] - o.bb[0] + 1), ny = (uint64_t)((int64_t)o.bb[4] - o.bb[1] + 1),
+                   nz = (uint64_t)((int64_t)o.bb[5] - o.bb[2] + 1);
     if (nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32)) {
       o.reason = GEOM_RETRY;  // (the host path decides: keys would not fit 32 bits)
     } else {
       const uint64_t R = nx * ny * nz;
-      int lr = 0, lw = 0;
-      while (lr < 64 && (1ull << lr) < R) ++lr;
-      while (lw < 64 && (1ull << lw) < want) ++lw;
-      int s = lr - lw;
-      s = s < 0 ? 0 : (s > 12 ? 12 : s);
-      // (the host sizes its tables for max(64, want) buckets - at most 4096 - see bucket_build_impl)
-      const uint64_t cap = want < 64 ? 64 : (want > (uint64_t)(1u << 12) ? (uint64_t)(1u << 12) : want);
-      if (((R - 1) >> s) + 1 > cap) {
+      const uint64_t Rt = (uint64_t)((int64_t)tb[3] - tb[0] + 1) * (uint64_t)((int64_t)tb[4] - tb[1] + 1) *
+                          (uint64_t)((int64_t)tb[5] - tb[2] + 1);
+      // (the host sizes its tables for as many buckets, see bucket_build_impl)
+      const uint64_t cap = geom_bucket_cap(ask.want);
+      // keys per bucket: `target` points in a box that is full ...
+      const uint64_t n = ask.n_alive > 0 ? (uint64_t)ask.n_alive : 1;
+      uint64_t w = ((uint64_t)ask.target * Rt + n / 2) / n;
+      if (w < 1) w = 1;
+      // ... and no more buckets than there is room for
+      const uint64_t wc = (R + cap - 1) / cap;
+      if (wc > w) w = wc;
+      if (w > (uint64_t)(1u << 12)) {
         o.reason = GEOM_RETRY;  // a sparse scene: more buckets than the single pass has room for
       } else {
         o.lp.minx = o.bb[0];
@@ -154,8 +211,11 @@ __device__ __forceinline__ void geom_from_box(const int32_t* bb, bool domain_err
         o.lp.minz = o.bb[2];
         o.lp.ny = (uint32_t)ny;
         o.lp.nz = (uint32_t)nz;
-        o.lp.shift = s;
-        o.lp.dshift = s;
+        o.lp.width = (uint32_t)w;
+        o.lp.winv = 1.0 / (double)w;
+        o.lp.whalf = 0.5 * o.lp.winv;
+        o.lp.shift = geom_ceil_log2(w);
+        o.lp.dshift = o.lp.shift;
         o.lp.dmask = 0xFFFFFFFFu;
         o.lp.raw_vp = 0;
         o.valid = 1;
@@ -164,72 +224,78 @@ __device__ __forceinline__ void geom_from_box(const int32_t* bb, bool domain_err
   }
 }
 
-__global__ void k_bucket_geom(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+__global__ void k_bucket_geom(const int32_t* __restrict__ bbox, GeomAsk ask, LinParams base,
                               GeomDev* __restrict__ g) {
   if (threadIdx.x != 0) return;
   GeomDev o;
-  geom_from_box(bbox, bbox[6] != 0, want, base, o);
+  geom_from_box(bbox, bbox[6] != 0, ask, base, o);
   *g = o;
 }
 
 // Hinted geometry.  A cloud that was taken in place (octl_forest_add_pose_adopt, a routed cloud) has not been
-// through the box pass of the ingest kernel.  When the context has the geometry of its previous single-pass
-// build (a SLAM loop feeds scans of the same scene), the histogram pass runs under THAT geometry and finds the
-// true box on the way (k_part_hist<true>); k_geom_validate then keeps the hint when every point fell inside
-// its box and the true box asks for the same bucket width - otherwise it writes the geometry of the true box
-// with valid = 0 / reason = GEOM_REHASH, every later kernel of the build returns at once, and the host runs
-// the build again from the (now known) box.  A miss costs one histogram pass and one round trip.
+// through the box pass of the ingest kernel.  When the context has the true box of its previous single-pass
+// build (a SLAM loop feeds scans of the same scene), the histogram pass runs under the geometry of THAT box and
+// finds this cloud's true box on the way (k_part_hist<true>); the validation keeps the hint when every point fell
+// inside its (padded) box and its buckets are within a factor of two of what this cloud's own geometry would use
+// - otherwise it writes the geometry of the true box with valid = 0 / reason = GEOM_REHASH, every later kernel of
+// the build returns at once, and the host runs the build again from the (now known) box.  A miss costs one
+// histogram pass and one round trip; a scene that moves by up to the margin per scan never misses.
 __global__ void k_geom_set(GeomDev hint, GeomDev* __restrict__ g) {
   if (threadIdx.x == 0) *g = hint;
 }
-__device__ __forceinline__ void geom_validate_body(const int32_t* __restrict__ bbox, uint64_t want,
+__device__ __forceinline__ void geom_validate_body(const int32_t* __restrict__ bbox, const GeomAsk& ask,
                                                    const LinParams& base, GeomDev* __restrict__ g) {
   GeomDev o;
-  geom_from_box(bbox, bbox[6] != 0, want, base, o);
+  geom_from_box(bbox, bbox[6] != 0, ask, base, o);
   const GeomDev h = *g;
   const bool inside = bbox[7] == 0;  // no point outside the hint's box
-  if (o.valid && inside && o.lp.shift == h.lp.shift) return;  // the hint stands
+  if (o.valid && inside && h.lp.width <= 2u * o.lp.width && o.lp.width <= 2u * h.lp.width) {
+    for (int a = 0; a < 6; ++a) g->tb[a] = bbox[a];  // the hint stands; the host forms the next one from this box
+    return;
+  }
   if (o.valid) {
     o.valid = 0;
     o.reason = GEOM_REHASH;
   }
   *g = o;
 }
-__global__ void k_geom_validate(const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+__global__ void k_geom_validate(const int32_t* __restrict__ bbox, GeomAsk ask, LinParams base,
                                 GeomDev* __restrict__ g) {
-  if (threadIdx.x == 0) geom_validate_body(bbox, want, base, g);
+  if (threadIdx.x == 0) geom_validate_body(bbox, ask, base, g);
 }
 
 // The same for a hinted TWO-pass build (more than 4096 buckets: 125 M points of one rank's shard).  There the host
-// forms the geometry - it needs the bucket count for its tables - from the hint's box instead of waiting for the
-// box pass; the hint stands when every point fell inside its box and the true box asks for the same bucket width.
-// Otherwise the true box is left in the record (valid = 0, GEOM_REHASH) and the host builds again from it.
-__device__ __forceinline__ void geom_validate2_body(const int32_t* __restrict__ bbox, uint64_t want,
+// forms the geometry - it needs the bucket count for its tables - from the hint's (padded) box instead of waiting
+// for the box pass; the hint stands when every point fell inside its box and the true box, padded, asks for the same
+// bucket width.  Otherwise the true box is left in the record (valid = 0, GEOM_REHASH) and the host builds again.
+__device__ __forceinline__ void geom_validate2_body(const int32_t* __restrict__ bbox, const GeomAsk& ask,
                                                     GeomDev* __restrict__ g) {
   GeomDev o = *g;
   const bool domain_error = bbox[6] != 0, inside = bbox[7] == 0;
   bool same = false;
   if (!domain_error && inside && bbox[0] <= bbox[3]) {
-    const uint64_t nx = (uint64_t)(bbox[3] - bbox[0] + 1), ny = (uint64_t)(bbox[4] - bbox[1] + 1),
-                   nz = (uint64_t)(bbox[5] - bbox[2] + 1);
+    int32_t pb[6];
+    geom_pad_box(bbox, ask.margin, pb);
+    const uint64_t nx = (uint64_t)((int64_t)pb[3] - pb[0] + 1), ny = (uint64_t)((int64_t)pb[4] - pb[1] + 1),
+                   nz = (uint64_t)((int64_t)pb[5] - pb[2] + 1);
     if (!(nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32))) {
       const uint64_t R = nx * ny * nz;
-      int lr = 0, lw = 0;
-      while (lr < 64 && (1ull << lr) < R) ++lr;
-      while (lw < 64 && (1ull << lw) < want) ++lw;
-      int s = lr - lw;
+      int s = geom_ceil_log2(R) - geom_ceil_log2(ask.want);
       s = s < 0 ? 0 : (s > 12 ? 12 : s);
       same = s == o.lp.shift;
     }
   }
-  if (same) return;  // the hint stands
-  for (int a = 0; a < 6; ++a) o.bb[a] = bbox[a];
+  if (same) {  // the hint stands
+    for (int a = 0; a < 6; ++a) g->tb[a] = bbox[a];
+    return;
+  }
+  for (int a = 0; a < 6; ++a) o.tb[a] = o.bb[a] = bbox[a];
   o.valid = 0;
   o.reason = domain_error ? GEOM_DOMAIN : (bbox[0] > bbox[3] ? GEOM_EMPTY : GEOM_REHASH);
   *g = o;
 }
-__global__ void k_geom_validate2(const int32_t* __restrict__ bbox, uint64_t want, GeomDev* __restrict__ g) {
-  if (threadIdx.x == 0) geom_validate2_body(bbox, want, g);
+__global__ void k_geom_validate2(const int32_t* __restrict__ bbox, GeomAsk ask, GeomDev* __restrict__ g) {
+  if (threadIdx.x == 0) geom_validate2_body(bbox, ask, g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -505,13 +571,13 @@ constexpr uint32_t TS_MAX_ROWS = 2048;   // beyond: the three-launch form (a wor
 __global__ __launch_bounds__(TS_THREADS) void k_table_scan(uint32_t* __restrict__ table, uint32_t nst, uint32_t nd,
                                                           uint32_t* __restrict__ bucket_start,
                                                           uint64_t* __restrict__ status, uint32_t epoch, int validate,
-                                                          const int32_t* __restrict__ bbox, uint64_t want, LinParams base,
+                                                          const int32_t* __restrict__ bbox, GeomAsk ask, LinParams base,
                                                           GeomDev* __restrict__ g) {
   __shared__ uint32_t s_w[TS_WAVES][TS_COLS];   // column sums per slice of the rows
   __shared__ uint32_t s_col[TS_COLS];           // exclusive prefix over the workgroup's columns
   __shared__ uint32_t s_tot, s_excl;
   if (validate && blockIdx.x == 0 && threadIdx.x == 0) {
-    if (validate == 1) geom_validate_body(bbox, want, base, g); else geom_validate2_body(bbox, want, g);
+    if (validate == 1) geom_validate_body(bbox, ask, base, g); else geom_validate2_body(bbox, ask, g);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t d = blockIdx.x * TS_COLS + lane;
@@ -667,7 +733,7 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
     // == memory order, so the partition is stable
     const int64_t wbase = tbase + (int64_t)wave * (64 * PT_IPT);
     double x[PT_IPT], y[PT_IPT], z[PT_IPT];
-    uint32_t lin[PT_IPT], rank[PT_IPT], pbits[PT_IPT], idxv[PT_IPT];
+    uint32_t lin[PT_IPT], rank[PT_IPT], pbits[PT_IPT], idxv[PT_IPT], dig[PT_IPT];
     uint8_t live[PT_IPT];
     // every load of the tile is issued before the first use: a load behind `if (alive[i])` waits for
     // the flag first, and 16 rounds of two dependent HBM latencies were 50 us per 4096-record tile
@@ -728,7 +794,8 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
           if (!FROM_REC && lp.mode == 2) lin[r] = d18 >> (18 - 3 * lp.pm);  // (the key IS the first pm digits)
         }
       }
-      rank[r] = wave_rank_u16<MBITS>(digit_of(lp, lin[r]), valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
+      dig[r] = digit_of(lp, lin[r]);
+      rank[r] = wave_rank_u16<MBITS>(dig[r], valid, cnt[wave]) | (valid ? 0x80000000u : 0u);
     }
     BB_STAMP(10);  // scatter: loads, keys, ranks (wave 0)
     __syncthreads();
@@ -756,7 +823,7 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
     for (int r = 0; r < PT_IPT; ++r) {
       if (rank[r] >> 31) {
         const int64_t i = wbase + r * 64 + lane;
-        const uint32_t d = digit_of(lp, lin[r]);
+        const uint32_t d = dig[r];
         const uint32_t dst = base[d] + cnt[wave][d] + (rank[r] & 0x7FFFFFFFu);
         uint32_t v = (uint32_t)i;
         if (FROM_REC) {
@@ -775,7 +842,8 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
         const uint64_t xb = (uint64_t)__double_as_longlong(x[r]), yb = (uint64_t)__double_as_longlong(y[r]),
                        zb = (uint64_t)__double_as_longlong(z[r]);
         o[0] = uint4{(uint32_t)xb, (uint32_t)(xb >> 32), (uint32_t)yb, (uint32_t)(yb >> 32)};
-        const uint32_t vl = lin[r] & ((1u << lp.shift) - 1u);
+        // the voxel's position inside its bucket (a single pass: d IS the bucket; records of a first pass carry lin)
+        const uint32_t vl = lp.winv != 0.0 ? lin[r] - d * lp.width : lin[r] & ((1u << lp.shift) - 1u);
         o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), lp.raw_vp ? lin[r] : ((vl << 19) | pbits[r]), v};
 #ifdef PS_DUP_STORE  // (experiments: the same record stored twice - what the scattered stores cost)
         asm volatile("" ::: "memory");
@@ -807,9 +875,9 @@ __global__ __launch_bounds__(256) void k_bucket_bounds(const uint4* __restrict__
   if (bq > nb || (G && !G->valid)) return;
   auto bucket_at = [&](uint32_t j) {
     const uint4 a = recs[2 * (size_t)j], b = recs[2 * (size_t)j + 1];
-    return lin_of(lp, __longlong_as_double((long long)(((uint64_t)a.y << 32) | a.x)),
-                  __longlong_as_double((long long)(((uint64_t)a.w << 32) | a.z)),
-                  __longlong_as_double((long long)(((uint64_t)b.y << 32) | b.x))) >> lp.shift;
+    return bucket_of(lp, lin_of(lp, __longlong_as_double((long long)(((uint64_t)a.y << 32) | a.x)),
+                                __longlong_as_double((long long)(((uint64_t)a.w << 32) | a.z)),
+                                __longlong_as_double((long long)(((uint64_t)b.y << 32) | b.x))));
   };
   uint32_t lo = 0, hi = n;
   while (lo < hi) {
@@ -1441,8 +1509,7 @@ __global__ __launch_bounds__(BB_THREADS, BB_WGS) void k_bucket_build(
     return;
   }
   __syncthreads();
-  const int s = P.lp.shift;
-  const uint32_t lin0 = b << s;
+  const uint32_t lin0 = bucket_lin0(P.lp, b);
   const PartRec* __restrict__ recs = part + start;
   const uint32_t fl = bucket_chunk<false>(recs, s_src, n, start, start, lin0, P, pose_off, ord_idx, xyz_ord, leafinfo,
                                           bk_vox, bk_node, start, (uint32_t)n, s_bins, s_slot, s_cnt, s_scr, s_tot,
@@ -1597,8 +1664,7 @@ __global__ __launch_bounds__(BB_THREADS, BB_ONE_READ ? 1 : 2) void k_bucket_chun
     const uint32_t start = bstart[(size_t)b * P.bstride];
     const uint32_t end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
     const int n = (int)(end - start);
-    const int s = P.lp.shift;
-    const uint32_t lin0 = b << s;
+    const uint32_t lin0 = bucket_lin0(P.lp, b);
     const PartRec* __restrict__ recs = part + start;
     if (tid < BK_ROWS) s_tot[tid] = 0;
     if (tid < (1 << PT_BITS) / 32) s_todo[tid] = 0;
@@ -2343,6 +2409,16 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // the host does not wait for the bounding box; all 4096 buckets exist then, the ones behind the last
   // voxel key are empty.  (OCTL_SYNC_GEOM: tests run the host-side form on small clouds too.)
   const bool async_geom = !force_sync && !ctx->geom_sparse && want <= (uint64_t)PT_BINS && !ctx->opt.sync_geom;
+  // voxels of slack around the true box in the geometry of the keys (geom_from_box): a scene that drifts by up to
+  // that much per scan keeps fitting the previous scan's geometry.  OCTL_GEOM_MARGIN: 0 = the shipped margin of one
+  // voxel, N > 0 = N voxels, negative = none (the tight box of rounds 2-5).  A single cube has no voxels to drift over.
+  const int margin = f->mode != 0 ? 0
+                                  : (ctx->opt.geom_margin == 0 ? 1 : (int)std::min<int64_t>(64, std::max<int64_t>(0, ctx->opt.geom_margin)));
+  GeomAsk ask;
+  ask.want = want;
+  ask.n_alive = n_alive;
+  ask.target = (uint32_t)target;
+  ask.margin = margin;
   // a cloud taken in place has not been through the box pass: with the geometry of the context's previous
   // single-pass build as a hint the histogram pass finds the box itself (k_part_hist<true>, k_geom_validate);
   // without one the box pass runs now
@@ -2355,35 +2431,38 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                         hint.lp.L == f->edge && hint.lp.c0x == f->corner[0] && hint.lp.c0y == f->corner[1] &&
                         hint.lp.c0z == f->corner[2] && !ctx->opt.no_geom_hint &&
                         hint.lp.exact_digits == (ctx->opt.no_exact_digits ? 0 : 1);
-    // (a hint was rejected lately: see geom_hint_cooldown below - the box pass is cheaper than another wasted attempt)
-    hinted = async_geom && usable && !ctx->geom_hint_two_pass && ctx->geom_hint_cooldown == 0;
+    hinted = async_geom && usable && !ctx->geom_hint_two_pass;
     hinted2 = !async_geom && !force_sync && usable && ctx->geom_hint_two_pass && f->mode == 0;
     if (!hinted && !hinted2) OCTL_TRY(store_compute_bbox(f));
   }
   // every stored point is alive (nothing was removed since the poses were added): the flags are not read
   if (f->n_alive != f->n_store) OCTL_TRY(alive_ensure(f));
   const uint8_t* alive_p = f->n_alive == f->n_store ? nullptr : f->alive.as<uint8_t>();
-  int bb[6] = {0, 0, 0, 0, 0, 0};
+  int bb[6] = {0, 0, 0, 0, 0, 0};   // the box of the linear keys (padded)
+  int tb[6] = {0, 0, 0, 0, 0, 0};   // the true voxel box
   uint64_t ny = 1, nz = 1;
   int s = 0;
-  // (single pass with the geometry formed on the device: tables and grids for max(64, want) buckets - geom_from_box
-  //  holds the geometry to that - instead of always 4096: a 100 k-point scan has 64)
-  uint32_t nb = async_geom ? (uint32_t)std::max<uint64_t>(64, want) : (uint32_t)PT_BINS;
+  // (single pass with the geometry formed on the device: tables and grids for geom_bucket_cap(want) buckets -
+  //  geom_from_box holds the geometry to that - instead of always 4096: a 100 k-point scan has 128)
+  uint32_t nb = async_geom ? (uint32_t)geom_bucket_cap(want) : (uint32_t)PT_BINS;
   bool two_pass = false;
   if (!async_geom) {
     if (hinted2) {
-      // the box of the context's previous two-pass build: validated on the device by the histogram pass itself
+      // the (padded) box of the context's previous two-pass build: validated on the device by the histogram pass itself
       std::memcpy(bb, hint.bb, sizeof(bb));
+      std::memcpy(tb, hint.tb, sizeof(tb));
     } else {
       // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
       int32_t* bbox_host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + 3584);
       HIP_TRY(ctx, hipMemcpyAsync(bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
       HIP_TRY(ctx, hipStreamSynchronize(st));
-      std::memcpy(bb, bbox_host, sizeof(bb));
+      std::memcpy(tb, bbox_host, sizeof(tb));
       if (bbox_host[6])
         return octl_set_error(ctx, OCTL_E_DOMAIN,
                               "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
                               OCTL_VOX_ABS_LIMIT);
+      if (tb[0] > tb[3]) return OCTL_OK;
+      geom_pad_box(tb, margin, bb);
     }
     if (bb[0] > bb[3]) return OCTL_OK;
     const uint64_t nx = (uint64_t)(bb[3] - bb[0] + 1);
@@ -2395,7 +2474,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     if (((R - 1) >> s) + 1 > ((uint64_t)PT_BINS << PT_BITS)) return OCTL_OK;  // a sparse scene: too many keys
     nb = (uint32_t)(((R - 1) >> s) + 1);
     two_pass = nb > (uint32_t)PT_BINS;
-    if (hinted2 && (!two_pass || s != hint.lp.shift))  // (cannot happen: same box, same `want`)
+    if (hinted2 && !two_pass)  // (cannot happen: same box, same `want`)
       return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
     ctx->geom_sparse = two_pass && want <= (uint64_t)PT_BINS;
     // Thin buckets: the 12-bit clamp on a bucket's key range left them under half their target.  A workgroup per
@@ -2421,6 +2500,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   lp.dmask = 0xFFFFFFFFu;
   lp.raw_vp = 0;
   lp.exact_digits = ctx->opt.no_exact_digits ? 0 : 1;
+  lp.width = 1u << s;   // (host-formed geometry: the shift form; geom_from_box overwrites these on the device)
+  lp.winv = 0.0;
+  lp.whalf = 0.0;
   uint32_t* small = ctx->small.as<uint32_t>();
   // supertiles: one round of workgroups (2 per CU) over the cloud, at most 16 tiles each
   const int cus = octl_ctx_cus(ctx);
@@ -2492,7 +2574,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     } else {
       LinParams base = lp;
       base.dshift = s;
-      hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want, base, gdev);
+      hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask, base, gdev);
     }
     HIP_TRY(ctx, hipGetLastError());
   } else if (hinted2) {
@@ -2503,6 +2585,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     std::memset(&g2, 0, sizeof(g2));
     g2.lp = lp_pass1;
     std::memcpy(g2.bb, bb, sizeof(bb));
+    std::memcpy(g2.tb, tb, sizeof(tb));
     g2.valid = 1;
     hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, g2, gdev);
     HIP_TRY(ctx, hipGetLastError());
@@ -2513,7 +2596,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     uint32_t epoch = 0;
     OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
     hipLaunchKernelGGL(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, bucket_start, status, epoch,
-                       validate, (const int32_t*)f->bbox_dev.as<int32_t>(), want, lp, gdev);
+                       validate, (const int32_t*)f->bbox_dev.as<int32_t>(), ask, lp, gdev);
     HIP_TRY(ctx, hipGetLastError());
     return (int)OCTL_OK;
   };
@@ -2529,10 +2612,10 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       if (fused_a) {
         // (k_table_scan validates the hint on its way)
       } else if (hinted)
-        hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
+        hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask,
                            lp, gdev);
       else
-        hipLaunchKernelGGL(k_geom_validate2, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), want,
+        hipLaunchKernelGGL(k_geom_validate2, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask,
                            gdev);
     } else {
       auto kh = f->edge == 1.0 ? k_part_hist<false, true> : k_part_hist<false, false>;
@@ -2776,12 +2859,16 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       ctx->geom_hint_valid = false;
       return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
     }
-  } else if (!async_geom && two_pass && f->mode == 0) {
-    // the geometry of this two-pass build is the hint of the context's next one
+    std::memcpy(tb, g.tb, sizeof(tb));   // the true box this cloud turned out to have
+  }
+  if (!async_geom && two_pass && f->mode == 0) {
+    // the true box of this two-pass build, padded, is the box of the context's next one (the keys of THIS build
+    // stay relative to bb; a scene that drifts is followed scan by scan)
     GeomDev g;
     std::memset(&g, 0, sizeof(g));
     g.lp = lp_pass1;
-    std::memcpy(g.bb, bb, sizeof(bb));
+    geom_pad_box(tb, margin, g.bb);
+    std::memcpy(g.tb, tb, sizeof(tb));
     g.valid = 1;
     static_assert(sizeof(GeomDev) <= sizeof(ctx->geom_hint), "hint storage");
     std::memcpy(ctx->geom_hint, &g, sizeof(g));
@@ -2798,40 +2885,35 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
                               "a point has a non-finite coordinate or a top-level voxel index outside +-%d",
                               OCTL_VOX_ABS_LIMIT);
       if (g.reason == GEOM_EMPTY) return OCTL_OK;
-      // the hinted geometry did not hold: the box is on the device now, the build runs again from it.  Hints are
-      // suspended until the scene has stood still for two scans: a rejected attempt costs a histogram pass, the
-      // launches behind it and a round trip - more than the box pass a build without a hint starts with.
-      if (g.reason == GEOM_REHASH) {
-        if (!ctx->opt.no_hint_cooldown) ctx->geom_hint_cooldown = 2;
+      // the hinted geometry did not hold (the scene jumped by more than the margin, or its density changed): the
+      // box is on the device now, the build runs again from it - one histogram pass and one round trip lost
+      if (g.reason == GEOM_REHASH)
         return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, false);
-      }
       // not a single-pass case after all (a sparse scene): the host-side form decides
       return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
     }
-    // (suspended hints: would the previous build's geometry have held for this cloud?  Two scans in a row that say
-    //  yes end the suspension, one that says no starts it again)
-    if (ctx->geom_hint_cooldown > 0 && !hinted) {
-      GeomDev prev;
-      std::memcpy(&prev, ctx->geom_hint, sizeof(prev));
-      bool held = ctx->geom_hint_valid && !ctx->geom_hint_two_pass && ctx->geom_hint_want == want &&
-                  prev.lp.shift == g.lp.shift;
-      for (int ax = 0; ax < 3 && held; ++ax) held = g.bb[ax] >= prev.bb[ax] && g.bb[3 + ax] <= prev.bb[3 + ax];
-      ctx->geom_hint_cooldown = held ? ctx->geom_hint_cooldown - 1 : 2;
+    // the next build's hint: the geometry of THIS cloud's true box (the same function the device evaluates) - under a
+    // hint that held, the box the histogram pass found on its way; the scene is followed scan by scan
+    {
+      LinParams base = lp;
+      GeomDev nh;
+      geom_from_box(g.tb, false, ask, base, nh);
+      static_assert(sizeof(GeomDev) <= sizeof(ctx->geom_hint), "hint storage");
+      std::memset(ctx->geom_hint, 0, sizeof(ctx->geom_hint));
+      std::memcpy(ctx->geom_hint, &nh, sizeof(nh));
+      ctx->geom_hint_valid = nh.valid != 0;
+      ctx->geom_hint_two_pass = false;
+      ctx->geom_hint_want = want;
     }
-    // the geometry of this build is the next build's hint
-    static_assert(sizeof(GeomDev) <= sizeof(ctx->geom_hint), "hint storage");
-    std::memcpy(ctx->geom_hint, &g, sizeof(g));
-    ctx->geom_hint_valid = true;
-    ctx->geom_hint_two_pass = false;
-    ctx->geom_hint_want = want;
     lp = g.lp;
     std::memcpy(bb, g.bb, sizeof(bb));
+    std::memcpy(tb, g.tb, sizeof(tb));
     ny = lp.ny;
     nz = lp.nz;
   }
   // the packed voxel keys of everything that follows (k_bucket_finish's walk over the previous scheme, the
   // incremental insertion, the host's voxel list) are relative to the origin this fixes on the first build
-  if (f->mode == 0) OCTL_TRY(forest_fix_origin(f, bb));
+  if (f->mode == 0) OCTL_TRY(forest_fix_origin(f, tb));
   // buckets beyond 4096 points that nobody has built yet: plan + chunks now, then the totals once more
   const bool overfull = sm[SM_BK_OVERFULL] > 0;
   if (overfull && !chunks_beside && !sm[SM_BK_FLAGS]) {
@@ -2976,7 +3058,7 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
       uint32_t epoch = 0;
       OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
       hipLaunchKernelGGL(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, table_dm, status, epoch, 0,
-                         (const int32_t*)nullptr, (uint64_t)0, lp, (GeomDev*)nullptr);
+                         (const int32_t*)nullptr, GeomAsk{0, 0, 0, 0}, lp, (GeomDev*)nullptr);
       HIP_TRY(ctx, hipGetLastError());
     } else {
       HIP_TRY(ctx, transpose(table, nst, nd, table_dm));

@@ -1383,8 +1383,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     // box is still to be found: bucket_build.hip decides and, if it does, finds the record in place)
     int hint_words = 0;
     ctx->geom_hint_staged = false;
-    if (f->bbox_pending && !keep_scheme && ctx->geom_hint_valid && !ctx->geom_hint_two_pass && !ctx->opt.no_geom_hint &&
-        ctx->geom_hint_cooldown == 0) {
+    if (f->bbox_pending && !keep_scheme && ctx->geom_hint_valid && !ctx->geom_hint_two_pass && !ctx->opt.no_geom_hint) {
       static_assert(sizeof(ctx->geom_hint) == 192, "hint words");
       std::memcpy(static_cast<char*>(ctx->small_host) + SM_GEOM * 4, ctx->geom_hint, sizeof(ctx->geom_hint));
       hint_words = (int)(sizeof(ctx->geom_hint) / 4);

@@ -92,7 +92,8 @@ struct OctlOptions {
   int64_t no_fused_tables = 0;     // OCTL_NO_FUSED_TABLES: the small table chains as separate launches (A/B)
   int64_t no_spin_wait = 0;        // OCTL_NO_SPIN_WAIT: every host wait is a hipStreamSynchronize (A/B)
   int64_t ransac_waves = 0;        // OCTL_RANSAC_WAVES: waves per block of the H > 256 RANSAC instances (0: the library's policy; 1, 2, 4)
-  int64_t no_hint_cooldown = 0;    // OCTL_NO_HINT_COOLDOWN: a rejected geometry hint does not suspend hinting (the form before the cooldown)
+  int64_t geom_margin = 0;         // OCTL_GEOM_MARGIN: voxels of slack around the true box in a single-pass / hinted key geometry (0: one voxel; negative: none)
+  int64_t no_ransac_prescreen = 0; // OCTL_NO_RANSAC_PRESCREEN: every hypothesis of a leaf through the exact plane fit (no approximate prescreen)
   int64_t no_spec_finish = 0;      // OCTL_NO_SPEC_FINISH: k_bucket_finish only behind the host's look at the totals (A/B)
 };
 // name (without the OCTL_ prefix or with it) -> field; nullptr when there is no such switch
@@ -139,14 +140,11 @@ struct octl_ctx {
   // blocks handed out by octl_dev_alloc (pointer -> capacity): they come from and go back to the pool too - a
   // hipMalloc / hipFree pair of a 240 MB scan buffer costs milliseconds and synchronises the device
   std::map<void*, size_t> user_blocks;
-  // key geometry (voxel box, bucket shift) of the last single-pass bucket build on this context: the next
-  // build of a cloud that was taken in place starts its histogram pass under this geometry and finds the true
-  // box in the same pass (bucket_build.hip: hinted geometry); opaque here
+  // key geometry (padded voxel box, bucket width) formed from the TRUE box of the last bucket build on this context:
+  // the next build of a cloud that was taken in place starts its histogram pass under this geometry and finds its own
+  // true box in the same pass (bucket_build.hip: hinted geometry); opaque here
   unsigned char geom_hint[192] = {0};
   bool geom_hint_valid = false;
-  // builds that must pass before a hint is trusted again after one was rejected (bucket_build.hip): a scene whose
-  // voxel box changes from scan to scan makes every hint cost a wasted attempt - the box pass is cheaper than that
-  int geom_hint_cooldown = 0;
   bool geom_hint_staged = false;  // forest_build's first launch has put the hint into the scalar block already
   uint64_t geom_hint_want = 0;
   bool geom_hint_two_pass = false;  // the hint is the geometry of a TWO-pass build (> 4096 buckets, host-side form)

@@ -31,7 +31,7 @@ const OptName kOptions[] = {
     {"TRACE_BUILD", &OctlOptions::trace_build},             {"SCAN", &OctlOptions::scan_mode},
     {"NO_FUSED_TABLES", &OctlOptions::no_fused_tables},     {"NO_SPIN_WAIT", &OctlOptions::no_spin_wait},
     {"NO_SPEC_FINISH", &OctlOptions::no_spec_finish},       {"RANSAC_WAVES", &OctlOptions::ransac_waves},
-    {"NO_HINT_COOLDOWN", &OctlOptions::no_hint_cooldown},
+    {"GEOM_MARGIN", &OctlOptions::geom_margin},             {"NO_RANSAC_PRESCREEN", &OctlOptions::no_ransac_prescreen},
 };
 }  // namespace
 

@@ -2735,8 +2735,8 @@ def test_round5_launch_trimming_changes_no_result(scene):
     want = _step_tables(clouds, K, adopt)
     again = _step_tables(clouds, K, adopt)          # (second build of the context: hinted geometry, chunk history)
     _assert_same_step(want, again)
-    for opt in ("NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_SPEC_FINISH", "NO_HINT_COOLDOWN", "NO_GEOM_HINT", "NO_BUCKET_BUILD"):
-        set_option(opt, 1)
+    for opt in ("NO_FUSED_TABLES", "NO_SPIN_WAIT", "NO_SPEC_FINISH", "GEOM_MARGIN", "NO_GEOM_HINT", "NO_BUCKET_BUILD"):
+        set_option(opt, 1 if opt != "GEOM_MARGIN" else -1)
         got = _step_tables(clouds, K, adopt)
         set_option(opt, 0)
         _assert_same_step(want, got, canonical=(opt == "NO_BUCKET_BUILD"))
@@ -2818,10 +2818,12 @@ def test_speculative_bucket_finish_holds_on_a_repeated_scan_and_misses_safely():
 
 
 @pytest.mark.gpu
-def test_a_rejected_geometry_hint_suspends_hinting_until_the_scene_stands_still():
-    """Round 5: a build whose hinted geometry is rejected costs a wasted attempt; after one, the context's builds start
-    with the box pass again until two scans in a row would have fitted the previous scan's geometry.  Counted by the
-    launches of a build (a rejected attempt launches the partition kernels twice); the results never depend on it."""
+def test_a_scene_that_drifts_by_a_voxel_keeps_its_geometry_and_a_jump_costs_one_attempt():
+    """Round 6: the key geometry is formed over the TRUE voxel box padded by a margin (one voxel), buckets are runs of
+    any width, and the next build's hint is formed from the box the histogram pass finds on its way.  A scene whose
+    box drifts by a voxel per scan never pays a box pass nor a rejected attempt; a jump beyond the margin costs ONE
+    rejected attempt (the partition kernels launched twice) and the scan after it runs under a hint again.  Counted by
+    the launches of a build; the results never depend on any of it (grid.py:72-90 rebuckets from scratch per call)."""
     import ctypes as C
 
     from octreelib_amd import _native as nat
@@ -2831,8 +2833,10 @@ def test_a_rejected_geometry_hint_suspends_hinting_until_the_scene_stands_still(
     lib = ctx.lib
     a = synthetic.planar_cloud(60_000, (5, 5, 5), seed=4, stream=1)
     a2 = synthetic.planar_cloud(60_000, (5, 5, 5), seed=4, stream=2)
-    c = a + np.array([1.0, 0.0, 0.0])       # the same scene one voxel further: the box of `a` does not hold it
     K = 32
+
+    def moved(pts, dx, dy=0.0, dz=0.0):
+        return pts + np.array([dx, dy, dz])
 
     def launches_of(pts):
         l0, l1 = C.c_uint64(0), C.c_uint64(0)
@@ -2841,33 +2845,57 @@ def test_a_rejected_geometry_hint_suspends_hinting_until_the_scene_stands_still(
         ctx.check(lib.octl_debug_launches(C.byref(l1)))
         return l1.value - l0.value, got
 
-    want = {}
+    def truth(pts):
+        set_option("NO_GEOM_HINT", 1)
+        try:
+            return _step_tables([pts], K, ctx)
+        finally:
+            set_option("NO_GEOM_HINT", 0)
+
     set_option("NO_GEOM_HINT", 1)
-    for name, pts in (("a", a), ("a2", a2), ("c", c)):
-        want[name] = _step_tables([pts], K, ctx)
+    nohint, _ = launches_of(a)                # every build with its own box pass
     set_option("NO_GEOM_HINT", 0)
     _step_tables([a], K, ctx)
-    _step_tables([a2], K, ctx)
-    _step_tables([a], K, ctx)                 # (standing still: whatever ran before, hints are in use now)
     base, got = launches_of(a2)               # a build under a hint that holds
-    _assert_same_step(want["a2"], got)
-    rej, got = launches_of(c)                 # rejected: the attempt's launches come on top
-    _assert_same_step(want["c"], got)
+    _assert_same_step(truth(a2), got)
+    _step_tables([a2], K, ctx)                # (truth() ran without a hint: one build to have one again)
+    assert base < nohint, (base, nohint)
+    # the scene walks away one voxel per scan, along x, then diagonally, then back: every build under a hint
+    walk = [(1, 0, 0), (2, 0, 0), (3, 1, 0), (4, 2, 1), (3, 1, 0), (2, 0, -1), (1, -1, -2), (0, 0, -1)]
+    for i, (dx, dy, dz) in enumerate(walk):
+        pts = moved(a if i % 2 else a2, float(dx), float(dy), float(dz))
+        n, got = launches_of(pts)
+        assert n == base, (i, base, n)
+        want = truth(pts)
+        _assert_same_step(want, got)
+        _step_tables([pts], K, ctx)           # (the hint again, formed from this cloud's box)
+    # a jump of six voxels: the hint is rejected once, the build runs again from the box the attempt has found
+    far = moved(a, 6.0, 0.0, -1.0)
+    _step_tables([a], K, ctx)
+    rej, got = launches_of(far)
+    _assert_same_step(truth(far), got)
     assert rej > base + 3, (base, rej)
-    seq = []
-    for name, pts in (("a", a), ("c", c), ("a2", a2), ("c", c)):     # the box keeps moving: no hint is tried
-        n, got = launches_of(pts)
-        _assert_same_step(want[name], got)
-        seq.append(n)
-    assert max(seq) < rej, (base, rej, seq)
-    for name, pts in (("a", a), ("a2", a2), ("a", a)):              # two scans that would have fitted: hints again
-        n, got = launches_of(pts)
-        _assert_same_step(want[name], got)
-    n, got = launches_of(a2)
-    _assert_same_step(want["a2"], got)
+    _step_tables([far], K, ctx)
+    n, got = launches_of(moved(a2, 7.0, 1.0, -1.0))   # ... and the next scan is followed again
     assert n == base, (base, n)
-    set_option("NO_HINT_COOLDOWN", 1)         # the form before: every moved box costs an attempt
-    launches_of(c)
-    n, got = launches_of(a)
-    _assert_same_step(want["a"], got)
-    assert n >= rej, (rej, n)
+    # without the margin (the tight box of rounds 2-5) a one-voxel drift is a rejected attempt
+    set_option("GEOM_MARGIN", -1)
+    try:
+        _step_tables([a], K, ctx)
+        n0, got = launches_of(a2)
+        _assert_same_step(truth(a2), got)
+        _step_tables([a], K, ctx)
+        n1, got = launches_of(moved(a2, 1.0))
+        assert n1 > n0 + 3, (n0, n1)
+    finally:
+        set_option("GEOM_MARGIN", 0)
+    # a wider margin follows a faster scene
+    set_option("GEOM_MARGIN", 2)
+    try:
+        _step_tables([a], K, ctx)             # (under the one-voxel hint; the next hint has the wider margin)
+        _step_tables([a], K, ctx)
+        n2, got = launches_of(moved(a2, 2.0, -2.0, 1.0))
+        _assert_same_step(truth(moved(a2, 2.0, -2.0, 1.0)), got)
+        assert n2 == base, (base, n2)
+    finally:
+        set_option("GEOM_MARGIN", 0)
