@@ -100,8 +100,11 @@ int octl_forest_clear(octl_forest* f);
  * slot through *slot.  Replaces Grid.insert_points' storage step.                        */
 int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* slot);
 /* Same, from a device pointer (device-to-device copy fused with the bounding-box pass; no PCIe).  The
- * source is consumed in stream order: it must stay unchanged until the next synchronising call on
- * the context (octl_forest_build, octl_ctx_sync, ...).                                      */
+ * source is consumed in stream order: it must stay unchanged until a call that leaves the context's stream IDLE:
+ * octl_ctx_sync and every call that downloads to host memory (octl_forest_get_mask, _get_blocks, _get_nodes,
+ * _gather_blocks, ...).  NOT among them since round 5: octl_forest_build and octl_forest_apply_mask - they
+ * return when the scalars they hand back have arrived in the pinned mirror, while their last kernels may still
+ * be running (stream order is kept: anything enqueued on the context afterwards runs behind them).           */
 int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n,
                                 int32_t* slot);
 /* Same, WITHOUT the copy: an empty forest reads the caller's device buffer in place as its first pose
@@ -235,7 +238,9 @@ int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, const int32_
 int octl_forest_get_mask(octl_forest* f, int64_t cap, uint8_t* mask, int64_t* n);
 /* Drop the points whose mask byte is 0 from the blocks that were evaluated (apply_mask,
  * octree.py:137-142): compacts the leaf-ordered arrays, updates the block table and marks
- * the points dead for later builds.  Returns the surviving point count.                    */
+ * the points dead for later builds.  Returns the surviving point count - as soon as the count has reached the
+ * host: the compaction kernel may still be running (it reads the forest's own arrays only, never a cloud that
+ * was taken in place; work enqueued on the context later runs behind it).  octl_ctx_sync waits for it.        */
 int octl_forest_apply_mask(octl_forest* f, int64_t* n_alive);
 /* OctreeNode.filter (octree/octree.py:102-112) for point-count predicates, on the device: every leaf of
  * the poses with slot_sel[slot] != 0 whose point count is outside [lo, hi] is emptied (its points

@@ -515,7 +515,7 @@ int bbox_ensure(octl_forest* f) {
     f->bbox_stale = true;
   }
   if (!f->bbox_stale) return OCTL_OK;
-  hipLaunchKernelGGL(k_bbox_reset, dim3(1), dim3(64), 0, ctx->stream, f->bbox_dev.as<int32_t>());
+  OCTL_LAUNCH(k_bbox_reset, dim3(1), dim3(64), 0, ctx->stream, f->bbox_dev.as<int32_t>());
   HIP_TRY(ctx, hipGetLastError());
   f->bbox_stale = false;
   return OCTL_OK;
@@ -559,23 +559,23 @@ int store_append(octl_forest* f, const double* xyz, int64_t n, bool from_device)
     const bool aligned = (f->n_store % 2) == 0 && (reinterpret_cast<uintptr_t>(xyz) % 16) == 0;
     if (from_device && xyz == dst) {
       // an adopted buffer (store_adopt): the points are in place already
-      hipLaunchKernelGGL(k_ingest<false>, dim3(grid), dim3(256), 0, st, (const double*)dst, dst, alive, n,
+      OCTL_LAUNCH(k_ingest<false>, dim3(grid), dim3(256), 0, st, (const double*)dst, dst, alive, n,
                          f->mode, f->edge, f->bbox_dev.as<int32_t>());
     } else if (from_device && aligned) {
-      hipLaunchKernelGGL(k_ingest<true>, dim3(grid), dim3(256), 0, st, xyz, dst, alive, n, f->mode,
+      OCTL_LAUNCH(k_ingest<true>, dim3(grid), dim3(256), 0, st, xyz, dst, alive, n, f->mode,
                          f->edge, f->bbox_dev.as<int32_t>());
     } else {
       HIP_TRY(ctx, hipMemcpyAsync(dst, xyz, (size_t)n * 24,
                                   from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
       if ((f->n_store % 2) == 0) {
-        hipLaunchKernelGGL(k_ingest<false>, dim3(grid), dim3(256), 0, st, (const double*)dst, dst, alive,
+        OCTL_LAUNCH(k_ingest<false>, dim3(grid), dim3(256), 0, st, (const double*)dst, dst, alive,
                            n, f->mode, f->edge, f->bbox_dev.as<int32_t>());
       } else {
         // first point alone, then the aligned rest
-        hipLaunchKernelGGL(k_ingest<false>, dim3(1), dim3(256), 0, st, (const double*)dst, dst, alive,
+        OCTL_LAUNCH(k_ingest<false>, dim3(1), dim3(256), 0, st, (const double*)dst, dst, alive,
                            (int64_t)1, f->mode, f->edge, f->bbox_dev.as<int32_t>());
         if (n > 1)
-          hipLaunchKernelGGL(k_ingest<false>, dim3((unsigned)std::max<int64_t>(1, ceil_div(3 * (n - 1) / 2, 256 * ING_UNITS))), dim3(256),
+          OCTL_LAUNCH(k_ingest<false>, dim3((unsigned)std::max<int64_t>(1, ceil_div(3 * (n - 1) / 2, 256 * ING_UNITS))), dim3(256),
                              0, st, (const double*)(dst + 3), dst + 3, alive + 1, n - 1, f->mode, f->edge,
                              f->bbox_dev.as<int32_t>());
       }
@@ -639,7 +639,7 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
       OCTL_TRY(alive_ensure(f));
     }
     if (!fused) {
-      hipLaunchKernelGGL(k_blk_kept, dim3((unsigned)nt + grid_for(nb)), dim3(256), 0, st, mask, n, (uint32_t)nt, raw,
+      OCTL_LAUNCH(k_blk_kept, dim3((unsigned)nt + grid_for(nb)), dim3(256), 0, st, mask, n, (uint32_t)nt, raw,
                          (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
                          raw + nt, raw + nt + nb, fill);
       HIP_TRY(ctx, hipGetLastError());
@@ -658,7 +658,7 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
       uint64_t* status = nullptr;
       uint32_t epoch = 0;
       OCTL_TRY(octl_scan_status_acquire(ctx, nt + 2 * nbw, &status, &epoch));
-      hipLaunchKernelGGL(k_mask_scan, dim3((unsigned)(nt + nbw)), dim3(256), 0, st, mask, n, (uint32_t)nt, scanned,
+      OCTL_LAUNCH(k_mask_scan, dim3((unsigned)(nt + nbw)), dim3(256), 0, st, mask, n, (uint32_t)nt, scanned,
                          (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
                          (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
                          f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
@@ -666,12 +666,12 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
                          static_cast<uint32_t*>(ctx->small_host), wait_seq, fill);
       HIP_TRY(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)scanned, n,
+    OCTL_LAUNCH(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)scanned, n,
                        (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
                        f->ord_idx2.as<uint32_t>(), f->xyz_ord2.as<double>(), f->alive.as<uint8_t>());
     HIP_TRY(ctx, hipGetLastError());
     if (!fused) {
-      hipLaunchKernelGGL(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)raw,
+      OCTL_LAUNCH(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)raw,
                          (const uint32_t*)scanned, (const uint32_t*)(small + 22), nt, nb,
                          (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
                          f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
@@ -729,7 +729,7 @@ int store_compute_bbox(octl_forest* f) {
   KTimer t(ctx, "ingest");
   const unsigned grid = (unsigned)std::max<int64_t>(1, ceil_div(3 * n / 2, 256 * ING_UNITS));
   double* p = f->xyz.as<double>();
-  hipLaunchKernelGGL(k_ingest<false>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)p, p,
+  OCTL_LAUNCH(k_ingest<false>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)p, p,
                      (uint8_t*)nullptr, n, f->mode, f->edge, f->bbox_dev.as<int32_t>());
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
@@ -1222,7 +1222,7 @@ int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* 
   if (size) HIP_TRY(ctx, hipMemcpyAsync(size, f->blk_size.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   if (start) {
     OCTL_TRY(devbuf_reserve(ctx, f->rs_scratch, (size_t)n * 8));
-    hipLaunchKernelGGL(k_widen_u32_i64, dim3(grid_for(n)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_widen_u32_i64, dim3(grid_for(n)), dim3(256), 0, st,
                        (const uint32_t*)f->blk_start.as<uint32_t>(), n,
                        f->rs_scratch.as<int64_t>());
     HIP_TRY(ctx, hipGetLastError());
@@ -1252,12 +1252,12 @@ int octl_forest_get_slot_voxels(octl_forest* f, int32_t slot, int64_t cap, int32
   int32_t* out = reinterpret_cast<int32_t*>(base + 2 * seg);
   uint32_t* total = ctx->small.as<uint32_t>() + 21;
   HIP_TRY(ctx, hipMemsetAsync(flags, 0, seg, st));
-  hipLaunchKernelGGL(k_slot_voxel_flags, dim3(grid_for(nb)), dim3(256), 0, st,
+  OCTL_LAUNCH(k_slot_voxel_flags, dim3(grid_for(nb)), dim3(256), 0, st,
                      (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
                      nb, slot, (const int32_t*)f->nodes[f->cur].voxel.as<int32_t>(), flags);
   HIP_TRY(ctx, hipGetLastError());
   OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, scanned, V, total));
-  hipLaunchKernelGGL(k_flag_indices, dim3(grid_for(V)), dim3(256), 0, st, (const uint32_t*)flags,
+  OCTL_LAUNCH(k_flag_indices, dim3(grid_for(V)), dim3(256), 0, st, (const uint32_t*)flags,
                      (const uint32_t*)scanned, V, out);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, total, 4, hipMemcpyDeviceToHost, st));
@@ -1284,7 +1284,7 @@ int octl_forest_slot_counts(octl_forest* f, int32_t slot, int64_t* n_points, int
   hipStream_t st = ctx->stream;
   unsigned long long* out = reinterpret_cast<unsigned long long*>(ctx->small.as<uint32_t>() + 28);
   HIP_TRY(ctx, hipMemsetAsync(out, 0, 16, st));
-  hipLaunchKernelGGL(k_slot_counts, dim3((unsigned)std::min<int64_t>(1024, ceil_div(f->n_blocks, 256))), dim3(256),
+  OCTL_LAUNCH(k_slot_counts, dim3((unsigned)std::min<int64_t>(1024, ceil_div(f->n_blocks, 256))), dim3(256),
                      0, st, (const int32_t*)f->blk_slot.as<int32_t>(), (const int32_t*)f->blk_size.as<int32_t>(),
                      f->n_blocks, slot, out);
   HIP_TRY(ctx, hipGetLastError());
@@ -1308,7 +1308,7 @@ int octl_forest_internal_per_voxel(octl_forest* f, int64_t cap, int32_t* counts,
   NodeTable& t = f->nodes[f->cur];
   OCTL_TRY(devbuf_reserve(ctx, f->rs_scratch, (size_t)f->n_voxels * 4));
   HIP_TRY(ctx, hipMemsetAsync(f->rs_scratch.p, 0, (size_t)f->n_voxels * 4, st));
-  hipLaunchKernelGGL(k_internal_per_voxel, dim3(grid_for(t.n)), dim3(256), 0, st,
+  OCTL_LAUNCH(k_internal_per_voxel, dim3(grid_for(t.n)), dim3(256), 0, st,
                      (const int32_t*)t.first_child.as<int32_t>(), (const int32_t*)t.voxel.as<int32_t>(), t.n,
                      f->rs_scratch.as<int32_t>());
   HIP_TRY(ctx, hipGetLastError());
@@ -1326,7 +1326,7 @@ int octl_forest_get_perm(octl_forest* f, int64_t cap, int64_t* perm, int64_t* n_
   if (n <= 0 || !perm) return OCTL_OK;
   hipStream_t st = ctx->stream;
   OCTL_TRY(devbuf_reserve(ctx, f->rs_scratch, (size_t)n * 8));
-  hipLaunchKernelGGL(k_widen_u32_i64, dim3(grid_for(n)), dim3(256), 0, st,
+  OCTL_LAUNCH(k_widen_u32_i64, dim3(grid_for(n)), dim3(256), 0, st,
                      (const uint32_t*)f->ord_idx.as<uint32_t>(), n, f->rs_scratch.as<int64_t>());
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(perm, f->rs_scratch.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
@@ -1367,7 +1367,7 @@ int octl_forest_gather_blocks(octl_forest* f, const int32_t* block_ids, int64_t 
   uint32_t* offs = reinterpret_cast<uint32_t*>(base + o_sz);
   uint32_t* total = reinterpret_cast<uint32_t*>(base + o_tot);
   HIP_TRY(ctx, hipMemcpyAsync(ids_d, block_ids, (size_t)m * 4, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_gather_sizes, dim3(grid_for(m)), dim3(256), 0, st, (const int32_t*)ids_d, m,
+  OCTL_LAUNCH(k_gather_sizes, dim3(grid_for(m)), dim3(256), 0, st, (const int32_t*)ids_d, m,
                      (const int32_t*)f->blk_size.as<int32_t>(), offs);
   HIP_TRY(ctx, hipGetLastError());
   OCTL_TRY(octl_exclusive_scan_u32(ctx, offs, offs, m, total));
@@ -1378,7 +1378,7 @@ int octl_forest_gather_blocks(octl_forest* f, const int32_t* block_ids, int64_t 
   if (tot_h == 0 || !xyz || cap < (int64_t)tot_h) return OCTL_OK;  // (size query, or nothing to copy)
   // the gathered rows go through the compaction target of apply_mask (free between calls)
   OCTL_TRY(devbuf_reserve(ctx, f->xyz_ord2, (size_t)tot_h * 24));
-  hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)ceil_div(m, 4)), dim3(256), 0, st, (const int32_t*)ids_d, m,
+  OCTL_LAUNCH(k_gather_rows, dim3((unsigned)ceil_div(m, 4)), dim3(256), 0, st, (const int32_t*)ids_d, m,
                      (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(),
                      (const uint32_t*)offs, (const double*)f->xyz_ord.as<double>(), f->xyz_ord2.as<double>());
   HIP_TRY(ctx, hipGetLastError());
@@ -1469,7 +1469,7 @@ int octl_forest_filter_count(octl_forest* f, const uint8_t* slot_sel, int32_t n_
     HIP_TRY(ctx, hipMemcpyAsync(f->scheme_dev.p, slot_sel, (size_t)n_poses, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));  // (a pageable source)
     KTimer t(ctx, "filter");
-    hipLaunchKernelGGL(k_filter_blocks, dim3((unsigned)ceil_div(f->n_blocks, 4)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_filter_blocks, dim3((unsigned)ceil_div(f->n_blocks, 4)), dim3(256), 0, st,
                        (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(),
                        (const int32_t*)f->blk_slot.as<int32_t>(), f->n_blocks,
                        (const uint8_t*)f->scheme_dev.as<uint8_t>(), lo, hi, f->mask.as<uint8_t>());

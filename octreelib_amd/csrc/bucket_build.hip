@@ -2453,7 +2453,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       std::memcpy(tb, hint.tb, sizeof(tb));
     } else {
       // ---- voxel bounding box (kept by the ingest kernel; the copy was enqueued with the last ingest) ------
-      int32_t* bbox_host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + 3584);
+      int32_t* bbox_host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + MIRROR_BBOX_WORD * 4);
       HIP_TRY(ctx, hipMemcpyAsync(bbox_host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, st));
       HIP_TRY(ctx, hipStreamSynchronize(st));
       std::memcpy(tb, bbox_host, sizeof(tb));
@@ -2556,7 +2556,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   uint32_t* table = f->bk_table.as<uint32_t>();
   uint32_t* table_dm = table + tab_elems;  // digit-major
   auto transpose = [&](const uint32_t* in, uint32_t R, uint32_t Cc, uint32_t* out) {
-    hipLaunchKernelGGL(k_transpose_u32, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, R, Cc, out);
+    OCTL_LAUNCH(k_transpose_u32, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, R, Cc, out);
     return hipGetLastError();
   };
   // (SM_BK_FLAGS / SM_BK_TOTAL / SM_BK_TODO are zero: forest_build has reset the scalar block)
@@ -2570,11 +2570,11 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     gdev = reinterpret_cast<GeomDev*>(small + SM_GEOM);
     if (hinted) {
       // (normally in place already: k_build_begin copied it with the scalar block)
-      if (!ctx->geom_hint_staged) hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, hint, gdev);
+      if (!ctx->geom_hint_staged) OCTL_LAUNCH(k_geom_set, dim3(1), dim3(64), 0, st, hint, gdev);
     } else {
       LinParams base = lp;
       base.dshift = s;
-      hipLaunchKernelGGL(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask, base, gdev);
+      OCTL_LAUNCH(k_bucket_geom, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask, base, gdev);
     }
     HIP_TRY(ctx, hipGetLastError());
   } else if (hinted2) {
@@ -2587,7 +2587,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     std::memcpy(g2.bb, bb, sizeof(bb));
     std::memcpy(g2.tb, tb, sizeof(tb));
     g2.valid = 1;
-    hipLaunchKernelGGL(k_geom_set, dim3(1), dim3(64), 0, st, g2, gdev);
+    OCTL_LAUNCH(k_geom_set, dim3(1), dim3(64), 0, st, g2, gdev);
     HIP_TRY(ctx, hipGetLastError());
   }
   auto table_scan = [&](uint32_t nst, uint32_t nd, uint32_t* bucket_start, int validate) {
@@ -2595,7 +2595,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     uint64_t* status = nullptr;
     uint32_t epoch = 0;
     OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
-    hipLaunchKernelGGL(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, bucket_start, status, epoch,
+    OCTL_LAUNCH(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, bucket_start, status, epoch,
                        validate, (const int32_t*)f->bbox_dev.as<int32_t>(), ask, lp, gdev);
     HIP_TRY(ctx, hipGetLastError());
     return (int)OCTL_OK;
@@ -2604,7 +2604,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     KTimer t(ctx, "part_hist");
     if (hinted || hinted2) {
       auto kh = f->edge == 1.0 ? k_part_hist<true, true> : k_part_hist<true, false>;
-      hipLaunchKernelGGL(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+      OCTL_LAUNCH(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
                          alive_p, N, lp, (const GeomDev*)gdev, nst_a, nd_a, (int64_t)st_tiles_a * tile, table,
                          f->bbox_dev.as<int32_t>());
       HIP_TRY(ctx, hipGetLastError());
@@ -2612,14 +2612,14 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       if (fused_a) {
         // (k_table_scan validates the hint on its way)
       } else if (hinted)
-        hipLaunchKernelGGL(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask,
+        OCTL_LAUNCH(k_geom_validate, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask,
                            lp, gdev);
       else
-        hipLaunchKernelGGL(k_geom_validate2, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask,
+        OCTL_LAUNCH(k_geom_validate2, dim3(1), dim3(64), 0, st, (const int32_t*)f->bbox_dev.as<int32_t>(), ask,
                            gdev);
     } else {
       auto kh = f->edge == 1.0 ? k_part_hist<false, true> : k_part_hist<false, false>;
-      hipLaunchKernelGGL(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
+      OCTL_LAUNCH(kh, dim3(nst_a), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(),
                          alive_p, N, lp, (const GeomDev*)gdev, nst_a, nd_a, (int64_t)st_tiles_a * tile, table,
                          (int32_t*)nullptr);
     }
@@ -2638,7 +2638,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   {
     KTimer t(ctx, "part_scatter");
     auto ks = nd_a <= 256u ? k_part_scatter<PT_IPT, false, 8> : k_part_scatter<PT_IPT, false, PT_BITS>;
-    hipLaunchKernelGGL(ks, dim3(nst_a), dim3(PT_THREADS), 0, st,
+    OCTL_LAUNCH(ks, dim3(nst_a), dim3(PT_THREADS), 0, st,
                        (const double*)f->xyz.as<double>(), alive_p, N, lp,
                        (const GeomDev*)gdev, nst_a, nd_a, st_tiles_a, (const uint32_t*)table,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
@@ -2655,7 +2655,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     lp.raw_vp = 0;
     {
       KTimer t(ctx, "part_hist");
-      hipLaunchKernelGGL(k_part_hist_rec, dim3(nst_b), dim3(PH_THREADS), 0, st,
+      OCTL_LAUNCH(k_part_hist_rec, dim3(nst_b), dim3(PH_THREADS), 0, st,
                          (const uint4*)f->part_xyz[0].as<uint4>(), n_alive, lp, (const GeomDev*)gdev, nst_b, nd_b,
                          (int64_t)st_tiles_b * tile, table);
       HIP_TRY(ctx, hipGetLastError());
@@ -2673,7 +2673,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     {
       KTimer t(ctx, "part_scatter");
       auto ks = nd_b <= 256u ? k_part_scatter<PT_IPT, true, 8> : k_part_scatter<PT_IPT, true, PT_BITS>;
-      hipLaunchKernelGGL(ks, dim3(nst_b), dim3(PT_THREADS), 0, st,
+      OCTL_LAUNCH(ks, dim3(nst_b), dim3(PT_THREADS), 0, st,
                          (const double*)f->part_xyz[0].as<double>(), (const uint8_t*)nullptr, n_alive, lp,
                          (const GeomDev*)gdev, nst_b, nd_b, st_tiles_b, (const uint32_t*)table, (const int64_t*)nullptr, 0,
                          (const uint8_t*)nullptr, f->part_xyz[1].as<PartRec>());
@@ -2682,7 +2682,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     uint32_t* bounds = table + 2 * tab_elems;
     {
       KTimer t(ctx, "bucket_bounds");
-      hipLaunchKernelGGL(k_bucket_bounds, dim3((unsigned)ceil_div((int64_t)nb + 1, 256)), dim3(256), 0, st,
+      OCTL_LAUNCH(k_bucket_bounds, dim3((unsigned)ceil_div((int64_t)nb + 1, 256)), dim3(256), 0, st,
                          (const uint4*)f->part_xyz[1].as<uint4>(), (uint32_t)n_alive, lp, (const GeomDev*)gdev, nb, bounds);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -2716,11 +2716,11 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // k_bucket_build, as round 4 did: a chunk is one workgroup's whole bucket build, worth hiding.
   const bool chunks_beside = ctx->had_chunks;
   auto launch_chunks = [&](hipStream_t on) {
-    hipLaunchKernelGGL(k_bucket_plan, dim3(nb), dim3(BB_THREADS), 0, on, recs, bstart, bp, (const GeomDev*)gdev, ck_desc,
+    OCTL_LAUNCH(k_bucket_plan, dim3(nb), dim3(BB_THREADS), 0, on, recs, bstart, bp, (const GeomDev*)gdev, ck_desc,
                        ck_of_bucket, bk_tot, small);
     HIP_TRY(ctx, hipGetLastError());
     // one workgroup per chunk; the list's length is on the device, the grid strides over it
-    hipLaunchKernelGGL(k_bucket_chunks, dim3((unsigned)std::min<int64_t>(2 * (int64_t)cus, CK_CAP)), dim3(BB_THREADS), 0, on,
+    OCTL_LAUNCH(k_bucket_chunks, dim3((unsigned)std::min<int64_t>(2 * (int64_t)cus, CK_CAP)), dim3(BB_THREADS), 0, on,
                        recs, bstart, bp, (const GeomDev*)gdev, (const ChunkDesc*)ck_desc, ck_tot,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
                        f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(), bk_tot, small);
@@ -2739,7 +2739,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     }
 #endif
     if (chunks_beside) OCTL_TRY(launch_chunks(side));
-    hipLaunchKernelGGL(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
+    OCTL_LAUNCH(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),
                        f->xyz_ord.as<double>(), f->leafinfo.as<uint32_t>(), f->bk_vox.as<uint32_t>(), f->bk_node.as<uint32_t>(),
                        bk_tot, small, chunks_beside ? 0 : 1);
@@ -2757,7 +2757,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   NodePtrs nd_launch;
   auto launch_finish = [&](const NodeParams& np, bool with_chunk_map) {
     KTimer t(ctx, "bucket_nodes");
-    hipLaunchKernelGGL(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd_launch, np, bstart,
+    OCTL_LAUNCH(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd_launch, np, bstart,
                        (const uint32_t*)bk_scan, (const uint32_t*)(small + SM_BK_TOTAL),
                        (const uint32_t*)f->leafinfo.as<uint32_t>(), (const uint32_t*)f->ord_idx.as<uint32_t>(),
                        (const uint32_t*)f->bk_vox.as<uint32_t>(), (const uint32_t*)f->bk_node.as<uint32_t>(),
@@ -2828,11 +2828,11 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
         uint64_t* status = nullptr;
         uint32_t epoch = 0;
         OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
-        hipLaunchKernelGGL(k_bucket_scan_totals, dim3(g), dim3(BT_THREADS), 0, st, (const uint32_t*)bk_tot, bk_scan, n_tot,
+        OCTL_LAUNCH(k_bucket_scan_totals, dim3(g), dim3(BT_THREADS), 0, st, (const uint32_t*)bk_tot, bk_scan, n_tot,
                            nb, status, epoch, small, static_cast<uint32_t*>(ctx->small_host), mirror_words, wait_seq);
       } else {
         OCTL_TRY(octl_exclusive_scan_u32(ctx, bk_tot, bk_scan, (int64_t)BK_ROWS * nb, small + SM_BK_TOTAL));
-        hipLaunchKernelGGL(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_scan, nb,
+        OCTL_LAUNCH(k_bucket_totals, dim3(1), dim3(64), 0, st, (const uint32_t*)bk_scan, nb,
                            (const uint32_t*)(small + SM_BK_TOTAL), small, static_cast<uint32_t*>(ctx->small_host),
                            mirror_words, wait_seq);
       }
@@ -2974,7 +2974,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     // a voxel of the previous scheme that has lost all its points keeps its (empty) octree in the reference:
     // roots this path cannot make - the general path takes the build then (nothing is committed yet)
     HIP_TRY(ctx, hipMemsetAsync(small + SM_BK_MISSING, 0, 4, st));
-    hipLaunchKernelGGL(k_old_voxels_missing, dim3((unsigned)ceil_div(a.old_voxels, 256)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_old_voxels_missing, dim3((unsigned)ceil_div(a.old_voxels, 256)), dim3(256), 0, st,
                        a.old_vcode, a.old_voxels, (const uint64_t*)f->vlin_dev.as<uint64_t>(), V, lp,
                        bb[3] - bb[0] + 1, f->vorg, small + SM_BK_MISSING);
     HIP_TRY(ctx, hipGetLastError());
@@ -3042,13 +3042,13 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
   HIP_TRY(ctx, hipMemsetAsync(flag, 0, 4, st));
   const bool fused = !ctx->opt.no_fused_tables && nst <= TS_MAX_ROWS;   // (the table in one launch: k_table_scan)
   auto transpose = [&](const uint32_t* in, uint32_t R, uint32_t Cc, uint32_t* out) {
-    hipLaunchKernelGGL(k_transpose_u32, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, R, Cc, out);
+    OCTL_LAUNCH(k_transpose_u32, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, in, R, Cc, out);
     return hipGetLastError();
   };
   {
     KTimer t(ctx, "prefix_hist");
     auto kh = f->edge == 1.0 ? k_part_hist<false, true> : k_part_hist<false, false>;
-    hipLaunchKernelGGL(kh, dim3(nst), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(), (const uint8_t*)nullptr,
+    OCTL_LAUNCH(kh, dim3(nst), dim3(PH_THREADS), 0, st, (const double*)f->xyz.as<double>(), (const uint8_t*)nullptr,
                        N, lp, (const GeomDev*)nullptr, nst, nd, (int64_t)st_tiles * tile, table,
                        reinterpret_cast<int32_t*>(flag));
     HIP_TRY(ctx, hipGetLastError());
@@ -3057,7 +3057,7 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
       uint64_t* status = nullptr;
       uint32_t epoch = 0;
       OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
-      hipLaunchKernelGGL(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, table_dm, status, epoch, 0,
+      OCTL_LAUNCH(k_table_scan, dim3(g), dim3(TS_THREADS), 0, st, table, nst, nd, table_dm, status, epoch, 0,
                          (const int32_t*)nullptr, GeomAsk{0, 0, 0, 0}, lp, (GeomDev*)nullptr);
       HIP_TRY(ctx, hipGetLastError());
     } else {
@@ -3069,7 +3069,7 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
   {
     KTimer t(ctx, "prefix_scatter");
     auto ks = nd <= 256u ? k_part_scatter<PT_IPT, false, 8> : k_part_scatter<PT_IPT, false, PT_BITS>;
-    hipLaunchKernelGGL(ks, dim3(nst), dim3(PT_THREADS), 0, st, (const double*)f->xyz.as<double>(), (const uint8_t*)nullptr, N,
+    OCTL_LAUNCH(ks, dim3(nst), dim3(PT_THREADS), 0, st, (const double*)f->xyz.as<double>(), (const uint8_t*)nullptr, N,
                        lp, (const GeomDev*)nullptr, nst, nd, st_tiles, (const uint32_t*)table,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, (const uint8_t*)nullptr,
                        f->part_xyz[0].as<PartRec>());

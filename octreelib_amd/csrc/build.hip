@@ -1071,17 +1071,17 @@ int forest_make_blocks(octl_forest* f) {
   OCTL_TRY(devbuf_reserve(ctx, f->blk_slot, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_start, (size_t)n * 4));
   OCTL_TRY(devbuf_reserve(ctx, f->blk_size, (size_t)n * 4));
-  hipLaunchKernelGGL(k_block_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
+  OCTL_LAUNCH(k_block_tiles<false>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
                      (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
                      n_poses, n, tile_cnt, (int32_t*)nullptr, (int32_t*)nullptr, (uint32_t*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   OCTL_TRY(octl_exclusive_scan_u32(ctx, tile_cnt, tile_cnt, n_tiles, small + SM_NBLOCKS));
-  hipLaunchKernelGGL(k_block_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
+  OCTL_LAUNCH(k_block_tiles<true>, dim3((unsigned)n_tiles), dim3(256), 0, st, pos_node,
                      (const uint32_t*)f->ord_idx.as<uint32_t>(), (const int64_t*)f->pose_off_dev.as<int64_t>(),
                      n_poses, n, tile_cnt, f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
                      f->blk_start.as<uint32_t>());
   HIP_TRY(ctx, hipGetLastError());
-  hipLaunchKernelGGL(k_block_sizes, dim3(grid_for(n)), dim3(256), 0, st,
+  OCTL_LAUNCH(k_block_sizes, dim3(grid_for(n)), dim3(256), 0, st,
                      (const uint32_t*)f->blk_start.as<uint32_t>(),
                      (const uint32_t*)(small + SM_NBLOCKS), n, f->blk_size.as<int32_t>());
   HIP_TRY(ctx, hipGetLastError());
@@ -1189,14 +1189,14 @@ static int run_level_loop(LevelLoop& L) {
     {
       KTimer t(ctx, "level_prepare");
       const int leaves_only = (L.resume && L.level == 0) ? 1 : 0;
-      hipLaunchKernelGGL(k_split_flags, dim3(grid_for(L.n_new)), dim3(256), 0, st, nd, L.first_new,
+      OCTL_LAUNCH(k_split_flags, dim3(grid_for(L.n_new)), dim3(256), 0, st, nd, L.first_new,
                          L.n_new, L.keep_scheme, L.K, L.old_fc, leaves_only, flags);
       HIP_TRY(ctx, hipGetLastError());
       OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, L.n_new, small + SM_NSPLIT));
       // tiles of the nodes that split: scanned over L.n_new entries (zeros beyond the ns that are
       // filled) so that ns and the tile count come back in ONE readback
       HIP_TRY(ctx, hipMemsetAsync(tile_base, 0, (size_t)(L.n_new + 8) * 4, st));
-      hipLaunchKernelGGL(k_compact_split, dim3(grid_for(L.n_new)), dim3(256), 0, st, nd, L.first_new,
+      OCTL_LAUNCH(k_compact_split, dim3(grid_for(L.n_new)), dim3(256), 0, st, nd, L.first_new,
                          L.n_new, (const uint32_t*)flags, L.keep_scheme, L.K, L.old_fc, leaves_only,
                          split_nodes, tile_base);
       HIP_TRY(ctx, hipGetLastError());
@@ -1216,7 +1216,7 @@ static int run_level_loop(LevelLoop& L) {
       // the roots that are subdivided here: their points are (re)written by k_finalize_marked
       OCTL_TRY(devbuf_reserve(ctx, f->root_up, (size_t)L.n_new));
       HIP_TRY(ctx, hipMemsetAsync(f->root_up.p, 0, (size_t)L.n_new, st));
-      hipLaunchKernelGGL(k_mark_nodes, dim3(grid_for(ns)), dim3(256), 0, st, (const int32_t*)split_nodes, ns,
+      OCTL_LAUNCH(k_mark_nodes, dim3(grid_for(ns)), dim3(256), 0, st, (const int32_t*)split_nodes, ns,
                          f->root_up.as<uint8_t>());
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -1238,7 +1238,7 @@ static int run_level_loop(LevelLoop& L) {
       if (L.resume && L.level == 0) {
         // resuming after the bucket build: the level buffers only exist for the voxels it left behind -
         // store index | scheme bit from the leaf-ordered permutation (insertion order inside a root)
-        hipLaunchKernelGGL(k_lv_init_idx, dim3(n_tiles), dim3(LV_THREADS), 0, st, (const int32_t*)split_nodes,
+        OCTL_LAUNCH(k_lv_init_idx, dim3(n_tiles), dim3(LV_THREADS), 0, st, (const int32_t*)split_nodes,
                            (const uint32_t*)tile_base, ns, n_tiles, nd,
                            (const uint32_t*)f->ord_idx.as<uint32_t>(),
                            (const int64_t*)f->pose_off_dev.as<int64_t>(), (int)f->pose_off.size() - 1,
@@ -1247,7 +1247,7 @@ static int run_level_loop(LevelLoop& L) {
       }
       if ((L.level > 0 || L.resume) && L.level % PATH_LEVELS == 0) {
         KTimer t(ctx, "level_rekey");
-        hipLaunchKernelGGL(k_lv_rekey, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+        OCTL_LAUNCH(k_lv_rekey, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                            (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
                            (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
                            f->pathbuf[src].as<uint32_t>(), gx, L.xs);
@@ -1256,14 +1256,14 @@ static int run_level_loop(LevelLoop& L) {
       {
         KTimer t(ctx, "level_hist");
         if (!L.all_scheme && !L.keep_scheme)
-          hipLaunchKernelGGL(k_lv_hist<true>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+          OCTL_LAUNCH(k_lv_hist<true>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                              (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
                              nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
                              (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
                              gx, L.xs, shift, entries,
                              f->child_sc.as<uint32_t>(), small);
         else
-          hipLaunchKernelGGL(k_lv_hist<false>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+          OCTL_LAUNCH(k_lv_hist<false>, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                              (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles,
                              nd, (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
                              (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
@@ -1278,7 +1278,7 @@ static int run_level_loop(LevelLoop& L) {
       }
       {
         KTimer t(ctx, "level_scatter");
-        hipLaunchKernelGGL(k_lv_scatter, dim3(n_tiles), dim3(LV_THREADS), 0, st,
+        OCTL_LAUNCH(k_lv_scatter, dim3(n_tiles), dim3(LV_THREADS), 0, st,
                            (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
                            (const uint32_t*)f->idxbuf[src].as<uint32_t>(),
                            (const uint32_t*)f->pathbuf[src].as<uint32_t>(),
@@ -1292,7 +1292,7 @@ static int run_level_loop(LevelLoop& L) {
     }
     {
       KTimer t(ctx, "level_children");
-      hipLaunchKernelGGL(k_make_children, dim3(grid_for((int64_t)8 * ns)), dim3(256), 0, st,
+      OCTL_LAUNCH(k_make_children, dim3(grid_for((int64_t)8 * ns)), dim3(256), 0, st,
                          (const int32_t*)split_nodes, (const uint32_t*)tile_base, ns, n_tiles, nd,
                          (const uint32_t*)entries, (const uint32_t*)small,
                          (const uint32_t*)f->child_sc.as<uint32_t>(),
@@ -1333,7 +1333,7 @@ static int forest_ensure_origin(octl_forest* f) {
   octl_ctx* ctx = f->ctx;
   if (f->bbox_pending) OCTL_TRY(store_compute_bbox(f));
   if (!f->bbox_dev.p) return OCTL_OK;
-  int32_t* host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + 3584);
+  int32_t* host = reinterpret_cast<int32_t*>(static_cast<char*>(ctx->small_host) + MIRROR_BBOX_WORD * 4);
   HIP_TRY(ctx, hipMemcpyAsync(host, f->bbox_dev.p, 32, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   int bb[6];
@@ -1395,7 +1395,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       f->bbox_stale = false;
     }
     // (a kernel copy out of page-locked memory, not a DMA: see octl_copy_from_pinned)
-    hipLaunchKernelGGL(k_build_begin, dim3(1), dim3(128), 0, st, static_cast<const uint32_t*>(ctx->small_host), small,
+    OCTL_LAUNCH(k_build_begin, dim3(1), dim3(128), 0, st, static_cast<const uint32_t*>(ctx->small_host), small,
                        hint_words, box);
     HIP_TRY(ctx, hipGetLastError());
   }
@@ -1499,7 +1499,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       if (L.n_internal > 0) {
         NodePtrs nd = node_ptrs(bt);
         KTimer t(ctx, "finalize");
-        hipLaunchKernelGGL(k_finalize_marked, dim3(grid_for(n_alive)), dim3(256), 0, st,
+        OCTL_LAUNCH(k_finalize_marked, dim3(grid_for(n_alive)), dim3(256), 0, st,
                            (const int32_t*)f->pos_node.as<int32_t>(), (const int32_t*)nd.depth,
                            (const int32_t*)nd.voxel, (const uint8_t*)f->root_up.as<uint8_t>(),
                            (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
@@ -1592,7 +1592,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     OCTL_TRY(devbuf_reserve(ctx, f->vkey, (size_t)N * 8));
     OCTL_TRY(devbuf_reserve(ctx, f->path, (size_t)N * 4));
     KTimer t(ctx, "keygen");
-    hipLaunchKernelGGL(k_keygen, dim3(grid_for(N)), dim3(256), 0, st, f->xyz.as<double>(),
+    OCTL_LAUNCH(k_keygen, dim3(grid_for(N)), dim3(256), 0, st, f->xyz.as<double>(),
                        f->alive.as<uint8_t>(), N, f->mode, f->edge, f->corner[0], f->corner[1],
                        f->corner[2], f->vorg, ctx->opt.no_exact_digits ? 0 : 1, f->vkey.as<uint64_t>(),
                        f->path.as<uint32_t>(), small);
@@ -1648,7 +1648,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
     {
       KTimer t(ctx, "linkey");
-      hipLaunchKernelGGL(k_linkey, dim3(grid_for(N)), dim3(256), 0, st, f->vkey.as<uint64_t>(), N,
+      OCTL_LAUNCH(k_linkey, dim3(grid_for(N)), dim3(256), 0, st, f->vkey.as<uint64_t>(), N,
                          bb[0], bb[1], bb[2], ny, nz, dead_lin, f->vorg, f->pose_off_dev.as<int64_t>(),
                          n_poses, scheme_dev, f->lin[0].as<uint64_t>(), f->val[0].as<uint32_t>());
       HIP_TRY(ctx, hipGetLastError());
@@ -1681,11 +1681,11 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     v_pts = 1;
   } else if (n_alive > 0) {
     KTimer t(ctx, "roots");
-    hipLaunchKernelGGL(k_root_tiles<false>, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted, n_alive, flags,
+    OCTL_LAUNCH(k_root_tiles<false>, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted, n_alive, flags,
                        (uint64_t*)nullptr, (uint32_t*)nullptr);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, flags, flags, n_rtiles, small + SM_NVOX));
-    hipLaunchKernelGGL(k_root_tiles<true>, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted, n_alive, flags,
+    OCTL_LAUNCH(k_root_tiles<true>, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted, n_alive, flags,
                        vlin_d, vstart_d);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t nv;
@@ -1713,7 +1713,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     // depth pm that does not split (few points, very uneven cloud) sends the build down the plain path
     OCTL_TRY(nodes_reserve(ctx, nt, top_base(pm + 1)));
     nd = node_ptrs(nt);
-    hipLaunchKernelGGL(k_top_tree, dim3(grid_for(top_base(pm + 1))), dim3(256), 0, st, pre_bstart, pre_stride, pm,
+    OCTL_LAUNCH(k_top_tree, dim3(grid_for(top_base(pm + 1))), dim3(256), 0, st, pre_bstart, pre_stride, pm,
                        n_alive, K, f->edge, f->corner[0], f->corner[1], f->corner[2], cur_epoch_new, nd,
                        small + SM_BK_MISSING);
     HIP_TRY(ctx, hipGetLastError());
@@ -1734,7 +1734,7 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     OCTL_TRY(nodes_reserve(ctx, nt, std::max<int64_t>(V, 1)));
     nt.n = V;
     nd = node_ptrs(nt);
-    hipLaunchKernelGGL(k_make_roots, dim3(grid_for(V)), dim3(256), 0, st, (const uint64_t*)vlin_d,
+    OCTL_LAUNCH(k_make_roots, dim3(grid_for(V)), dim3(256), 0, st, (const uint64_t*)vlin_d,
                        (const uint32_t*)vstart_d, V, n_alive, f->mode, f->edge, f->corner[0],
                        f->corner[1], f->corner[2], bb[0], bb[1], bb[2], ny, nz,
                        (int)(all_scheme || keep_scheme), nd);
@@ -1848,22 +1848,22 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
     }
     KTimer t(ctx, "init_level0");
     if (pm)
-      hipLaunchKernelGGL(k_pre_level0, dim3(grid_for(N)), dim3(256), 0, st, static_cast<const uint4*>(pre_recs), N, pm,
+      OCTL_LAUNCH(k_pre_level0, dim3(grid_for(N)), dim3(256), 0, st, static_cast<const uint4*>(pre_recs), N, pm,
                          pos_node, f->idxbuf[pm & 1].as<uint32_t>(), f->pathbuf[pm & 1].as<uint32_t>());
     else if (cube_fast)
-      hipLaunchKernelGGL(k_cube_level0, dim3(grid_for(N)), dim3(256), 0, st, (const double*)f->xyz.as<double>(), N,
+      OCTL_LAUNCH(k_cube_level0, dim3(grid_for(N)), dim3(256), 0, st, (const double*)f->xyz.as<double>(), N,
                          f->edge, f->corner[0], f->corner[1], f->corner[2],
                          (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, scheme_dev,
                          ctx->opt.no_exact_digits ? 0 : 1, pos_node,
                          f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint32_t>());
     else
-      hipLaunchKernelGGL(k_init_level0, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted,
+      OCTL_LAUNCH(k_init_level0, dim3((unsigned)n_rtiles), dim3(256), 0, st, lin_sorted,
                          (const uint32_t*)flags, val_sorted, (const uint32_t*)f->path.as<uint32_t>(),
                          n_alive, l2r, pos_node,
                          f->idxbuf[0].as<uint32_t>(), f->pathbuf[0].as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
     if (!all_scheme && !keep_scheme) {
-      hipLaunchKernelGGL(k_count_scheme, dim3((unsigned)ceil_div(n_alive, 2048)), dim3(256), 0, st,
+      OCTL_LAUNCH(k_count_scheme, dim3((unsigned)ceil_div(n_alive, 2048)), dim3(256), 0, st,
                          (const int32_t*)pos_node, (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
                          n_alive, nd.scount);
       HIP_TRY(ctx, hipGetLastError());
@@ -1899,13 +1899,13 @@ int forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t 
       //  than one per thread at full occupancy)
       KTimer t(ctx, "finalize");
       if (pm)
-        hipLaunchKernelGGL(k_finalize_rec, dim3(grid_for(n_alive)), dim3(256), 0, st,
+        OCTL_LAUNCH(k_finalize_rec, dim3(grid_for(n_alive)), dim3(256), 0, st,
                            (const int32_t*)pos_node, (const int32_t*)nd.depth,
                            (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
                            (const uint32_t*)f->idxbuf[1].as<uint32_t>(), static_cast<const uint4*>(pre_recs),
                            n_alive, f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>());
       else
-        hipLaunchKernelGGL(k_finalize, dim3(grid_for(n_alive)), dim3(256), 0, st,
+        OCTL_LAUNCH(k_finalize, dim3(grid_for(n_alive)), dim3(256), 0, st,
                            (const int32_t*)pos_node, (const int32_t*)nd.depth,
                            (const uint32_t*)f->idxbuf[0].as<uint32_t>(),
                            (const uint32_t*)f->idxbuf[1].as<uint32_t>(),

@@ -32,11 +32,12 @@ static inline hipError_t octl_counted_event_sync(hipEvent_t e) {
 extern std::atomic<uint64_t> g_octl_launches;
 // speculative launches of k_bucket_finish that did the work / that the host had to repeat (octl_debug_spec_finish)
 extern std::atomic<uint64_t> g_octl_spec_held, g_octl_spec_missed;
-#undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(kernelName, ...)                                   \
+// (the project's own launch macro around the PUBLIC hipLaunchKernelGGL - not a redefinition of the runtime's macro
+//  through its internals: a ROCm update that renames those would break every translation unit)
+#define OCTL_LAUNCH(...)                                                      \
   do {                                                                        \
     g_octl_launches.fetch_add(1, std::memory_order_relaxed);                  \
-    hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                    \
+    hipLaunchKernelGGL(__VA_ARGS__);                                          \
   } while (0)
 #define hipMemsetAsync(...) (g_octl_launches.fetch_add(1, std::memory_order_relaxed), hipMemsetAsync(__VA_ARGS__))
 
@@ -183,7 +184,16 @@ int octl_set_error(octl_ctx* ctx, int code, const char* fmt, ...);
 // after the kernel has finished - interrupt, wake-up - which is a tenth of a 100 k-point scan.)  Counted as a host
 // wait like a synchronisation.  Words of the mirror: MIRROR_FLAG_BUILD (bucket totals), MIRROR_FLAG_MASK0/1
 // (apply_mask: kept points, surviving blocks), MIRROR_MASK_TOTALS (the two totals themselves).
-enum { MIRROR_MASK_TOTALS = 992, MIRROR_FLAG_BUILD = 1000, MIRROR_FLAG_MASK0 = 1001, MIRROR_FLAG_MASK1 = 1002 };
+// Layout of the 4 KB mirror (words): [0, MIRROR_COPY_WORDS) targets of small device-to-host copies and the scalar
+// block a build mirrors; MIRROR_BBOX_WORD.. the voxel box read back by the host-side geometry; then the words above,
+// which no copy may reach.
+// MIRROR_RS_VIOLATION: set by ransac.hip's preparation kernel when a block is larger than the launch was told any
+// block could be (max_block: the instances for larger blocks are not launched then) - every host wait checks it.
+enum { MIRROR_COPY_WORDS = 512, MIRROR_BBOX_WORD = 896, MIRROR_RS_VIOLATION = 990, MIRROR_MASK_TOTALS = 992,
+       MIRROR_FLAG_BUILD = 1000, MIRROR_FLAG_MASK0 = 1001, MIRROR_FLAG_MASK1 = 1002 };
+static_assert(MIRROR_COPY_WORDS <= MIRROR_BBOX_WORD && MIRROR_BBOX_WORD + 8 <= MIRROR_RS_VIOLATION &&
+              MIRROR_RS_VIOLATION < MIRROR_MASK_TOTALS &&
+              MIRROR_MASK_TOTALS + 2 <= MIRROR_FLAG_BUILD && MIRROR_FLAG_MASK1 < 1024, "mirror layout");
 uint32_t octl_wait_next_seq(octl_ctx* ctx);
 int octl_wait_mirror_flags(octl_ctx* ctx, const int* words, int n_words, uint32_t seq, int64_t budget_us);
 // device side: publish `seq` behind everything this thread (and, through the barriers in front of the call, its

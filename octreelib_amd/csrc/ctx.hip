@@ -88,9 +88,30 @@ extern "C" int octl_debug_host_syncs(uint64_t* count) {
   return OCTL_OK;
 }
 
+// a polite spin: the x86 PAUSE / the arm YIELD hint where there is one, nothing elsewhere
+static inline void octl_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+  __asm__ __volatile__("yield");
+#else
+  std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
+
 uint32_t octl_wait_next_seq(octl_ctx* ctx) {
   if (++ctx->wait_seq == 0) ++ctx->wait_seq;
   return ctx->wait_seq;
+}
+
+// a RANSAC launch met a block larger than it was promised (ransac.hip: k_block_prepare): reported by the next wait
+static int mirror_check_violation(octl_ctx* ctx) {
+  volatile uint32_t* m = static_cast<volatile uint32_t*>(ctx->small_host);
+  if (!m[MIRROR_RS_VIOLATION]) return OCTL_OK;
+  m[MIRROR_RS_VIOLATION] = 0;
+  return octl_set_error(ctx, OCTL_E_STATE,
+                        "RANSAC: a block is larger than the launch's size bound (the kernels for larger blocks were not "
+                        "launched, its mask is stale): the block table changed without resetting the bound");
 }
 
 int octl_wait_mirror_flags(octl_ctx* ctx, const int* words, int n_words, uint32_t seq, int64_t budget_us) {
@@ -107,9 +128,9 @@ int octl_wait_mirror_flags(octl_ctx* ctx, const int* words, int n_words, uint32_
       for (int spin = 0; spin < 64; ++spin) {
         if (all_there()) {
           std::atomic_thread_fence(std::memory_order_acquire);
-          return OCTL_OK;
+          return mirror_check_violation(ctx);
         }
-        __builtin_ia32_pause();
+        octl_cpu_relax();
       }
       if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > budget_us)
         break;
@@ -119,7 +140,7 @@ int octl_wait_mirror_flags(octl_ctx* ctx, const int* words, int n_words, uint32_
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (!all_there())
     return octl_set_error(ctx, OCTL_E_HIP, "a kernel did not publish its results (mirror flag %d)", words[0]);
-  return OCTL_OK;
+  return mirror_check_violation(ctx);
 }
 
 bool octl_ctx_side_stream(octl_ctx* ctx) {
@@ -260,7 +281,7 @@ int octl_copy_from_pinned(octl_ctx* ctx, void* dst_dev, const void* src_pinned, 
   const size_t n = bytes / 8;
   if (n == 0) return OCTL_OK;
   const unsigned grid = (unsigned)std::min<size_t>(64, (n + 255) / 256);
-  hipLaunchKernelGGL(k_copy_u64, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(src_pinned),
+  OCTL_LAUNCH(k_copy_u64, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(src_pinned),
                      static_cast<uint64_t*>(dst_dev), n);
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
@@ -355,6 +376,9 @@ int octl_ctx_create(int device_id, octl_ctx** out) {
     return OCTL_E_NOMEM;
   }
   ctx->small.cap = 4096;
+  // (the mirror carries the sequence flags the host polls: a recycled page must not hold a word that equals the first
+  //  sequence number a context waits for)
+  std::memset(ctx->small_host, 0, 4096);
   (void)hipMemsetAsync(ctx->small.p, 0, 4096, ctx->stream);
   (void)hipStreamSynchronize(ctx->stream);
   *out = ctx;
@@ -413,7 +437,7 @@ const char* octl_last_error(const octl_ctx* ctx) { return ctx ? ctx->err.c_str()
 int octl_ctx_sync(octl_ctx* ctx) {
   if (!ctx) return OCTL_E_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return OCTL_OK;
+  return mirror_check_violation(ctx);
 }
 
 // ---- asynchronous host feed ----------------------------------------------------------------------------------

@@ -330,7 +330,7 @@ int forest_sync_vcodes(octl_forest* f) {
   OCTL_TRY(devbuf_reserve(ctx, f->vcode_dev[0], (size_t)std::max<int64_t>(V, 1) * 8));
   if (V > 0) {
     if (f->vkeys_stale) {  // the last build left linear keys on the device
-      hipLaunchKernelGGL(k_lin_to_code, dim3(grid_for(V)), dim3(256), 0, ctx->stream,
+      OCTL_LAUNCH(k_lin_to_code, dim3(grid_for(V)), dim3(256), 0, ctx->stream,
                          (const uint64_t*)f->vlin_dev.as<uint64_t>(), V, f->vl_min[0], f->vl_min[1], f->vl_min[2],
                          f->vl_ny, f->vl_nz, f->vorg, f->vcode_dev[0].as<uint64_t>());
       HIP_TRY(ctx, hipGetLastError());
@@ -368,7 +368,7 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
   NodePtrs nd = node_ptrs(cur);
   {
     KTimer t(ctx, "inc_place");
-    hipLaunchKernelGGL(k_inc_place, dim3(grid_for(n_new)), dim3(256), 0, st, (const double*)f->xyz.as<double>(),
+    OCTL_LAUNCH(k_inc_place, dim3(grid_for(n_new)), dim3(256), 0, st, (const double*)f->xyz.as<double>(),
                        (const uint8_t*)f->alive.as<uint8_t>(), first, n_new, f->mode, f->edge, f->vorg,
                        (const uint64_t*)f->vcode_dev[0].as<uint64_t>(), V, (const int32_t*)nd.first_child,
                        (const double*)nd.corner, (const double*)nd.edge, keys[0], vals[0], small);
@@ -413,10 +413,10 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
     uint64_t* ucode = reinterpret_cast<uint64_t*>(base + o_ucode);
     int32_t* shift_w = reinterpret_cast<int32_t*>(base + o_shift);
     int32_t* root_w = reinterpret_cast<int32_t*>(base + o_root);
-    hipLaunchKernelGGL(k_inc_miss_heads, dim3(grid_for(n_miss)), dim3(256), 0, st, skey, n_hit, n_miss, rank);
+    OCTL_LAUNCH(k_inc_miss_heads, dim3(grid_for(n_miss)), dim3(256), 0, st, skey, n_hit, n_miss, rank);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, rank, rank, n_miss, small + SM_INC_NEWVOX));
-    hipLaunchKernelGGL(k_inc_new_codes, dim3(grid_for(n_miss)), dim3(256), 0, st, skey, n_hit, n_miss,
+    OCTL_LAUNCH(k_inc_new_codes, dim3(grid_for(n_miss)), dim3(256), 0, st, skey, n_hit, n_miss,
                        (const uint32_t*)rank, ucode);
     HIP_TRY(ctx, hipGetLastError());
     uint32_t u32 = 0;
@@ -424,7 +424,7 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
     U = u32;
     if (n_nodes + U >= ((int64_t)1 << 31)) return OCTL_OK;
     OCTL_TRY(devbuf_reserve(ctx, f->vcode_dev[1], (size_t)(V + U) * 8));
-    hipLaunchKernelGGL(k_inc_merge_roots, dim3(grid_for(V + U)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_inc_merge_roots, dim3(grid_for(V + U)), dim3(256), 0, st,
                        (const uint64_t*)f->vcode_dev[0].as<uint64_t>(), V, (const uint64_t*)ucode, U,
                        f->vcode_dev[1].as<uint64_t>(), shift_w, root_w);
     HIP_TRY(ctx, hipGetLastError());
@@ -432,15 +432,15 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
     OCTL_TRY(nodes_reserve(ctx, nxt, n_nodes + U));
     nxt.n = n_nodes + U;
     NodePtrs dst = node_ptrs(nxt);
-    hipLaunchKernelGGL(k_inc_copy_nodes, dim3(grid_for(n_nodes)), dim3(256), 0, st, nd, dst, n_nodes, V,
+    OCTL_LAUNCH(k_inc_copy_nodes, dim3(grid_for(n_nodes)), dim3(256), 0, st, nd, dst, n_nodes, V,
                        (int32_t)U, (const int32_t*)shift_w);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_inc_new_roots, dim3(grid_for(U)), dim3(256), 0, st, (const uint64_t*)ucode,
+    OCTL_LAUNCH(k_inc_new_roots, dim3(grid_for(U)), dim3(256), 0, st, (const uint64_t*)ucode,
                        (const int32_t*)root_w, U, f->mode, f->edge, f->corner[0], f->corner[1], f->corner[2], f->vorg,
                        dst);
     HIP_TRY(ctx, hipGetLastError());
     if (n_blocks > 0) {
-      hipLaunchKernelGGL(k_inc_remap, dim3(grid_for(n_blocks)), dim3(256), 0, st, f->blk_node.as<int32_t>(),
+      OCTL_LAUNCH(k_inc_remap, dim3(grid_for(n_blocks)), dim3(256), 0, st, f->blk_node.as<int32_t>(),
                          n_blocks, V, (int32_t)U, (const int32_t*)shift_w);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -469,17 +469,17 @@ int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info) 
       // the miss ranks live in f->entries, the heads go to f->flags (reserved above)
     }
     const int64_t* pose_off = f->pose_off_dev.as<int64_t>();
-    hipLaunchKernelGGL(k_inc_gather, dim3(grid_for(n_live)), dim3(256), 0, st, skey, sval, n_live, first, n_ord,
+    OCTL_LAUNCH(k_inc_gather, dim3(grid_for(n_live)), dim3(256), 0, st, skey, sval, n_live, first, n_ord,
                        (const double*)f->xyz.as<double>(), pose_off, n_poses, V, (int32_t)U, shift, n_hit,
                        miss_rank, new_root, f->ord_idx.as<uint32_t>(), f->xyz_ord.as<double>(),
                        f->pos_node.as<int32_t>(), heads);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, heads, heads, n_live, small + SM_NBLOCKS));
-    hipLaunchKernelGGL(k_inc_blocks, dim3(grid_for(n_live)), dim3(256), 0, st, (const uint32_t*)heads, skey, sval,
+    OCTL_LAUNCH(k_inc_blocks, dim3(grid_for(n_live)), dim3(256), 0, st, (const uint32_t*)heads, skey, sval,
                        n_live, first, n_ord, n_blocks, pose_off, n_poses, (const int32_t*)f->pos_node.as<int32_t>(),
                        f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(), f->blk_start.as<uint32_t>());
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_inc_block_sizes, dim3(grid_for(n_live)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_inc_block_sizes, dim3(grid_for(n_live)), dim3(256), 0, st,
                        (const uint32_t*)f->blk_start.as<uint32_t>(), n_blocks, (const uint32_t*)(small + SM_NBLOCKS),
                        n_total, f->blk_size.as<int32_t>());
     HIP_TRY(ctx, hipGetLastError());

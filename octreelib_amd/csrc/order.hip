@@ -193,7 +193,7 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
                    [](const octl_forest::LevelSeg& x, const octl_forest::LevelSeg& y) { return x.depth > y.depth; });
   for (const auto& sg : segs) {
     if (sg.b > sg.a) {
-      hipLaunchKernelGGL(k_sub_up, dim3(grid_for(sg.b - sg.a)), dim3(256), 0, st, fc, sg.a, sg.b, nint);
+      OCTL_LAUNCH(k_sub_up, dim3(grid_for(sg.b - sg.a)), dim3(256), 0, st, fc, sg.a, sg.b, nint);
       HIP_TRY(ctx, hipGetLastError());
     }
   }
@@ -201,7 +201,7 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   OCTL_TRY(octl_exclusive_scan_u32(ctx, nint, rank, V, nullptr));
   for (auto it = segs.rbegin(); it != segs.rend(); ++it) {
     if (it->b > it->a) {
-      hipLaunchKernelGGL(k_rank_down, dim3(grid_for(it->b - it->a)), dim3(256), 0, st, fc, it->a, it->b,
+      OCTL_LAUNCH(k_rank_down, dim3(grid_for(it->b - it->a)), dim3(256), 0, st, fc, it->a, it->b,
                          (const uint32_t*)nint, rank);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -220,24 +220,24 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
     uint32_t* table = reinterpret_cast<uint32_t*>(base + off_tab);
     uint32_t* tflags = reinterpret_cast<uint32_t*>(base + off_flg);
     HIP_TRY(ctx, hipMemsetAsync(seq, 0, off_flg, st));  // seq and table
-    hipLaunchKernelGGL(k_leaf_children, dim3(grid_for(t.n)), dim3(256), 0, st, fc,
+    OCTL_LAUNCH(k_leaf_children, dim3(grid_for(t.n)), dim3(256), 0, st, fc,
                        (const int32_t*)t.parent.as<int32_t>(), (const int32_t*)t.voxel.as<int32_t>(),
                        (const uint32_t*)rank, t.n, seq);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, seq, seq, (int64_t)f->n_internal + V, nullptr));
-    hipLaunchKernelGGL(k_block_positions, dim3(grid_for(nb)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_block_positions, dim3(grid_for(nb)), dim3(256), 0, st,
                        (const int32_t*)f->blk_node.as<int32_t>(),
                        (const int32_t*)f->blk_slot.as<int32_t>(), nb,
                        (const int32_t*)t.parent.as<int32_t>(), fc,
                        (const int32_t*)t.voxel.as<int32_t>(), (const uint32_t*)rank,
                        (const uint32_t*)seq, (uint64_t)n_leaves_total, table);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(k_table_flags, dim3(grid_for(table_n)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_table_flags, dim3(grid_for(table_n)), dim3(256), 0, st,
                        (const uint32_t*)table, table_n, tflags);
     HIP_TRY(ctx, hipGetLastError());
     OCTL_TRY(octl_exclusive_scan_u32(ctx, tflags, tflags, table_n, nullptr));
     OCTL_TRY(devbuf_reserve(ctx, f->rs_order, (size_t)nb * 4));
-    hipLaunchKernelGGL(k_table_compact, dim3(grid_for(table_n)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_table_compact, dim3(grid_for(table_n)), dim3(256), 0, st,
                        (const uint32_t*)table, (const uint32_t*)tflags, table_n,
                        f->rs_order.as<int32_t>());
     HIP_TRY(ctx, hipGetLastError());
@@ -286,7 +286,7 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   uint64_t* keys[2] = {f->lin[0].as<uint64_t>(), f->lin[1].as<uint64_t>()};
   uint32_t* vals[2] = {f->val[0].as<uint32_t>(), f->val[1].as<uint32_t>()};
   uint64_t* key2 = f->vkey.as<uint64_t>();
-  hipLaunchKernelGGL(k_block_keys, dim3(grid_for(nb)), dim3(256), 0, st,
+  OCTL_LAUNCH(k_block_keys, dim3(grid_for(nb)), dim3(256), 0, st,
                      (const int32_t*)f->blk_node.as<int32_t>(),
                      (const int32_t*)f->blk_slot.as<int32_t>(), nb,
                      (const int32_t*)t.parent.as<int32_t>(), fc,
@@ -298,7 +298,7 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   // second (more significant) key, gathered in the order of the first sort
   uint64_t* keys_b[2] = {keys[res ^ 1], keys[res]};
   uint32_t* vals_b[2] = {vals[res], vals[res ^ 1]};
-  hipLaunchKernelGGL(k_gather_key2, dim3(grid_for(nb)), dim3(256), 0, st, (const uint64_t*)key2,
+  OCTL_LAUNCH(k_gather_key2, dim3(grid_for(nb)), dim3(256), 0, st, (const uint64_t*)key2,
                      (const uint32_t*)vals[res], nb, keys_b[0]);
   HIP_TRY(ctx, hipGetLastError());
   int res2 = 0;
@@ -311,8 +311,9 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
   if (!need_slot_counts) {
     // nothing to do
   } else if (n_poses <= 256) {
+    static_assert(256 <= MIRROR_COPY_WORDS, "the slot counts land in the copy area of the mirror, below its flag words");
     HIP_TRY(ctx, hipMemsetAsync(hist, 0, (size_t)n_poses * 4, st));
-    hipLaunchKernelGGL(k_slot_hist, dim3((unsigned)ceil_div(nb, 2048)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_slot_hist, dim3((unsigned)ceil_div(nb, 2048)), dim3(256), 0, st,
                        (const int32_t*)f->blk_slot.as<int32_t>(), nb, hist);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->small_host, hist, (size_t)n_poses * 4, hipMemcpyDeviceToHost, st));

@@ -101,7 +101,7 @@ int octl_radix_sort_u64_u32(octl_ctx* ctx, uint64_t* keys[2], uint32_t* vals[2],
     const int shift = 8 * p;
     {
       KTimer t(ctx, "sort_hist");
-      hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(RS_THREADS), 0, ctx->stream,
+      OCTL_LAUNCH(k_rs_hist, dim3(ntiles), dim3(RS_THREADS), 0, ctx->stream,
                          (const uint64_t*)keys[cur], n, shift, ntiles, hist);
       HIP_TRY(ctx, hipGetLastError());
     }
@@ -111,7 +111,7 @@ int octl_radix_sort_u64_u32(octl_ctx* ctx, uint64_t* keys[2], uint32_t* vals[2],
     }
     {
       KTimer t(ctx, "sort_scatter");
-      hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(RS_THREADS), 0, ctx->stream,
+      OCTL_LAUNCH(k_rs_scatter, dim3(ntiles), dim3(RS_THREADS), 0, ctx->stream,
                          (const uint64_t*)keys[cur], (const uint32_t*)vals[cur], keys[cur ^ 1],
                          vals[cur ^ 1], n, shift, ntiles, (const uint32_t*)hist);
       HIP_TRY(ctx, hipGetLastError());

@@ -644,6 +644,99 @@ __device__ __forceinline__ void screen_group(const f4* __restrict__ loc, int n, 
 }
 #endif
 
+#if RS_SCREEN
+// ---- the prescreen of the hypotheses (round 6) ----------------------------------------------------------------
+// The reference fits 1024 planes per leaf and keeps the one with the most inliers, the lowest index among the tied
+// (cuda_ransac.py:100-146).  After the first 64 hypotheses have been evaluated exactly, a later one matters only if
+// its inlier count EXCEEDS the best count L so far - and on a planar leaf hardly any does (2-3 of the other 960 on the
+// benchmark scene, 8-9 on a uniform cloud).  The prescreen decides that without the reference's arithmetic: an
+// APPROXIMATE plane of the same six sample points (centroid and residuals in f64 with ordinary roundings, everything
+// behind them in f32 with FMAs, no division, no square root), a rigorous bound eps on how far its distances can be
+// from the reference's, and the count of the block's points inside the threshold WIDENED by eps - an upper bound of
+// the reference's count.  A hypothesis whose upper bound does not exceed L cannot win (a tie goes to the lower index,
+// which L belongs to); the others - and every hypothesis the bound cannot vouch for - are fitted and scored exactly
+// as before.  Results are bit-identical.
+//
+// The bound (u = 2^-24; E = the block's extent in local coordinates, G >= |coordinate| of its points; "ideal" =
+// exact arithmetic on the exact coordinates; T = trace of the six-sample covariance sums = sum of |residual|^2):
+//   residual component r of a sample against the centroid   |err| <= u |r| + 2^-49 G
+//       (here: f64 sum / product by 1/6 / difference on global coordinates, 7 2^-53 G, then ONE rounding to f32;
+//        the reference: the same f64 operations, util.py:35-52)
+//   each of the six covariance sums (sum over samples of |r_a| <= sqrt(6 T), sqrt(T) <= (T / E + E) / 2)
+//                                                            |err| <= sigma = T (10 u + 2^-46 G / E) + 2^-46 G E
+//   each cofactor (|S_ab| <= T)                              |err| <= mu = T (4 sigma + 4 u T) + 4 sigma^2 (+ 2^-100)
+//   the reference branches on its three diagonal cofactors (util.py:63-74): the approximate ones pick the same row
+//       when the largest exceeds the other two by more than 4 mu;
+//   normal = row / |row|: |n_approx - n_ideal|, |n_ref - n_ideal| <= 2 sqrt3 mu / |row| (+ 4 u), valid while
+//       |row| > 4 mu (the reference's zero-norm plane, util.py:77-78, has |row| <= 2 sqrt3 mu: never vouched for);
+//   distance of a block point p (|p - centroid| <= 2 sqrt3 E): normal error x lever, the f32 evaluation of the
+//       approximate plane in local coordinates (23 u E), the f32 rounding of the reference's GLOBAL plane
+//       (3.5 u G, cuda_ransac.py:110-113):
+//       |s_approx - t_ref| <= eps = 3.5 E (4 mu / |row|) + 48 u E + 2^-21 G.
+// Blocks outside 2^-7 <= E <= 2^7 (f32 under- / overflow of the fourth-order terms), without the range certificate
+// of RS_BLKFAST, or whose constant part of eps exceeds thr / 8 take every hypothesis through the exact path.
+struct PreConst {     // block-uniform constants of the bound, every one rounded UP
+  float k1, k0;           // 16 sigma = T k1 + k0
+  float e35;              // 3.5 E (1 + 2^-10)
+  float thrblk;           // (thr + 48 u E + 2^-21 G) (1 + 2^-10)
+};
+__device__ __forceinline__ bool prescreen_constants(float extent, double ox, double oy, double oz, double thr,
+                                                    PreConst& pc) {
+  const float up = 0x1.004p0f;                    // 1 + 2^-10
+  const float u = 0x1p-24f;
+  const float E = extent;
+  const float G = ((float)(fabs(ox) + fabs(oy) + fabs(oz)) + E) * 0x1.0002p0f;
+  pc.k1 = 16.f * (10.f * u + 0x1p-46f * (G / E) * 0x1.0002p0f) * 0x1.0002p0f;
+  pc.k0 = 16.f * (0x1p-46f * G * E) * 0x1.0002p0f;
+  pc.e35 = 3.5f * E * up;
+  const float eblk = (48.f * u * E + 0x1p-21f * G) * 0x1.0002p0f;
+  const float thr_f = (float)thr * 0x1.0002p0f;
+  pc.thrblk = (thr_f + eblk) * up;
+  // (all comparisons are false for NaN)
+  return E >= 0x1p-7f && E <= 0x1p7f && thr >= 0x1p-40 && thr <= 0x1p40 && eblk * 8.f <= thr_f;
+}
+// 4 mu (1 + 2^-10) of a hypothesis from the trace of its covariance sums
+__device__ __forceinline__ float prescreen_mu4(const PreConst& pc, float T) {
+  const float s16 = fma32(T, pc.k1, pc.k0);                       // 16 sigma
+  const float t1 = fma32(T, 0x1p-20f, s16);                       // 16 sigma + 16 u T
+  const float m = fma32(s16 * s16, 0x1p-4f, T * t1);              // 4 mu = T (16 sigma + 16 u T) + 16 sigma^2
+  return fma32(m, 0x1.004p0f, 0x1p-98f);
+}
+
+// count of the block's points inside each hypothesis' WIDENED threshold: e = fma(s, s, -T2) < 0, s as in
+// screen_group.  No margins: the widening is the bound.
+template <int NH>
+__device__ __forceinline__ void screen_ub(const f4* __restrict__ loc, int n, const float* fa, const float* fb,
+                                          const float* fc, const float* sto, const float* T2, int* cnt) {
+  for (int base = 0; base < n; base += 32) {
+    const int m = __builtin_amdgcn_readfirstlane(min(32, n - base));
+    uint32_t hist[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) hist[h] = 0;
+    auto score = [&](const f4 L) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const float sv = fma32(fa[h], L.x, fma32(fb[h], L.y, fma32(fc[h], L.z, sto[h])));
+        float e;
+        asm("v_fma_f32 %0, %1, %1, -%2" : "=v"(e) : "v"(sv), "v"(T2[h]));
+        hist[h] = __builtin_amdgcn_alignbit(hist[h], __float_as_uint(e), 31);
+      }
+    };
+    int i = 0;
+    for (; i + 4 <= m; i += 4) {
+      const f4 L0 = loc[base + i], L1 = loc[base + i + 1], L2 = loc[base + i + 2], L3 = loc[base + i + 3];
+      score(L0);
+      score(L1);
+      score(L2);
+      score(L3);
+    }
+    for (; i < m; ++i) score(loc[base + i]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) cnt[h] += __popc(hist[h]);
+  }
+}
+#endif
+
 template <int B, int NB, class Fn>
 __device__ __forceinline__ void static_for(Fn&& f) {
   if constexpr (B < NB) {
@@ -732,8 +825,16 @@ template <int THREADS, int HPL, int KT, int ABL, bool FULLH, bool PT>
 __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ xyz, const BlockDesc* __restrict__ sdesc,
     const uint32_t* __restrict__ lo_ptr, const uint32_t* __restrict__ hi_ptr, const double* __restrict__ hyp, int H,
-    int k_rt, double thr, RansacOut out, const uint2* __restrict__ pos_tab) {
+    int k_rt, double thr, RansacOut out, const uint2* __restrict__ pos_tab, int no_prescreen) {
   static_assert(!PT || (KT > 0 && KT <= 6), "the position table packs up to six positions and their risk bits");
+  // PRE: the instance with the prescreen of the hypotheses (see prescreen_constants): one wave per block, sixteen
+  // hypotheses per lane, positions from the table.  Slot 0 of the per-group arrays holds whichever hypothesis a
+  // lane is fitting exactly (t0); the other instances keep hypothesis t = lane + q THREADS in slot q.
+  constexpr bool PRE = RS_SCREEN && THREADS == 64 && HPL == 16 && KT == 6 && ABL == 0 && FULLH && PT;
+  constexpr int PRE_LIST = 512;   // survivors a block can queue; more: every hypothesis takes the exact path
+  __shared__ uint16_t s_surv[PRE ? PRE_LIST : 1];
+  int t0 = 0;          // (PRE) hypothesis of slot 0
+  bool act0 = true;    // (PRE) the lane's slot 0 holds a hypothesis that counts
   constexpr int KS = KT > 0 ? KT : RS_KMAX;
   constexpr int GW = (KS + 3) / 4;  // packed sample positions: one byte each
   constexpr int W = THREADS / 64;
@@ -838,9 +939,10 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ lz = s_pts[buf][2];
 
     // (PT) positions of hypothesis group q out of the table: 8 bytes per lane, issued a batch ahead of their fits
+    auto hyp_of = [&](const int q) -> int { return PRE ? t0 : (int)tx + q * THREADS; };
     auto load_pos = [&](const int q) {
       if constexpr (PT) {
-        const int t = tx + q * THREADS;
+        const int t = hyp_of(q);
         uint2 e = uint2{0u, 0u};
         if (FULLH || t < H) e = pos_tab[(size_t)n * (size_t)H + t];
         gpk[q][0] = e.x;
@@ -939,7 +1041,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     int cnt[HPL];
     // plane of hypothesis group q (f32, as the reference stores it) + its screening constants
     auto fit = [&](const int q) {
-      const int t = tx + q * THREADS;
+      const int t = hyp_of(q);
       cnt[q] = 0;
       fa[q] = fb[q] = fc[q] = fd[q] = sto[q] = sdl[q] = 0.f;
       if (FULLH || t < H) {
@@ -1013,7 +1115,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
 #ifdef RS_NO_REDO  // timing experiment only: results are wrong where the screen cannot decide
         const bool redo = false;
 #else
-        const bool redo = (FULLH || (int)tx + q * THREADS < H) && !(margin[h] > sdl[q]);  // (NaN: recount)
+        const bool redo = (FULLH || (int)tx + q * THREADS < H) && (!PRE || act0) && !(margin[h] > sdl[q]);  // (NaN: recount)
 #endif
         // The recount is done by the whole wavefront for one flagged lane at a time (almost
         // always exactly one): its plane is broadcast, every lane tests one point per round and
@@ -1057,8 +1159,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     auto take = [&](const int q0, const int nh) {
 #pragma unroll
       for (int q = q0; q < q0 + nh; ++q) {
-        const int t = tx + q * THREADS;
-        if (FULLH || t < H) {
+        const int t = hyp_of(q);
+        if ((FULLH || t < H) && (!PRE || act0)) {
           const uint32_t key = ((uint32_t)(cnt[q] + 1) << 10) | (uint32_t)(1023 - t);
           if (key > best) {
             best = key;
@@ -1075,6 +1177,133 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     constexpr int SUB0 = RS_SUB > 0 ? RS_SUB : (HPL >= 8 ? 3 : REST);
     constexpr int SUB = SUB0 < REST ? SUB0 : REST;
     constexpr int FULL_BATCHES = REST / SUB, TAIL = REST % SUB;
+    if constexpr (PRE) {
+      // ---- group 0 (hypotheses 0..63), exactly ----------------------------------------------------------------
+      t0 = (int)tx;
+      act0 = true;
+      load_pos(0);
+      fit(0);
+      RS_STAMP(1);
+      score(std::integral_constant<int, 1>{}, 0);
+      RS_STAMP(2);
+      take(0, 1);
+      // the best exact count so far (wave-uniform); a hypothesis that holds every point ends the block (see above)
+      int Lcur = (int)(wave_max_u32((uint32_t)cnt[0]));
+      skipped = RS_EARLY_EXIT && Lcur == n;
+      if (!skipped) {
+        // ---- prescreen of hypotheses 64..1023 -----------------------------------------------------------------
+        PreConst pc;
+        const bool elig = prescreen_constants(extent, ox, oy, oz, thr, pc) && blk_fast && !no_prescreen;
+        int S = 0;   // survivors queued (wave-uniform)
+        if (elig) {
+          RS_COUNT(4, 1);
+#pragma unroll 1
+          for (int qb = 1; qb < HPL; qb += 3) {
+            uint2 pe[3];
+#pragma unroll
+            for (int h = 0; h < 3; ++h) pe[h] = pos_tab[(size_t)n * (size_t)H + (size_t)((int)tx + (qb + h) * 64)];
+            float qa[3], qb_[3], qc[3], qto[3], qT2[3];
+            bool qok[3];
+            int qcnt[3];
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+              const uint32_t w0 = pe[h].x, w1 = pe[h].y;
+              const uint32_t g0 = w0 & 0xFFu, g1 = (w0 >> 8) & 0xFFu, g2 = (w0 >> 16) & 0xFFu, g3 = w0 >> 24,
+                             g4 = w1 & 0xFFu, g5 = (w1 >> 8) & 0xFFu;
+              // centroid and residuals in f64 on the global coordinates (ordinary roundings: util.py:35-52 up to
+              // 2^-50 G), rounded to f32 ONCE: a residual carries a RELATIVE error of 2^-24
+              const double sixth = 1.0 / 6.0;
+              const double X0 = lx[g0], X1 = lx[g1], X2 = lx[g2], X3 = lx[g3], X4 = lx[g4], X5 = lx[g5];
+              const double Y0 = ly[g0], Y1 = ly[g1], Y2 = ly[g2], Y3 = ly[g3], Y4 = ly[g4], Y5 = ly[g5];
+              const double Z0 = lz[g0], Z1 = lz[g1], Z2 = lz[g2], Z3 = lz[g3], Z4 = lz[g4], Z5 = lz[g5];
+              const double cxd = (((((X0 + X1) + X2) + X3) + X4) + X5) * sixth;
+              const double cyd = (((((Y0 + Y1) + Y2) + Y3) + Y4) + Y5) * sixth;
+              const double czd = (((((Z0 + Z1) + Z2) + Z3) + Z4) + Z5) * sixth;
+              float xx, xy, xz, yy, yz, zz;
+              {
+                const float rx = (float)(X0 - cxd), ry = (float)(Y0 - cyd), rz = (float)(Z0 - czd);
+                xx = rx * rx; xy = rx * ry; xz = rx * rz; yy = ry * ry; yz = ry * rz; zz = rz * rz;
+              }
+              auto acc = [&](const double X, const double Y, const double Z) {
+                const float rx = (float)(X - cxd), ry = (float)(Y - cyd), rz = (float)(Z - czd);
+                xx = fma32(rx, rx, xx); xy = fma32(rx, ry, xy); xz = fma32(rx, rz, xz);
+                yy = fma32(ry, ry, yy); yz = fma32(ry, rz, yz); zz = fma32(rz, rz, zz);
+              };
+              acc(X1, Y1, Z1); acc(X2, Y2, Z2); acc(X3, Y3, Z3); acc(X4, Y4, Z4); acc(X5, Y5, Z5);
+              // the centroid in the block's local coordinates (the screen's)
+              const float cx = (float)(cxd - ox), cy = (float)(cyd - oy), cz = (float)(czd - oz);
+              // the three diagonal cofactors and the row the reference's branch takes (util.py:59-74)
+              const float dx = fma32(yy, zz, -(yz * yz)), dy = fma32(xx, zz, -(xz * xz)), dz = fma32(xx, yy, -(xy * xy));
+              const float cA = fma32(xz, yz, -(xy * zz)), cB = fma32(xy, yz, -(xz * yy)), cC = fma32(xy, xz, -(yz * xx));
+              const bool is_x = dx > dy && dx > dz;
+              const bool is_y = !is_x && dy > dz;
+              const float m1 = is_x ? dx : (is_y ? cA : cB);
+              const float m2 = is_x ? cA : (is_y ? dy : cC);
+              const float m3 = is_x ? cB : (is_y ? cC : dz);
+              const float ss = fma32(m3, m3, fma32(m2, m2, m1 * m1));
+              const float r = __builtin_amdgcn_rsqf(ss);
+              const float a = m1 * r, b = m2 * r, c = m3 * r;
+              qa[h] = a; qb_[h] = b; qc[h] = c;
+              qto[h] = -fma32(c, cz, fma32(b, cy, a * cx));
+              // the bound
+              const float T = (xx + yy) + zz;
+              const float mu4 = prescreen_mu4(pc, T);
+              const float gap = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz) - __builtin_amdgcn_fmed3f(dx, dy, dz);
+              qok[h] = (ss * r > mu4) && (gap > mu4) && (w1 >> 16) == 0u;   // (false for NaN)
+              const float thr_h = fma32(pc.e35, mu4 * r, pc.thrblk);
+              qT2[h] = thr_h * thr_h;
+              qcnt[h] = 0;
+            }
+            screen_ub<3>(loc, n, qa, qb_, qc, qto, qT2, qcnt);
+            RS_COUNT(12, 3);
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+              const bool sv = !(qok[h] && qcnt[h] <= Lcur);
+              const unsigned long long mk = __ballot(sv);
+              if (sv) {
+                const int pos = S + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                const uint32_t ub = qok[h] ? (uint32_t)qcnt[h] : 63u;
+                if (pos < PRE_LIST) s_surv[pos] = (uint16_t)((ub << 10) | (uint32_t)((int)tx + (qb + h) * 64));
+              }
+              S += __popcll(mk);
+            }
+          }
+          RS_COUNT(2, S);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- the survivors (in index order) - or, without a prescreen, groups 1..15 - exactly ------------------------
+        const bool use_list = elig && S <= PRE_LIST;
+        if (elig && !use_list) RS_COUNT(5, 1);
+        const int nbatch = use_list ? ((S + 63) >> 6) : HPL - 1;
+        bool done = false;
+#pragma unroll 1
+        for (int bt = 0; bt < nbatch && !done; ++bt) {
+          if (use_list) {
+            const int idx = bt * 64 + (int)tx;
+            const uint32_t ent = s_surv[idx < S ? idx : S - 1];
+            t0 = (int)(ent & 1023u);
+            // (the best count may have grown since the hypothesis was queued - by a hypothesis of lower index)
+            act0 = idx < S && (int)(ent >> 10) > Lcur;
+            if (!__any(act0)) continue;
+          } else {
+            t0 = (int)tx + (bt + 1) * 64;
+            act0 = true;
+          }
+          RS_COUNT(3, 1);
+          load_pos(0);
+          fit(0);
+          RS_STAMP(3);
+          score(std::integral_constant<int, 1>{}, 0);
+          take(0, 1);
+          RS_STAMP(4);
+          const int c0 = act0 ? cnt[0] : 0;
+          Lcur = max(Lcur, (int)wave_max_u32((uint32_t)c0));
+          done = RS_EARLY_EXIT && Lcur == n;   // (every later hypothesis has a higher index)
+        }
+      } else {
+        RS_COUNT(9, 1);
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < F; ++q) load_pos(q);
 #pragma unroll
@@ -1136,6 +1365,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       } else {
         RS_COUNT(9, 1);
       }
+    }
     }
     const uint32_t wbest = wave_max_u32(best);
     float f0, f1, f2, f3;
@@ -1497,7 +1727,8 @@ __global__ __launch_bounds__(256) void k_block_prepare(const int32_t* __restrict
                                                        const int32_t* __restrict__ size, int64_t nb, int64_t n_points,
                                                        int cap, int k, BlockDesc* __restrict__ desc,
                                                        uint32_t* __restrict__ big_list, uint32_t* __restrict__ counters,
-                                                       RansacOut out, uint64_t* __restrict__ status, uint32_t epoch) {
+                                                       RansacOut out, uint64_t* __restrict__ status, uint32_t epoch,
+                                                       int64_t max_block, uint32_t* __restrict__ mirror) {
   __shared__ uint32_t bins[256];
   __shared__ uint32_t s_wave[4];
   __shared__ uint32_t s_excl;
@@ -1568,6 +1799,10 @@ __global__ __launch_bounds__(256) void k_block_prepare(const int32_t* __restrict
     } else {
       atomicAdd(&bins[d.n], 1u);
     }
+    // the launch was told that no block holds more than max_block points and left out the instances for larger
+    // ones: a block that breaks the promise would keep a stale mask - the next host wait reports it instead
+    if (d.n >= k && (int64_t)d.n > max_block)
+      __hip_atomic_store(&mirror[MIRROR_RS_VIOLATION], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   if (bins[threadIdx.x]) atomicAdd(&counters[RC_BINS + threadIdx.x], bins[threadIdx.x]);
@@ -1588,7 +1823,9 @@ __device__ __forceinline__ void pos_table_part(const double* __restrict__ hyp, i
     bool risky;
     const uint32_t g = (uint32_t)sample_index_cached(row[i], n, &risky);
     if (i < 4) x |= g << (8 * i); else y |= g << (8 * (i - 4));
-    y |= risky ? (0x10000u << i) : 0u;
+    // (g == n: fl(R n) rounded up to n - the spill point, outside the block; the exact path re-derives the position
+    //  of a flagged draw from the block's start, the prescreen does not vouch for its hypothesis)
+    y |= (risky || g == (uint32_t)n) ? (0x10000u << i) : 0u;
   }
   tab[(size_t)n * (size_t)H + t] = uint2{x, y};
 }
@@ -1726,15 +1963,16 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
       uint64_t* status = nullptr;
       uint32_t epoch = 0;
       OCTL_TRY(octl_scan_status_acquire(ctx, g, &status, &epoch));
-      hipLaunchKernelGGL(k_block_prepare, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size, nb, n_points,
-                         any_k ? 0 : threads - 1, (int)k, desc, big_list, counters, out, status, epoch);
+      OCTL_LAUNCH(k_block_prepare, dim3(g), dim3(256), 0, st, order_dev, blk_start, blk_size, nb, n_points,
+                         any_k ? 0 : threads - 1, (int)k, desc, big_list, counters, out, status, epoch, max_block,
+                         static_cast<uint32_t*>(ctx->small_host));
       HIP_TRY(ctx, hipGetLastError());
     } else {
       const unsigned g = (unsigned)ceil_div(nb, 256);
-      hipLaunchKernelGGL(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp, counters);
+      OCTL_LAUNCH(k_block_sizes_in_order, dim3(g), dim3(256), 0, st, order_dev, blk_size, nb, tmp, counters);
       HIP_TRY(ctx, hipGetLastError());
       OCTL_TRY(octl_exclusive_scan_u32(ctx, tmp, tmp, nb, nullptr));
-      hipLaunchKernelGGL(k_block_desc, dim3((unsigned)ceil_div(nb, 256 * BD_PER_THREAD)), dim3(256), 0, st, order_dev,
+      OCTL_LAUNCH(k_block_desc, dim3((unsigned)ceil_div(nb, 256 * BD_PER_THREAD)), dim3(256), 0, st, order_dev,
                          blk_start, blk_size,
                          (const uint32_t*)tmp, nb, n_points, any_k ? 0 : threads - 1, (int)k, desc, big_list,
                          counters, out);
@@ -1743,7 +1981,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     // (size-class starts and the position table are made by k_block_scatter's own workgroups)
     const unsigned n_scatter = (unsigned)ceil_div(nb, 256 * BS_PER_THREAD);
     const unsigned n_table = use_tab ? 256u * (unsigned)ceil_div(H, 256) : 0u;
-    hipLaunchKernelGGL(k_block_scatter, dim3(n_scatter + n_table), dim3(256), 0, st,
+    OCTL_LAUNCH(k_block_scatter, dim3(n_scatter + n_table), dim3(256), 0, st,
                        (const BlockDesc*)desc, nb, any_k ? 0 : threads - 1, (int)k, counters, sdesc, n_scatter, hyp_dev,
                        (int)H, pos_tab, next_counters);
     HIP_TRY(ctx, hipGetLastError());
@@ -1772,6 +2010,8 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   }
 #if RS_SIDE_STREAM
   // (max_block: no block of the launch holds more points - the instances for larger blocks are not launched at all)
+  // (only the fused preparation kernel checks the promise on the device: the A/B chain launches every instance)
+  if (!fused) max_block = INT64_MAX;
   const bool need_small = max_block >= RS_TINY_THREADS, need_mid = max_block >= RS_SMALL_THREADS,
              need_big = any_k || max_block >= threads;
   // (the side stream is gated in and out with events: only when one of the instances below will go there)
@@ -1784,18 +2024,19 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     on_side = true;
   }
 #endif
+  const int no_prescreen = ctx->opt.no_ransac_prescreen ? 1 : 0;
   // (LO, HI: device words holding the launch's part [lo, hi) of the size-sorted list; LO nullptr = from the front)
 #define OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, LO, HI, PT, ST)                         \
   do {                                                                                           \
     const unsigned g = (unsigned)std::min<int64_t>(nb, (int64_t)cus * (PER_CU));                 \
     if (H == (THREADS) * (HPL))                                                                  \
-      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, true, PT>), dim3(g), dim3(THREADS), 0, ST, \
+      OCTL_LAUNCH((k_ransac<THREADS, HPL, KT, ABL, true, PT>), dim3(g), dim3(THREADS), 0, ST, \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
-                         hyp_dev, H, k, thr, out, (const uint2*)pos_tab);                         \
+                         hyp_dev, H, k, thr, out, (const uint2*)pos_tab, no_prescreen);           \
     else                                                                                         \
-      hipLaunchKernelGGL((k_ransac<THREADS, HPL, KT, ABL, false, PT>), dim3(g), dim3(THREADS), 0, ST, \
+      OCTL_LAUNCH((k_ransac<THREADS, HPL, KT, ABL, false, PT>), dim3(g), dim3(THREADS), 0, ST, \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
-                         hyp_dev, H, k, thr, out, (const uint2*)pos_tab);                         \
+                         hyp_dev, H, k, thr, out, (const uint2*)pos_tab, no_prescreen);           \
   } while (0)
 #define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU) \
   OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED, false, st)
@@ -1869,7 +2110,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   HIP_TRY(ctx, hipGetLastError());
   // the (rare) blocks that do not fit the LDS staging; the grid is fixed, the count is on the device
 #define OCTL_RANSAC_BIG(THREADS, HPL, KT)                                                       \
-  hipLaunchKernelGGL((k_ransac_big<THREADS, HPL, KT>), dim3((unsigned)std::min<int64_t>(nb, (int64_t)RS_BIG_PER_CU * cus)), \
+  OCTL_LAUNCH((k_ransac_big<THREADS, HPL, KT>), dim3((unsigned)std::min<int64_t>(nb, (int64_t)RS_BIG_PER_CU * cus)), \
                      dim3(THREADS), 0, side, xyz_dev, (const BlockDesc*)desc,                   \
                      (const uint32_t*)big_list, (const uint32_t*)(counters + RC_BIG), hyp_dev,  \
                      H, k, thr, out)
@@ -1967,7 +2208,7 @@ static int debug_plane_arith(octl_ctx* ctx, const double* num3, const double* de
       hipMemcpyAsync(d_c, c, (size_t)n * 8, hipMemcpyHostToDevice, st) != hipSuccess)
     rc = OCTL_E_HIP;
   if (rc == OCTL_OK) {
-    hipLaunchKernelGGL(k_debug_plane_arith, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
+    OCTL_LAUNCH(k_debug_plane_arith, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st,
                        (const double*)d_num, (const double*)d_den, (const double*)d_c, (int)kdiv, n,
                        d_q, d_ck, d_sq, certified);
     if (hipGetLastError() != hipSuccess ||

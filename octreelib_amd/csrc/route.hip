@@ -226,17 +226,17 @@ static int route_partition(octl_ctx* ctx, const double* xyz_dev, const int64_t* 
   if (n > 0) {
     {
       KTimer t(ctx, "route_hist");
-      hipLaunchKernelGGL(k_route_hist, dim3(ntiles), dim3(RT_THREADS), 0, st, xyz_dev, n, L, R, ntiles,
+      OCTL_LAUNCH(k_route_hist, dim3(ntiles), dim3(RT_THREADS), 0, st, xyz_dev, n, L, R, ntiles,
                          hist.as<uint32_t>(), err);
       HIP_TRY(ctx, hipGetLastError());
       uint32_t* total = err + 1;
       OCTL_TRY(octl_exclusive_scan_u32(ctx, hist.as<uint32_t>(), hist.as<uint32_t>(), (int64_t)R * ntiles, total));
-      hipLaunchKernelGGL(k_route_counts, dim3(1), dim3(256), 0, st, (const uint32_t*)hist.as<uint32_t>(), ntiles, R,
+      OCTL_LAUNCH(k_route_counts, dim3(1), dim3(256), 0, st, (const uint32_t*)hist.as<uint32_t>(), ntiles, R,
                          (const uint32_t*)total, counts_d.as<unsigned long long>());
       HIP_TRY(ctx, hipGetLastError());
     }
     KTimer t(ctx, "route_scatter");
-    hipLaunchKernelGGL(k_route_scatter, dim3(ntiles), dim3(RT_THREADS), 0, st, xyz_dev, gidx_dev, index_base,
+    OCTL_LAUNCH(k_route_scatter, dim3(ntiles), dim3(RT_THREADS), 0, st, xyz_dev, gidx_dev, index_base,
                        n, L, R, ntiles, (const uint32_t*)hist.as<uint32_t>(), send_xyz.as<double>(),
                        send_gidx.as<int64_t>());
     HIP_TRY(ctx, hipGetLastError());
@@ -383,7 +383,7 @@ int octl_route_points(octl_ctx* ctx, const double* xyz_dev, const int64_t* gidx_
   const int W = R + 2;  // words per row
   std::vector<int64_t> matrix((size_t)R * W, 0);
   if (use_rccl) {
-    hipLaunchKernelGGL(k_route_status, dim3(1), dim3(64), 0, st, counts_d.as<unsigned long long>(), R,
+    OCTL_LAUNCH(k_route_status, dim3(1), dim3(64), 0, st, counts_d.as<unsigned long long>(), R,
                        (const uint32_t*)err, (unsigned long long)cap_pts);
     if (hipGetLastError() != hipSuccess) return octl_set_error(ctx, OCTL_E_HIP, "route: status launch failed");
     ncclResult_t r = g_rccl.AllGather(counts_d.p, matrix_d.p, (size_t)W, ncclInt64, comm, st);

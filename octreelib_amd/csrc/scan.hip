@@ -158,7 +158,7 @@ int scan_single_pass(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n
   uint64_t* status = nullptr;
   uint32_t epoch = 0;
   OCTL_TRY(octl_scan_status_acquire(ctx, nb, &status, &epoch));
-  hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in,
+  OCTL_LAUNCH(k_scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in,
                      out, n, status, epoch, total_dev);
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;
@@ -168,7 +168,7 @@ int scan_rec(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n, uint32
              int level) {
   const int64_t nb = ceil_div(n, SCAN_TILE);
   if (nb <= 1) {
-    hipLaunchKernelGGL(k_scan_down, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n,
+    OCTL_LAUNCH(k_scan_down, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n,
                        (const uint32_t*)nullptr, total_dev);
     HIP_TRY(ctx, hipGetLastError());
     return OCTL_OK;
@@ -176,11 +176,11 @@ int scan_rec(octl_ctx* ctx, const uint32_t* in, uint32_t* out, int64_t n, uint32
   if (level >= 3) return octl_set_error(ctx, OCTL_E_INVALID, "scan: input too large");
   OCTL_TRY(devbuf_reserve(ctx, ctx->scan_tmp[level], (size_t)nb * sizeof(uint32_t)));
   uint32_t* sums = ctx->scan_tmp[level].as<uint32_t>();
-  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, n,
+  OCTL_LAUNCH(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, n,
                      sums);
   HIP_TRY(ctx, hipGetLastError());
   OCTL_TRY(scan_rec(ctx, sums, sums, nb, total_dev, level + 1));
-  hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out,
+  OCTL_LAUNCH(k_scan_down, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out,
                      n, (const uint32_t*)sums, (uint32_t*)nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return OCTL_OK;

@@ -6,6 +6,7 @@ the leaf ordering, the per-leaf RANSAC and the mask application all run as HIP k
 the C ABI (include/octreelib_hip.h).
 """
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
 
@@ -20,6 +21,7 @@ from octreelib_amd.internal.voxel import Voxel
 __all__ = ["Grid", "GridConfig"]
 
 RANSAC_MAX_HYPOTHESES = 1024  # the reference's CUDA_THREADS (ransac/cuda_ransac.py:15)
+_CHECKS = os.environ.get("OCTREELIB_AMD_CHECKS", "0") not in ("", "0")   # invariants asserted (the GPU tests set it)
 
 
 @dataclass
@@ -99,7 +101,12 @@ class Grid(GridBase):
         vox_rank = f.nodes["voxel"][blk["node"][sel]]
         creation = f.creation_ranks(f.voxels)[vox_rank]
         # managers in creation order, storage order inside one (= the DFS order of octree.get_points); a grid whose
-        # voxels were created in voxel order - one pose, or poses over the same voxels - is in that order already
+        # voxels were created in voxel order - one pose, or poses over the same voxels - is in that order already.
+        # INVARIANT the shortcut relies on: the block table is in storage order - `start` strictly ascending over the
+        # non-empty blocks (forest.h: "block table of non-empty (leaf, pose) runs in storage order") - so that equal
+        # creation ranks are already ordered by start.  OCTREELIB_AMD_CHECKS=1 verifies it.
+        if _CHECKS and len(sel) > 1:
+            assert np.all(np.diff(blk["start"][sel].astype(np.int64)) > 0), "block table out of storage order"
         if len(sel) > 1 and np.any(creation[1:] < creation[:-1]):
             sel = sel[np.lexsort((blk["start"][sel], creation))]
         return f.gather_blocks(sel)

@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("OCTREELIB_AMD_CHECKS", "1")   # the package asserts its internal invariants under the tests
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

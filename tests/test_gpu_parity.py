@@ -2899,3 +2899,88 @@ def test_a_scene_that_drifts_by_a_voxel_keeps_its_geometry_and_a_jump_costs_one_
         assert n2 == base, (base, n2)
     finally:
         set_option("GEOM_MARGIN", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["planar", "noise", "collinear", "clusters", "lattice", "two_planes", "thin", "far", "small_extent",
+                                  "large_extent", "tight_threshold", "wide_threshold"])
+def test_ransac_prescreen_never_changes_a_result(kind):
+    """Round 6: after the first 64 hypotheses of a leaf the kernel fits a hypothesis exactly only when an approximate f32
+    plane of its six sample points, with a rigorous bound on its distances, cannot rule out that it beats the best count
+    so far (ransac.hip: prescreen_constants).  Whatever the prescreen does, count, winner index, f32 plane bits and mask
+    must be the reference's (oracle) - on leaves where it prunes nearly everything (planar), nearly nothing (noise),
+    where its bound is weak (collinear samples, point clusters: tiny cofactors), where counts tie all over (lattice),
+    where a later hypothesis is the winner by one point (two planes), and where it must stand aside (coordinates,
+    extents and thresholds outside its range).  The same launch with the prescreen switched off must agree too."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    import zlib
+
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    sizes = rng.integers(6, 64, 1500).astype(np.int32)
+    sizes[::50] = 63
+    sizes[1::50] = 6
+    n = int(sizes.sum())
+    starts = np.concatenate(([0], np.cumsum(sizes)))
+    base = rng.random((len(sizes), 3)) * 30.0          # one voxel-sized neighbourhood per block
+    cloud = np.repeat(base, sizes, axis=0) + rng.random((n, 3)) * 0.5
+    thr = 0.01
+
+    def plane_z(s, e, a, b, sigma):
+        cloud[s:e, 2] = base_of(s)[2] + 0.25 + a * (cloud[s:e, 0] - base_of(s)[0]) + b * (cloud[s:e, 1] - base_of(s)[1]) \
+            + rng.normal(0, sigma, e - s)
+
+    def base_of(s):
+        return base[np.searchsorted(starts, s, side="right") - 1]
+
+    for bi in range(len(sizes)):
+        s, e = starts[bi], starts[bi + 1]
+        if kind == "planar" or kind in ("far", "small_extent", "large_extent", "tight_threshold", "wide_threshold"):
+            plane_z(s, e, rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), 0.005)
+            out = rng.random(e - s) < 0.2
+            cloud[s:e, 2][out] = base_of(s)[2] + rng.random(int(out.sum())) * 0.5
+        elif kind == "collinear":     # points along a line + a little noise: every sample is nearly collinear
+            t = rng.random(e - s)
+            d = rng.normal(size=3)
+            cloud[s:e] = base_of(s) + 0.25 + np.outer(t - 0.5, d / np.linalg.norm(d)) * 0.4 + rng.normal(0, 0.004, (e - s, 3))
+        elif kind == "clusters":      # three tight clusters: samples within one cluster have tiny covariances
+            c = rng.random((3, 3)) * 0.4
+            which = rng.integers(0, 3, e - s)
+            cloud[s:e] = base_of(s) + c[which] + rng.normal(0, 1e-4, (e - s, 3))
+        elif kind == "lattice":       # counts tie everywhere; distances exactly on the threshold
+            cloud[s:e] = np.floor(base_of(s)) + rng.integers(0, 8, (e - s, 3)) / 64.0
+            cloud[s:e, 2] = np.floor(base_of(s)[2]) + rng.integers(0, 3, e - s) / 64.0
+        elif kind == "two_planes":    # two parallel planes 2.5 thresholds apart, nearly equal populations
+            plane_z(s, e, 0.1, -0.2, 0.002)
+            cloud[s:e, 2] += 0.025 * (rng.random(e - s) < 0.5)
+        elif kind == "thin":          # a sliver: extent along one axis only
+            cloud[s:e, 1] = base_of(s)[1] + rng.random(e - s) * 1e-3
+            plane_z(s, e, 0.3, 0.0, 0.004)
+    if kind == "far":
+        cloud += 3.0e5                 # the f32 rounding of the reference's global plane dwarfs the threshold
+    elif kind == "small_extent":
+        cloud = base.repeat(sizes, axis=0) + (cloud - base.repeat(sizes, axis=0)) * 2.0 ** -9
+        thr = 0.01 * 2.0 ** -9
+    elif kind == "large_extent":
+        cloud = cloud * 600.0
+        thr = 6.0
+    elif kind == "tight_threshold":
+        thr = 1.0e-5
+    elif kind == "wide_threshold":
+        thr = 0.3
+    if kind != "lattice":
+        assert len(np.unique(cloud, axis=0)) == n
+    np.random.seed(11)
+    op = CudaRansac(threshold=thr, hypotheses_number=1024, initial_points_number=6)
+    o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, thr, details=True)
+    for off in (0, 1):
+        set_option("NO_RANSAC_PRESCREEN", off)
+        mask, planes, counts, index = op.evaluate(cloud, sizes, details=True)
+        assert np.array_equal(counts, o_count), off
+        assert np.array_equal(index, o_index), off
+        assert np.array_equal(planes.view(np.uint32), o_plane.view(np.uint32)), off
+        assert np.array_equal(mask, o_mask), off
+    set_option("NO_RANSAC_PRESCREEN", 0)
+    if kind in ("planar", "two_planes", "noise"):
+        assert (o_index >= 64).any()     # winners beyond the first group exist: the survivors' path decides them

@@ -25,28 +25,31 @@ for _ in range(reps):
 ctx.sync()
 ctx.check(lib.octl_debug_rs_stamps(ctx.handle, out, 0))
 v = [out[i] / reps for i in range(16)]
-blocks, skipped1, pts = v[8], v[9], v[11]
-H, F, HPL, LANES = 1024, 64, 16, 64   # (F: hypotheses in front of the first exit check, RS_FIRST_GROUPS x 64)
-groups_total = blocks * HPL                       # hypothesis groups of 64 the reference's 1024 threads amount to
-groups_skipped = skipped1 * (HPL - F // LANES) + v[12]
-groups_scored = v[14]
+blocks, exit0, pts = v[8], v[9], v[11]
+H, LANES, HPL = 1024, 64, 16
+eligible, a_groups, survivors, b_batches, overflow = v[4], v[12], v[2], v[3], v[5]
+exact_groups = v[14]           # hypothesis groups of 64 fitted and scored exactly (group 0 + the batches of survivors)
 res = {
     # the kernel's own clock: shader-clock ticks over 100 MHz ticks, summed over the workgroups' lives
     "in_kernel_clock_GHz": (v[0] / v[1]) * 0.1 if v[1] else None,
     "instance": "k_ransac<64,16,6,0,true,true> (blocks of 6..63 points; the 64-point leaves run in k_ransac<128,8,...> "
                 "and are not counted here)",
     "blocks_per_launch": blocks, "mean_block_size": pts / blocks,
-    "blocks_leaving_after_pass_1": skipped1, "fraction_blocks_leaving_after_pass_1": skipped1 / blocks,
-    "hypothesis_groups_skipped_by_later_exits": v[12],
-    "plane_fits_asked": blocks * H, "plane_fits_executed": groups_scored * LANES,
-    "fraction_plane_fits_executed": groups_scored / groups_total,
-    "pairs_asked": pts * H, "pairs_screened_f32": v[15] * LANES,
+    "blocks_leaving_after_group_0": exit0, "fraction_blocks_leaving_after_group_0": exit0 / blocks,
+    "blocks_with_prescreen": eligible, "fraction_blocks_with_prescreen": eligible / blocks,
+    "blocks_whose_survivors_overflowed_the_queue": overflow,
+    "hypotheses_prescreened": a_groups * LANES, "hypotheses_prescreened_per_block": a_groups * LANES / max(eligible, 1),
+    "survivors": survivors, "survivors_per_prescreened_block": survivors / max(eligible, 1),
+    "fraction_prescreened_that_survive": survivors / max(a_groups * LANES, 1),
+    "survivor_batches": b_batches, "survivor_batches_per_block": b_batches / blocks,
+    "plane_fits_asked": blocks * H, "plane_fits_executed_exactly": exact_groups * LANES,
+    "fraction_plane_fits_executed_exactly": exact_groups / (blocks * HPL),
+    "fraction_plane_fits_executed": exact_groups / (blocks * HPL),   # (the key bench.py reads)
+    "pairs_asked": pts * H, "pairs_screened_f32_exact_path": v[15] * LANES,
     "fraction_pairs_scored": v[15] * LANES / (pts * H),
-    "hypotheses_recounted_f64": v[13], "fraction_hypotheses_recounted": v[13] / (groups_scored * LANES),
-    "pairs_recounted_f64_estimate": v[13] * (pts / blocks),
-    "check_groups": {"scored_plus_skipped": groups_scored + groups_skipped, "total": groups_total},
-    "note": "average per launch over %d steps of the rotating headline workload; wave 0 of every workgroup counts "
-            "(the instance runs one wave per block, so wave 0 is the block)" % reps,
+    "hypotheses_recounted_f64": v[13], "fraction_hypotheses_recounted": v[13] / max(exact_groups * LANES, 1),
+    "fraction_blocks_leaving_after_pass_1": exit0 / blocks,          # (the key bench.py reads)
+    "note": "average per launch over %d steps of the rotating headline workload; the instance runs one wave per block" % reps,
 }
 print(json.dumps(res, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
