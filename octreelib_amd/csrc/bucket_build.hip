@@ -45,34 +45,18 @@ constexpr int PT_THREADS = 256;
 constexpr int PT_BITS = 12;
 constexpr int PT_BINS = 1 << PT_BITS;            // buckets
 
-// BB_ONE_READ (the shipped form; -DBB_ONE_READ=0 builds the round-3 kernel for comparison): the bucket kernel reads
+// The bucket kernel reads
 // every record ONCE - the coordinates stay in registers from the first pass to the output, which goes through an
 // LDS window - instead of the tail first and the whole record again for the output.  It needs 8 instead of 16
 // items per thread (42 VGPRs of coordinates for BB_KEEP_ROUNDS = 7 of the 8 rounds; a bucket fuller than that reads
 // its last round again) and so 512 threads per bucket, two workgroups per CU instead of three.  (The second argument
 // of __launch_bounds__ is WAVES PER SIMD with this compiler, not workgroups per CU: 4 = 2 workgroups of 8 waves.)
-#ifndef BB_ONE_READ
-#define BB_ONE_READ 1
-#endif
-#if BB_ONE_READ
 constexpr int BB_THREADS = 512;
 constexpr int BB_IPT = 8;
 constexpr int BB_WGS = 4;   // waves per SIMD asked of the compiler (2 workgroups of 8 waves per CU)
-#else
-constexpr int BB_THREADS = 256;
-constexpr int BB_IPT = 16;
-constexpr int BB_WGS = 3;   // (3 workgroups of 4 waves per CU)
-#endif
-#ifndef BB_SIDE_STREAM
-#define BB_SIDE_STREAM 1
-#endif
-#ifndef BB_LEAF_UNROLL
 #define BB_LEAF_UNROLL 2
-#endif
-#ifndef BB_KEEP_ROUNDS
 #define BB_KEEP_ROUNDS 7
-#endif
-constexpr int BB_KEEP = BB_KEEP_ROUNDS < BB_IPT ? BB_KEEP_ROUNDS : BB_IPT;   // rounds whose coordinates stay in registers (BB_ONE_READ)
+constexpr int BB_KEEP = BB_KEEP_ROUNDS < BB_IPT ? BB_KEEP_ROUNDS : BB_IPT;   // rounds whose coordinates stay in registers 
 constexpr int BB_CAP = BB_THREADS * BB_IPT;      // points per bucket handled in LDS
 static_assert(BB_CAP == 4096, "leaf words, 16-bit item ids and the chunk plan assume 4096 points per piece");
 constexpr int BB_LEVELS = 7;                     // child digits per point (21 bits)
@@ -783,13 +767,6 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
           } else {
             d18 = path_levels(x[r], y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad) >> 3;
           }
-#ifdef PS_DUP_KEYS  // (experiments: the child digits computed twice - what they cost)
-          {
-            double x2 = x[r];
-            asm volatile("" : "+v"(x2));
-            d18 &= path_levels(x2, y[r], z[r], cx, cy, cz, lp.L, PATH_EAGER, &bad) >> 3;
-          }
-#endif
           pbits[r] = (d18 << 1) | (bad ? 1u : 0u);
           if (!FROM_REC && lp.mode == 2) lin[r] = d18 >> (18 - 3 * lp.pm);  // (the key IS the first pm digits)
         }
@@ -845,11 +822,6 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
         // the voxel's position inside its bucket (a single pass: d IS the bucket; records of a first pass carry lin)
         const uint32_t vl = lp.winv != 0.0 ? lin[r] - d * lp.width : lin[r] & ((1u << lp.shift) - 1u);
         o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), lp.raw_vp ? lin[r] : ((vl << 19) | pbits[r]), v};
-#ifdef PS_DUP_STORE  // (experiments: the same record stored twice - what the scattered stores cost)
-        asm volatile("" ::: "memory");
-        o[0] = uint4{(uint32_t)xb, (uint32_t)(xb >> 32), (uint32_t)yb, (uint32_t)(yb >> 32)};
-        o[1] = uint4{(uint32_t)zb, (uint32_t)(zb >> 32), lp.raw_vp ? lin[r] : ((vl << 19) | pbits[r]), v};
-#endif
       }
     }
     BB_STAMP(13);  // scatter: stores issued
@@ -952,9 +924,7 @@ __device__ __forceinline__ void load_rec(const PartRec* __restrict__ p, double& 
 // puts the bucket in the final order - voxel, leaf path, insertion order inside the leaf - and the
 // outputs are written with coalesced stores.
 constexpr int BB_BINS = 8192;          // histogram bins per level (nodes of a level x 8)
-#ifndef BB_OUT_UNROLL
 #define BB_OUT_UNROLL 4
-#endif
 constexpr int BB_SORT_BITS = 9;        // digit of the in-bucket radix sort
 constexpr int BB_SORT_BINS = 1 << BB_SORT_BITS;
 constexpr int BB_SORT_DPT = BB_SORT_BINS / BB_THREADS;  // sort digits per thread in the offset scan
@@ -1007,27 +977,22 @@ __device__ __forceinline__ uint32_t bucket_chunk(
   //      decided: bits 28..30 leaf depth d, bits 0..15 ordinal of the leaf's PARENT among the overfull nodes
   //      of level d - 1 (d = 0: the voxel ordinal again)
   uint32_t pth[BB_IPT], vlv[BB_IPT], stt[BB_IPT];
-#if BB_ONE_READ
   // the records' coordinates: read once, held to the output - for the first BB_KEEP rounds; a bucket of more
   // than BB_KEEP * BB_THREADS points (the average bucket holds 60 % of BB_CAP) reads the coordinates of the
   // rest again at the output, when the pyramid's registers are free (held through, they spill: 132 B of
   // scratch per lane were +166 MB of reads and +197 MB of writes per 10 M points)
   double cxr[BB_KEEP], cyr[BB_KEEP], czr[BB_KEEP];
-#endif
   bool bad_any = false;
 #pragma unroll
   for (int r = 0; r < BB_IPT; ++r) {
     pth[r] = 0;
     vlv[r] = 0;
     stt[r] = 0;
-#if BB_ONE_READ
     if (r < BB_KEEP) cxr[r] = cyr[r] = czr[r] = 0.0;
-#endif
     if (r < rounds) {
       const int i = wave * per_wave + r * 64 + lane;
       if (i < n) {
         // (16-byte loads: the second half of the record holds voxel, child digits and index)
-#if BB_ONE_READ
         const uint4* q4 = reinterpret_cast<const uint4*>(part + (CHUNKED ? (int)SRC[i] : i));
         const uint4 w4 = q4[1];
         if (r < BB_KEEP) {
@@ -1037,9 +1002,6 @@ __device__ __forceinline__ uint32_t bucket_chunk(
           czr[r] = __longlong_as_double((long long)(((uint64_t)w4.y << 32) | w4.x));
         }
         s_idx[i] = w4.w;
-#else
-        const uint4 w4 = reinterpret_cast<const uint4*>(part + (CHUNKED ? (int)SRC[i] : i))[1];
-#endif
         const uint2 w = uint2{w4.z, w4.w};
         const bool bad = w.x & 1u;
         pth[r] = (((w.x >> 1) & 0x3FFFFu) << 3) | (w.y & 0x80000000u) | (bad ? 0x40000000u : 0u);
@@ -1333,7 +1295,6 @@ __device__ __forceinline__ uint32_t bucket_chunk(
 
   // ---- 5. outputs (coalesced) ------------------------------------------------------------------------------------
   uint32_t nblk = 0;
-#if BB_ONE_READ
   // item -> final position, in the sort buffer that is free now
   uint16_t* INV = s_slot[cur ^ 1];
   // (these two loops touch no per-item register array: rolled or nearly so - BB_LEAF_UNROLL - they leave the
@@ -1409,36 +1370,6 @@ __device__ __forceinline__ uint32_t bucket_chunk(
       __syncthreads();
     }
   }
-#else
-#pragma unroll BB_OUT_UNROLL
-  for (int r = 0; r < BB_IPT; ++r) {
-    const int f = r * BB_THREADS + tid;
-    if (f < n) {
-      const uint32_t it = RS[f];
-      const uint32_t key = KEY[it];
-      const uint32_t pit = f > 0 ? (uint32_t)RS[f - 1] : 0u;
-      const uint32_t pkey = f > 0 ? KEY[pit] : ~key;
-      const bool leaf_head = key != pkey;
-      const bool vox_head = f == 0 || (key >> kshift) != (pkey >> kshift);
-      double x, y, z;
-      uint32_t vp, idx;
-      load_rec(part + (CHUNKED ? (uint32_t)SRC[it] : it), x, y, z, vp, idx);
-      idx &= IDX_MASK;
-      bool blk_head = leaf_head;
-      if (!leaf_head && P.n_poses > 1) {
-        const uint32_t pidx = part[CHUNKED ? (uint32_t)SRC[pit] : pit].idx & IDX_MASK;
-        blk_head = find_slot_dev(pose_off, P.n_poses, idx) != find_slot_dev(pose_off, P.n_poses, pidx);
-      }
-      nblk += blk_head ? 1u : 0u;
-      const size_t o = (size_t)out_base + f;
-      leafinfo[o] = INFO[it] | (vox_head ? LI_VHEAD : 0u) | (blk_head ? LI_BHEAD : 0u);
-      ord_idx[o] = idx;
-      xyz_ord[3 * o] = x;
-      xyz_ord[3 * o + 1] = y;
-      xyz_ord[3 * o + 2] = z;
-    }
-  }
-#endif
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) nblk += __shfl_xor(nblk, off);
   if (lane == 0 && nblk) atomicAdd(&s_tot[BK_NBLK], nblk);
@@ -1485,11 +1416,7 @@ __global__ __launch_bounds__(BB_THREADS, BB_WGS) void k_bucket_build(
   __shared__ uint32_t s_tot[BK_ROWS];
   __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
   __shared__ uint16_t s_src[1];
-#if BB_ONE_READ
   __shared__ uint32_t s_idx[BB_CAP];              // index | scheme bit of every item (the records are read once)
-#else
-  uint32_t* s_idx = nullptr;
-#endif
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
   const uint32_t start = bstart[(size_t)b * P.bstride];
@@ -1632,7 +1559,7 @@ __global__ __launch_bounds__(BB_THREADS) void k_bucket_plan(
 }
 
 // one workgroup per chunk (the grid strides over the list: its length is on the device)
-__global__ __launch_bounds__(BB_THREADS, BB_ONE_READ ? 1 : 2) void k_bucket_chunks(
+__global__ __launch_bounds__(BB_THREADS, 1) void k_bucket_chunks(
     const PartRec* __restrict__ part, const uint32_t* __restrict__ bstart, BkParams P,
     const GeomDev* __restrict__ G, const ChunkDesc* __restrict__ ck_desc, uint32_t* __restrict__ ck_tot,
     const int64_t* __restrict__ pose_off, uint32_t* __restrict__ ord_idx, double* __restrict__ xyz_ord,
@@ -1650,11 +1577,7 @@ __global__ __launch_bounds__(BB_THREADS, BB_ONE_READ ? 1 : 2) void k_bucket_chun
   __shared__ uint32_t s_tot[BK_ROWS];
   __shared__ uint32_t s_todo[(1 << PT_BITS) / 32];
   __shared__ uint16_t s_src[BB_CAP];  // chunk item -> record of the bucket
-#if BB_ONE_READ
   __shared__ uint32_t s_idx[BB_CAP];
-#else
-  uint32_t* s_idx = nullptr;
-#endif
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t total = min(small[SM_CK_COUNT], CK_CAP);
   if (small[SM_BK_FLAGS] & BF_OVERFLOW) return;  // (the plan gave up: the general path takes the build)
@@ -1977,9 +1900,7 @@ __global__ __launch_bounds__(256) void k_old_voxels_missing(const uint64_t* __re
   if (!found) atomicAdd(missing, 1u);
 }
 
-#ifndef BF_WAVES
 #define BF_WAVES 8   // waves per SIMD asked of the compiler for k_bucket_finish: 64 VGPRs, 16 B of scratch per lane (A/B on one box: 4 waves at 128 VGPRs 0.109 ms, 5: 0.121, 6: 0.104, 8: 0.092 - the kernel is latency bound)
-#endif
 __global__ __launch_bounds__(256, BF_WAVES) void k_bucket_finish(
     NodePtrs nd, NodeParams P, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bk_base,
     const uint32_t* __restrict__ grand_total, const uint32_t* __restrict__ leafinfo,
@@ -2508,12 +2429,8 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   const int cus = octl_ctx_cus(ctx);
 // (A/B on the headline scene, tools/ab_build.sh: 8 records per thread 0.264 ms, 16: 0.284, 4: 0.295, 12 with 3
 //  workgroups per CU: 0.329 - the kernel is latency bound at 2 waves per SIMD, 254 VGPRs with 16 records)
-#ifndef OCTL_PT_IPT
 #define OCTL_PT_IPT 8
-#endif
-#ifndef OCTL_PT_WGS
 #define OCTL_PT_WGS 2
-#endif
   constexpr int PT_IPT = OCTL_PT_IPT;  // (records per thread and tile of the partition kernels; -D for experiments)
   constexpr int tile = PT_THREADS * PT_IPT;
   auto supertiles = [&](int64_t items, int* st_tiles) {
@@ -2731,13 +2648,11 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     KTimer t(ctx, "bucket_build");
     hipStream_t side = st;
     bool on_side = false;
-#if BB_SIDE_STREAM
     if (chunks_beside && octl_ctx_side_stream(ctx) && hipEventRecord(ctx->self_gate, st) == hipSuccess &&
         hipStreamWaitEvent(ctx->self_stream, ctx->self_gate, 0) == hipSuccess) {
       side = ctx->self_stream;
       on_side = true;
     }
-#endif
     if (chunks_beside) OCTL_TRY(launch_chunks(side));
     OCTL_LAUNCH(k_bucket_build, dim3(nb), dim3(BB_THREADS), 0, st, recs, bstart, bp,
                        (const GeomDev*)gdev, (const int64_t*)f->pose_off_dev.as<int64_t>(), f->ord_idx.as<uint32_t>(),

@@ -45,9 +45,8 @@ extern std::atomic<uint64_t> g_octl_spec_held, g_octl_spec_missed;
 // belong in a shipped library: they only compile when the variant build script defines OCTL_EXPERIMENTS
 // (tools/build_variant.sh -> build/variants/NAME.so, loaded through OCTREELIB_AMD_LIB; the Makefile never does).
 #if !defined(OCTL_EXPERIMENTS) && \
-    (defined(RS_NO_REDO) || (defined(RS_ABLATE) && RS_ABLATE != 0) || defined(PS_DUP_KEYS) || defined(PS_DUP_STORE) || \
-     defined(RS_STAMPS) || defined(RS_COUNTS) || defined(BB_STAMPS))
-#error "RS_NO_REDO / RS_ABLATE / PS_DUP_* / RS_STAMPS / RS_COUNTS / BB_STAMPS are experiments: build them with tools/build_variant.sh (-DOCTL_EXPERIMENTS)"
+    (defined(PS_DUP_KEYS) || defined(PS_DUP_STORE) || defined(RS_COUNTS) || defined(BB_STAMPS))
+#error "PS_DUP_* / RS_COUNTS / BB_STAMPS are experiments: build them with tools/build_variant.sh (-DOCTL_EXPERIMENTS)"
 #endif
 
 #define OCTL_WAVE 64

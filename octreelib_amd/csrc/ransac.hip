@@ -30,10 +30,6 @@
 
 namespace {
 
-#ifndef RS_FAST_DIV
-#define RS_FAST_DIV 1
-#endif
-
 // c / k, correctly rounded, for an integer 1 <= k <= 16 (see plane_from_samples).
 // zh = RN(1/k), zl = RN(1/k - zh); denormal / overflow ranges fall back to the true division.
 __device__ __forceinline__ double div_by_small_int(double c, int k) {
@@ -45,7 +41,7 @@ __device__ __forceinline__ double div_by_small_int(double c, int k) {
   return copysign(fma(c, zh, c * zl), c);         // (the sign: zl may be negative, c may be -0)
 }
 
-// ---- wave-uniform range certificate (RS_BLKFAST) -----------------------------------------------------------
+// ---- wave-uniform range certificate ----------------------------------------------------------------------------
 // The three shortcuts below (division of the centroid by k, in-range square root, shared-reciprocal
 // division by the norm) are exact only while no operand or intermediate leaves the normal range, and each
 // used to test that per lane and per fit: ~20 f64 compares out of ~250 instructions.  Almost all of that
@@ -68,9 +64,6 @@ __device__ __forceinline__ double div_by_small_int(double c, int k) {
 // Blocks that fail the property (denormal-scale or astronomically large coordinates, -0.0, NaN, inf) keep the
 // per-lane guards.  tests/test_gpu_primitives.py checks the unguarded forms bit-for-bit against IEEE division
 // and square root over this wider domain.
-#ifndef RS_BLKFAST
-#define RS_BLKFAST 1
-#endif
 __device__ __forceinline__ bool coord_in_fast_range(double v) {
   const uint32_t hi = (uint32_t)__double2hiint(v), lo = (uint32_t)__double2loint(v);
   const uint32_t e = (hi >> 20) & 0x7FFu;
@@ -178,9 +171,8 @@ __device__ __forceinline__ void plane_from_moments(double cx, double cy, double 
   double ay = is_x ? cA : (is_y ? det_y : cC);
   double az = is_x ? cB : (is_y ? cC : det_z);
   const double s = ax * ax + ay * ay + az * az;  // util.py:76
-#if RS_FAST_DIV
   // one integer compare on the high word: s >= 2^-400 (s is finite and non-negative here)
-  if (RS_BLKFAST && fast && (uint32_t)__double2hiint(s) >= ((1023u - 400u) << 20)) {
+  if (fast && (uint32_t)__double2hiint(s) >= ((1023u - 400u) << 20)) {
     const double norm = sqrt_rn_inrange(s);
     div3_by_norm_inrange(ax, ay, az, norm);
   } else {
@@ -191,16 +183,6 @@ __device__ __forceinline__ void plane_from_moments(double cx, double cy, double 
     }
     div3_by_norm(ax, ay, az, norm);
   }
-#else
-  const double norm = __dsqrt_rn(s);
-  if (norm == 0.0) {  // util.py:77-78
-    plane[0] = plane[1] = plane[2] = plane[3] = 0.0f;
-    return;
-  }
-  ax /= norm;
-  ay /= norm;
-  az /= norm;
-#endif
   const double d = -(ax * cx + ay * cy + az * cz);  // util.py:83
   plane[0] = (float)ax;
   plane[1] = (float)ay;
@@ -217,7 +199,7 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
                                                    float (&plane)[4], bool fast = false) {
   const int k = KT > 0 ? KT : k_rt;
   double cx = 0.0, cy = 0.0, cz = 0.0;
-  if (RS_BLKFAST && fast) {  // (wave-uniform) no -0.0 among the coordinates: 0.0 + x == x
+  if (fast) {  // (wave-uniform) no -0.0 among the coordinates: 0.0 + x == x
     cx = sx[0];
     cy = sy[0];
     cz = sz[0];
@@ -239,7 +221,7 @@ __device__ __forceinline__ void plane_from_samples(const double (&sx)[KMAX],
   // divisor k <= 16 the quotient c/k is never closer than 1/(2k) ulp to a rounding midpoint, so
   // RN(c*zh + RN(c*zl)) with zh + zl = 1/k to ~2^-106 IS the correctly rounded quotient:
   // one multiply + one FMA instead of the 11-instruction IEEE division sequence.
-  div3_by_small_int(cx, cy, cz, k, RS_BLKFAST && fast);
+  div3_by_small_int(cx, cy, cz, k, fast);
   // util.py:48-57.  The reference starts every sum at 0.0: for the squares 0.0 + r*r == r*r exactly
   // (a square is never -0), so their first add is dropped; a cross product CAN be -0 and 0.0 + (-0) is
   // +0, so the cross terms keep it (axis-aligned samples reach the sign of a zero plane coefficient).
@@ -273,69 +255,14 @@ __device__ __forceinline__ double plane_distance(double a, double b, double c, d
   return fabs(((a * x + b * y) + c * z) + d);
 }
 
-#ifndef RS_MINWAVES
-#define RS_MINWAVES 4
-#endif
-#ifndef RS_BIG_PER_CU
-#define RS_BIG_PER_CU 16  // workgroups per CU striding over the list of large blocks
-#endif
-#ifndef RS_EARLY_EXIT
-#define RS_EARLY_EXIT 1  // skip the later hypothesis groups once one hypothesis holds all points
-#endif
-#ifndef RS_FIRST_GROUPS
-#define RS_FIRST_GROUPS 1  // hypothesis groups (of THREADS) evaluated before the first early-exit check (0: RS_FIRST_HYPS / THREADS).
-                           // Round 5: ONE group - 64 hypotheses in the one-wave instance - instead of 256 hypotheses: the
-                           // blocks some early hypothesis explains completely (one leaf in five on the benchmark scene)
-                           // leave after 1/16 of the work instead of 1/4; k_ransac 3.43-3.48 -> 3.34-3.36 ms (two groups: 3.42-3.43)
-#endif
-#ifndef RS_SCHED_BARRIER
-#define RS_SCHED_BARRIER 1
-#endif
-#ifndef RS_SCREEN
-#define RS_SCREEN 1  // f32 screening of the scoring loop (exact counts; see "Screening" in k_ransac)
-#endif
-#ifndef RS_ABLATE
-#define RS_ABLATE 0
-#endif
-#ifndef RS_F32_BOUND
-#define RS_F32_BOUND 1  // the screening bound of a hypothesis in f32 (rounded up) where the block is certified
-#endif
-#ifndef RS_BIG_THREADS
-#define RS_BIG_THREADS 256  // lanes per workgroup for H > 256 (x RS_BIG_HPL hypotheses per lane)
-#endif
-#define RS_BIG_HPL (1024 / RS_BIG_THREADS)
-#ifndef RS_SMALL_THREADS
-#define RS_SMALL_THREADS 128  // H > 256: blocks with fewer points than this get workgroups of this many lanes (0: no split)
-#endif
-#ifndef RS_POS_TABLE
-#define RS_POS_TABLE 1   // H > 256, k <= 6: sample positions from a per-launch table instead of a register cache
-#endif
-#ifndef RS_TINY_THREADS
-#define RS_TINY_THREADS 64  // ... and blocks with fewer points than this get ONE wave x 16 hypotheses per lane (0: off)
-#endif
-#ifndef RS_SIDE_STREAM
-#define RS_SIDE_STREAM 1  // the instances for the larger blocks of a split launch run on the context's side stream
-#endif
-#ifndef RS_TINY_PER_CU
-#define RS_TINY_PER_CU 256
-#endif
-#ifndef RS_SUB
-#define RS_SUB 0  // hypothesis groups per batch of pass 2 (0: three with 8 or more hypotheses per lane, else all in one)
-#endif
-#ifndef RS_EXIT_EVERY_BATCH
-#define RS_EXIT_EVERY_BATCH 1  // the early exit is tested after every batch of pass 2 as well
-#endif
-#ifndef RS_FIRST_HYPS
-#define RS_FIRST_HYPS 256  // hypotheses evaluated before the early-exit check (whole groups of THREADS)
-#endif
-#ifndef RS_PER_CU
-#define RS_PER_CU 64
-#endif
-#ifndef RS_SMALL_PER_CU
-#define RS_SMALL_PER_CU 128
-#endif
-#define RS_PRAGMA_(x) _Pragma(#x)
-#define RS_PRAGMA(x) RS_PRAGMA_(x)
+// launch shapes (A/B history of every number: HISTORY.md 4 and 8)
+constexpr int RS_MINWAVES = 4;         // waves per SIMD asked of the compiler
+constexpr int RS_BIG_PER_CU = 16;      // workgroups per CU striding over the list of large blocks
+constexpr int RS_BIG_THREADS = 256;    // H > 256: lanes per workgroup of the instance for blocks of 128 .. 255 points
+constexpr int RS_BIG_HPL = 1024 / RS_BIG_THREADS;
+constexpr int RS_SMALL_THREADS = 128;  // ... blocks with fewer points than this get two waves x 8 hypotheses per lane
+constexpr int RS_TINY_THREADS = 64;    // ... and blocks with fewer points than this ONE wave x 16
+constexpr int RS_PER_CU = 64, RS_SMALL_PER_CU = 128, RS_TINY_PER_CU = 256;   // workgroups per CU of the three
 constexpr int RS_KMAX = 16;   // initial_points_number supported by the register path
 
 // everything the kernel needs to know about one batch entry, written by k_block_desc so that a
@@ -507,7 +434,6 @@ __device__ __forceinline__ void ransac_block_global(const BlockDesc& d, int be,
                                            pts[3 * (int64_t)i + 2]) < thr) ? 1 : 0;
 }
 
-#if RS_SCREEN
 // Helpers of the screened scoring loop, as inline asm on purpose: the loop's instruction mix is
 // the whole point.  Plain v_fma_f32: left to itself hipcc SLP-packs neighbouring hypotheses into
 // v_pk_fma_f32, which measured SLOWER than two scalar FMAs on gfx950 (both as compiler output
@@ -532,16 +458,12 @@ __device__ __forceinline__ float min3abs(float m, float a, float b) {
 // broadcasts of gfx9) and one v_readlane - instead of six ds_bpermute round trips through the LDS crossbar per
 // 32-bit word (the block's winner key and the block's extent are reduced once per block by every wave: with
 // 64-bit keys that was 18 bpermutes + 6 64-bit compare / select pairs per wave and block).
-#ifndef RS_DPP_REDUCE
-#define RS_DPP_REDUCE 1
-#endif
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
   // (lanes the row mask leaves out keep `old` = their own value: max(v, v) = v)
   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#if RS_DPP_REDUCE
   v = max(v, dpp_u32<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]
   v = max(v, dpp_u32<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]
   v = max(v, dpp_u32<0x141, 0xF>(v));  // row_half_mirror
@@ -549,11 +471,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   v = max(v, dpp_u32<0x142, 0xA>(v));  // row_bcast:15 into rows 1 and 3
   v = max(v, dpp_u32<0x143, 0xC>(v));  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-#else
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
-  return v;
-#endif
 }
 // (non-negative floats order like their bit patterns; +inf included, NaN excluded by the caller)
 __device__ __forceinline__ float wave_max_nonneg_f32(float m) {
@@ -642,43 +559,42 @@ __device__ __forceinline__ void screen_group(const f4* __restrict__ loc, int n, 
 #pragma unroll
   for (int h = 0; h < NH; ++h) margin[h] = fminf(mg[0][h], mg[1][h]);
 }
-#endif
 
-#if RS_SCREEN
 // ---- the prescreen of the hypotheses (round 6) ----------------------------------------------------------------
 // The reference fits 1024 planes per leaf and keeps the one with the most inliers, the lowest index among the tied
 // (cuda_ransac.py:100-146).  After the first 64 hypotheses have been evaluated exactly, a later one matters only if
 // its inlier count EXCEEDS the best count L so far - and on a planar leaf hardly any does (2-3 of the other 960 on the
 // benchmark scene, 8-9 on a uniform cloud).  The prescreen decides that without the reference's arithmetic: an
-// APPROXIMATE plane of the same six sample points (centroid and residuals in f64 with ordinary roundings, everything
-// behind them in f32 with FMAs, no division, no square root), a rigorous bound eps on how far its distances can be
-// from the reference's, and the count of the block's points inside the threshold WIDENED by eps - an upper bound of
-// the reference's count.  A hypothesis whose upper bound does not exceed L cannot win (a tie goes to the lower index,
-// which L belongs to); the others - and every hypothesis the bound cannot vouch for - are fitted and scored exactly
-// as before.  Results are bit-identical.
+// APPROXIMATE plane of the same six sample points in f32 on the block's local coordinates (FMAs, no division, no
+// square root), a rigorous bound eps on how far its distances can be from the reference's, and the count of the
+// block's points inside the threshold WIDENED by eps - an upper bound of the reference's count.  A hypothesis whose
+// upper bound does not exceed L cannot win (a tie goes to the lower index, which L belongs to); the others - and
+// every hypothesis the bound cannot vouch for - are fitted and scored exactly as before.  Results are bit-identical.
 //
 // The bound (u = 2^-24; E = the block's extent in local coordinates, G >= |coordinate| of its points; "ideal" =
-// exact arithmetic on the exact coordinates; T = trace of the six-sample covariance sums = sum of |residual|^2):
-//   residual component r of a sample against the centroid   |err| <= u |r| + 2^-49 G
-//       (here: f64 sum / product by 1/6 / difference on global coordinates, 7 2^-53 G, then ONE rounding to f32;
-//        the reference: the same f64 operations, util.py:35-52)
-//   each of the six covariance sums (sum over samples of |r_a| <= sqrt(6 T), sqrt(T) <= (T / E + E) / 2)
-//                                                            |err| <= sigma = T (10 u + 2^-46 G / E) + 2^-46 G E
-//   each cofactor (|S_ab| <= T)                              |err| <= mu = T (4 sigma + 4 u T) + 4 sigma^2 (+ 2^-100)
+// exact arithmetic on the exact coordinates; T = trace of the six-sample covariance sums = sum of |residual|^2).
+// The covariance about ANY point c~ near the centroid c differs from the one about c by 6 (c - c~)_a (c - c~)_b, so the
+// f32 centroid (error 8 u E) only has to be subtracted accurately:
+//   residual component r of a sample against c~      |err| <= u E + u |r|     (input rounding of the local coordinate,
+//       one f32 subtraction; the reference: f64 operations on global coordinates, util.py:35-52, 2^-49 G)
+//   each of the six covariance sums (sum over samples of |r_a| <= sqrt(6 T), sqrt(T) <= (T / E + E) / 2,
+//       FMA chain 7 u T, the shifted centre 384 u^2 E^2)
+//                                                     |err| <= sigma = T (12 u + 2^-46 G / E) + 3 u E^2 + 2^-46 G E
+//   each cofactor (|S_ab| <= T)                       |err| <= mu = T (4 sigma + 4 u T) + 4 sigma^2 (+ 2^-100)
 //   the reference branches on its three diagonal cofactors (util.py:63-74): the approximate ones pick the same row
 //       when the largest exceeds the other two by more than 4 mu;
 //   normal = row / |row|: |n_approx - n_ideal|, |n_ref - n_ideal| <= 2 sqrt3 mu / |row| (+ 4 u), valid while
 //       |row| > 4 mu (the reference's zero-norm plane, util.py:77-78, has |row| <= 2 sqrt3 mu: never vouched for);
 //   distance of a block point p (|p - centroid| <= 2 sqrt3 E): normal error x lever, the f32 evaluation of the
-//       approximate plane in local coordinates (23 u E), the f32 rounding of the reference's GLOBAL plane
-//       (3.5 u G, cuda_ransac.py:110-113):
-//       |s_approx - t_ref| <= eps = 3.5 E (4 mu / |row|) + 48 u E + 2^-21 G.
+//       approximate plane in local coordinates and through c~ instead of c (36 u E), the f32 rounding of the
+//       reference's GLOBAL plane (3.5 u G, cuda_ransac.py:110-113):
+//       |s_approx - t_ref| <= eps = 3.5 E (4 mu / |row|) + 64 u E + 2^-21 G.
 // Blocks outside 2^-7 <= E <= 2^7 (f32 under- / overflow of the fourth-order terms), without the range certificate
-// of RS_BLKFAST, or whose constant part of eps exceeds thr / 8 take every hypothesis through the exact path.
+// (coord_in_fast_range), or whose constant part of eps exceeds thr / 8 take every hypothesis through the exact path.
 struct PreConst {     // block-uniform constants of the bound, every one rounded UP
-  float k1, k0;           // 16 sigma = T k1 + k0
+  float qa, qb, qc;       // 4 mu (1 + 2^-10) = (qa T + qb) T + qc
   float e35;              // 3.5 E (1 + 2^-10)
-  float thrblk;           // (thr + 48 u E + 2^-21 G) (1 + 2^-10)
+  float thrblk;           // (thr + 64 u E + 2^-21 G) (1 + 2^-10)
 };
 __device__ __forceinline__ bool prescreen_constants(float extent, double ox, double oy, double oz, double thr,
                                                     PreConst& pc) {
@@ -686,21 +602,19 @@ __device__ __forceinline__ bool prescreen_constants(float extent, double ox, dou
   const float u = 0x1p-24f;
   const float E = extent;
   const float G = ((float)(fabs(ox) + fabs(oy) + fabs(oz)) + E) * 0x1.0002p0f;
-  pc.k1 = 16.f * (10.f * u + 0x1p-46f * (G / E) * 0x1.0002p0f) * 0x1.0002p0f;
-  pc.k0 = 16.f * (0x1p-46f * G * E) * 0x1.0002p0f;
+  // 16 sigma = k1 T + k0
+  const float k1 = 16.f * (12.f * u + 0x1p-46f * (G / E) * 0x1.0002p0f) * 0x1.0002p0f;
+  const float k0 = 16.f * (3.f * u * (E * E) + 0x1p-46f * G * E) * 0x1.0002p0f;
+  // 4 mu = T (16 sigma + 16 u T) + 16 sigma^2 = T^2 (k1 + 16 u + k1^2 / 16) + T (k0 + k1 k0 / 8) + k0^2 / 16 (+ 2^-98)
+  pc.qa = (k1 + 0x1p-20f + k1 * k1 * 0x1p-4f) * up;
+  pc.qb = (k0 + k1 * k0 * 0x1p-3f) * up;
+  pc.qc = (k0 * k0 * 0x1p-4f) * up + 0x1p-98f;
   pc.e35 = 3.5f * E * up;
-  const float eblk = (48.f * u * E + 0x1p-21f * G) * 0x1.0002p0f;
+  const float eblk = (64.f * u * E + 0x1p-21f * G) * 0x1.0002p0f;
   const float thr_f = (float)thr * 0x1.0002p0f;
   pc.thrblk = (thr_f + eblk) * up;
   // (all comparisons are false for NaN)
   return E >= 0x1p-7f && E <= 0x1p7f && thr >= 0x1p-40 && thr <= 0x1p40 && eblk * 8.f <= thr_f;
-}
-// 4 mu (1 + 2^-10) of a hypothesis from the trace of its covariance sums
-__device__ __forceinline__ float prescreen_mu4(const PreConst& pc, float T) {
-  const float s16 = fma32(T, pc.k1, pc.k0);                       // 16 sigma
-  const float t1 = fma32(T, 0x1p-20f, s16);                       // 16 sigma + 16 u T
-  const float m = fma32(s16 * s16, 0x1p-4f, T * t1);              // 4 mu = T (16 sigma + 16 u T) + 16 sigma^2
-  return fma32(m, 0x1.004p0f, 0x1p-98f);
 }
 
 // count of the block's points inside each hypothesis' WIDENED threshold: e = fma(s, s, -T2) < 0, s as in
@@ -735,126 +649,87 @@ __device__ __forceinline__ void screen_ub(const f4* __restrict__ loc, int n, con
     for (int h = 0; h < NH; ++h) cnt[h] += __popc(hist[h]);
   }
 }
-#endif
 
-template <int B, int NB, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-  if constexpr (B < NB) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, NB>(f);
-  }
-}
-
-// -DRS_STAMPS: phase clocks of k_ransac (experiments only, like BB_STAMPS in bucket_build.hip).  Wave 0 of every
-// workgroup reads s_memtime at the phase boundaries of every block and keeps the sums in SGPRs; at the end of the
-// kernel they are added to a device array that tools/rs_stamps.py reads through octl_debug_rs_stamps:
-//   [0] iteration head (descriptor prefetch, next block's loads issued, sample positions when the size changes)
-//   [1] plane fits of hypothesis group 0 (LDS gathers included)      [2] scoring of group 0 (screen + recounts)
-//   [3] plane fits of groups 1..HPL-1                                [4] their scoring
-//   [5] reduction over the lane / wave + staging of the next block   [6] the block's barrier
-//   [7] winner, outputs, final mask
-//   [8] blocks  [9] blocks that skipped pass 2  [10] workgroups  [11] sum of block sizes
-//   [12] hypothesis groups of pass 2 skipped by the exit after a later batch   [13] hypotheses recounted exactly
-//   [14] hypothesis groups scored (wave 0's: x 64 lanes = hypotheses)   [15] sum over the scored groups of the block size
-// -DRS_COUNTS: the counts [8..15] alone, no clocks (the clocks' accumulators make the 16-hypothesis instance spill):
-// what the kernel EXECUTES of what the algorithm asks for (tools/rs_counts.py -> profiles/rNN_ransac_counts.json).
-#if defined(RS_STAMPS) || defined(RS_COUNTS)
+// -DRS_COUNTS (experiments only: tools/build_variant.sh): what the kernel EXECUTES of what the algorithm asks for.
+// Wave 0 of every workgroup keeps the counts in registers and adds them to a device array at the end of the kernel;
+// tools/rs_counts.py reads it through octl_debug_rs_stamps (-> profiles/rNN_ransac_counts.json):
+//   [0] shader-clock ticks / [1] 100 MHz ticks over the workgroups' lives (s_memtime / s_memrealtime: the clock the chip
+//       held under this kernel's load, MI355X_MICROARCH.md "DVFS give-back")
+//   [2] survivors of the prescreen   [3] batches of hypotheses fitted exactly behind group 0   [4] blocks prescreened
+//   [5] blocks whose survivors overflowed the queue   [8] blocks   [9] blocks that ended with group 0
+//   [10] workgroups   [11] sum of block sizes   [12] hypothesis groups prescreened   [13] hypotheses recounted exactly
+//   [14] hypothesis groups fitted and scored exactly   [15] sum over those groups of the block size
+#ifdef RS_COUNTS
 __device__ unsigned long long g_rs_stamps[16];
-#ifdef RS_STAMPS
-#define RS_STAMP_INIT unsigned long long _rs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
-                      unsigned long long _rs_t0 = __builtin_readcyclecounter()
-#define RS_STAMP(k)                                                   \
-  do {                                                                \
-    const unsigned long long _t = __builtin_readcyclecounter();       \
-    _rs_acc[k] += _t - _rs_t0;                                        \
-    _rs_t0 = _t;                                                      \
-  } while (0)
-#else
-// (RS_COUNTS: slots [0] / [1] carry the kernel's own clock instead - s_memtime ticks at the shader clock,
-//  s_memrealtime at 100 MHz: their ratio over a workgroup's life is the clock the chip held under this kernel's load,
-//  MI355X_MICROARCH.md "DVFS give-back" (6))
-#define RS_STAMP_INIT unsigned long long _rs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+#define RS_COUNT_INIT unsigned long long _rs_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
                       const unsigned long long _rs_m0 = __builtin_amdgcn_s_memtime(),                      \
                                                _rs_r0 = __builtin_amdgcn_s_memrealtime()
-#define RS_STAMP(k) do {} while (0)
-#define RS_CLOCK_FLUSH                                                  \
-  do {                                                                  \
-    _rs_acc[0] = __builtin_amdgcn_s_memtime() - _rs_m0;                 \
-    _rs_acc[1] = __builtin_amdgcn_s_memrealtime() - _rs_r0;             \
-  } while (0)
-#endif
-#ifndef RS_CLOCK_FLUSH
-#define RS_CLOCK_FLUSH do {} while (0)
-#endif
 #define RS_COUNT(k, v) _rs_acc[k] += (unsigned long long)(v)
-#define RS_STAMP_FLUSH                                                                  \
+#define RS_COUNT_FLUSH                                                                  \
   do {                                                                                  \
     if (threadIdx.x == 0) {                                                             \
-      RS_CLOCK_FLUSH;                                                                   \
+      _rs_acc[0] = __builtin_amdgcn_s_memtime() - _rs_m0;                               \
+      _rs_acc[1] = __builtin_amdgcn_s_memrealtime() - _rs_r0;                           \
       _rs_acc[10] += 1;                                                                 \
       for (int _k = 0; _k < 16; ++_k) atomicAdd(&g_rs_stamps[_k], _rs_acc[_k]);         \
     }                                                                                   \
   } while (0)
 #else
-#define RS_STAMP_INIT do {} while (0)
-#define RS_STAMP(k) do {} while (0)
+#define RS_COUNT_INIT do {} while (0)
 #define RS_COUNT(k, v) do {} while (0)
-#define RS_STAMP_FLUSH do {} while (0)
+#define RS_COUNT_FLUSH do {} while (0)
 #endif
 
 // Persistent workgroups over the descriptors of all blocks with k <= n <= THREADS-1 points,
 // SORTED BY SIZE (largest first): workgroup w handles a contiguous chunk of the list
 //   * the grid is oversubscribed (64 ... 256 workgroups per CU, 4 ... 16 resident): the chunks with the largest
 //     blocks are dispatched first and the dispatcher evens out the rest (no tail);
-//   * consecutive blocks of a workgroup have the same size, so the positions of the sampled
-//     points - a function of (hypothesis, n) only, see sample_index_cached - are computed once
-//     per size and kept packed in registers (PT = false), or come out of the launch's position table a batch of
-//     hypothesis groups ahead of their plane fits (PT = true: the instances with more than 256 hypotheses);
 //   * while entry e is computed out of one LDS buffer the points of entry e+1 are already in
 //     flight into registers and the descriptor of entry e+2 is being fetched, so the per-block
 //     latency chain (descriptor -> points) is off the critical path;
-//   * the block's points are three f64 LDS arrays: the 6 sampled points of a hypothesis are
+//   * the block's points are three f64 LDS arrays: the sampled points of a hypothesis are
 //     per-lane LDS gathers (conflict free up to 32 points), the scoring loop reads each point as
 //     a wave-uniform broadcast;
 //   * ONE barrier per block (three rotating point buffers, reduction slots by parity).
-// FULLH: the table has exactly THREADS x HPL hypotheses (the default 1024): every lane owns HPL of them and the
-// `index < H` guards (a compare, an EXEC save / restore and six zero-initialisations per plane fit) fold away.
-// PT: the sample positions come from the launch's position table (pos_table_part, written by k_block_scatter's extra workgroups: a function of (block size,
-// hypothesis) alone) instead of being cached in registers while the block size stays the same.
-template <int THREADS, int HPL, int KT, int ABL, bool FULLH, bool PT>
+// A lane fits ONE hypothesis at a time: first its hypothesis of group 0 (index lane < THREADS), then - HPL > 1 -
+// whichever later ones the prescreen could not rule out (or all of them, where there is no prescreen).
+// FULLH: the table has exactly THREADS x HPL hypotheses (the default 1024): the `index < H` guards fold away.
+// PT: the sample positions - a function of (block size, hypothesis) alone, see sample_index_cached - come from the
+// launch's position table (pos_table_part: k <= 6); otherwise they are computed from the table row in front of a fit.
+template <int THREADS, int HPL, int KT, bool FULLH, bool PT>
 __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ xyz, const BlockDesc* __restrict__ sdesc,
     const uint32_t* __restrict__ lo_ptr, const uint32_t* __restrict__ hi_ptr, const double* __restrict__ hyp, int H,
     int k_rt, double thr, RansacOut out, const uint2* __restrict__ pos_tab, int no_prescreen) {
   static_assert(!PT || (KT > 0 && KT <= 6), "the position table packs up to six positions and their risk bits");
-  // PRE: the instance with the prescreen of the hypotheses (see prescreen_constants): one wave per block, sixteen
-  // hypotheses per lane, positions from the table.  Slot 0 of the per-group arrays holds whichever hypothesis a
-  // lane is fitting exactly (t0); the other instances keep hypothesis t = lane + q THREADS in slot q.
-  constexpr bool PRE = RS_SCREEN && THREADS == 64 && HPL == 16 && KT == 6 && ABL == 0 && FULLH && PT;
-  constexpr int PRE_LIST = 512;   // survivors a block can queue; more: every hypothesis takes the exact path
-  __shared__ uint16_t s_surv[PRE ? PRE_LIST : 1];
-  int t0 = 0;          // (PRE) hypothesis of slot 0
-  bool act0 = true;    // (PRE) the lane's slot 0 holds a hypothesis that counts
+  static_assert(THREADS * HPL <= 1024, "hypothesis index in 10 bits");
+  // PRE: the instances with the prescreen of the hypotheses (see prescreen_constants): three to six sample points,
+  // positions from the table, more than one hypothesis per lane - one, two or four waves per block.  Every WAVE
+  // prescreens its own hypotheses against the best count of its OWN first group (indices below THREADS, lower than
+  // every later one): no exchange between the waves before the block's one barrier.
+  constexpr bool PRE = PT && KT >= 3 && HPL >= 2;
+  constexpr int W = THREADS / 64;
   constexpr int KS = KT > 0 ? KT : RS_KMAX;
   constexpr int GW = (KS + 3) / 4;  // packed sample positions: one byte each
-  constexpr int W = THREADS / 64;
+  // survivors a wave can queue (more: every hypothesis takes the exact path); an entry is the hypothesis index, and
+  // with one wave per block (under 64 points) its count bound above it
+  constexpr int PRE_LIST = THREADS == 64 ? 512 : 256;
+  __shared__ uint16_t s_surv_all[PRE ? W : 1][PRE ? PRE_LIST : 1];
+  uint16_t* const s_surv = s_surv_all[PRE ? (threadIdx.x >> 6) : 0];
   const int k = KT > 0 ? KT : k_rt;
   __shared__ double s_pts[3][3][THREADS];        // rotated: block t lives in buffer t % 3
   __shared__ uint32_t s_wbest[2][W];             // by block parity
   __shared__ float s_wplane[2][W][4];
-#if RS_SCREEN
   // f32 screening of the scoring loop (see "screening" below): block-local f32 coordinates
   // relative to the block's first point and, per wave, the largest |coordinate|
   __shared__ f4 s_loc[3][THREADS];
   __shared__ float s_wext[3][W];
   __shared__ uint32_t s_wfast[3][W];
-#endif
   // this launch's part [lo, hi) of the size-sorted list (device-side counts; lo_ptr == nullptr: from the front)
   const int lo = lo_ptr ? (int)*lo_ptr : 0;
   const int hi = (int)*hi_ptr;
   const int nbs = hi - lo;
-  // workgroup w owns the CONTIGUOUS chunk [w*C, (w+1)*C) of the size-sorted list: its blocks have
-  // (almost always) the same size, so the cached sample positions stay valid, and the chunks with
+  // workgroup w owns the CONTIGUOUS chunk [w*C, (w+1)*C) of the size-sorted list: the chunks with
   // the largest blocks are dispatched first
   const int C = (nbs + (int)gridDim.x - 1) / (int)gridDim.x;
   int j = lo + (int)blockIdx.x * C;
@@ -876,35 +751,13 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       s_pts[0][1][threadIdx.x] = py;
       s_pts[0][2][threadIdx.x] = pz;
     }
-#if RS_SCREEN
     stage_local<THREADS>(xyz[3 * (int64_t)cur.pstart], xyz[3 * (int64_t)cur.pstart + 1],
                          xyz[3 * (int64_t)cur.pstart + 2], cur, px, py, pz, s_loc[0], s_wext[0], s_wfast[0],
                          W == 1 ? &ext_carry : nullptr, W == 1 ? &fast_carry : nullptr);
-#endif
   }
   __syncthreads();
-  int buf = 0, par = 0, cached_n = -1;
-  RS_STAMP_INIT;
-  bool any_risk = false;
-  uint32_t gpk[HPL][GW];
-  uint32_t rkq[HPL];  // (PT) risky-draw bits of the loaded positions
-  // "risky" draws of the lane's hypotheses (sample_index_cached), KS bits per hypothesis packed into words
-  constexpr int RW = (HPL * KS + 31) / 32;
-  uint32_t riskw[RW];
-#pragma unroll
-  for (int w = 0; w < RW; ++w) riskw[w] = 0;
-  auto risk_of = [&](const int q) -> uint32_t {
-    const int w0 = (q * KS) >> 5, sh = (q * KS) & 31;
-    uint32_t r = riskw[w0] >> sh;
-    if (sh + KS > 32) r |= riskw[w0 + 1] << (32 - sh);
-    return r & ((1u << KS) - 1u);
-  };
-#pragma unroll
-  for (int q = 0; q < HPL; ++q) {
-    rkq[q] = 0;
-#pragma unroll
-    for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
-  }
+  int buf = 0, par = 0;
+  RS_COUNT_INIT;
   for (;;) {
     // lane-constant addresses (LDS slots, output offsets) are cheap to recompute; derived from
     // threadIdx.x directly the compiler hoists them out of this loop and then SPILLS them (48 B of
@@ -925,7 +778,7 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       rz = xyz[3 * p + 2];
     }
     // ... and its first point, the origin of its block-local coordinates: a wave-uniform load whose latency
-    // used to sit in front of the staging at the END of the iteration (behind the sched_barriers of the fits)
+    // used to sit in front of the staging at the END of the iteration
     double nox = 0.0, noy = 0.0, noz = 0.0;
     if (has_next) {
       nox = xyz[3 * (int64_t)nxt.pstart];
@@ -938,55 +791,6 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const double* __restrict__ ly = s_pts[buf][1];
     const double* __restrict__ lz = s_pts[buf][2];
 
-    // (PT) positions of hypothesis group q out of the table: 8 bytes per lane, issued a batch ahead of their fits
-    auto hyp_of = [&](const int q) -> int { return PRE ? t0 : (int)tx + q * THREADS; };
-    auto load_pos = [&](const int q) {
-      if constexpr (PT) {
-        const int t = hyp_of(q);
-        uint2 e = uint2{0u, 0u};
-        if (FULLH || t < H) e = pos_tab[(size_t)n * (size_t)H + t];
-        gpk[q][0] = e.x;
-        if (GW > 1) gpk[q][GW - 1] = e.y & 0xFFFFu;
-        rkq[q] = e.y >> 16;
-      }
-    };
-    // sampled positions: recomputed only when the block size changes (wave-uniform branch)
-    if (!PT && n != cached_n) {
-      cached_n = n;
-      uint32_t risk_any = 0;
-#pragma unroll
-      for (int w = 0; w < RW; ++w) riskw[w] = 0;
-#pragma unroll
-      for (int q = 0; q < HPL; ++q) {
-        const int t = tx + q * THREADS;
-        uint32_t rq = 0;
-#pragma unroll
-        for (int w = 0; w < GW; ++w) gpk[q][w] = 0;
-        if (FULLH || t < H) {
-          const double* __restrict__ row = hyp + (int64_t)t * k;
-#pragma unroll
-          for (int i = 0; i < KS; ++i) {
-            if (i < k) {
-              bool risky;
-              const int g = sample_index_cached(row[i], n, &risky);
-              gpk[q][i >> 2] |= (uint32_t)g << (8 * (i & 3));
-              rq |= risky ? (1u << i) : 0u;
-            }
-          }
-        }
-        {
-          const int w0 = (q * KS) >> 5, sh = (q * KS) & 31;
-          riskw[w0] |= rq << sh;
-          if (sh + KS > 32) riskw[w0 + 1] |= rq >> (32 - sh);
-        }
-        risk_any |= rq;
-      }
-      // does any lane of this wave hold a draw that needs the block's start (probability 2^-20
-      // per draw)?  Otherwise the gathers below skip the per-sample check.
-      any_risk = __any(risk_any != 0);
-    }
-
-    RS_STAMP(0);
     RS_COUNT(8, 1);
     RS_COUNT(11, n);
     // ---- the block's hypotheses -------------------------------------------------------------
@@ -1010,19 +814,18 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     // (screen_group: 5.5 instructions per point and hypothesis against 8 f64 ones).
     //
     // Early exit (exact).  The winner is the LOWEST index among the hypotheses with the maximal
-    // count, and no count exceeds n.  Hypotheses 0 .. THREADS-1 (group 0 of every lane) go first;
-    // when one of them holds all n points, no hypothesis of a later group can win - their plane
-    // fits and scores are skipped.  On the benchmark scene this is one leaf in five.
+    // count, and no count exceeds n.  Hypotheses 0 .. THREADS-1 (group 0) go first; when one of them holds
+    // all n points, no later hypothesis can win - on the benchmark scene this is one leaf in five.
     const double ox = lx[0], oy = ly[0], oz = lz[0];
     float extent = W == 1 ? ext_carry : s_wext[buf][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) extent = fmaxf(extent, s_wext[buf][w]);
     // every staged coordinate (block + spill point) is +0.0 or in [2^-30, 2^31): the plane fits run without
-    // their per-lane range guards (RS_BLKFAST).  Wave-uniform, kept in an SGPR.
+    // their per-lane range guards (see coord_in_fast_range).  Wave-uniform, kept in an SGPR.
     uint32_t fastw = W == 1 ? fast_carry : s_wfast[buf][0];
 #pragma unroll
     for (int w = 1; w < W; ++w) fastw &= s_wfast[buf][w];
-    const bool blk_fast = RS_BLKFAST && __builtin_amdgcn_readfirstlane((int)fastw) != 0;
+    const bool blk_fast = __builtin_amdgcn_readfirstlane((int)fastw) != 0;
     // block-uniform parts of the bound.  Thresholds or extents outside the sane range (nobody's
     // plane tolerance) are always recounted exactly.
     const double delta_blk = fma(0x1p-23 * 9.0, (double)extent,
@@ -1031,28 +834,53 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     const bool blk_sane = thr >= 0x1p-40 && thr <= 0x1p40 && extent < 0x1p60f;
     const float nthr2 = -(float)(thr * thr);
     const f4* __restrict__ loc = s_loc[buf];
-    // f32 forms of the bound's block-uniform parts, rounded up (RS_F32_BOUND)
+    // f32 forms of the bound's block-uniform parts, rounded up
     const bool fast_screen = blk_fast && thr >= 0x1p-40 && thr <= 0x1p40;
     const float delta_blk_f = (float)delta_blk * 0x1.0002p0f;
     const float thr2_f = (float)(thr + thr) * 0x1.0002p0f;
     const float dprime_thr_f = (float)dprime_thr * 0x1.0002p0f;
 
-    float fa[HPL], fb[HPL], fc[HPL], fd[HPL], sto[HPL], sdl[HPL];
-    int cnt[HPL];
-    // plane of hypothesis group q (f32, as the reference stores it) + its screening constants
-    auto fit = [&](const int q) {
-      const int t = hyp_of(q);
-      cnt[q] = 0;
-      fa[q] = fb[q] = fc[q] = fd[q] = sto[q] = sdl[q] = 0.f;
-      if (FULLH || t < H) {
+    // ---- one hypothesis per lane, exactly: positions, plane fit, count --------------------------------------------
+    uint32_t gpk[GW], rk = 0;     // packed sample positions of the lane's hypothesis and their risky-draw bits
+    float fa = 0.f, fb = 0.f, fc = 0.f, fd = 0.f, sto = 0.f, sdl = 0.f;
+    int cnt = 0;
+    auto load_pos = [&](const int t, const bool act) {
+#pragma unroll
+      for (int w = 0; w < GW; ++w) gpk[w] = 0;
+      rk = 0;
+      if constexpr (PT) {
+        // (8 bytes per lane out of the launch's table)
+        const uint2 e = pos_tab[(size_t)n * (size_t)H + (size_t)(act ? t : 0)];
+        gpk[0] = e.x;
+        if (GW > 1) gpk[GW - 1] = e.y & 0xFFFFu;
+        rk = e.y >> 16;
+      } else if (act) {
+        const double* __restrict__ row = hyp + (int64_t)t * k;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+          if (i < k) {
+            bool risky;
+            const int g = sample_index_cached(row[i], n, &risky);
+            gpk[i >> 2] |= (uint32_t)g << (8 * (i & 3));
+            rk |= (risky || g == n) ? (1u << i) : 0u;
+          }
+        }
+      }
+    };
+    // plane of hypothesis t (f32, as the reference stores it) + its screening constants
+    auto fit = [&](const int t, const bool act) {
+      cnt = 0;
+      fa = fb = fc = fd = sto = sdl = 0.f;
+      if (FULLH || act) {
         double sx[KS], sy[KS], sz[KS];
-        const bool some_risk = PT ? (bool)__any(rkq[q] != 0u) : any_risk;
-        if (!some_risk) {  // wave-uniform: practically always
+        // does any lane of this wave hold a draw that needs the block's start (probability 2^-20
+        // per draw)?  Otherwise the gathers skip the per-sample check.
+        if (!__any(rk != 0u)) {  // wave-uniform: practically always
 #pragma unroll
           for (int i = 0; i < KS; ++i) {
             sx[i] = sy[i] = sz[i] = 0.0;
             if (i < k) {
-              const int g = (int)((gpk[q][i >> 2] >> (8 * (i & 3))) & 0xFFu);
+              const int g = (int)((gpk[i >> 2] >> (8 * (i & 3))) & 0xFFu);
               sx[i] = lx[g];
               sy[i] = ly[g];
               sz[i] = lz[g];
@@ -1063,8 +891,8 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
           for (int i = 0; i < KS; ++i) {
             sx[i] = sy[i] = sz[i] = 0.0;
             if (i < k) {
-              int g = (int)((gpk[q][i >> 2] >> (8 * (i & 3))) & 0xFFu);
-              if ((PT ? rkq[q] : risk_of(q)) & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
+              int g = (int)((gpk[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+              if (rk & (1u << i)) g = sample_index_exact(hyp[(int64_t)t * k + i], n, cur.vstart);
               sx[i] = lx[g];
               sy[i] = ly[g];
               sz[i] = lz[g];
@@ -1072,300 +900,212 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
           }
         }
         float pf[4];
-        if (ABL == 2) {  // ablation: no plane fit (timing only, results meaningless)
-          pf[0] = (float)sx[0]; pf[1] = (float)sy[1]; pf[2] = (float)sz[2]; pf[3] = (float)sx[3];
-        } else {
-          plane_from_samples<KT, KS>(sx, sy, sz, k, pf, blk_fast);
-        }
+        plane_from_samples<KT, KS>(sx, sy, sz, k, pf, blk_fast);
         // (explicit fma: error BOUNDS and the screen's own inputs, not parity arithmetic)
         const double A = (double)pf[0], B = (double)pf[1], Cc = (double)pf[2], D = (double)pf[3];
         const double to = fma(A, ox, fma(B, oy, fma(Cc, oz, D)));
-        fa[q] = pf[0]; fb[q] = pf[1]; fc[q] = pf[2]; fd[q] = pf[3];
-        sto[q] = (float)to;
-        if (RS_F32_BOUND && fast_screen) {
+        fa = pf[0]; fb = pf[1]; fc = pf[2]; fd = pf[3];
+        sto = (float)to;
+        if (fast_screen) {
           // (wave-uniform) the same bound evaluated in f32, every constant rounded UP and the result
           // inflated by 2^-15 - the f32 roundings and the rounding of `to` lose at most 2^-21 of it;
           // |to| < 2^35 and no NaN under the block's range certificate, thr is in range: always "sane"
-          const float dl = fma32(fabsf(sto[q]), 0x1.0002p-21f, fma32(fabsf(pf[3]), 0x1.0002p-49f, delta_blk_f));
-          sdl[q] = fma32(dl, thr2_f + dl, dprime_thr_f) * 0x1.0002p0f;
+          const float dl = fma32(fabsf(sto), 0x1.0002p-21f, fma32(fabsf(pf[3]), 0x1.0002p-49f, delta_blk_f));
+          sdl = fma32(dl, thr2_f + dl, dprime_thr_f) * 0x1.0002p0f;
         } else {
           const double delta = fma(0x1p-21, fabs(to), fma(0x1p-49, fabs(D), delta_blk));
           const double dprime = fma(delta, thr + thr + delta, dprime_thr) * 1.000001;
           const bool sane = blk_sane && (fabs(to) < 0x1p60);  // false for NaN
-          sdl[q] = sane ? (float)dprime : __int_as_float(0x7f800000);
-        }
-      }
-      // keep the plane fits of the lane's hypotheses apart: interleaved they need > 200 VGPRs
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // counts of the groups [q0, q0 + NH): the screen, then the exact recount where it cannot decide
-    auto score = [&](auto nh_tag, const int q0) {
-      constexpr int NH = decltype(nh_tag)::value;
-      if (ABL == 1) return;  // ablation: no scoring
-      float margin[NH];
-      RS_COUNT(14, NH);
-      RS_COUNT(15, NH * n);
-      screen_group<NH>(loc, n, fa + q0, fb + q0, fc + q0, sto + q0, nthr2, cnt + q0, margin);
-      // a hypothesis whose smallest |e| does not clear its bound is recounted exactly (per
-      // hypothesis: a recount costs the whole wave 8 n instructions, and by the bound some lane
-      // needs one in a few percent of the (wave, hypothesis group) pairs of the benchmark scene)
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int q = q0 + h;
-#ifdef RS_NO_REDO  // timing experiment only: results are wrong where the screen cannot decide
-        const bool redo = false;
-#else
-        const bool redo = (FULLH || (int)tx + q * THREADS < H) && (!PRE || act0) && !(margin[h] > sdl[q]);  // (NaN: recount)
-#endif
-        // The recount is done by the whole wavefront for one flagged lane at a time (almost
-        // always exactly one): its plane is broadcast, every lane tests one point per round and
-        // a ballot counts.  Left to the flagged lane alone it is a serial loop over the block
-        // that holds up the lane's wave - and behind it the workgroup's barrier - for ~n LDS
-        // round trips: measured 7 % of the kernel although only 2 % of the checks recount.
-        unsigned long long todo = __ballot(redo);
-        RS_COUNT(13, __popcll(todo));
-        while (todo) {
-          const int src = __ffsll((long long)todo) - 1;
-          todo &= todo - 1;
-          const double A = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fa[q]), src));
-          const double B = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fb[q]), src));
-          const double Cc = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fc[q]), src));
-          const double D = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fd[q]), src));
-          int c = 0;
-          for (int base = 0; base < n; base += 64) {
-            const int ii = base + (int)(tx & 63u);
-            const bool in = ii < n && plane_distance(A, B, Cc, D, lx[ii < n ? ii : 0], ly[ii < n ? ii : 0],
-                                                     lz[ii < n ? ii : 0]) < thr;
-            c += __popcll(__ballot(in));
-          }
-          if ((int)(tx & 63u) == src) cnt[q] = c;
+          sdl = sane ? (float)dprime : __int_as_float(0x7f800000);
         }
       }
     };
-    // pass 1: the first F groups (hypotheses 0 .. F * THREADS - 1), pass 2: the rest.
-    // (Measured with the exit disabled: the two-pass structure costs ~1.5 % against fitting all
-    // groups and scoring them in one loop; the exit removes 10 % of the VALU instructions on the
-    // benchmark scene.  Gating the two passes by block size - inside the kernel or as two
-    // launches - was slower than the plain two-pass kernel.)
-    constexpr int F0 = RS_FIRST_GROUPS > 0 ? RS_FIRST_GROUPS : (RS_FIRST_HYPS >= THREADS ? RS_FIRST_HYPS / THREADS : 1);
-    constexpr int F = HPL > F0 ? F0 : HPL;
-    // The lane's best hypothesis so far - maximum over the lane, then over the wave; lowest hypothesis index among
-    // the tied (cuda_ransac.py:125-146) - is taken over after every batch of groups, so that the planes of a
-    // batch are dead when the next one is fitted (RS_SUB groups per batch of pass 2).
+    // its count: the screen, then the exact recount where it cannot decide
+    auto score = [&](const bool act) {
+      float margin[1];
+      int c1[1] = {0};
+      RS_COUNT(14, 1);
+      RS_COUNT(15, n);
+      screen_group<1>(loc, n, &fa, &fb, &fc, &sto, nthr2, c1, margin);
+      cnt = c1[0];
+      // a hypothesis whose smallest |e| does not clear its bound is recounted exactly, by the whole wavefront
+      // for one flagged lane at a time (almost always exactly one): its plane is broadcast, every lane tests one
+      // point per round and a ballot counts.  Left to the flagged lane alone it is a serial loop over the block
+      // that holds up the lane's wave - and behind it the workgroup's barrier - for ~n LDS round trips.
+      const bool redo = act && !(margin[0] > sdl);  // (NaN: recount)
+      unsigned long long todo = __ballot(redo);
+      RS_COUNT(13, __popcll(todo));
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const double A = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fa), src));
+        const double B = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fb), src));
+        const double Cc = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fc), src));
+        const double D = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(fd), src));
+        int c = 0;
+        for (int base = 0; base < n; base += 64) {
+          const int ii = base + (int)(tx & 63u);
+          const bool in = ii < n && plane_distance(A, B, Cc, D, lx[ii < n ? ii : 0], ly[ii < n ? ii : 0],
+                                                   lz[ii < n ? ii : 0]) < thr;
+          c += __popcll(__ballot(in));
+        }
+        if ((int)(tx & 63u) == src) cnt = c;
+      }
+    };
+    // The lane's best hypothesis so far - lowest hypothesis index among the tied (cuda_ransac.py:125-146)
     // (one 32-bit key: (count + 1) << 10 | 1023 - index; count <= 255, index < 1024 <= H_max; 0 = no hypothesis)
-    static_assert(THREADS * HPL <= 1024, "hypothesis index in 10 bits");
     uint32_t best = 0;
     float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
-    auto take = [&](const int q0, const int nh) {
-#pragma unroll
-      for (int q = q0; q < q0 + nh; ++q) {
-        const int t = hyp_of(q);
-        if ((FULLH || t < H) && (!PRE || act0)) {
-          const uint32_t key = ((uint32_t)(cnt[q] + 1) << 10) | (uint32_t)(1023 - t);
-          if (key > best) {
-            best = key;
-            wa = fa[q]; wb = fb[q]; wc = fc[q]; wd = fd[q];
-          }
+    auto take = [&](const int t, const bool act) {
+      if (act) {
+        const uint32_t key = ((uint32_t)(cnt + 1) << 10) | (uint32_t)(1023 - t);
+        if (key > best) {
+          best = key;
+          wa = fa; wb = fb; wc = fc; wd = fd;
         }
       }
     };
-    bool skipped = false;  // pass 2 not evaluated (wave-uniform)
-    // (8 hypotheses per lane make this section 88 KB of straight-line code - 8 plane fits, 3 scoring loops - against
-    //  the 64 KB instruction cache two CUs share; as a rolled loop over batches of two groups, the packed sample
-    //  positions rotating through the slots, it is 16 KB and 5 % SLOWER: 3.76 against 3.57 ms on the same box.)
-    constexpr int REST = HPL > F ? HPL - F : 1;
-    constexpr int SUB0 = RS_SUB > 0 ? RS_SUB : (HPL >= 8 ? 3 : REST);
-    constexpr int SUB = SUB0 < REST ? SUB0 : REST;
-    constexpr int FULL_BATCHES = REST / SUB, TAIL = REST % SUB;
-    if constexpr (PRE) {
-      // ---- group 0 (hypotheses 0..63), exactly ----------------------------------------------------------------
-      t0 = (int)tx;
-      act0 = true;
-      load_pos(0);
-      fit(0);
-      RS_STAMP(1);
-      score(std::integral_constant<int, 1>{}, 0);
-      RS_STAMP(2);
-      take(0, 1);
-      // the best exact count so far (wave-uniform); a hypothesis that holds every point ends the block (see above)
-      int Lcur = (int)(wave_max_u32((uint32_t)cnt[0]));
-      skipped = RS_EARLY_EXIT && Lcur == n;
-      if (!skipped) {
-        // ---- prescreen of hypotheses 64..1023 -----------------------------------------------------------------
-        PreConst pc;
-        const bool elig = prescreen_constants(extent, ox, oy, oz, thr, pc) && blk_fast && !no_prescreen;
+    // ---- group 0 (hypotheses 0 .. THREADS-1) ----------------------------------------------------------------------
+    {
+      const int t = (int)tx;
+      const bool act = FULLH || t < H;
+      load_pos(t, act);
+      fit(t, act);
+      score(act);
+      take(t, act);
+    }
+    if constexpr (HPL > 1) {
+      // the best exact count so far (wave-uniform); a hypothesis that holds every point ends the block for this wave:
+      // every later hypothesis of the wave has a higher index (decided per wavefront, no barrier)
+      int Lcur = (int)wave_max_u32((FULLH || (int)tx < H) ? (uint32_t)cnt : 0u);
+      if (Lcur != n) {
+        // ---- prescreen of the wave's later hypotheses ---------------------------------------------------------------
         int S = 0;   // survivors queued (wave-uniform)
-        if (elig) {
-          RS_COUNT(4, 1);
+        bool use_list = false;
+        if constexpr (PRE) {
+          PreConst pc;
+          const bool elig = prescreen_constants(extent, ox, oy, oz, thr, pc) && blk_fast && !no_prescreen;
+          if (elig) {
+            RS_COUNT(4, 1);
 #pragma unroll 1
-          for (int qb = 1; qb < HPL; qb += 3) {
-            uint2 pe[3];
+            for (int qb = 1; qb < HPL; qb += 3) {
+              uint2 pe[3];
+              // (a last trio that reaches past the lane's hypotheses repeats the last one; copies are not queued)
+              auto hyp_a = [&](const int h) { return (int)tx + min(qb + h, HPL - 1) * THREADS; };
 #pragma unroll
-            for (int h = 0; h < 3; ++h) pe[h] = pos_tab[(size_t)n * (size_t)H + (size_t)((int)tx + (qb + h) * 64)];
-            float qa[3], qb_[3], qc[3], qto[3], qT2[3];
-            bool qok[3];
-            int qcnt[3];
+              for (int h = 0; h < 3; ++h)
+                pe[h] = pos_tab[(size_t)n * (size_t)H + (size_t)((FULLH || hyp_a(h) < H) ? hyp_a(h) : 0)];
+              float qa[3], qb_[3], qc[3], qto[3], qT2[3];
+              bool qok[3];
+              int qcnt[3];
+              uint32_t risk = 0;   // a draw of these hypotheses that the position table cannot vouch for (bits 16..21)
 #pragma unroll
-            for (int h = 0; h < 3; ++h) {
-              const uint32_t w0 = pe[h].x, w1 = pe[h].y;
-              const uint32_t g0 = w0 & 0xFFu, g1 = (w0 >> 8) & 0xFFu, g2 = (w0 >> 16) & 0xFFu, g3 = w0 >> 24,
-                             g4 = w1 & 0xFFu, g5 = (w1 >> 8) & 0xFFu;
-              // centroid and residuals in f64 on the global coordinates (ordinary roundings: util.py:35-52 up to
-              // 2^-50 G), rounded to f32 ONCE: a residual carries a RELATIVE error of 2^-24
-              const double sixth = 1.0 / 6.0;
-              const double X0 = lx[g0], X1 = lx[g1], X2 = lx[g2], X3 = lx[g3], X4 = lx[g4], X5 = lx[g5];
-              const double Y0 = ly[g0], Y1 = ly[g1], Y2 = ly[g2], Y3 = ly[g3], Y4 = ly[g4], Y5 = ly[g5];
-              const double Z0 = lz[g0], Z1 = lz[g1], Z2 = lz[g2], Z3 = lz[g3], Z4 = lz[g4], Z5 = lz[g5];
-              const double cxd = (((((X0 + X1) + X2) + X3) + X4) + X5) * sixth;
-              const double cyd = (((((Y0 + Y1) + Y2) + Y3) + Y4) + Y5) * sixth;
-              const double czd = (((((Z0 + Z1) + Z2) + Z3) + Z4) + Z5) * sixth;
-              float xx, xy, xz, yy, yz, zz;
-              {
-                const float rx = (float)(X0 - cxd), ry = (float)(Y0 - cyd), rz = (float)(Z0 - czd);
-                xx = rx * rx; xy = rx * ry; xz = rx * rz; yy = ry * ry; yz = ry * rz; zz = rz * rz;
+              for (int h = 0; h < 3; ++h) {
+                const uint32_t w0 = pe[h].x, w1 = pe[h].y;
+                f4 P[KS];
+#pragma unroll
+                for (int i = 0; i < KS; ++i) P[i] = loc[((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xFFu];
+                // centroid (only a centre near it is needed), residuals, covariance sums: util.py:35-57 in f32
+                const float inv_k = 1.0f / (float)KS;
+                float cx = P[0].x, cy = P[0].y, cz = P[0].z;
+#pragma unroll
+                for (int i = 1; i < KS; ++i) {
+                  cx += P[i].x;
+                  cy += P[i].y;
+                  cz += P[i].z;
+                }
+                cx *= inv_k;
+                cy *= inv_k;
+                cz *= inv_k;
+                float xx, xy, xz, yy, yz, zz;
+                {
+                  const float ax = P[0].x - cx, ay = P[0].y - cy, az = P[0].z - cz;
+                  xx = ax * ax; xy = ax * ay; xz = ax * az; yy = ay * ay; yz = ay * az; zz = az * az;
+                }
+#pragma unroll
+                for (int i = 1; i < KS; ++i) {
+                  const float ax = P[i].x - cx, ay = P[i].y - cy, az = P[i].z - cz;
+                  xx = fma32(ax, ax, xx); xy = fma32(ax, ay, xy); xz = fma32(ax, az, xz);
+                  yy = fma32(ay, ay, yy); yz = fma32(ay, az, yz); zz = fma32(az, az, zz);
+                }
+                // the three diagonal cofactors and the row the reference's branch takes (util.py:59-74)
+                const float dx = fma32(yy, zz, -(yz * yz)), dy = fma32(xx, zz, -(xz * xz)), dz = fma32(xx, yy, -(xy * xy));
+                const float cA = fma32(xz, yz, -(xy * zz)), cB = fma32(xy, yz, -(xz * yy)), cC = fma32(xy, xz, -(yz * xx));
+                const bool is_x = dx > dy && dx > dz;
+                const bool is_y = !is_x && dy > dz;
+                const float m1 = is_x ? dx : (is_y ? cA : cB);
+                const float m2 = is_x ? cA : (is_y ? dy : cC);
+                const float m3 = is_x ? cB : (is_y ? cC : dz);
+                const float ss = fma32(m3, m3, fma32(m2, m2, m1 * m1));
+                const float r = __builtin_amdgcn_rsqf(ss);
+                const float a = m1 * r, b = m2 * r, c = m3 * r;
+                qa[h] = a; qb_[h] = b; qc[h] = c;
+                float to = -fma32(c, cz, fma32(b, cy, a * cx));
+                asm volatile("" : "+v"(to));   // (materialised here: left symbolic, the negation is redone per point of the screen)
+                qto[h] = to;
+                // the bound
+                const float T = (xx + yy) + zz;
+                const float mu4 = fma32(fma32(pc.qa, T, pc.qb), T, pc.qc);
+                const float gap = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz) - __builtin_amdgcn_fmed3f(dx, dy, dz);
+                qok[h] = (ss * r > mu4) && (gap > mu4);   // (false for NaN)
+                risk |= w1;
+                const float thr_h = fma32(pc.e35, mu4 * r, pc.thrblk);
+                qT2[h] = thr_h * thr_h;
+                qcnt[h] = 0;
               }
-              auto acc = [&](const double X, const double Y, const double Z) {
-                const float rx = (float)(X - cxd), ry = (float)(Y - cyd), rz = (float)(Z - czd);
-                xx = fma32(rx, rx, xx); xy = fma32(rx, ry, xy); xz = fma32(rx, rz, xz);
-                yy = fma32(ry, ry, yy); yz = fma32(ry, rz, yz); zz = fma32(rz, rz, zz);
-              };
-              acc(X1, Y1, Z1); acc(X2, Y2, Z2); acc(X3, Y3, Z3); acc(X4, Y4, Z4); acc(X5, Y5, Z5);
-              // the centroid in the block's local coordinates (the screen's)
-              const float cx = (float)(cxd - ox), cy = (float)(cyd - oy), cz = (float)(czd - oz);
-              // the three diagonal cofactors and the row the reference's branch takes (util.py:59-74)
-              const float dx = fma32(yy, zz, -(yz * yz)), dy = fma32(xx, zz, -(xz * xz)), dz = fma32(xx, yy, -(xy * xy));
-              const float cA = fma32(xz, yz, -(xy * zz)), cB = fma32(xy, yz, -(xz * yy)), cC = fma32(xy, xz, -(yz * xx));
-              const bool is_x = dx > dy && dx > dz;
-              const bool is_y = !is_x && dy > dz;
-              const float m1 = is_x ? dx : (is_y ? cA : cB);
-              const float m2 = is_x ? cA : (is_y ? dy : cC);
-              const float m3 = is_x ? cB : (is_y ? cC : dz);
-              const float ss = fma32(m3, m3, fma32(m2, m2, m1 * m1));
-              const float r = __builtin_amdgcn_rsqf(ss);
-              const float a = m1 * r, b = m2 * r, c = m3 * r;
-              qa[h] = a; qb_[h] = b; qc[h] = c;
-              qto[h] = -fma32(c, cz, fma32(b, cy, a * cx));
-              // the bound
-              const float T = (xx + yy) + zz;
-              const float mu4 = prescreen_mu4(pc, T);
-              const float gap = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz) - __builtin_amdgcn_fmed3f(dx, dy, dz);
-              qok[h] = (ss * r > mu4) && (gap > mu4) && (w1 >> 16) == 0u;   // (false for NaN)
-              const float thr_h = fma32(pc.e35, mu4 * r, pc.thrblk);
-              qT2[h] = thr_h * thr_h;
-              qcnt[h] = 0;
-            }
-            screen_ub<3>(loc, n, qa, qb_, qc, qto, qT2, qcnt);
-            RS_COUNT(12, 3);
+              if (__any((risk >> 16) != 0u)) {   // (2^-20 per draw: such a hypothesis takes the exact path)
 #pragma unroll
-            for (int h = 0; h < 3; ++h) {
-              const bool sv = !(qok[h] && qcnt[h] <= Lcur);
-              const unsigned long long mk = __ballot(sv);
-              if (sv) {
-                const int pos = S + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
-                const uint32_t ub = qok[h] ? (uint32_t)qcnt[h] : 63u;
-                if (pos < PRE_LIST) s_surv[pos] = (uint16_t)((ub << 10) | (uint32_t)((int)tx + (qb + h) * 64));
+                for (int h = 0; h < 3; ++h) qok[h] = qok[h] && (pe[h].y >> 16) == 0u;
               }
-              S += __popcll(mk);
+              screen_ub<3>(loc, n, qa, qb_, qc, qto, qT2, qcnt);
+              RS_COUNT(12, 3);
+#pragma unroll
+              for (int h = 0; h < 3; ++h) {
+                const bool sv = !(qok[h] && qcnt[h] <= Lcur) && qb + h < HPL && (FULLH || hyp_a(h) < H);
+                const unsigned long long mk = __ballot(sv);
+                if (sv) {
+                  const int pos = S + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                  const uint32_t ub = (THREADS == 64 && qok[h]) ? (uint32_t)qcnt[h] : 63u;
+                  if (pos < PRE_LIST) s_surv[pos] = (uint16_t)((ub << 10) | (uint32_t)hyp_a(h));
+                }
+                S += __popcll(mk);
+              }
             }
+            RS_COUNT(2, S);
+            use_list = S <= PRE_LIST;
+            if (!use_list) RS_COUNT(5, 1);
           }
-          RS_COUNT(2, S);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // ---- the survivors (in index order) - or, without a prescreen, groups 1..15 - exactly ------------------------
-        const bool use_list = elig && S <= PRE_LIST;
-        if (elig && !use_list) RS_COUNT(5, 1);
+        // ---- the survivors (in index order) - or, without a prescreen, groups 1 .. HPL-1 - exactly ------------------
         const int nbatch = use_list ? ((S + 63) >> 6) : HPL - 1;
-        bool done = false;
 #pragma unroll 1
-        for (int bt = 0; bt < nbatch && !done; ++bt) {
+        for (int bt = 0; bt < nbatch; ++bt) {
+          int t;
+          bool act;
           if (use_list) {
-            const int idx = bt * 64 + (int)tx;
+            const int idx = bt * 64 + (int)(tx & 63u);
             const uint32_t ent = s_surv[idx < S ? idx : S - 1];
-            t0 = (int)(ent & 1023u);
-            // (the best count may have grown since the hypothesis was queued - by a hypothesis of lower index)
-            act0 = idx < S && (int)(ent >> 10) > Lcur;
-            if (!__any(act0)) continue;
+            t = (int)(ent & 1023u);
+            // (one wave per block: the best count may have grown since the hypothesis was queued - by a hypothesis of
+            //  lower index - beyond what its bound allows)
+            act = idx < S && (THREADS != 64 || (int)(ent >> 10) > Lcur);
           } else {
-            t0 = (int)tx + (bt + 1) * 64;
-            act0 = true;
+            t = (int)tx + (bt + 1) * THREADS;
+            act = FULLH || t < H;
           }
+          if (!__any(act)) continue;
           RS_COUNT(3, 1);
-          load_pos(0);
-          fit(0);
-          RS_STAMP(3);
-          score(std::integral_constant<int, 1>{}, 0);
-          take(0, 1);
-          RS_STAMP(4);
-          const int c0 = act0 ? cnt[0] : 0;
-          Lcur = max(Lcur, (int)wave_max_u32((uint32_t)c0));
-          done = RS_EARLY_EXIT && Lcur == n;   // (every later hypothesis has a higher index)
+          load_pos(t, act);
+          fit(t, act);
+          score(act);
+          take(t, act);
+          Lcur = max(Lcur, (int)wave_max_u32(act ? (uint32_t)cnt : 0u));
+          if (Lcur == n) break;   // (every later hypothesis of the wave has a higher index)
         }
       } else {
         RS_COUNT(9, 1);
       }
-    } else {
-#pragma unroll
-    for (int q = 0; q < F; ++q) load_pos(q);
-#pragma unroll
-    for (int q = 0; q < F; ++q) fit(q);
-    RS_STAMP(1);
-    if (HPL > F) {  // (PT) the first batch of pass 2 is on its way while pass 1 is scored
-#pragma unroll
-      for (int q = F; q < F + SUB && q < HPL; ++q) load_pos(q);
-    }
-    score(std::integral_constant<int, F>{}, 0);
-    RS_STAMP(2);
-    if (HPL > F) {
-      // does a hypothesis of pass 1 hold every point?  (every index of pass 2 is higher: nothing
-      // there can beat it, and a tie goes to the lower index).  Decided per wavefront, no
-      // barrier: the pass-2 hypotheses of THIS wave all have higher indices than its full
-      // hypothesis; a wave without one carries on (a barrier + shared flag measured no better).
-      bool full = false;
-#pragma unroll
-      for (int q = 0; q < F; ++q) full = full || ((FULLH || (int)tx + q * THREADS < H) && cnt[q] == n);
-      skipped = RS_EARLY_EXIT && __any(full);
-    }
-    take(0, F);
-    if (HPL > F) {
-      if (!skipped) {
-        bool done = false;  // (RS_EXIT_EVERY_BATCH) a hypothesis of an earlier batch of this wave holds every point
-        static_for<0, FULL_BATCHES>([&](auto bt) {
-          constexpr int q0 = F + decltype(bt)::value * SUB;
-          if (!done) {
-#pragma unroll
-            for (int q = q0; q < q0 + SUB; ++q) fit(q);
-#pragma unroll
-            for (int q = q0 + SUB; q < q0 + 2 * SUB && q < HPL; ++q) load_pos(q);
-            RS_STAMP(3);
-            score(std::integral_constant<int, SUB>{}, q0);
-            take(q0, SUB);
-            RS_STAMP(4);
-            if (RS_EXIT_EVERY_BATCH && q0 + SUB < HPL) {
-              // the same argument as after pass 1: every later hypothesis of this wave has a higher index
-              bool full = false;
-#pragma unroll
-              for (int q = q0; q < q0 + SUB; ++q) full = full || ((FULLH || (int)tx + q * THREADS < H) && cnt[q] == n);
-              done = __any(full);
-            }
-          } else {
-            RS_COUNT(12, SUB);
-          }
-        });
-        if (TAIL > 0 && !done) {
-          constexpr int q0 = F + FULL_BATCHES * SUB;
-#pragma unroll
-          for (int q = q0; q < HPL; ++q) fit(q);
-          RS_STAMP(3);
-          score(std::integral_constant<int, (TAIL > 0 ? TAIL : 1)>{}, q0);
-          take(q0, TAIL);
-          RS_STAMP(4);
-        } else if (TAIL > 0) {
-          RS_COUNT(12, TAIL);
-        }
-      } else {
-        RS_COUNT(9, 1);
-      }
-    }
     }
     const uint32_t wbest = wave_max_u32(best);
     float f0, f1, f2, f3;
@@ -1399,14 +1139,10 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
       s_pts[nbuf][1][tx] = ry;
       s_pts[nbuf][2][tx] = rz;
     }
-#if RS_SCREEN
     if (has_next)
       stage_local<THREADS>(nox, noy, noz, nxt, rx, ry, rz, s_loc[nbuf], s_wext[nbuf], s_wfast[nbuf],
                            W == 1 ? &ext_carry : nullptr, W == 1 ? &fast_carry : nullptr);
-#endif
-    RS_STAMP(5);
     __syncthreads();
-    RS_STAMP(6);
     if constexpr (W > 1) {
       gbest = s_wbest[par][0];
       int gw = 0;
@@ -1433,7 +1169,6 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
                                          lx[tx], ly[tx], lz[tx]);
       out.mask[(int64_t)cur.pstart + tx] = (dist < thr) ? 1 : 0;
     }
-    RS_STAMP(7);
     if (!has_next) break;
     cur = nxt;
     nxt = nxt2;
@@ -1441,10 +1176,9 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
     buf = nbuf;
     par ^= 1;
   }
-  RS_STAMP_FLUSH;
+  RS_COUNT_FLUSH;
 }
 
-#if RS_SCREEN
 // A block with more than THREADS-1 points (unsplit voxels - what Grid.map_leaf_points_cuda_ransac sees
 // when nobody called subdivide, as in the reference's own test - poses outside the scheme, large K):
 // the same screened scoring as k_ransac, the block taken in TILES of THREADS points staged in LDS as
@@ -1603,7 +1337,6 @@ __device__ __forceinline__ void ransac_block_tiled(const BlockDesc& d, int be,
     out.mask[pstart + i] = (plane_distance(a, bb, c, dd, pts[3 * (int64_t)i], pts[3 * (int64_t)i + 1],
                                            pts[3 * (int64_t)i + 2]) < thr) ? 1 : 0;
 }
-#endif
 
 // Blocks with more than THREADS-1 points (unsplit voxels, poses outside the scheme, large K):
 // points stay in global memory (wave-uniform scalar loads in the scoring loop).  The list of such
@@ -1618,22 +1351,16 @@ __global__ __launch_bounds__(THREADS) void k_ransac_big(const double* __restrict
                                                         int k, double thr, RansacOut out) {
   __shared__ unsigned long long s_best[THREADS / 64];
   __shared__ float s_plane[4];
-#if RS_SCREEN
   __shared__ f4 s_loc[THREADS];
   __shared__ float s_wext[THREADS / 64];
-#endif
   const uint32_t count = *big_count;
   for (uint32_t j = blockIdx.x; j < count; j += gridDim.x) {
     const int be = (int)big_list[j];
     const BlockDesc d = desc[be];
-#if RS_SCREEN
     if constexpr (KT < 0)
       ransac_block_global<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_best, s_plane);
     else
       ransac_block_tiled<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_loc, s_wext, s_best, s_plane);
-#else
-    ransac_block_global<THREADS, HPL, KT>(d, be, xyz, hyp, H, k, thr, out, s_best, s_plane);
-#endif
     __syncthreads();
   }
 }
@@ -1927,8 +1654,8 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   const size_t off_s = off_d + (size_t)nb * sizeof(BlockDesc);
   const size_t off_b = off_s + (size_t)nb * sizeof(BlockDesc);
   const size_t off_c = (off_b + (size_t)nb * 4 + 31) & ~(size_t)31;
-  // (position table of the H > 256, k <= 6 instances: 256 sizes x H entries of 8 bytes)
-  const bool use_tab = RS_POS_TABLE && !any_k && H > 256 && k >= 3 && k <= 6;
+  // (position table of the instances with compile-time k = 3 .. 6: 256 sizes x H entries of 8 bytes)
+  const bool use_tab = !any_k && k >= 3 && k <= 6 && (H > 256 || k == 6);
   const size_t off_t = (off_c + RC_WORDS * 4 + 31) & ~(size_t)31;
   OCTL_TRY(devbuf_reserve(ctx, scratch, off_t + (use_tab ? (size_t)256 * (size_t)H * sizeof(uint2) : 0)));
   char* base = static_cast<char*>(scratch.p);
@@ -2008,10 +1735,7 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     if (nb * 2 <= slots) waves_per_block = 4;
     else if (nb <= 6 * slots) waves_per_block = 2;
   }
-#if RS_SIDE_STREAM
   // (max_block: no block of the launch holds more points - the instances for larger blocks are not launched at all)
-  // (only the fused preparation kernel checks the promise on the device: the A/B chain launches every instance)
-  if (!fused) max_block = INT64_MAX;
   const bool need_small = max_block >= RS_TINY_THREADS, need_mid = max_block >= RS_SMALL_THREADS,
              need_big = any_k || max_block >= threads;
   // (the side stream is gated in and out with events: only when one of the instances below will go there)
@@ -2023,88 +1747,72 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     side = ctx->self_stream;
     on_side = true;
   }
-#endif
   const int no_prescreen = ctx->opt.no_ransac_prescreen ? 1 : 0;
   // (LO, HI: device words holding the launch's part [lo, hi) of the size-sorted list; LO nullptr = from the front)
-#define OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, LO, HI, PT, ST)                         \
+#define OCTL_RANSAC_RANGE(THREADS, HPL, KT, PER_CU, LO, HI, PT, ST)                              \
   do {                                                                                           \
     const unsigned g = (unsigned)std::min<int64_t>(nb, (int64_t)cus * (PER_CU));                 \
     if (H == (THREADS) * (HPL))                                                                  \
-      OCTL_LAUNCH((k_ransac<THREADS, HPL, KT, ABL, true, PT>), dim3(g), dim3(THREADS), 0, ST, \
+      OCTL_LAUNCH((k_ransac<THREADS, HPL, KT, true, PT>), dim3(g), dim3(THREADS), 0, ST,         \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
                          hyp_dev, H, k, thr, out, (const uint2*)pos_tab, no_prescreen);           \
     else                                                                                         \
-      OCTL_LAUNCH((k_ransac<THREADS, HPL, KT, ABL, false, PT>), dim3(g), dim3(THREADS), 0, ST, \
+      OCTL_LAUNCH((k_ransac<THREADS, HPL, KT, false, PT>), dim3(g), dim3(THREADS), 0, ST,        \
                          xyz_dev, (const BlockDesc*)sdesc, (const uint32_t*)(LO), (const uint32_t*)(HI), \
                          hyp_dev, H, k, thr, out, (const uint2*)pos_tab, no_prescreen);           \
   } while (0)
-#define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, ABL, PER_CU) \
-  OCTL_RANSAC_RANGE(THREADS, HPL, KT, ABL, PER_CU, nullptr, counters + RC_SORTED, false, st)
+  // one instance over the whole sorted list (H <= 256: one hypothesis per lane; other sample sizes)
+#define OCTL_RANSAC_LAUNCH(THREADS, HPL, KT, PER_CU, PT) \
+  OCTL_RANSAC_RANGE(THREADS, HPL, KT, PER_CU, nullptr, counters + RC_SORTED, PT, st)
   // H > 256: a block of n points is worked on by one workgroup, and every wave of it pays the per-block work
   // (staging, reduction, barrier, the winner's mask) whatever n is.  Three instances therefore share the size-sorted
   // list, split at the device-side starts of size classes RS_SMALL_THREADS - 1 and RS_TINY_THREADS - 1:
   //   n < RS_TINY_THREADS (64)     ONE wave x 16 hypotheses per lane - the bulk: a leaf has at most K points
   //   n < RS_SMALL_THREADS (128)   two waves x 8
   //   n < RS_BIG_THREADS (256)     four waves x 4
-  // (four -> two waves per block: -8 % on the benchmark scene; one wave, which needs the position table: -3 % more).
-#if RS_POS_TABLE && RS_TINY_THREADS > 0 && RS_TINY_THREADS < RS_SMALL_THREADS
-#define RS_SMALL_END (counters + RC_START + RS_TINY_THREADS - 1)
-#define OCTL_RANSAC_TINY(KT, ABL)                                                                                \
-  do {                                                                                                           \
-    HIP_TRY(ctx, hipGetLastError());                                                                             \
-    OCTL_RANSAC_RANGE(RS_TINY_THREADS, (1024 / RS_TINY_THREADS), KT, ABL, RS_TINY_PER_CU,                        \
-                      counters + RC_START + RS_TINY_THREADS - 1, counters + RC_SORTED, true, st);                \
-  } while (0)
-#else
-#define RS_SMALL_END (counters + RC_SORTED)
-#define OCTL_RANSAC_TINY(KT, ABL) do {} while (0)
-#endif
-#if RS_SMALL_THREADS > 0 && RS_SMALL_THREADS < RS_BIG_THREADS
-#define OCTL_RANSAC_SPLIT(KT, ABL)                                                                               \
+  // (four -> two waves per block: -8 % on the benchmark scene; one wave: -3 % more; a launch with few blocks puts
+  //  every block on two or four waves: waves_per_block above.)
+#define OCTL_RANSAC_SPLIT(KT)                                                                                    \
   do {                                                                                                           \
     if (waves_per_block == 4) {                                                                                  \
-      OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr, counters + RC_SORTED,           \
-                        (RS_POS_TABLE != 0), st);                                                                \
+      OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, RS_PER_CU, nullptr, counters + RC_SORTED, true, st);     \
     } else if (waves_per_block == 2) {                                                                           \
       if (need_mid)                                                                                              \
-        OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                               \
-                          counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                \
+        OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, RS_PER_CU, nullptr,                                    \
+                          counters + RC_START + RS_SMALL_THREADS - 1, true, side);                               \
       HIP_TRY(ctx, hipGetLastError());                                                                           \
-      OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                   \
-                        counters + RC_START + RS_SMALL_THREADS - 1, counters + RC_SORTED, (RS_POS_TABLE != 0), st); \
+      OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, RS_SMALL_PER_CU,                        \
+                        counters + RC_START + RS_SMALL_THREADS - 1, counters + RC_SORTED, true, st);             \
     } else {                                                                                                     \
       if (need_mid)                                                                                              \
-        OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU, nullptr,                               \
-                          counters + RC_START + RS_SMALL_THREADS - 1, (RS_POS_TABLE != 0), side);                \
+        OCTL_RANSAC_RANGE(RS_BIG_THREADS, RS_BIG_HPL, KT, RS_PER_CU, nullptr,                                    \
+                          counters + RC_START + RS_SMALL_THREADS - 1, true, side);                               \
       HIP_TRY(ctx, hipGetLastError());                                                                           \
       if (need_small)                                                                                            \
-        OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, ABL, RS_SMALL_PER_CU,                 \
-                          counters + RC_START + RS_SMALL_THREADS - 1, RS_SMALL_END, (RS_POS_TABLE != 0), side);  \
-      OCTL_RANSAC_TINY(KT, ABL);                                                                                 \
+        OCTL_RANSAC_RANGE(RS_SMALL_THREADS, (1024 / RS_SMALL_THREADS), KT, RS_SMALL_PER_CU,                      \
+                          counters + RC_START + RS_SMALL_THREADS - 1, counters + RC_START + RS_TINY_THREADS - 1, \
+                          true, side);                                                                           \
+      HIP_TRY(ctx, hipGetLastError());                                                                           \
+      OCTL_RANSAC_RANGE(RS_TINY_THREADS, (1024 / RS_TINY_THREADS), KT, RS_TINY_PER_CU,                           \
+                        counters + RC_START + RS_TINY_THREADS - 1, counters + RC_SORTED, true, st);              \
     }                                                                                                            \
   } while (0)
-#else
-#define OCTL_RANSAC_SPLIT(KT, ABL) OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, KT, ABL, RS_PER_CU)
-#endif
   if (any_k) {
     // (nothing was put on the sorted list)
   } else if (H <= 64) {
-    if (k == 6) OCTL_RANSAC_LAUNCH(64, 1, 6, 0, 16); else OCTL_RANSAC_LAUNCH(64, 1, 0, 0, 8);
+    if (k == 6) OCTL_RANSAC_LAUNCH(64, 1, 6, 16, true); else OCTL_RANSAC_LAUNCH(64, 1, 0, 8, false);
   } else if (H <= 256) {
-    if (k == 6) OCTL_RANSAC_LAUNCH(256, 1, 6, 0, 8); else OCTL_RANSAC_LAUNCH(256, 1, 0, 0, 4);
+    if (k == 6) OCTL_RANSAC_LAUNCH(256, 1, 6, 8, true); else OCTL_RANSAC_LAUNCH(256, 1, 0, 4, false);
   } else {
-    // (timing experiments - no fit / no scoring, results meaningless - exist only in builds made with
-    //  -DRS_ABLATE=1|2, tools/build_variant.sh; the shipped library has no such switch)
-    if (k == 6) OCTL_RANSAC_SPLIT(6, RS_ABLATE);
-    // the other small sample sizes also get compile-time k (sample arrays in registers; the generic
-    // instantiation indexes them at run time and spills)
-    else if (k == 5) OCTL_RANSAC_SPLIT(5, 0);
-    else if (k == 4) OCTL_RANSAC_SPLIT(4, 0);
-    else if (k == 3) OCTL_RANSAC_SPLIT(3, 0);
-    else OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 0, 0, 2);
+    // the small sample sizes get compile-time k (sample arrays in registers; the generic
+    // instantiation indexes them at run time)
+    if (k == 6) OCTL_RANSAC_SPLIT(6);
+    else if (k == 5) OCTL_RANSAC_SPLIT(5);
+    else if (k == 4) OCTL_RANSAC_SPLIT(4);
+    else if (k == 3) OCTL_RANSAC_SPLIT(3);
+    else OCTL_RANSAC_LAUNCH(RS_BIG_THREADS, RS_BIG_HPL, 0, 2, false);
   }
 #undef OCTL_RANSAC_SPLIT
-#undef OCTL_RANSAC_TINY
 #undef OCTL_RANSAC_LAUNCH
 #undef OCTL_RANSAC_RANGE
   HIP_TRY(ctx, hipGetLastError());
@@ -2222,7 +1930,7 @@ static int debug_plane_arith(octl_ctx* ctx, const double* num3, const double* de
   return rc == OCTL_OK ? OCTL_OK : octl_set_error(ctx, rc, "octl_debug_plane_arith failed");
 }
 
-#if defined(RS_STAMPS) || defined(RS_COUNTS)
+#ifdef RS_COUNTS
 extern "C" int octl_debug_rs_stamps(octl_ctx* ctx, unsigned long long out[16], int reset) {
   if (!ctx || !out) return OCTL_E_INVALID;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -6,7 +6,7 @@ outliers; shape follows the reference's own test generator, test/grid/test_cuda_
 
 import numpy as np
 
-__all__ = ["uniform_cloud", "planar_cloud"]
+__all__ = ["uniform_cloud", "planar_cloud", "sweep_order"]
 
 
 def uniform_cloud(n: int, dims=(32, 32, 32), seed: int = 0, voxels=None) -> np.ndarray:
@@ -72,3 +72,33 @@ def sparse_scene(n: int, dims=(256, 256, 32), seed: int = 7, cluster_fraction: f
     pts = np.vstack([sheet, blob])
     rng.shuffle(pts)
     return np.ascontiguousarray(pts)
+
+
+def sweep_order(points: np.ndarray, seed: int = 0, run_min: int = 8, run_max: int = 64, edge: float = 1.0) -> np.ndarray:
+    """The same points in the order a rotating LiDAR delivers them: RUNS of run_min .. run_max consecutive points that
+    fall into one top-level voxel (a beam sweeping over a surface), the runs themselves in random order.  (The
+    benchmark's clouds are shuffled point by point - the partition's worst case; the reference's own generator emits
+    voxel after voxel, test/grid/test_cuda_ransac.py:9-24.)"""
+    pts = np.asarray(points, dtype=np.float64)
+    n = len(pts)
+    rng = np.random.default_rng(seed)
+    q = np.floor(pts / edge).astype(np.int64)
+    q -= q.min(axis=0)
+    dims = q.max(axis=0) + 1
+    lin = (q[:, 0] * dims[1] + q[:, 1]) * dims[2] + q[:, 2]
+    by_voxel = np.argsort(lin, kind="stable")
+    lin_sorted = lin[by_voxel]
+    # cut the voxel-sorted sequence into runs: at every voxel boundary and after a random length inside a voxel
+    cut = np.zeros(n + 1, dtype=bool)
+    cut[0] = cut[n] = True
+    cut[1:n] = lin_sorted[1:] != lin_sorted[:-1]
+    pos = 0
+    lengths = rng.integers(run_min, run_max + 1, size=n // run_min + 2)
+    marks = np.cumsum(lengths)
+    marks = marks[marks < n]
+    cut[marks] = True        # (a run may end early at a voxel boundary: still between 1 and run_max points of one voxel)
+    starts = np.flatnonzero(cut[:-1])
+    ends = np.flatnonzero(cut[1:]) + 1
+    order = rng.permutation(len(starts))
+    idx = np.concatenate([by_voxel[starts[r]:ends[r]] for r in order]) if n else by_voxel
+    return np.ascontiguousarray(pts[idx])

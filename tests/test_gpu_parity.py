@@ -2984,3 +2984,103 @@ def test_ransac_prescreen_never_changes_a_result(kind):
     set_option("NO_RANSAC_PRESCREEN", 0)
     if kind in ("planar", "two_planes", "noise"):
         assert (o_index >= 64).any()     # winners beyond the first group exist: the survivors' path decides them
+
+
+def _input_forms(pts64):
+    """The same cloud as the reference's callers may hand it over (the reference upcasts everything to f64:
+    internal/voxel.py:81-83, octree/octree.py:100): values are f32-representable so that every form holds the same
+    numbers."""
+    strided = np.zeros((len(pts64), 7), dtype=np.float64)
+    strided[:, 1::2] = pts64
+    wide = np.zeros((2 * len(pts64), 3), dtype=np.float64)
+    wide[::2] = pts64
+    return {
+        "f64_c": np.ascontiguousarray(pts64),
+        "f32": pts64.astype(np.float32),
+        "f64_fortran": np.asfortranarray(pts64),
+        "strided_columns": strided[:, 1::2],
+        "strided_rows": wide[::2],
+        "reversed_view": pts64[::-1][::-1],
+        "list": pts64.tolist(),
+        "f16_upcast_f32": pts64.astype(np.float32).astype(np.float64).astype(np.float32),
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["f32", "f64_fortran", "strided_columns", "strided_rows", "reversed_view", "list", "f16_upcast_f32"])
+def test_input_dtypes_and_layouts_through_the_drop_in_classes(form):
+    """Grid / Octree / OctreeManager .insert_points and CudaRansac.evaluate take whatever array-like the reference's
+    callers pass - f32, Fortran order, strided views, Python lists - and must give the results of the f64 C-contiguous
+    cloud (which the oracle pins)."""
+    from octreelib_amd import MaxPoints
+    from octreelib_amd.grid import Grid, GridConfig
+    from octreelib_amd.octree import Octree, OctreeConfig
+    from octreelib_amd.octree_manager import OctreeManager
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import octree_np as onp
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(3)
+    pts = (rng.random((6000, 3)) * 4.0 - 1.0).astype(np.float32).astype(np.float64)   # (negatives too; f32-exact values)
+    pts = np.unique(pts, axis=0)
+    rng.shuffle(pts)
+    forms = _input_forms(pts)
+    base, alt = forms["f64_c"], forms[form]
+    if form != "list":
+        assert not (isinstance(alt, np.ndarray) and alt.dtype == np.float64 and alt.flags.c_contiguous and form != "reversed_view")
+    K = 16
+
+    def leaves_of(obj, getter):
+        index = index_map(pts)
+        return canon_from_list(views_table(getter(obj), index))
+
+    # Grid
+    tabs = []
+    for cloud in (base, alt):
+        g = Grid(GridConfig(voxel_edge_length=1))
+        g.insert_points(0, cloud)
+        g.subdivide([MaxPoints(K)])
+        tabs.append((leaves_of(g, lambda o: o.get_leaf_points(0)), g.n_nodes(0), g.n_leaves(0), g.n_points(0)))
+        assert g.get_points(0).dtype == np.float64
+    assert tabs[0][1:] == tabs[1][1:]
+    assert_same_leaves(tabs[0][0], tabs[1][0])
+    og = onp.OGrid(1)
+    og.insert_points(0, base)
+    og.subdivide(K)
+    assert_same_leaves(tabs[1][0], _oracle_pose_table(og, 0))
+    # Octree and OctreeManager over the cube [-1, 3)^3
+    cube = pts
+    otabs = []
+    for cloud in (base, alt):
+        o = Octree(OctreeConfig(), np.array([-1.0, -1.0, -1.0]), 4.0)
+        o.insert_points(cloud)
+        o.subdivide([MaxPoints(K)])
+        m = OctreeManager(Octree, OctreeConfig(), np.array([-1.0, -1.0, -1.0]), 4.0)
+        m.insert_points(0, cloud)
+        m.subdivide([MaxPoints(K)])
+        otabs.append((leaves_of(o, lambda x: x.get_leaf_points()), o.n_nodes, o.n_leaves, o.n_points,
+                      leaves_of(m, lambda x: x.get_leaf_points(True, 0)), m.n_nodes(0), m.n_leaves(0)))
+    assert otabs[0][1:4] == otabs[1][1:4] and otabs[0][5:] == otabs[1][5:]
+    assert_same_leaves(otabs[0][0], otabs[1][0])
+    assert_same_leaves(otabs[0][4], otabs[1][4])
+    assert_same_leaves(otabs[0][0], otabs[0][4])
+    ot = onp.OTree(np.array([-1.0, -1.0, -1.0]), np.float64(4))
+    ot.insert_points(cube)
+    ot.subdivide(K)
+    assert_same_leaves(otabs[1][0], canon_from_list(onp.tree_leaf_table(ot)))
+    assert otabs[1][1:4] == (ot.n_nodes, ot.n_leaves, ot.n_points)
+    # CudaRansac.evaluate: cloud and block sizes in the same forms
+    sizes = rng.integers(0, 70, 120).astype(np.int32)
+    cloud = pts[: int(sizes.sum())]
+    cforms = _input_forms(cloud)
+    np.random.seed(5)
+    op = CudaRansac(threshold=0.05, hypotheses_number=1024, initial_points_number=6)
+    want = op.evaluate(cforms["f64_c"], sizes, details=True)
+    size_forms = {"f32": sizes.astype(np.float32), "list": sizes.tolist(), "strided_rows": np.repeat(sizes, 2)[::2],
+                  "f64_fortran": sizes.astype(np.int64)}
+    got = op.evaluate(cforms[form], size_forms.get(form, sizes), details=True)
+    for a, b in zip(want, got):
+        assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+    o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud, sizes, op.random_hypotheses, 0.05, details=True)
+    assert np.array_equal(got[0], o_mask) and np.array_equal(got[2], o_count) and np.array_equal(got[3], o_index)
+    assert np.array_equal(got[1].view(np.uint32), o_plane.view(np.uint32))
