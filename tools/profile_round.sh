@@ -10,7 +10,7 @@
 # 3. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters), as MI355X_MICROARCH.md asks
 # 4. the same kernel-stats pass on the uniform scene               -> profiles/TAG_uniform_kernel_stats.csv
 # then tools/summarize_profiles.py condenses them into profiles/TAG_*.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$PWD}
 HEAD="--no-secondary --no-cpu-baseline"
 cd /tmp && export TMPDIR=/tmp
@@ -26,6 +26,11 @@ python3 tools/probes/step_timeline.py gpurun_out/prof_$TAG planar 4 > profiles/$
 if [ -f build/variants/rs_counts.so ]; then
   OCTREELIB_AMD_LIB=$R/build/variants/rs_counts.so python3 tools/rs_counts.py > gpurun_out/rs_counts.log 2>&1 && cp gpurun_out/rs_counts.json profiles/${TAG}_ransac_counts.json
 fi
+# the opcode ledger of the benchmarked k_ransac instance: static histogram by phase x the execution counts above
+python3 tools/ransac_isa.py profiles/${TAG}_ransac_counts.json > profiles/${TAG}_ransac_isa.txt 2> gpurun_out/ransac_isa.err
+# one step of a dense 100 k-point scan, kernel by kernel
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_small -- python3 $R/bench.py --workload small --steps 20 --warmup 3 > /dev/null 2>&1)
+python3 tools/probes/step_timeline.py gpurun_out/prof_${TAG}_small planar 40 > profiles/${TAG}_small_scan_timeline.txt 2>&1
 cp $(ls gpurun_out/prof_${TAG}_uniform/*/*kernel_stats.csv | head -1) profiles/${TAG}_uniform_kernel_stats.csv
 # 5. the two largest BASELINE configs alone (bench.py --workload c4 / c5shard): kernel stats + FETCH / WRITE passes
 #    -> profiles/TAG_c4_*, profiles/TAG_c5shard_*
