@@ -1587,28 +1587,21 @@ def valu_executed(ransac_ms_live):
         "f64_issue_cycles_share": (4.0 * f64 / simd_cycles) if simd_cycles else None,
         "f64_share_of_valu_instructions": f64 / all_valu if all_valu else None,
         "f32_share_of_valu_instructions": f32 / all_valu if all_valu else None,
-        "note": "wave-level instruction counts of the tracked profile (all k_ransac instances of a step); issue "
-                "effective_clock_GHz (GRBM_GUI_ACTIVE / 8 / time, the SQ pass) under-reads this kernel - with it VALU busy "
-                "exceeds 1 and an instruction would cost 3.5 cycles; the kernel's own clock (in_kernel_clock_GHz: s_memtime "
-                "over s_memrealtime in the counting build) is near nominal, and valu_issue_time = all VALU wave "
-                "instructions x 4 cycles / 1024 SIMDs / that clock reproduces the launch time: the kernel is VALU-ISSUE "
-                "bound, every instruction of any type costs the same four cycles, the chip is not throttling",
+        "note": "wave-level instruction counts of the tracked profile (all k_ransac instances of a step).  "
+                "effective_clock_GHz (GRBM_GUI_ACTIVE / 8 / time, the SQ pass) under-reads this kernel; in_kernel_clock_GHz "
+                "(s_memtime over s_memrealtime in the counting build) is the clock it holds.  Round 6: most instructions "
+                "are f32 / integer ones of the prescreen (3.2-3.7 SIMD cycles per wave instruction in isolation, "
+                "profiles/r05_pkfma_probe.txt), the f64 ones of the exact plane fits (4.5-4.9 cycles) are a seventh of "
+                "round 5's - the opcode ledger by phase is profiles/r06_ransac_isa.txt",
     }
     if cnt and cnt.get("in_kernel_clock_GHz"):
-        # the kernel's OWN clock (s_memtime over s_memrealtime inside the counting build): with it the launch time
-        # follows from the instruction count alone - 4 cycles per 64-lane VALU instruction of any type
-        ck = cnt["in_kernel_clock_GHz"]
-        t_issue = 4.0 * all_valu / 1024.0 / (ck * 1e9)
-        out.update({"in_kernel_clock_GHz": ck, "valu_issue_time_ms_at_in_kernel_clock": t_issue * 1e3,
-                    "valu_issue_time_over_live_launch_time": t_issue * 1e3 / ransac_ms_live if ransac_ms_live else None})
+        out["in_kernel_clock_GHz"] = cnt["in_kernel_clock_GHz"]
     if cnt:
-        out.update({
-            "fraction_blocks_leaving_after_the_first_64_hypotheses": cnt["fraction_blocks_leaving_after_pass_1"],
-            "fraction_plane_fits_executed": cnt["fraction_plane_fits_executed"],
-            "fraction_pairs_scored_by_f32_screen": cnt["fraction_pairs_scored"],
-            "fraction_hypotheses_recounted_in_f64": cnt["fraction_hypotheses_recounted"],
-            "counts_profile": _tracked("ransac_counts.json"),
-        })
+        out.update({k: cnt[k] for k in (
+            "fraction_blocks_leaving_after_group_0", "fraction_blocks_with_prescreen", "hypotheses_prescreened_per_block",
+            "survivors_per_prescreened_block", "survivor_batches_per_block", "fraction_plane_fits_executed_exactly",
+            "fraction_pairs_scored", "fraction_hypotheses_recounted") if k in cnt})
+        out["counts_profile"] = _tracked("ransac_counts.json")
     return out
 
 

@@ -209,5 +209,21 @@ if cnt:
         tot_all += tot
         print(c.ljust(38) + "".join(f"{v / 1e6:12.1f}" for v in row) + f"{tot / 1e6:12.1f}")
     print("VALU total".ljust(38) + " " * (12 * len(phases)) + f"{tot_all / 1e6:12.1f}")
-    print("(the loop-body share of a class is taken as the phase's average: an estimate - the measured total is "
-          "SQ_INSTS_VALU of profiles/rNN_sq_counters.json)")
+    print("(the loop-body share of a class is taken as the phase's average: an estimate, high on the classes that sit "
+          "outside the loops)")
+    # the counters' own totals beside the estimate (tools/profile_round.sh: the SQ pass and the VALU-mix pass)
+    tag = os.path.basename(sys.argv[1]).split("_")[0]
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.json")))["kernels"]
+        mix = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_valu_mix.json")))["kernels"]
+        key = next(k for k in sq if k.startswith("k_ransac<64"))
+        m = mix[key]
+        f64 = m["add_f64"] + m["mul_f64"] + m["fma_f64"] + m["trans_f64"]
+        f32 = m["add_f32"] + m["mul_f32"] + m["fma_f32"]
+        allv = sq[key]["wave_valu_instructions"]
+        print()
+        print(f"MEASURED per launch (profiles/{tag}_sq_counters.json, {tag}_valu_mix.json): all VALU {allv / 1e6:.1f} M wave "
+              f"instructions; f64 {f64 / 1e6:.1f} M, f32 {f32 / 1e6:.1f} M, int32 {m['int32'] / 1e6:.1f} M, everything else "
+              f"{(allv - f64 - f32 - m['int32']) / 1e6:.1f} M.  Estimate / measured: all {tot_all / allv:.2f}")
+    except (OSError, KeyError, StopIteration):
+        pass
