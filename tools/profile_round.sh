@@ -46,7 +46,7 @@ if [ -z "$OCTL_PROFILE_HEADLINE_ONLY" ]; then
 fi
 # 6. the full default bench.py run LAST: its counter figures (roofline.traffic, roofline_build) are read from the
 #    profiles/TAG_* files the passes above have just written
-cd /tmp && python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err || exit 1
-cd $R && cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
+cd /tmp && python3 $R/bench.py --detail $R/gpurun_out/${TAG}_bench_detail.json > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err || exit 1
+cd $R && cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json && cp gpurun_out/${TAG}_bench_detail.json profiles/${TAG}_bench_detail.json
 # profiles/ is not writable back from the box: the condensed files are copied to gpurun_out/ too
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
