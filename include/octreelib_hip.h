@@ -361,6 +361,18 @@ int octl_device_identity(octl_ctx* ctx, char pci_bus_id[32], uint8_t uuid[16], i
  * context.  0 = the shipped behaviour.  The reference has no counterpart.                                     */
 int octl_debug_set_option(octl_ctx* ctx, const char* name, int64_t value);
 
+/* The key geometry of a single-pass bucket build as a pure HOST function (no context, no GPU: the same code the
+ * device evaluates, csrc/bucket_build.hip: geom_from_box): for a cloud whose true voxel box is tb = {min x, y, z,
+ * max x, y, z}, `want` buckets wanted (a power of two), n_alive points, `target` points per bucket and `margin`
+ * voxels of slack, it returns the padded box of the linear keys, the bucket width in keys, the bucket count - and
+ * *mismatches = the number of keys of that box for which the kernels' division-free bucket index
+ * (trunc(fma(key, 1/width, 0.5/width))) differs from key / width (must be 0).  *valid = 0 with the library's reason
+ * code when the box is not a single-pass case.  Replaces nothing in the reference, which rebuckets every call from
+ * scratch (grid/grid.py:72-90); tests/test_cpu_abi.py drives it.                                              */
+int octl_debug_key_geometry(const int32_t tb[6], uint64_t want, int64_t n_alive, uint32_t target, int32_t margin,
+                            int32_t bb_out[6], uint32_t* width, uint32_t* n_buckets, int32_t* valid,
+                            int64_t* mismatches);
+
 /* ---- test hooks for the device-wide primitives (host in / host out) ----------------------- */
 int octl_debug_exclusive_scan(octl_ctx* ctx, const uint32_t* in, int64_t n, uint32_t* out,
                               uint32_t* total);

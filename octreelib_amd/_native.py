@@ -106,6 +106,7 @@ SIGNATURES = {
     "octl_debug_spec_finish": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "octl_debug_fail_alloc": (C.c_int, [_i64, _pi64]),
     "octl_debug_set_option": (C.c_int, [_p, C.c_char_p, _i64]),
+    "octl_debug_key_geometry": (C.c_int, [_p, C.c_uint64, _i64, C.c_uint32, _i32, _p, _p, _p, _p, _p]),
     "octl_route_get_gidx": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_comm_allreduce_i64": (C.c_int, [_p, _p, _i32]),
     "octl_dev_alloc": (C.c_int, [_p, _i64, C.POINTER(_p)]),

@@ -3009,3 +3009,36 @@ extern "C" int octl_debug_bb_stamps(octl_ctx* ctx, unsigned long long out[16], i
   return OCTL_OK;
 }
 #endif
+
+
+// ---- test hook: the key geometry on the host (include/octreelib_hip.h) ------------------------------------------
+extern "C" int octl_debug_key_geometry(const int32_t tb[6], uint64_t want, int64_t n_alive, uint32_t target,
+                                       int32_t margin, int32_t bb_out[6], uint32_t* width, uint32_t* n_buckets,
+                                       int32_t* valid, int64_t* mismatches) {
+  if (!tb || !bb_out || !width || !n_buckets || !valid || !mismatches || margin < 0 || margin > 64)
+    return OCTL_E_INVALID;
+  GeomAsk ask;
+  ask.want = want;
+  ask.n_alive = n_alive;
+  ask.target = target;
+  ask.margin = margin;
+  LinParams base;
+  std::memset(&base, 0, sizeof(base));
+  base.L = 1.0;
+  GeomDev g;
+  geom_from_box(tb, false, ask, base, g);
+  for (int a = 0; a < 6; ++a) bb_out[a] = g.bb[a];
+  *valid = g.valid ? 1 : -(int32_t)g.reason;
+  *width = 0;
+  *n_buckets = 0;
+  *mismatches = 0;
+  if (!g.valid) return OCTL_OK;
+  const uint64_t R = (uint64_t)(g.bb[3] - g.bb[0] + 1) * (uint64_t)(g.bb[4] - g.bb[1] + 1) * (uint64_t)(g.bb[5] - g.bb[2] + 1);
+  *width = g.lp.width;
+  *n_buckets = (uint32_t)((R + g.lp.width - 1) / g.lp.width);
+  int64_t bad = 0;
+  for (uint64_t lin = 0; lin < R; ++lin)
+    bad += (uint32_t)std::fma((double)lin, g.lp.winv, g.lp.whalf) != (uint32_t)(lin / g.lp.width);
+  *mismatches = bad;
+  return OCTL_OK;
+}

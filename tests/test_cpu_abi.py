@@ -203,3 +203,54 @@ def test_bench_plan_touches_no_gpu_and_fits_the_drivers_budget():
                          capture_output=True, text=True, timeout=120)
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["ranks"] == 4 and d["points_per_rank"] == 2_500_000 and d["resident_clouds_per_rank"] == 3
+
+
+def test_key_geometry_pads_the_box_and_divides_exactly():
+    """The geometry of a single-pass bucket build (csrc/bucket_build.hip: geom_from_box, the same code on the host and
+    on the device) through its host-side test hook: the keys' box is the true box padded by the margin, buckets are
+    runs of `width` keys with no more buckets than the tables hold, and the kernels' division-free bucket index is
+    key / width for EVERY key of the box (grid.py:72-90 rebuckets from scratch per call; here a geometry must only
+    depend on the true box)."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+
+    lib = nat.load()
+    rng = np.random.default_rng(0)
+    cases = [((0, 0, 0, 31, 31, 31), 4096, 10_000_000, 1), ((0, 0, 0, 6, 6, 6), 64, 100_000, 1),
+             ((-3, 5, 100, 4, 9, 131), 256, 600_000, 2), ((0, 0, 0, 0, 0, 0), 1, 50, 1), ((7, 7, 7, 7, 7, 7), 8, 20_000, 0),
+             ((0, 0, 0, 255, 255, 31), 4096, 10_000_000, 1), ((0, 0, 0, 31, 31, 31), 4096, 10_000_000, 0)]
+    for _ in range(40):
+        lo = rng.integers(-50, 50, 3)
+        ext = rng.integers(1, 40, 3)
+        n = int(rng.integers(1_000, 20_000_000))
+        want = 1
+        while want < 4096 and want * 2560 < n:
+            want *= 2
+        cases.append((tuple(int(v) for v in lo) + tuple(int(v) for v in lo + ext - 1), want, n, int(rng.integers(0, 4))))
+    seen_valid = 0
+    for tb, want, n, margin in cases:
+        tb_a = (C.c_int32 * 6)(*tb)
+        bb = (C.c_int32 * 6)()
+        width, nb, valid, bad = C.c_uint32(0), C.c_uint32(0), C.c_int32(0), C.c_int64(-1)
+        rc = lib.octl_debug_key_geometry(C.cast(tb_a, C.c_void_p), want, n, 2560, margin, C.cast(bb, C.c_void_p),
+                                         C.byref(width), C.byref(nb), C.byref(valid), C.byref(bad))
+        assert rc == 0
+        if valid.value != 1:
+            assert valid.value == -3       # GEOM_RETRY: not a single-pass case (too many keys for the tables)
+            continue
+        seen_valid += 1
+        assert list(bb) == [tb[0] - margin, tb[1] - margin, tb[2] - margin, tb[3] + margin, tb[4] + margin, tb[5] + margin]
+        cap = min(4096, max(64, 2 * want))
+        assert 1 <= width.value <= 4096 and 1 <= nb.value <= cap, (tb, want, width.value, nb.value)
+        assert bad.value == 0, (tb, width.value, bad.value)
+        # about `target` points per bucket of a full box, unless the tables force wider buckets
+        rt = (tb[3] - tb[0] + 1) * (tb[4] - tb[1] + 1) * (tb[5] - tb[2] + 1)
+        rp = (bb[3] - bb[0] + 1) * (bb[4] - bb[1] + 1) * (bb[5] - bb[2] + 1)
+        assert width.value == max(1, (2560 * rt + n // 2) // n, -(-rp // cap))
+    assert seen_valid >= 30
+    # the headline scene: 32^3 voxels, one voxel of slack -> 34^3 keys in buckets of 10
+    tb_a = (C.c_int32 * 6)(0, 0, 0, 31, 31, 31)
+    lib.octl_debug_key_geometry(C.cast(tb_a, C.c_void_p), 4096, 10_000_000, 2560, 1, C.cast(bb, C.c_void_p),
+                                C.byref(width), C.byref(nb), C.byref(valid), C.byref(bad))
+    assert (width.value, nb.value, valid.value, bad.value) == (10, 3931, 1, 0)
