@@ -263,8 +263,11 @@ __device__ __forceinline__ void geom_validate2_body(const int32_t* __restrict__ 
     const uint64_t nx = (uint64_t)((int64_t)pb[3] - pb[0] + 1), ny = (uint64_t)((int64_t)pb[4] - pb[1] + 1),
                    nz = (uint64_t)((int64_t)pb[5] - pb[2] + 1);
     if (!(nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32))) {
-      const uint64_t R = nx * ny * nz;
-      int s = geom_ceil_log2(R) - geom_ceil_log2(ask.want);
+      // (the bucket width follows the TRUE box: a padded 128^3 box has more than 2^21 keys, and a width taken from
+      //  that would be twice what the points ask for - the host forms it the same way)
+      const uint64_t Rt = (uint64_t)((int64_t)bbox[3] - bbox[0] + 1) * (uint64_t)((int64_t)bbox[4] - bbox[1] + 1) *
+                          (uint64_t)((int64_t)bbox[5] - bbox[2] + 1);
+      int s = geom_ceil_log2(Rt) - geom_ceil_log2(ask.want);
       s = s < 0 ? 0 : (s > 12 ? 12 : s);
       same = s == o.lp.shift;
     }
@@ -2391,13 +2394,20 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     nz = (uint64_t)(bb[5] - bb[2] + 1);
     if (nx * ny > (1ull << 32) || nx * ny * nz >= (1ull << 32)) return OCTL_OK;  // keys would not fit 32 bits
     const uint64_t R = nx * ny * nz;
-    s = std::min(12, std::max(0, ceil_log2_u64(R) - ceil_log2_u64(want)));
+    // the host-formed geometry keeps buckets of 2^s keys (two passes split the bucket number's bits); s follows the
+    // TRUE box - padding a 128^3 box crosses a power of two and would double every bucket (one rank's 125 M-point
+    // shard: k_bucket_build 3.7 -> 4.9 ms, the chunk kernels 1.7 -> 4.4 ms) - the padded keys only add buckets
+    const uint64_t Rt = (uint64_t)((int64_t)tb[3] - tb[0] + 1) * (uint64_t)((int64_t)tb[4] - tb[1] + 1) *
+                        (uint64_t)((int64_t)tb[5] - tb[2] + 1);
+    s = std::min(12, std::max(0, ceil_log2_u64(Rt) - ceil_log2_u64(want)));
     if (((R - 1) >> s) + 1 > ((uint64_t)PT_BINS << PT_BITS)) return OCTL_OK;  // a sparse scene: too many keys
     nb = (uint32_t)(((R - 1) >> s) + 1);
     two_pass = nb > (uint32_t)PT_BINS;
     if (hinted2 && !two_pass)  // (cannot happen: same box, same `want`)
       return bucket_build_impl(f, a, nt, done, segs, n_internal, levels, n_voxels, n_blocks, pending, geom, true);
-    ctx->geom_sparse = two_pass && want <= (uint64_t)PT_BINS;
+    // (a SPARSE scene - more keys per wanted bucket than the 12-bit clamp on a bucket's key range allows - makes the
+    //  context skip the single-pass attempt next time; judged on the true box: the padding alone never does)
+    ctx->geom_sparse = ((Rt - 1) >> s) + 1 > (uint64_t)PT_BINS && want <= (uint64_t)PT_BINS;
     // Thin buckets: the 12-bit clamp on a bucket's key range left them under half their target.  A workgroup per
     // bucket is mostly set-up then, and the cost grows with the BOX (10 M points in 1024 x 1024 x 64 voxels:
     // 2.46 ms, in 8192 x 8192 x 64: 37 ms), while the level loop's depends on the points alone (1.5-1.7 ms for
