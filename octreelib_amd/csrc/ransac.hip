@@ -987,20 +987,21 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
           const bool elig = prescreen_constants(extent, ox, oy, oz, thr, pc) && blk_fast && !no_prescreen;
           if (elig) {
             RS_COUNT(4, 1);
-#pragma unroll 1
-            for (int qb = 1; qb < HPL; qb += 3) {
-              uint2 pe[3];
-              // (a last trio that reaches past the lane's hypotheses repeats the last one; copies are not queued)
-              auto hyp_a = [&](const int h) { return (int)tx + min(qb + h, HPL - 1) * THREADS; };
+            // NH hypothesis groups at a time (three; the last one or two of a lane's HPL - 1 on their own): every point
+            // read from LDS serves NH hypotheses of the lane
+            auto prescreen = [&](auto nh_tag, const int qb) {
+              constexpr int NH = decltype(nh_tag)::value;
+              uint2 pe[NH];
+              auto hyp_a = [&](const int h) { return (int)tx + (qb + h) * THREADS; };
 #pragma unroll
-              for (int h = 0; h < 3; ++h)
+              for (int h = 0; h < NH; ++h)
                 pe[h] = pos_tab[(size_t)n * (size_t)H + (size_t)((FULLH || hyp_a(h) < H) ? hyp_a(h) : 0)];
-              float qa[3], qb_[3], qc[3], qto[3], qT2[3];
-              bool qok[3];
-              int qcnt[3];
+              float qa[NH], qb_[NH], qc[NH], qto[NH], qT2[NH];
+              bool qok[NH];
+              int qcnt[NH];
               uint32_t risk = 0;   // a draw of these hypotheses that the position table cannot vouch for (bits 16..21)
 #pragma unroll
-              for (int h = 0; h < 3; ++h) {
+              for (int h = 0; h < NH; ++h) {
                 const uint32_t w0 = pe[h].x, w1 = pe[h].y;
                 f4 P[KS];
 #pragma unroll
@@ -1055,13 +1056,13 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
               }
               if (__any((risk >> 16) != 0u)) {   // (2^-20 per draw: such a hypothesis takes the exact path)
 #pragma unroll
-                for (int h = 0; h < 3; ++h) qok[h] = qok[h] && (pe[h].y >> 16) == 0u;
+                for (int h = 0; h < NH; ++h) qok[h] = qok[h] && (pe[h].y >> 16) == 0u;
               }
-              screen_ub<3>(loc, n, qa, qb_, qc, qto, qT2, qcnt);
-              RS_COUNT(12, 3);
+              screen_ub<NH>(loc, n, qa, qb_, qc, qto, qT2, qcnt);
+              RS_COUNT(12, NH);
 #pragma unroll
-              for (int h = 0; h < 3; ++h) {
-                const bool sv = !(qok[h] && qcnt[h] <= Lcur) && qb + h < HPL && (FULLH || hyp_a(h) < H);
+              for (int h = 0; h < NH; ++h) {
+                const bool sv = !(qok[h] && qcnt[h] <= Lcur) && (FULLH || hyp_a(h) < H);
                 const unsigned long long mk = __ballot(sv);
                 if (sv) {
                   const int pos = S + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
@@ -1070,7 +1071,11 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
                 }
                 S += __popcll(mk);
               }
-            }
+            };
+            constexpr int TRIOS = (HPL - 1) / 3, REST = (HPL - 1) % 3;
+#pragma unroll 1
+            for (int i = 0; i < TRIOS; ++i) prescreen(std::integral_constant<int, 3>{}, 1 + 3 * i);
+            if constexpr (REST > 0) prescreen(std::integral_constant<int, (REST > 0 ? REST : 1)>{}, 1 + 3 * TRIOS);
             RS_COUNT(2, S);
             use_list = S <= PRE_LIST;
             if (!use_list) RS_COUNT(5, 1);
