@@ -35,7 +35,7 @@ def test_line_is_bounded_and_complete():
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["unit"] == "GB/s"
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-6
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
-    assert set(line["roofline_valu"]) == {"achieved", "peak", "unit", "frac", "frac_no_fma"}
+    assert set(line["roofline_valu"]) == {"achieved", "peak", "unit", "frac", "frac_no_fma", "basis"}
     assert set(line["roofline_build"]) == {"kernel", "frac", "counter_frac", "whole_build"}
     assert set(line["roofline_build"]["whole_build"]) == {"section8d_frac", "counter_bytes_per_point"}
     assert "launches_per_step" in line and "host_syncs_per_step" in line
