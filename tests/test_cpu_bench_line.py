@@ -80,3 +80,23 @@ def test_emit_writes_detail_and_one_stdout_line(tmp_path, capsys):
     with open(path) as fh:
         assert json.load(fh)["secondary"].keys() == full["secondary"].keys()
     assert "bench.py detail: " in cap.err
+
+
+def test_sweep_order_is_a_permutation_in_runs_per_voxel():
+    """octreelib_amd.synthetic.sweep_order (bench.py's secondary.sweep_ordered): the same points, regrouped into runs of
+    8 .. 64 consecutive points that share a top-level voxel."""
+    import numpy as np
+
+    from octreelib_amd import synthetic
+
+    pts = synthetic.planar_cloud(60_000, (6, 6, 6), seed=1)
+    out = synthetic.sweep_order(pts, seed=3)
+    assert out.shape == pts.shape and out.dtype == np.float64
+    key = lambda a: np.sort(a.view([("x", "f8"), ("y", "f8"), ("z", "f8")]).ravel(), order=["x", "y", "z"])
+    assert np.array_equal(key(np.ascontiguousarray(out)), key(np.ascontiguousarray(pts)))
+    q = np.floor(out).astype(np.int64)
+    lin = (q[:, 0] * 6 + q[:, 1]) * 6 + q[:, 2]
+    cuts = np.flatnonzero(np.diff(lin) != 0)
+    runs = np.diff(np.concatenate(([0], cuts + 1, [len(out)])))
+    assert runs.max() <= 2 * 64 and 20 < runs.mean() < 64     # (two runs of one voxel may follow each other)
+    assert not np.array_equal(out, pts)
