@@ -1072,10 +1072,11 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
                 S += __popcll(mk);
               }
             };
-            constexpr int TRIOS = (HPL - 1) / 3, REST = (HPL - 1) % 3;
+            constexpr int PNH = 3;   // (four or five at a time: within the box-to-box noise, HISTORY 9)
+            constexpr int TRIOS = (HPL - 1) / PNH, REST = (HPL - 1) % PNH;
 #pragma unroll 1
-            for (int i = 0; i < TRIOS; ++i) prescreen(std::integral_constant<int, 3>{}, 1 + 3 * i);
-            if constexpr (REST > 0) prescreen(std::integral_constant<int, (REST > 0 ? REST : 1)>{}, 1 + 3 * TRIOS);
+            for (int i = 0; i < TRIOS; ++i) prescreen(std::integral_constant<int, PNH>{}, 1 + PNH * i);
+            if constexpr (REST > 0) prescreen(std::integral_constant<int, (REST > 0 ? REST : 1)>{}, 1 + PNH * TRIOS);
             RS_COUNT(2, S);
             use_list = S <= PRE_LIST;
             if (!use_list) RS_COUNT(5, 1);
