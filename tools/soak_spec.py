@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Soak of the speculative k_bucket_finish (run on the GPU box): a random sequence of scans - sizes from 2 k to 1.5 M
 points, dense, thin and skewed scenes, K from 4 to 200, fresh forests on one context - each built with the speculative
-launch allowed and again with NO_SPEC_FINISH; scheme, blocks, order, permutation, RANSAC mask and compaction must be
-identical.  usage: tools/soak_spec.py [iterations] [seed]"""
+launch allowed and again with NO_SPEC_FINISH, without the geometry hint, and under another margin of the key geometry;
+scheme, blocks, order, permutation, RANSAC mask and compaction must be identical.  usage: tools/soak_spec.py [iterations] [seed]"""
 import ctypes as C
 import sys
 sys.path.insert(0, '.')
@@ -43,9 +43,19 @@ for it in range(iters):
         want = T._step_tables([pts], K, adopt)
         ctx.set_option("NO_SPEC_FINISH", 0)
         T._assert_same_step(want, got)
+        # round 6: the same scan without the geometry hint of the context's previous build (its own box pass), and
+        # under another margin of the key geometry - the tables never depend on either
+        ctx.set_option("NO_GEOM_HINT", 1)
+        T._assert_same_step(want, T._step_tables([pts], K, adopt))
+        ctx.set_option("NO_GEOM_HINT", 0)
+        ctx.set_option("GEOM_MARGIN", int(rng.choice([-1, 2, 3])))
+        T._assert_same_step(want, T._step_tables([pts], K, adopt))
+        ctx.set_option("GEOM_MARGIN", 0)
     except Exception as e:  # noqa: BLE001
         bad += 1
         ctx.set_option("NO_SPEC_FINISH", 0)
+        ctx.set_option("NO_GEOM_HINT", 0)
+        ctx.set_option("GEOM_MARGIN", 0)
         print("FAILED at", it, n, kind, side, K, repr(e)[:200], flush=True)
     if it % 20 == 19:
         print("iteration", it + 1, "speculative launches held / missed so far:", tuple(a - b for a, b in zip(counters(), (h0, m0))),
