@@ -385,7 +385,7 @@ int octl_debug_radix_sort(octl_ctx* ctx, uint64_t* keys, uint32_t* vals, int64_t
 int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const double* den, const double* c,
                            int32_t kdiv, int64_t n, double* q3, double* ck, double* sq);
 /* The same three operations without their per-lane range guards, as the plane fit runs them on a block whose
- * coordinates are all +0.0 or in [2^-30, 2^31) (the range certificate of csrc/ransac.hip, RS_BLKFAST).  The
+ * coordinates are all +0.0 or in [2^-30, 2^31) (the range certificate of csrc/ransac.hip: coord_in_fast_range).  The
  * caller keeps the operands in the certified ranges: den in [2^-200, 2^138], num3 zero or in [2^-552, den],
  * c = +0.0 or |c| in [2^-82, 2^35) for c / kdiv, c in [2^-400, 2^276] for sqrt(c).                  */
 int octl_debug_plane_arith_certified(octl_ctx* ctx, const double* num3, const double* den, const double* c,

@@ -15,10 +15,17 @@
 // (cuda_ransac.py:140-145) - is resolved to the LOWEST hypothesis index.
 //
 // Mapping on CDNA4: one workgroup of W waves per (leaf, pose) block, hypotheses on the lanes
-// (HPL per lane), the block's points broadcast to all lanes through wave-uniform loads.  The
-// kernel is VALU bound: 1024 plane fits per block (~265 f64-dominated instructions each) and
-// H x n distance tests, which are decided on an f32 screen wherever a rigorous error bound
-// allows and recounted in the reference's f64 sequence otherwise (exact counts either way).
+// (HPL per lane), the block's points broadcast to all lanes through wave-uniform LDS reads.  The
+// kernel is VALU bound.  What the reference asks for is 1024 plane fits per block (~260
+// f64-dominated instructions each) and H x n distance tests; what runs (round 6):
+//   * the first THREADS hypotheses exactly - the fit in the reference's f64 order, the distance
+//     tests on an f32 screen wherever a rigorous error bound allows, recounted in the reference's
+//     f64 sequence otherwise (exact counts either way);
+//   * for every later hypothesis an APPROXIMATE f32 plane with a rigorous bound on its distances
+//     and the count inside the widened threshold: an upper bound of its exact count.  Only the
+//     hypotheses whose bound exceeds the best exact count so far - a handful per block - are
+//     fitted and counted exactly (see "the prescreen of the hypotheses" below).
+// Results are the reference's, bit for bit.
 // MFMA is not used: the f64 evaluation order (and the f32-rounded plane) must be reproduced
 // exactly, and the product is 4 deep; an f32 MFMA screen was measured slower.
 #include <algorithm>
@@ -493,7 +500,7 @@ __device__ __forceinline__ void stage_local(double ox, double oy, double oz, con
     if (!(m == m) || u != u || v != v || w != w) m = __int_as_float(0x7f800000);
   }
   m = wave_max_nonneg_f32(m);
-  // the range certificate of the plane fit's shortcuts (see RS_BLKFAST): lanes that stage nothing hold +0.0
+  // the range certificate of the plane fit's shortcuts (see coord_in_fast_range): lanes that stage nothing hold +0.0
   const bool inr = coord_in_fast_range(px) && coord_in_fast_range(py) && coord_in_fast_range(pz);
   const bool wave_fast = __all(inr);
   if (ext_out) {  // (one wave per block: the two words stay in the wave's registers)
@@ -1863,7 +1870,7 @@ __global__ __launch_bounds__(256) void k_debug_plane_arith(const double* __restr
   double a = num3[3 * i], b = num3[3 * i + 1], cc = num3[3 * i + 2];
   double c0 = c[i], c1 = c[i + 1 < n ? i + 1 : 0], c2 = c[i + 2 < n ? i + 2 : 0];
   if (certified) {
-    // the guard-free forms a block with the range certificate (RS_BLKFAST) runs
+    // the guard-free forms a block with the range certificate (coord_in_fast_range) runs
     div3_by_norm_inrange(a, b, cc, den[i]);
     div3_by_small_int(c0, c1, c2, kdiv, true);
     ck[i] = c0;
@@ -1892,7 +1899,7 @@ extern "C" int octl_debug_plane_arith(octl_ctx* ctx, const double* num3, const d
   return debug_plane_arith(ctx, num3, den, c, kdiv, n, q3, ck, sq, 0);
 }
 // the same three operations WITHOUT their range guards, as the plane fit runs them on a block that holds the
-// range certificate (RS_BLKFAST): the caller keeps the operands inside the certified ranges
+// range certificate (coord_in_fast_range): the caller keeps the operands inside the certified ranges
 // (den in [2^-200, 2^138], num3 zero or >= 2^-552 and <= den, c zero (+0.0) or in [2^-82, 2^35) for the
 // division by kdiv, c in [2^-400, 2^276] for the square root)
 extern "C" int octl_debug_plane_arith_certified(octl_ctx* ctx, const double* num3, const double* den,

@@ -161,7 +161,7 @@ def test_plane_fit_divisions_near_rounding_midpoints():
 
 
 def _certified_cases(seed, n=2_000_000):
-    """Operands inside the ranges the block certificate of csrc/ransac.hip (RS_BLKFAST) guarantees:
+    """Operands inside the ranges the block certificate of csrc/ransac.hip (coord_in_fast_range) guarantees:
     norm in [2^-200, 2^138], numerators zero or in [2^-552, norm (1 + 2^-52)], centroid sums +0.0 or in
     [2^-82, 2^35), s in [2^-400, 2^276] - with the edges of every range over-represented."""
     rng = np.random.default_rng(seed)
@@ -199,7 +199,7 @@ def _certified_cases(seed, n=2_000_000):
 @pytest.mark.parametrize("seed", [10, 11, 12])
 def test_certified_plane_fit_arithmetic_is_ieee_without_guards(seed):
     """A block whose coordinates are all +0.0 or in [2^-30, 2^31) runs the plane fit's division / square
-    root shortcuts WITHOUT their per-lane range guards (csrc/ransac.hip, RS_BLKFAST).  Over the operand
+    root shortcuts WITHOUT their per-lane range guards (csrc/ransac.hip, coord_in_fast_range).  Over the operand
     ranges that certificate implies the unguarded forms must still be the IEEE results."""
     num3, den, c, s = _certified_cases(seed)
     for k in (1, 3, 6, 7, 16):
