@@ -1055,7 +1055,10 @@ __global__ __launch_bounds__(THREADS, RS_MINWAVES) void k_ransac(
                 const float T = (xx + yy) + zz;
                 const float mu4 = fma32(fma32(pc.qa, T, pc.qb), T, pc.qc);
                 const float gap = __builtin_fmaxf(__builtin_fmaxf(dx, dy), dz) - __builtin_amdgcn_fmed3f(dx, dy, dz);
-                qok[h] = (ss * r > mu4) && (gap > mu4);   // (false for NaN)
+                // (false for NaN.  f32 range: with E >= 2^-7, 4 mu >= 2^-65; a row that passes with |row|^2 in the
+                //  denormal range - its normalisation good to 2^-18 only - has 4 mu / |row| > 2^-3, an eps of half the
+                //  block's extent: nothing is ruled out on such a plane.  |row|^2 flushed to zero fails the test.)
+                qok[h] = (ss * r > mu4) && (gap > mu4);
                 risk |= w1;
                 const float thr_h = fma32(pc.e35, mu4 * r, pc.thrblk);
                 qT2[h] = thr_h * thr_h;
