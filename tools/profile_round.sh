@@ -27,7 +27,7 @@ if [ -f build/variants/rs_counts.so ]; then
   OCTREELIB_AMD_LIB=$R/build/variants/rs_counts.so python3 tools/rs_counts.py > gpurun_out/rs_counts.log 2>&1 && cp gpurun_out/rs_counts.json profiles/${TAG}_ransac_counts.json
 fi
 # the opcode ledger of the benchmarked k_ransac instance: static histogram by phase x the execution counts above
-python3 tools/ransac_isa.py profiles/${TAG}_ransac_counts.json > profiles/${TAG}_ransac_isa.txt 2> gpurun_out/ransac_isa.err
+python3 tools/ransac_isa.py profiles/${TAG}_ransac_counts.json > gpurun_out/ransac_isa.txt 2> gpurun_out/ransac_isa.err && [ -s gpurun_out/ransac_isa.txt ] && cp gpurun_out/ransac_isa.txt profiles/${TAG}_ransac_isa.txt || echo "profile_round: opcode ledger FAILED (gpurun_out/ransac_isa.err) - profiles/${TAG}_ransac_isa.txt left as it was" >&2
 # one step of a dense 100 k-point scan, kernel by kernel
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_small -- python3 $R/bench.py --workload small --steps 20 --warmup 3 > /dev/null 2>&1)
 python3 tools/probes/step_timeline.py gpurun_out/prof_${TAG}_small planar 40 > profiles/${TAG}_small_scan_timeline.txt 2>&1

@@ -51,7 +51,7 @@ L["score"] = line_of(r"auto score = \[&\]", L["kernel"])
 L["take"] = line_of(r"auto take = \[&\]", L["kernel"])
 L["group0"] = line_of(r"---- group 0", L["kernel"])
 L["prescreen"] = line_of(r"---- prescreen of the wave's later hypotheses", L["kernel"])
-L["pre_bound_end"] = line_of(r"screen_ub<3>\(loc, n", L["kernel"])
+L["pre_bound_end"] = line_of(r"screen_ub<\w+>\(loc, n", L["kernel"])
 L["survivors"] = line_of(r"---- the survivors \(in index order\)", L["kernel"])
 L["tail"] = line_of(r"const uint32_t wbest = wave_max_u32\(best\);", L["kernel"])
 L["kernel_end"] = line_of(r"^// A block with more than THREADS-1 points", L["kernel"])
