@@ -100,3 +100,21 @@ def test_sweep_order_is_a_permutation_in_runs_per_voxel():
     runs = np.diff(np.concatenate(([0], cuts + 1, [len(out)])))
     assert runs.max() <= 2 * 64 and 20 < runs.mean() < 64     # (two runs of one voxel may follow each other)
     assert not np.array_equal(out, pts)
+
+
+def test_committed_profiles_are_not_empty_and_the_bench_line_parses():
+    """profiles/ is what the review cites: a tool that failed on the GPU box must not leave an empty file behind."""
+    import glob
+    import json
+    import os
+    root = os.path.join(os.path.dirname(__file__), "..", "profiles")
+    files = glob.glob(os.path.join(root, "r06_*"))
+    assert files
+    empty = [os.path.basename(f) for f in files if os.path.getsize(f) == 0]
+    assert not empty, empty
+    line = open(os.path.join(root, "r06_bench.json")).read()
+    assert len(line) <= 8192
+    rec = json.loads(line)
+    assert rec["roofline"]["launch_ms"] > 0 and rec["cpu_baseline"]["value"] > 0
+    ledger = open(os.path.join(root, "r06_ransac_isa.txt")).read()
+    assert "VALU total" in ledger and "MEASURED per launch" in ledger
