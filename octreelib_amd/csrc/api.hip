@@ -200,9 +200,92 @@ __global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ ma
 }
 
 
+// tile-wise stable compaction (8 rows of 256 points per workgroup, ballot ranks); dropped points die in the store.
+// offset_of(kept points of the tile) -> kept points in front of the tile: read from the scanned table
+// (k_compact_tiles) or found by look-back (the tile workgroups of k_mask_scan, small clouds: no launch of its own).
+template <typename OffsetOf>
+__device__ __forceinline__ void compact_tile(
+    uint32_t tile, const uint8_t* __restrict__ mask, int64_t n,
+    const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
+    uint32_t* __restrict__ ord_idx2, double* __restrict__ xyz_ord2, uint8_t* __restrict__ alive,
+    uint8_t* __restrict__ alive_fill, uint32_t* s_cnt /* [33] */, OffsetOf offset_of) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t base = (int64_t)tile * 2048;
+  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  uint32_t rk[8];
+  uint32_t keepbits = 0;
+  // (every load of the tile is issued before the first dependent instruction: 8 rounds x (index + 3 coordinates)
+  //  in flight per lane; loading them behind `if (kept)` round by round left the kernel at 4.9 TB/s)
+  uint32_t iv[8];
+  double px[8], py[8], pz[8];
+  uint8_t mk[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    mk[r] = 0;
+    iv[r] = 0;
+    px[r] = py[r] = pz[r] = 0.0;
+    if (i < n) {
+      mk[r] = mask[i];
+      iv[r] = ord_idx[i];
+      px[r] = xyz_ord[3 * i];
+      py[r] = xyz_ord[3 * i + 1];
+      pz[r] = xyz_ord[3 * i + 2];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    const bool k = i < n && mk[r] != 0;
+    const unsigned long long bal = __ballot(k);
+    rk[r] = (uint32_t)__popcll(bal & lt);
+    keepbits |= (k ? 1u : 0u) << r;
+    if (lane == 0) s_cnt[r * 4 + wave] = (uint32_t)__popcll(bal);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    uint32_t v = lane < 32 ? s_cnt[lane] : 0u, inc = v;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off);
+      if (lane >= off) inc += t;
+    }
+    if (lane < 32) s_cnt[lane] = inc - v;
+    if (lane == 31) s_cnt[32] = inc;  // kept points of the tile
+  }
+  __syncthreads();
+  const uint32_t toff = offset_of(s_cnt[32]);
+  // (alive flags that were never written: position range = store range, every flag of the tile is written here)
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i >= n) continue;
+    if ((keepbits >> r) & 1u) {
+      const int64_t d = (int64_t)toff + s_cnt[r * 4 + wave] + rk[r];
+      ord_idx2[d] = iv[r];
+      xyz_ord2[3 * d] = px[r];
+      xyz_ord2[3 * d + 1] = py[r];
+      xyz_ord2[3 * d + 2] = pz[r];
+      if (alive_fill) alive_fill[iv[r]] = 1;
+    } else {
+      alive[iv[r]] = 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_compact_tiles(
+    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ tile_off, int64_t n,
+    const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
+    uint32_t* __restrict__ ord_idx2, double* __restrict__ xyz_ord2, uint8_t* __restrict__ alive) {
+  __shared__ uint32_t s_cnt[33];  // [row][wave] -> exclusive offsets | total
+  compact_tile(blockIdx.x, mask, n, ord_idx, xyz_ord, ord_idx2, xyz_ord2, alive, nullptr, s_cnt,
+               [&](uint32_t) { return tile_off[blockIdx.x]; });
+}
+
+
 // apply_mask's counts, prefix sums and block-table compaction in ONE launch (round 5; before: k_blk_kept, a scan over
 // [tile counts | kept per block | block non-empty], k_blk_compact).  Workgroups [0, nt) take a tile of 2048 positions:
-// kept points of the tile, chained by decoupled look-back into the tile's offset (k_compact_tiles reads it).
+// kept points of the tile, chained by decoupled look-back into the tile's offset, and the tile's compaction.
 // Workgroups [nt, nt + nbw) take 256 blocks each: kept points and "non-empty" per block, two look-back chains over
 // the block workgroups (kept points in front = the block's new start, non-empty blocks in front = its new id), and
 // the surviving blocks are written straight into the compacted table.  Chains never cross: each has its own status
@@ -210,7 +293,9 @@ __global__ __launch_bounds__(256) void k_blk_kept(const uint8_t* __restrict__ ma
 // kept points, surviving blocks.  fill_alive: the store's alive flags have never been written (a cloud taken in
 // place): the tile workgroups write 1s over their range - position range = store range while every point is alive.
 __global__ __launch_bounds__(256) void k_mask_scan(
-    const uint8_t* __restrict__ mask, int64_t n, uint32_t nt, uint32_t* __restrict__ tile_off,
+    const uint8_t* __restrict__ mask, int64_t n, uint32_t nt,
+    const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
+    uint32_t* __restrict__ ord_idx2, double* __restrict__ xyz_ord2, uint8_t* __restrict__ alive,
     const uint32_t* __restrict__ blk_start, const int32_t* __restrict__ blk_size, int64_t nb,
     const int32_t* __restrict__ blk_node, const int32_t* __restrict__ blk_slot, int32_t* __restrict__ blk_node2,
     int32_t* __restrict__ blk_slot2, uint32_t* __restrict__ blk_start2, int32_t* __restrict__ blk_size2,
@@ -218,35 +303,21 @@ __global__ __launch_bounds__(256) void k_mask_scan(
     uint32_t* __restrict__ mirror, uint32_t seq, uint8_t* __restrict__ alive_fill) {
   __shared__ uint32_t s_w[2][4];
   __shared__ uint32_t s_excl;
+  __shared__ uint32_t s_cnt[33];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (blockIdx.x < nt) {
+    // a tile of 2048 positions: its loads are in flight while the look-back finds the kept points in front of it,
+    // then it compacts itself (round 6: was a count here and k_compact_tiles behind - one launch more)
     const uint32_t tile = blockIdx.x;
-    const int64_t i0 = (int64_t)tile * 2048 + (int64_t)threadIdx.x * 8;
-    uint32_t c = 0;
-    if (i0 + 8 <= n) {
-      const uint64_t w = *reinterpret_cast<const uint64_t*>(mask + i0);  // (the mask buffer is 16-byte aligned)
-      const uint64_t nz = ((w & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | w;   // bytes that are not zero
-      c = (uint32_t)__popcll(nz & 0x8080808080808080ull);
-      if (alive_fill) *reinterpret_cast<uint64_t*>(alive_fill + i0) = 0x0101010101010101ull;
-    } else {
-      for (int64_t i = i0; i < n; ++i) {
-        c += mask[i] ? 1u : 0u;
-        if (alive_fill) alive_fill[i] = 1;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    if (lane == 0) s_w[0][wave] = c;
-    __syncthreads();
-    const uint32_t total = (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3]);
-    const uint32_t excl = lookback_exclusive(st_tiles, epoch, tile, total, &s_excl);
-    if (threadIdx.x == 0) {
-      tile_off[tile] = excl;
-      if (tile == nt - 1) {
-        mirror[MIRROR_MASK_TOTALS] = excl + total;
-        mirror_publish(mirror, MIRROR_FLAG_MASK0, seq);
-      }
-    }
+    compact_tile(tile, mask, n, ord_idx, xyz_ord, ord_idx2, xyz_ord2, alive, alive_fill, s_cnt,
+                 [&](uint32_t total) {
+                   const uint32_t excl = lookback_exclusive(st_tiles, epoch, tile, total, &s_excl);
+                   if (threadIdx.x == 0 && tile == nt - 1) {
+                     mirror[MIRROR_MASK_TOTALS] = excl + total;
+                     mirror_publish(mirror, MIRROR_FLAG_MASK0, seq);
+                   }
+                   return excl;
+                 });
     return;
   }
   const uint32_t bw = blockIdx.x - nt;
@@ -309,73 +380,6 @@ __global__ __launch_bounds__(256) void k_mask_scan(
     blk_slot2[id] = blk_slot[b];
     blk_start2[id] = ex_c + pc;
     blk_size2[id] = (int32_t)c;
-  }
-}
-
-// tile-wise stable compaction (8 rows of 256 points per workgroup, ballot ranks); dropped points die in the store
-__global__ __launch_bounds__(256) void k_compact_tiles(
-    const uint8_t* __restrict__ mask, const uint32_t* __restrict__ tile_off, int64_t n,
-    const uint32_t* __restrict__ ord_idx, const double* __restrict__ xyz_ord,
-    uint32_t* __restrict__ ord_idx2, double* __restrict__ xyz_ord2, uint8_t* __restrict__ alive) {
-  __shared__ uint32_t s_cnt[32];  // [row][wave] -> exclusive offsets
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t base = (int64_t)blockIdx.x * 2048;
-  const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-  uint32_t rk[8];
-  uint32_t keepbits = 0;
-  // (every load of the tile is issued before the first dependent instruction: 8 rounds x (index + 3 coordinates)
-  //  in flight per lane; loading them behind `if (kept)` round by round left the kernel at 4.9 TB/s)
-  uint32_t iv[8];
-  double px[8], py[8], pz[8];
-  uint8_t mk[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    mk[r] = 0;
-    iv[r] = 0;
-    px[r] = py[r] = pz[r] = 0.0;
-    if (i < n) {
-      mk[r] = mask[i];
-      iv[r] = ord_idx[i];
-      px[r] = xyz_ord[3 * i];
-      py[r] = xyz_ord[3 * i + 1];
-      pz[r] = xyz_ord[3 * i + 2];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    const bool k = i < n && mk[r] != 0;
-    const unsigned long long bal = __ballot(k);
-    rk[r] = (uint32_t)__popcll(bal & lt);
-    keepbits |= (k ? 1u : 0u) << r;
-    if (lane == 0) s_cnt[r * 4 + wave] = (uint32_t)__popcll(bal);
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    uint32_t v = lane < 32 ? s_cnt[lane] : 0u, inc = v;
-#pragma unroll
-    for (int off = 1; off < 32; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off);
-      if (lane >= off) inc += t;
-    }
-    if (lane < 32) s_cnt[lane] = inc - v;
-  }
-  __syncthreads();
-  const uint32_t toff = tile_off[blockIdx.x];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    if (i >= n) continue;
-    if ((keepbits >> r) & 1u) {
-      const int64_t d = (int64_t)toff + s_cnt[r * 4 + wave] + rk[r];
-      ord_idx2[d] = iv[r];
-      xyz_ord2[3 * d] = px[r];
-      xyz_ord2[3 * d + 1] = py[r];
-      xyz_ord2[3 * d + 2] = pz[r];
-    } else {
-      alive[iv[r]] = 0;
-    }
   }
 }
 
@@ -630,7 +634,8 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     const bool fused = !ctx->opt.no_fused_tables && nt + 2 * ceil_div(nb, 256) <= 1024;
     const uint32_t wait_seq = octl_wait_next_seq(ctx);
     // (alive flags that were never written - a cloud taken in place - are filled by the tile workgroups of the
-    //  first kernel: k_compact_tiles, a later launch, then clears the dropped points')
+    //  first kernel: by position in k_blk_kept - k_compact_tiles, a later launch, then clears the dropped points' -
+    //  and by store index, each flag once, where k_mask_scan compacts in the same launch)
     uint8_t* fill = nullptr;
     if (f->alive_stale && f->n_ord == f->n_store) {
       fill = f->alive.as<uint8_t>();
@@ -658,7 +663,9 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
       uint64_t* status = nullptr;
       uint32_t epoch = 0;
       OCTL_TRY(octl_scan_status_acquire(ctx, nt + 2 * nbw, &status, &epoch));
-      OCTL_LAUNCH(k_mask_scan, dim3((unsigned)(nt + nbw)), dim3(256), 0, st, mask, n, (uint32_t)nt, scanned,
+      OCTL_LAUNCH(k_mask_scan, dim3((unsigned)(nt + nbw)), dim3(256), 0, st, mask, n, (uint32_t)nt,
+                         (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
+                         f->ord_idx2.as<uint32_t>(), f->xyz_ord2.as<double>(), f->alive.as<uint8_t>(),
                          (const uint32_t*)f->blk_start.as<uint32_t>(), (const int32_t*)f->blk_size.as<int32_t>(), nb,
                          (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),
                          f->blk_node2.as<int32_t>(), f->blk_slot2.as<int32_t>(), f->blk_start2.as<uint32_t>(),
@@ -666,11 +673,11 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
                          static_cast<uint32_t*>(ctx->small_host), wait_seq, fill);
       HIP_TRY(ctx, hipGetLastError());
     }
-    OCTL_LAUNCH(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)scanned, n,
-                       (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
-                       f->ord_idx2.as<uint32_t>(), f->xyz_ord2.as<double>(), f->alive.as<uint8_t>());
-    HIP_TRY(ctx, hipGetLastError());
     if (!fused) {
+      OCTL_LAUNCH(k_compact_tiles, dim3((unsigned)nt), dim3(256), 0, st, mask, (const uint32_t*)scanned, n,
+                         (const uint32_t*)f->ord_idx.as<uint32_t>(), (const double*)f->xyz_ord.as<double>(),
+                         f->ord_idx2.as<uint32_t>(), f->xyz_ord2.as<double>(), f->alive.as<uint8_t>());
+      HIP_TRY(ctx, hipGetLastError());
       OCTL_LAUNCH(k_blk_compact, dim3(grid_for(nb)), dim3(256), 0, st, (const uint32_t*)raw,
                          (const uint32_t*)scanned, (const uint32_t*)(small + 22), nt, nb,
                          (const int32_t*)f->blk_node.as<int32_t>(), (const int32_t*)f->blk_slot.as<int32_t>(),

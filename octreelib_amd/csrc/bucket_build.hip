@@ -2324,9 +2324,12 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // level loop's job from the start
   if (f->mode == 1 && n_alive > 65535) return OCTL_OK;
   const int n_poses = (int)f->pose_off.size() - 1;
-  // buckets: runs of 2^s consecutive voxel keys, sized for ~2500 points on average (at most 2^24)
+  // buckets: runs of consecutive voxel keys, sized for ~2500 points on average (~1250 in a small cloud)
   // (OCTL_BUCKET_POINTS: tests force many small buckets - and with them the two-pass partition - on small clouds)
-  const uint64_t target = ctx->opt.bucket_points > 0 ? (uint64_t)ctx->opt.bucket_points : 2560;
+  // (a small cloud fills few workgroups and its kernels are chains of latencies, not bytes: half the bucket shortens
+  //  every chain - 100 k points 0.165 -> 0.157 ms, 30 k 0.126 -> 0.117; from 1 M points on the larger bucket wins)
+  const uint64_t target = ctx->opt.bucket_points > 0 ? (uint64_t)ctx->opt.bucket_points
+                                                     : (n_alive <= 400000 ? 1280 : 2560);
   uint64_t want = 1;
   while (want < ((uint64_t)PT_BINS << PT_BITS) && want * target < (uint64_t)n_alive) want <<= 1;
   // One partition pass (want <= 4096 buckets): the key geometry is formed on the device (k_bucket_geom) and

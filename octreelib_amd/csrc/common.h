@@ -76,7 +76,7 @@ struct DevBuf {
 // build's path calls getenv.  All default to 0 = the shipped behaviour.
 struct OctlOptions {
   int64_t no_bucket_build = 0;     // OCTL_NO_BUCKET_BUILD: every build through the level-synchronous path
-  int64_t bucket_points = 0;       // OCTL_BUCKET_POINTS: average points per bucket (0: 2560)
+  int64_t bucket_points = 0;       // OCTL_BUCKET_POINTS: average points per bucket (0: 2560; 1280 up to 400 k points)
   int64_t sync_geom = 0;           // OCTL_SYNC_GEOM: the host-side form of the key geometry on small clouds too
   int64_t no_geom_hint = 0;        // OCTL_NO_GEOM_HINT: no geometry carried over from the context's previous build
   int64_t no_exact_digits = 0;     // OCTL_NO_EXACT_DIGITS: child digits level by level, never six at once

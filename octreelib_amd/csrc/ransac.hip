@@ -1555,11 +1555,8 @@ __global__ __launch_bounds__(256) void k_block_prepare(const int32_t* __restrict
 // one 8-byte entry per (size, hypothesis) - positions in bytes 0..5, the risky-draw bits (sample_index_cached) in
 // bits 16..21 of the second word.  k_ransac<..., PT = true> reads its entries a batch ahead of the plane fits.
 // (Run by the extra workgroups of k_block_scatter: part `part` of the hypotheses, block size n.)
-__device__ __forceinline__ void pos_table_part(const double* __restrict__ hyp, int H, int k,
-                                               const uint32_t* __restrict__ counters, uint2* __restrict__ tab,
-                                               int n, int part) {
-  const int t = part * 256 + (int)threadIdx.x;
-  if (t >= H || n < k || counters[RC_BINS + n] == 0u) return;
+__device__ __forceinline__ void pos_table_entry(const double* __restrict__ hyp, int H, int k,
+                                                uint2* __restrict__ tab, int n, int t) {
   const double* __restrict__ row = hyp + (int64_t)t * k;
   uint32_t x = 0, y = 0;
   for (int i = 0; i < k; ++i) {
@@ -1571,6 +1568,13 @@ __device__ __forceinline__ void pos_table_part(const double* __restrict__ hyp, i
     y |= (risky || g == (uint32_t)n) ? (0x10000u << i) : 0u;
   }
   tab[(size_t)n * (size_t)H + t] = uint2{x, y};
+}
+__device__ __forceinline__ void pos_table_part(const double* __restrict__ hyp, int H, int k,
+                                               const uint32_t* __restrict__ counters, uint2* __restrict__ tab,
+                                               int n, int part) {
+  const int t = part * 256 + (int)threadIdx.x;
+  if (t >= H || n < k || counters[RC_BINS + n] == 0u) return;
+  pos_table_entry(hyp, H, k, tab, n, t);
 }
 
 // descriptors -> size-sorted list.  Position inside a size class: rank inside the workgroup (LDS
@@ -1636,6 +1640,126 @@ __global__ __launch_bounds__(256) void k_block_scatter(const BlockDesc* __restri
   }
 }
 
+// k_block_prepare and k_block_scatter in ONE launch for a launch of up to BPS_MAX blocks (round 6: a 100 k-point scan
+// has ~5 000 leaves and its two preparation kernels were 21 of its 165 us - each a chain of latencies, not work).
+// Workgroup 0: sizes in batch order, their prefix sums, the descriptors (registers), the per-size counts and the
+// ranks inside a size class (LDS atomics), the starts of the size classes, the sorted list - no look-back, no
+// global atomics, no unsorted list in between (only the oversize blocks' descriptors are written there, for
+// k_ransac_big).  Workgroups [1, ...): the position table for EVERY size k .. cap - which sizes occur is only known
+// to workgroup 0, and a size costs one workgroup.
+constexpr int BPS_THREADS = 1024, BPS_PER_THREAD = 8, BPS_MAX = BPS_THREADS * BPS_PER_THREAD;
+__global__ __launch_bounds__(BPS_THREADS) void k_block_prepare_small(
+    const int32_t* __restrict__ order, const uint32_t* __restrict__ start, const int32_t* __restrict__ size,
+    int64_t nb, int64_t n_points, int cap, int k, BlockDesc* __restrict__ desc, BlockDesc* __restrict__ sdesc,
+    uint32_t* __restrict__ big_list, uint32_t* __restrict__ counters, RansacOut out, int64_t max_block,
+    uint32_t* __restrict__ mirror, const double* __restrict__ hyp, int H, uint2* __restrict__ tab,
+    uint32_t* __restrict__ next_counters) {
+  if (blockIdx.x > 0) {
+    const int parts = (H + BPS_THREADS - 1) / BPS_THREADS;
+    const int id = (int)blockIdx.x - 1;
+    const int n = k + id / parts, t = (id % parts) * BPS_THREADS + (int)threadIdx.x;
+    if (t < H && n <= cap) pos_table_entry(hyp, H, k, tab, n, t);
+    return;
+  }
+  __shared__ uint32_t bins[256];
+  __shared__ uint32_t first[256];
+  __shared__ uint32_t s_wave[BPS_THREADS / 64];
+  // (the counter set of the context's NEXT launch: its previous users finished before this launch started)
+  if (next_counters)
+    for (int w = threadIdx.x; w < RC_WORDS; w += BPS_THREADS) next_counters[w] = 0;
+  if (threadIdx.x < 256) bins[threadIdx.x] = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t b0 = (int64_t)threadIdx.x * BPS_PER_THREAD;
+  int32_t phys[BPS_PER_THREAD + 1];
+  int32_t nn[BPS_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r <= BPS_PER_THREAD; ++r) {
+    const int64_t b = b0 + r;
+    phys[r] = b < nb ? (order ? order[b] : (int32_t)b) : -1;
+  }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int r = 0; r < BPS_PER_THREAD; ++r) {
+    nn[r] = phys[r] >= 0 ? size[phys[r]] : 0;
+    sum += (uint32_t)nn[r];
+  }
+  uint32_t pst[BPS_PER_THREAD + 1];
+#pragma unroll
+  for (int r = 0; r <= BPS_PER_THREAD; ++r) pst[r] = phys[r] >= 0 ? start[phys[r]] : 0u;
+  uint32_t inc = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t pre = inc - sum;
+  for (int w = 0; w < wave; ++w) pre += s_wave[w];
+  BlockDesc dd[BPS_PER_THREAD];
+  uint32_t rank[BPS_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r < BPS_PER_THREAD; ++r) {
+    const int64_t b = b0 + r;
+    BlockDesc& d = dd[r];
+    d.n = -1;
+    rank[r] = 0;
+    if (phys[r] < 0) continue;
+    d.pstart = pst[r];
+    d.n = nn[r];
+    d.vstart = (int64_t)pre;
+    pre += (uint32_t)nn[r];
+    uint32_t sp = d.n > 0 ? d.pstart + (uint32_t)d.n - 1u : d.pstart;
+    if (phys[r + 1] >= 0) {
+      sp = pst[r + 1];
+    } else if (!order) {
+      // stand-alone operator: the cloud may continue past the last block (cuda_ransac.py:43-81)
+      const int64_t e = (int64_t)d.pstart + d.n;
+      if (e < n_points) sp = (uint32_t)e;
+    }
+    d.pspill = sp;
+    d.pad[0] = 0;
+    d.pad[1] = (uint32_t)b;  // batch entry: index of the per-block outputs
+    d.pad[2] = 0;
+    const int n = d.n;
+    d.n = -1;                // (-1 from here on: not a member of the sorted list)
+    if (n < k) {
+      // finished right here: the reference's kernel returns at once, the mask stays False (cuda_ransac.py:96-97)
+      for (int i = 0; i < n; ++i) out.mask[(int64_t)d.pstart + i] = 0;
+      if (out.plane) {
+        out.plane[4 * b + 0] = 0.f; out.plane[4 * b + 1] = 0.f;
+        out.plane[4 * b + 2] = 0.f; out.plane[4 * b + 3] = 0.f;
+      }
+      if (out.count) out.count[b] = 0;
+      if (out.index) out.index[b] = -1;
+    } else if (n > cap) {
+      d.n = n;
+      desc[b] = d;
+      d.n = -1;
+      big_list[atomicAdd(&counters[RC_BIG], 1u)] = (uint32_t)b;
+    } else {
+      d.n = n;
+      rank[r] = atomicAdd(&bins[n], 1u);
+    }
+    if (n >= k && (int64_t)n > max_block)
+      __hip_atomic_store(&mirror[MIRROR_RS_VIOLATION], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  // start of size class t in the list, largest size first
+  if (threadIdx.x < 256) {
+    uint32_t f = 0;
+    for (int m = 255; m > (int)threadIdx.x; --m) f += bins[m];
+    first[threadIdx.x] = f;
+    counters[RC_BINS + threadIdx.x] = bins[threadIdx.x];
+    counters[RC_START + threadIdx.x] = f;
+    if (threadIdx.x == 0) counters[RC_SORTED] = f + bins[0];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < BPS_PER_THREAD; ++r)
+    if (dd[r].n >= 0) sdesc[first[dd[r].n] + rank[r]] = dd[r];
+}
+
 }  // namespace
 
 int ransac_check_table(octl_ctx* ctx, const double* hyp, int32_t H, int32_t k) {
@@ -1699,7 +1823,16 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
   uint2* pos_tab = use_tab ? reinterpret_cast<uint2*>(base + off_t) : nullptr;
   const int threads = (H <= 64) ? 64 : (H <= 256 ? 256 : RS_BIG_THREADS);
   RansacOut out{mask_dev, plane_dev, count_dev, index_dev};
-  {
+  if (fused && nb <= BPS_MAX) {
+    KTimer t(ctx, "ransac_prepare");
+    const int cap = any_k ? 0 : threads - 1;
+    const unsigned n_table = use_tab && cap >= k ? (unsigned)(cap - k + 1) * (unsigned)ceil_div(H, BPS_THREADS) : 0u;
+    OCTL_LAUNCH(k_block_prepare_small, dim3(1 + n_table), dim3(BPS_THREADS), 0, st, order_dev, blk_start, blk_size, nb,
+                       n_points, cap, (int)k, desc, sdesc, big_list, counters, out, max_block,
+                       static_cast<uint32_t*>(ctx->small_host), hyp_dev, (int)H, pos_tab, next_counters);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->rs_counters_dirty = false;
+  } else {
     KTimer t(ctx, "ransac_prepare");
     if (fused) {
       const unsigned g = (unsigned)ceil_div(nb, 256 * BP_PER_THREAD);
