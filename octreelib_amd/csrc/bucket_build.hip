@@ -1903,8 +1903,55 @@ __global__ __launch_bounds__(256) void k_old_voxels_missing(const uint64_t* __re
   if (!found) atomicAdd(missing, 1u);
 }
 
+constexpr int BF_SCAN_IPT = 9, BF_SCAN_MAX = 256 * BF_SCAN_IPT;  // words of totals a finish launch scans itself
+// k_bucket_finish<true>'s own scan of the totals (see there; that instance runs over few buckets and is compiled for
+// 128 registers - the ordinary one keeps its 64 and its 16 bytes of scratch)
+__device__ __forceinline__ void finish_own_scan(const uint32_t* __restrict__ bk_raw, uint32_t n_tot, uint32_t nb,
+                                             uint32_t* s_tab, uint32_t* s_scr, bool publish,
+                                             uint32_t* __restrict__ bk_scan_out, uint32_t* small,
+                                             uint32_t* __restrict__ mirror, int mirror_words, uint32_t seq) {
+  const int tid = threadIdx.x;
+  const uint32_t i0 = (uint32_t)tid * BF_SCAN_IPT;
+  uint32_t x[BF_SCAN_IPT], sum = 0;
+#pragma unroll
+  for (int j = 0; j < BF_SCAN_IPT; ++j) {
+    x[j] = i0 + j < n_tot ? bk_raw[i0 + j] : 0u;
+    sum += x[j];
+  }
+  const uint32_t inc = wave_inclusive_add(sum);
+  if ((tid & 63) == 63) s_scr[tid >> 6] = inc;
+  __syncthreads();
+  uint32_t pre = inc - sum;
+  for (int w = 0; w < (tid >> 6); ++w) pre += s_scr[w];
+#pragma unroll
+  for (int j = 0; j < BF_SCAN_IPT; ++j) {
+    if (i0 + j < n_tot) s_tab[i0 + j] = pre;
+    pre += x[j];
+  }
+  if (tid == 255) s_tab[n_tot] = pre;
+  __syncthreads();
+  if (!publish) return;
+  const uint32_t grand = s_tab[n_tot];
+  for (uint32_t i = tid; i < n_tot; i += 256) bk_scan_out[i] = s_tab[i];
+  if (tid == 0) {
+    small[SM_BK_TOTAL] = grand;
+    small[SM_NVOX] = s_tab[(size_t)BK_NINT * nb];
+  }
+  if (tid < BB_LEVELS)
+    small[SM_BK_LEVEL + tid] = s_tab[(size_t)(BK_NINT + tid + 1) * nb] - s_tab[(size_t)(BK_NINT + tid) * nb];
+  if (tid == 8) small[SM_NBLOCKS] = grand - s_tab[(size_t)BK_NBLK * nb];
+  __threadfence();
+  __syncthreads();
+  for (int w = tid; w < mirror_words; w += 256)
+    mirror[w] = __hip_atomic_load(&small[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) mirror_publish(mirror, MIRROR_FLAG_BUILD, seq);
+}
+
 #define BF_WAVES 8   // waves per SIMD asked of the compiler for k_bucket_finish: 64 VGPRs, 16 B of scratch per lane (A/B on one box: 4 waves at 128 VGPRs 0.109 ms, 5: 0.121, 6: 0.104, 8: 0.092 - the kernel is latency bound)
-__global__ __launch_bounds__(256, BF_WAVES) void k_bucket_finish(
+template <bool OWN_SCAN>
+__global__ __launch_bounds__(256, OWN_SCAN ? 4 : BF_WAVES) void k_bucket_finish(
     NodePtrs nd, NodeParams P, const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bk_base,
     const uint32_t* __restrict__ grand_total, const uint32_t* __restrict__ leafinfo,
     const uint32_t* __restrict__ ord_idx, const uint32_t* __restrict__ bk_vox,
@@ -1912,7 +1959,11 @@ __global__ __launch_bounds__(256, BF_WAVES) void k_bucket_finish(
     const ChunkDesc* __restrict__ ck_desc, const uint32_t* __restrict__ ck_tot, const uint2* __restrict__ ck_of_bucket,
     int32_t* __restrict__ pos_node, uint64_t* __restrict__ vlin,
     int32_t* __restrict__ blk_node, int32_t* __restrict__ blk_slot, uint32_t* __restrict__ blk_start,
-    int32_t* __restrict__ blk_size, uint32_t* small) {
+    int32_t* __restrict__ blk_size, uint32_t* small,
+    const uint32_t* __restrict__ bk_raw, uint32_t* __restrict__ bk_scan_out, uint32_t* __restrict__ mirror,
+    int mirror_words, uint32_t seq) {
+  // (dynamic: only a launch that scans the totals itself - bk_raw != nullptr - asks for it)
+  extern __shared__ uint32_t s_tab[];                 // the scanned table of totals | its grand total
   __shared__ uint32_t s_scr[8];
   __shared__ unsigned long long s_bal[BB_CAP / 64];   // block-head ballots of the piece, position order
   __shared__ uint32_t s_hp[256];                      // head positions of one round (pieces beyond BB_CAP)
@@ -1927,29 +1978,43 @@ __global__ __launch_bounds__(256, BF_WAVES) void k_bucket_finish(
   const int tid = threadIdx.x;
   const uint32_t b = blockIdx.x;
   const bool spec = P.spec_geom != nullptr;
+  // A launch over few buckets scans the table of totals ITSELF (round 6: k_bucket_scan_totals was 9-12 us in front of
+  // a 100 k-point scan's finish for a table of 2 304 words): every workgroup with points scans the raw table into
+  // LDS - BF_SCAN_IPT words per thread - and workgroup 0 also writes what the scan kernel wrote: the scanned table
+  // (the ordinary launch that follows a refused speculative one reads it), the build's scalars and the pinned mirror
+  // the host is waiting for.
+  constexpr bool own_scan = OWN_SCAN;   // (an instance of its own: the ordinary one keeps its 64 registers to itself)
+  const uint32_t n_tot = (uint32_t)BK_ROWS * P.nb;
+  const uint32_t bucket_start = bstart[(size_t)b * P.bstride];
+  const uint32_t bucket_end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
+  if constexpr (own_scan) {
+    if (b != 0 && bucket_end == bucket_start) return;
+    finish_own_scan(bk_raw, n_tot, P.nb, s_tab, s_scr, b == 0, bk_scan_out, small, mirror, mirror_words, seq);
+  }
+  // entries of the scanned table: row r, bucket b; the entry behind the last one of the table is the total
+  auto at = [&](int r, uint32_t q) {
+    const size_t i = (size_t)r * P.nb + q;
+    if constexpr (own_scan) return s_tab[i];
+    else return i < (size_t)n_tot ? bk_base[i] : *grand_total;
+  };
   if (spec) {
-    // (kernel-uniform; the words are final: k_bucket_scan_totals is in front of this launch)
+    // (kernel-uniform; the words are final: k_bucket_scan_totals is in front of this launch, or the scan above)
     if (!P.spec_geom->valid) return;
     if (small[SM_BK_FLAGS] | small[SM_BK_TODO] | small[SM_BK_NOORDER]) return;
     if (!P.spec_chunks && small[SM_BK_OVERFULL]) return;
-    if ((int64_t)small[SM_NVOX] > P.vox_cap || (int64_t)small[SM_NBLOCKS] > P.blk_cap) return;
+    const int64_t nvox_all = own_scan ? (int64_t)at(BK_NINT, 0) : (int64_t)small[SM_NVOX];
+    const int64_t nblk_all = own_scan ? (int64_t)(at(BK_ROWS, 0) - at(BK_NBLK, 0)) : (int64_t)small[SM_NBLOCKS];
+    if (nvox_all > P.vox_cap || nblk_all > P.blk_cap) return;
     P.lp = P.spec_geom->lp;
   }
-  const uint32_t bucket_start = bstart[(size_t)b * P.bstride];
-  const uint32_t bucket_end = (b + 1 < P.nb) ? bstart[(size_t)(b + 1) * P.bstride] : P.n_alive;
   if (bucket_end == bucket_start) return;
-  const uint32_t head_int = bk_base[(size_t)BK_NINT * P.nb], head_blk = bk_base[(size_t)BK_NBLK * P.nb];
+  const uint32_t head_int = at(BK_NINT, 0), head_blk = at(BK_NBLK, 0);
   const int64_t V = (int64_t)head_int;                     // total of row BK_NVOX
   const int64_t n_int = (int64_t)(head_blk - head_int);    // total of the level rows
   if (V + 8 * n_int > P.node_cap) {
     if (tid == 0 && !spec) atomicOr(&small[SM_BK_FLAGS], 0x100u);  // the host grows the table and launches again
     return;
   }
-  // entries of the scanned table: row r, bucket b; the entry behind the last one of the table is the total
-  auto at = [&](int r, uint32_t q) {
-    const size_t i = (size_t)r * P.nb + q;
-    return i < (size_t)BK_ROWS * P.nb ? bk_base[i] : *grand_total;
-  };
   // A bucket is ONE piece, or - when it held more than BB_CAP points - the chunks k_bucket_chunks built one by
   // one: each piece numbered its voxels / internal nodes / blocks from zero, the bases below add the bucket's
   // share of the global scan and the pieces in front of it inside the bucket.
@@ -2683,16 +2748,21 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // k_bucket_finish, launched the ordinary way (behind the host's look at the totals) or speculatively (in front of
   // it: NodeParams::spec_geom)
   NodePtrs nd_launch;
-  auto launch_finish = [&](const NodeParams& np, bool with_chunk_map) {
+  // (own_scan_seq != 0: the launch scans the totals itself and publishes them under that wait sequence number)
+  auto launch_finish = [&](const NodeParams& np, bool with_chunk_map, uint32_t own_scan_seq = 0) {
     KTimer t(ctx, "bucket_nodes");
-    OCTL_LAUNCH(k_bucket_finish, dim3(nb), dim3(256), 0, st, nd_launch, np, bstart,
+    const size_t lds = own_scan_seq ? ((size_t)BK_ROWS * nb + 1) * 4 : 0;
+    auto kern = own_scan_seq ? k_bucket_finish<true> : k_bucket_finish<false>;
+    OCTL_LAUNCH(kern, dim3(nb), dim3(256), lds, st, nd_launch, np, bstart,
                        (const uint32_t*)bk_scan, (const uint32_t*)(small + SM_BK_TOTAL),
                        (const uint32_t*)f->leafinfo.as<uint32_t>(), (const uint32_t*)f->ord_idx.as<uint32_t>(),
                        (const uint32_t*)f->bk_vox.as<uint32_t>(), (const uint32_t*)f->bk_node.as<uint32_t>(),
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), (const ChunkDesc*)ck_desc, (const uint32_t*)ck_tot,
                        (const uint2*)(with_chunk_map ? ck_of_bucket : nullptr), f->pos_node.as<int32_t>(),
                        f->vlin_dev.as<uint64_t>(), f->blk_node.as<int32_t>(), f->blk_slot.as<int32_t>(),
-                       f->blk_start.as<uint32_t>(), f->blk_size.as<int32_t>(), small);
+                       f->blk_start.as<uint32_t>(), f->blk_size.as<int32_t>(), small,
+                       (const uint32_t*)(own_scan_seq ? bk_tot : nullptr), bk_scan,
+                       static_cast<uint32_t*>(ctx->small_host), mirror_words, own_scan_seq);
     return hipGetLastError();
   };
   NodeParams np;
@@ -2716,7 +2786,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   // (the voxel origin is only read against a previous scheme: NodeParams::org)
   const bool spec_want = async_geom && gdev && !a.old_fc && !a.old_vcode && ctx->spec_nodes > 0 &&
                          !ctx->opt.no_spec_finish;
-  auto spec_finish = [&]() {
+  // (few buckets: the speculative launch scans the totals itself - no k_bucket_scan_totals in front of it)
+  const bool own_scan = spec_want && !ctx->opt.no_fused_tables && (uint32_t)BK_ROWS * nb <= (uint32_t)BF_SCAN_MAX;
+  auto spec_finish = [&](uint32_t own_scan_seq) {
     // (a table that held the previous build is taken as it is - growing a live buffer waits for the stream, and the
     //  kernel checks the real capacities anyway; one that did not is sized 25 % above that build)
     // (the previous build's counts, in proportion to the points: a scan ten times larger is not given tables that
@@ -2741,14 +2813,14 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     sp.spec_chunks = chunks_beside ? 1 : 0;
     sp.vox_cap = spec_vox_cap;
     sp.blk_cap = spec_blk_cap;
-    HIP_TRY(ctx, launch_finish(sp, chunks_beside));
+    HIP_TRY(ctx, launch_finish(sp, chunks_beside, own_scan_seq));
     spec_launched = true;
     return (int)OCTL_OK;
   };
   // raw totals -> scanned totals + the build's scalars in the pinned mirror; the host polls for them
   auto scan_totals = [&](bool with_spec) {
     const uint32_t wait_seq = octl_wait_next_seq(ctx);
-    {
+    if (!(with_spec && own_scan)) {
       KTimer t(ctx, "bucket_scan");
       if (!ctx->opt.no_fused_tables) {
         const uint32_t n_tot = (uint32_t)BK_ROWS * nb;
@@ -2766,7 +2838,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       }
       HIP_TRY(ctx, hipGetLastError());
     }
-    if (with_spec) OCTL_TRY(spec_finish());
+    if (with_spec) OCTL_TRY(spec_finish(own_scan ? wait_seq : 0u));
     // (the totals kernel writes the scalars and then its flag into the pinned mirror)
     const int flag = MIRROR_FLAG_BUILD;
     OCTL_TRY(octl_wait_mirror_flags(ctx, &flag, 1, wait_seq, 200 + n_alive / 20000));
