@@ -34,6 +34,7 @@
 
 #include "forest.h"
 #include "lookback.h"
+#include "wave_utils.h"
 
 namespace {
 
@@ -1745,14 +1746,23 @@ __global__ __launch_bounds__(BPS_THREADS) void k_block_prepare_small(
       __hip_atomic_store(&mirror[MIRROR_RS_VIOLATION], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
-  // start of size class t in the list, largest size first
+  // start of size class m in the list, largest size first: an exclusive scan over the sizes in descending order
+  // (thread t < 256 holds size 255 - t)
+  uint32_t cm = 0, incm = 0;
   if (threadIdx.x < 256) {
-    uint32_t f = 0;
-    for (int m = 255; m > (int)threadIdx.x; --m) f += bins[m];
-    first[threadIdx.x] = f;
-    counters[RC_BINS + threadIdx.x] = bins[threadIdx.x];
-    counters[RC_START + threadIdx.x] = f;
-    if (threadIdx.x == 0) counters[RC_SORTED] = f + bins[0];
+    cm = bins[255 - threadIdx.x];
+    incm = wave_inclusive_add(cm);
+    if (lane == 63) s_wave[wave] = incm;
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    uint32_t f = incm - cm;
+    for (int w = 0; w < wave; ++w) f += s_wave[w];
+    const int m = 255 - (int)threadIdx.x;
+    first[m] = f;
+    counters[RC_BINS + m] = cm;
+    counters[RC_START + m] = f;
+    if (m == 0) counters[RC_SORTED] = f + cm;
   }
   __syncthreads();
 #pragma unroll
