@@ -25,7 +25,8 @@
 //                                  coalesced stores of permutation, coordinates and a leaf word per
 //                                  point; voxels, internal nodes and leaves are numbered INSIDE the
 //                                  bucket (staging records per voxel and per internal node);
-//   one exclusive scan             bucket totals -> voxel / node / block numbering bases;
+//   one exclusive scan             bucket totals -> voxel / node / block numbering bases (k_bucket_scan_totals; over few
+//                                  buckets the speculative k_bucket_finish<true> scans the table itself);
 //   k_bucket_finish                one workgroup per bucket, parallel sweeps: roots, internal nodes and
 //                                  their children in the level-major numbering of the level-synchronous
 //                                  path, (leaf, pose) block table, position -> leaf map when needed.

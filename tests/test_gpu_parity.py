@@ -2986,6 +2986,51 @@ def test_ransac_prescreen_never_changes_a_result(kind):
         assert (o_index >= 64).any()     # winners beyond the first group exist: the survivors' path decides them
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_blocks", [1, 257, 8191, 8192, 8193])
+@pytest.mark.parametrize("H,k", [(1024, 6), (64, 3)])
+def test_one_launch_preparation_of_a_small_ransac_launch(n_blocks, H, k):
+    """Round 6: a launch of up to 8192 blocks is prepared by ONE kernel (k_block_prepare_small: descriptors, size
+    classes, sorted list, position table), a larger one by k_block_prepare + k_block_scatter; NO_FUSED_TABLES takes the
+    round-3 form (sizes, scan, descriptors, scatter).  All three must give the same count, winner, plane bits and mask
+    for every block - blocks below k points (finished at once: cuda_ransac.py:96-97), up to 63, 64 .. 255 and beyond
+    the register path's capacity in one batch - and the oracle's on a prefix of the batch."""
+    from octreelib_amd.ransac import CudaRansac
+    from oracle import ransac_np as rnp
+
+    rng = np.random.default_rng(n_blocks * 7 + H + k)
+    sizes = rng.integers(1, 64, n_blocks).astype(np.int32)
+    sizes[::97] = rng.integers(64, 256, len(sizes[::97]))
+    sizes[5::1500] = rng.integers(256, 700, len(sizes[5::1500]))
+    sizes[3::11] = rng.integers(1, k, len(sizes[3::11]))     # finished at once
+    n = int(sizes.sum())
+    base = rng.random((n_blocks, 3)) * 40.0
+    cloud = np.repeat(base, sizes, axis=0) + rng.random((n, 3)) * 0.5
+    cloud[:, 2] = np.repeat(base[:, 2], sizes) + 0.2 * (cloud[:, 0] - np.repeat(base[:, 0], sizes)) \
+        + rng.normal(0, 0.004, n)
+    np.random.seed(5)
+    op = CudaRansac(threshold=0.01, hypotheses_number=H, initial_points_number=k)
+    res = {}
+    try:
+        for fused_off in (0, 1):
+            set_option("NO_FUSED_TABLES", fused_off)
+            res[fused_off] = op.evaluate(cloud, sizes, details=True)
+    finally:
+        set_option("NO_FUSED_TABLES", 0)
+    (m0, p0, c0, i0), (m1, p1, c1, i1) = res[0], res[1]
+    assert np.array_equal(c0, c1) and np.array_equal(i0, i1)
+    assert np.array_equal(p0.view(np.uint32), p1.view(np.uint32)) and np.array_equal(m0, m1)
+    assert (c0[sizes < k] == 0).all() and (i0[sizes < k] == -1).all()
+    # the oracle on the first blocks (a block's result depends on its own points and the point behind it only)
+    nb = min(n_blocks, 120 if H == 1024 else 600)
+    npts = int(sizes[:nb].sum())
+    o_mask, o_count, o_plane, o_index, _ = rnp.evaluate(cloud[:npts + (1 if npts < n else 0)], sizes[:nb],
+                                                        op.random_hypotheses, 0.01, details=True)
+    assert np.array_equal(c0[:nb], o_count) and np.array_equal(i0[:nb], o_index)
+    assert np.array_equal(p0[:nb].view(np.uint32), o_plane.view(np.uint32))
+    assert np.array_equal(m0[:npts], o_mask[:npts])
+
+
 def _input_forms(pts64):
     """The same cloud as the reference's callers may hand it over (the reference upcasts everything to f64:
     internal/voxel.py:81-83, octree/octree.py:100): values are f32-representable so that every form holds the same
