@@ -1646,7 +1646,8 @@ TIMER_KERNELS = {
 # the kernel that runs exactly ONCE per step of a workload: dispatch counts are taken relative to it
 # (k_bucket_finish: a build whose hinted geometry is rejected launches the partition kernels and the totals twice,
 #  the finish once; round-4 profiles: k_bucket_totals)
-PROFILE_REF = {"headline": ("k_bucket_finish", "k_bucket_totals"), "c5shard": ("k_bucket_finish", "k_bucket_totals"),
+PROFILE_REF = {"headline": ("k_bucket_finish<false>", "k_bucket_finish", "k_bucket_totals"),
+               "c5shard": ("k_bucket_finish<false>", "k_bucket_finish", "k_bucket_totals"),
                "c4": ("k_finalize_rec",)}
 
 # DESIGN bytes per point of the streaming kernels of insert + subdivide: what each one has to read and write

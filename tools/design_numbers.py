@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """The numbers DESIGN.md quotes, out of the tracked profile files of a round (profiles/rNN_*): the per-kernel table of
-one step of the headline and the one-liners of the secondaries.   usage: tools/design_numbers.py r05"""
+one step of the headline and the one-liners of the secondaries.   usage: tools/design_numbers.py r06"""
 import csv, json, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
-b = json.load(open(f"profiles/{tag}_bench.json"))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+import os
+# (round 6: the bounded line is TAG_bench.json, the full result TAG_bench_detail.json)
+b = json.load(open(f"profiles/{tag}_bench_detail.json" if os.path.exists(f"profiles/{tag}_bench_detail.json")
+               else f"profiles/{tag}_bench.json"))
 tr = json.load(open(f"profiles/{tag}_hbm_traffic.json"))["kernels"]
 sq = json.load(open(f"profiles/{tag}_sq_counters.json"))["kernels"]
 st = {}
@@ -18,8 +21,8 @@ except OSError:
 print("| kernel | µs (median of its full launches) | fetch / write MB | counter TB/s (of 8) | waves/SIMD, wait | bound by |")
 print("|---|---|---|---|---|---|")
 for k in ("k_build_begin", "k_part_hist<true,true>", "k_part_hist<false,true>", "k_table_scan", "k_part_scatter<8,false,12>",
-          "k_bucket_build", "k_bucket_scan_totals", "k_bucket_finish", "k_block_prepare", "k_block_scatter",
-          "k_ransac<64,16,6,0,true,true>", "k_ransac<128,8,6,0,true,true>", "k_blk_kept", "k_scan_lookback",
+          "k_bucket_build", "k_bucket_scan_totals", "k_bucket_finish<false>", "k_block_prepare", "k_block_scatter",
+          "k_ransac<64,16,6,true,true>", "k_ransac<128,8,6,true,true>", "k_blk_kept", "k_scan_lookback",
           "k_compact_tiles", "k_blk_compact"):
     us = st.get(k, (None, 0))
     if k in fl:
