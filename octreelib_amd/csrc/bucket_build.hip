@@ -1904,7 +1904,7 @@ __global__ __launch_bounds__(256) void k_old_voxels_missing(const uint64_t* __re
   if (!found) atomicAdd(missing, 1u);
 }
 
-constexpr int BF_SCAN_IPT = 9, BF_SCAN_MAX = 256 * BF_SCAN_IPT;  // words of totals a finish launch scans itself
+constexpr int BF_SCAN_IPT = 18, BF_SCAN_MAX = 256 * BF_SCAN_IPT;  // words of totals a finish launch scans itself
 // k_bucket_finish<true>'s own scan of the totals (see there; that instance runs over few buckets and is compiled for
 // 128 registers - the ordinary one keeps its 64 and its 16 bytes of scratch)
 __device__ __forceinline__ void finish_own_scan(const uint32_t* __restrict__ bk_raw, uint32_t n_tot, uint32_t nb,
@@ -1980,7 +1980,7 @@ __global__ __launch_bounds__(256, OWN_SCAN ? 4 : BF_WAVES) void k_bucket_finish(
   const uint32_t b = blockIdx.x;
   const bool spec = P.spec_geom != nullptr;
   // A launch over few buckets scans the table of totals ITSELF (round 6: k_bucket_scan_totals was 9-12 us in front of
-  // a 100 k-point scan's finish for a table of 2 304 words): every workgroup with points scans the raw table into
+  // a 100 k-point scan's finish for a table of 2 304 words; up to BF_SCAN_MAX words = 512 buckets): every workgroup with points scans the raw table into
   // LDS - BF_SCAN_IPT words per thread - and workgroup 0 also writes what the scan kernel wrote: the scanned table
   // (the ordinary launch that follows a refused speculative one reads it), the build's scalars and the pinned mirror
   // the host is waiting for.

@@ -1648,7 +1648,10 @@ __global__ __launch_bounds__(256) void k_block_scatter(const BlockDesc* __restri
 // global atomics, no unsorted list in between (only the oversize blocks' descriptors are written there, for
 // k_ransac_big).  Workgroups [1, ...): the position table for EVERY size k .. cap - which sizes occur is only known
 // to workgroup 0, and a size costs one workgroup.
-constexpr int BPS_THREADS = 1024, BPS_PER_THREAD = 8, BPS_MAX = BPS_THREADS * BPS_PER_THREAD;
+// (BPS_PER_THREAD blocks per thread, 2 / 4 / 6 / 8 by the size of the launch: the workgroup's time is its threads'
+//  serial work - sixteen per thread for launches of up to 16 384 blocks was slower than the two kernels)
+constexpr int BPS_THREADS = 1024, BPS_MAX = BPS_THREADS * 8;
+template <int BPS_PER_THREAD>
 __global__ __launch_bounds__(BPS_THREADS) void k_block_prepare_small(
     const int32_t* __restrict__ order, const uint32_t* __restrict__ start, const int32_t* __restrict__ size,
     int64_t nb, int64_t n_points, int cap, int k, BlockDesc* __restrict__ desc, BlockDesc* __restrict__ sdesc,
@@ -1837,7 +1840,10 @@ int ransac_launch(octl_ctx* ctx, const double* xyz_dev, int64_t n_points,
     KTimer t(ctx, "ransac_prepare");
     const int cap = any_k ? 0 : threads - 1;
     const unsigned n_table = use_tab && cap >= k ? (unsigned)(cap - k + 1) * (unsigned)ceil_div(H, BPS_THREADS) : 0u;
-    OCTL_LAUNCH(k_block_prepare_small, dim3(1 + n_table), dim3(BPS_THREADS), 0, st, order_dev, blk_start, blk_size, nb,
+    auto kp = nb <= 2 * BPS_THREADS ? k_block_prepare_small<2>
+              : (nb <= 4 * BPS_THREADS ? k_block_prepare_small<4>
+                                       : (nb <= 6 * BPS_THREADS ? k_block_prepare_small<6> : k_block_prepare_small<8>));
+    OCTL_LAUNCH(kp, dim3(1 + n_table), dim3(BPS_THREADS), 0, st, order_dev, blk_start, blk_size, nb,
                        n_points, cap, (int)k, desc, sdesc, big_list, counters, out, max_block,
                        static_cast<uint32_t*>(ctx->small_host), hyp_dev, (int)H, pos_tab, next_counters);
     HIP_TRY(ctx, hipGetLastError());

@@ -2987,7 +2987,7 @@ def test_ransac_prescreen_never_changes_a_result(kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_blocks", [1, 257, 8191, 8192, 8193])
+@pytest.mark.parametrize("n_blocks", [1, 257, 2048, 2049, 4097, 6145, 8192, 8193])
 @pytest.mark.parametrize("H,k", [(1024, 6), (64, 3)])
 def test_one_launch_preparation_of_a_small_ransac_launch(n_blocks, H, k):
     """Round 6: a launch of up to 8192 blocks is prepared by ONE kernel (k_block_prepare_small: descriptors, size
