@@ -228,19 +228,25 @@ __global__ void k_bucket_geom(const int32_t* __restrict__ bbox, GeomAsk ask, Lin
 __global__ void k_geom_set(GeomDev hint, GeomDev* __restrict__ g) {
   if (threadIdx.x == 0) *g = hint;
 }
-__device__ __forceinline__ void geom_validate_body(const int32_t* __restrict__ bbox, const GeomAsk& ask,
-                                                   const LinParams& base, GeomDev* __restrict__ g) {
-  GeomDev o;
+// (the decision alone: does the hinted geometry of width hint_width stand for the cloud whose box the histogram
+//  pass found?  o: the record to leave behind when it does not)
+__device__ __forceinline__ bool geom_validate_decide(const int32_t* __restrict__ bbox, const GeomAsk& ask,
+                                                     const LinParams& base, uint32_t hint_width, GeomDev& o) {
   geom_from_box(bbox, bbox[6] != 0, ask, base, o);
-  const GeomDev h = *g;
   const bool inside = bbox[7] == 0;  // no point outside the hint's box
-  if (o.valid && inside && h.lp.width <= 2u * o.lp.width && o.lp.width <= 2u * h.lp.width) {
-    for (int a = 0; a < 6; ++a) g->tb[a] = bbox[a];  // the hint stands; the host forms the next one from this box
-    return;
-  }
+  if (o.valid && inside && hint_width <= 2u * o.lp.width && o.lp.width <= 2u * hint_width) return true;
   if (o.valid) {
     o.valid = 0;
     o.reason = GEOM_REHASH;
+  }
+  return false;
+}
+__device__ __forceinline__ void geom_validate_body(const int32_t* __restrict__ bbox, const GeomAsk& ask,
+                                                   const LinParams& base, GeomDev* __restrict__ g) {
+  GeomDev o;
+  if (geom_validate_decide(bbox, ask, base, g->lp.width, o)) {
+    for (int a = 0; a < 6; ++a) g->tb[a] = bbox[a];  // the hint stands; the host forms the next one from this box
+    return;
   }
   *g = o;
 }
@@ -678,13 +684,28 @@ __device__ __forceinline__ uint32_t wave_rank_u16(uint32_t digit, bool valid, ui
 
 // MBITS: ballot rounds of the in-wave rank = bits of the pass's digit (12 for a single pass over up to 4096 buckets,
 // 8 when a pass of a two-pass partition has at most 256 digits: a third of the rounds less)
-template <int PT_IPT, bool FROM_REC, int MBITS>
+// OWN_SCAN (round 6, small clouds: <= 256 digits, <= PS_OWN_MAX_ROWS supertiles): the table is the RAW one of the
+// histogram pass and every workgroup forms its own row of the scanned one - column totals over all rows, their
+// exclusive scan over the digits, plus the rows in front of its own - and decides about a hinted geometry itself
+// (the same pure function on the same box: the same verdict everywhere); workgroup 0 also leaves behind what
+// k_table_scan left: the buckets' starts and the verdict / the true box in the geometry record.  k_table_scan was
+// 6.6 us of a 100 k-point scan in front of this kernel for a table of 50 rows.
+struct ScatterOwnScan {
+  uint32_t* bucket_start;
+  int validate;            // 0 / 1 (geom_validate_decide)
+  const int32_t* bbox;
+  GeomAsk ask;
+  LinParams base;
+  GeomDev* g;
+};
+constexpr uint32_t PS_OWN_MAX_ROWS = 64;
+template <int PT_IPT, bool FROM_REC, int MBITS, bool OWN_SCAN = false>
 __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter(
     const double* __restrict__ xyz, const uint8_t* __restrict__ alive, int64_t N, LinParams lp,
     const GeomDev* __restrict__ G, uint32_t nst, uint32_t nd, int st_tiles,
     const uint32_t* __restrict__ table_scanned,
     const int64_t* __restrict__ pose_off, int n_poses, const uint8_t* __restrict__ scheme,
-    PartRec* __restrict__ out) {
+    PartRec* __restrict__ out, ScatterOwnScan own) {
   // (sized by the pass's digit: 48 KB for the 4096 digits of a single pass, 3 KB for the <= 256 of a two-pass
   //  partition - whose tiles then also zero and scan a sixteenth of the counters)
   constexpr int NB = 1 << MBITS;
@@ -696,8 +717,55 @@ __global__ __launch_bounds__(PT_THREADS, MBITS <= 8 ? 3 : 2) void k_part_scatter
     if (!FROM_REC) lp = G->lp;  // (the second pass of a two-pass partition runs under the host's digit parameters)
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
-    base[d] = table_scanned[(size_t)blockIdx.x * nd + d];  // ([supertile][digit]: see k_part_hist)
+  if constexpr (OWN_SCAN) {
+    static_assert(NB == PT_THREADS, "one digit column per thread");
+    __shared__ uint32_t s_ws[PT_THREADS / 64];
+    __shared__ int s_stands;
+    // (the rows first: their loads are in flight while thread 0 decides about the hint - 64-bit divisions)
+    const uint32_t d = threadIdx.x;
+    uint32_t tot = 0, before = 0;
+    if (d < nd) {
+      // (all of a column's rows in flight at once: 4 batches of 16 loads)
+      for (uint32_t r0 = 0; r0 < nst; r0 += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = r0 + u < nst ? table_scanned[(size_t)(r0 + u) * nd + d] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          tot += v[u];
+          before += r0 + u < blockIdx.x ? v[u] : 0u;
+        }
+      }
+    }
+    if (own.validate && threadIdx.x == PT_THREADS - 1) {
+      GeomDev o;
+      const bool stands = geom_validate_decide(own.bbox, own.ask, own.base, lp.width, o);
+      s_stands = stands ? 1 : 0;
+      if (blockIdx.x == 0) {
+        if (stands) {
+          for (int a = 0; a < 6; ++a) own.g->tb[a] = own.bbox[a];
+        } else {
+          *own.g = o;   // (the other workgroups reach the same verdict themselves and return)
+        }
+      }
+    }
+    const uint32_t inc = wave_inclusive_add(tot);
+    if (lane == 63) s_ws[wave] = inc;
+    __syncthreads();
+    if (own.validate && !s_stands) return;
+    uint32_t excl = inc - tot;
+    for (int w = 0; w < wave; ++w) excl += s_ws[w];
+    if (d < nd) {
+      base[d] = excl + before;
+      if (blockIdx.x == 0) {
+        own.bucket_start[d] = excl;
+        if (d == nd - 1) own.bucket_start[nd] = excl + tot;
+      }
+    }
+  } else {
+    for (uint32_t d = threadIdx.x; d < nd; d += PT_THREADS)
+      base[d] = table_scanned[(size_t)blockIdx.x * nd + d];  // ([supertile][digit]: see k_part_hist)
+  }
   constexpr int PT_TILE = PT_THREADS * PT_IPT;
   // (kernel-uniform) the cubes the digits are taken against have integer-valued, non-negative corners and edges:
   // always in a grid (corner = q L, edge = L, L integer) for a non-negative point; a single cube when its own
@@ -2621,7 +2689,9 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     }
     HIP_TRY(ctx, hipGetLastError());
   }
-  {
+  // (a small table: the scatter kernel's workgroups scan it themselves - ScatterOwnScan)
+  const bool own_scan_a = fused_a && !two_pass && !hinted2 && nd_a <= 256u && nst_a <= PS_OWN_MAX_ROWS;
+  if (!own_scan_a) {
     KTimer t(ctx, "part_scan");
     if (fused_a) {
       OCTL_TRY(table_scan(nst_a, nd_a, table_dm, hinted ? 1 : (hinted2 ? 2 : 0)));
@@ -2633,12 +2703,23 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
   }
   {
     KTimer t(ctx, "part_scatter");
-    auto ks = nd_a <= 256u ? k_part_scatter<PT_IPT, false, 8> : k_part_scatter<PT_IPT, false, PT_BITS>;
+    auto ks = own_scan_a ? k_part_scatter<PT_IPT, false, 8, true>
+                         : (nd_a <= 256u ? k_part_scatter<PT_IPT, false, 8> : k_part_scatter<PT_IPT, false, PT_BITS>);
+    ScatterOwnScan own;
+    std::memset(&own, 0, sizeof(own));
+    if (own_scan_a) {
+      own.bucket_start = table_dm;
+      own.validate = hinted ? 1 : 0;
+      own.bbox = (const int32_t*)f->bbox_dev.as<int32_t>();
+      own.ask = ask;
+      own.base = lp;
+      own.g = gdev;
+    }
     OCTL_LAUNCH(ks, dim3(nst_a), dim3(PT_THREADS), 0, st,
                        (const double*)f->xyz.as<double>(), alive_p, N, lp,
                        (const GeomDev*)gdev, nst_a, nd_a, st_tiles_a, (const uint32_t*)table,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, a.scheme_dev,
-                       f->part_xyz[0].as<PartRec>());
+                       f->part_xyz[0].as<PartRec>(), own);
     HIP_TRY(ctx, hipGetLastError());
   }
   const PartRec* recs = f->part_xyz[0].as<PartRec>();
@@ -2672,7 +2753,7 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
       OCTL_LAUNCH(ks, dim3(nst_b), dim3(PT_THREADS), 0, st,
                          (const double*)f->part_xyz[0].as<double>(), (const uint8_t*)nullptr, n_alive, lp,
                          (const GeomDev*)gdev, nst_b, nd_b, st_tiles_b, (const uint32_t*)table, (const int64_t*)nullptr, 0,
-                         (const uint8_t*)nullptr, f->part_xyz[1].as<PartRec>());
+                         (const uint8_t*)nullptr, f->part_xyz[1].as<PartRec>(), ScatterOwnScan{});
       HIP_TRY(ctx, hipGetLastError());
     }
     uint32_t* bounds = table + 2 * tab_elems;
@@ -3073,7 +3154,7 @@ int forest_prefix_partition(octl_forest* f, int pm, const void** recs_out, const
     OCTL_LAUNCH(ks, dim3(nst), dim3(PT_THREADS), 0, st, (const double*)f->xyz.as<double>(), (const uint8_t*)nullptr, N,
                        lp, (const GeomDev*)nullptr, nst, nd, st_tiles, (const uint32_t*)table,
                        (const int64_t*)f->pose_off_dev.as<int64_t>(), n_poses, (const uint8_t*)nullptr,
-                       f->part_xyz[0].as<PartRec>());
+                       f->part_xyz[0].as<PartRec>(), ScatterOwnScan{});
     HIP_TRY(ctx, hipGetLastError());
   }
   *recs_out = f->part_xyz[0].p;

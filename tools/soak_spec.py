@@ -53,11 +53,21 @@ for it in range(iters):
         ctx.set_option("GEOM_MARGIN", int(rng.choice([-1, 2, 3])))
         T._assert_same_step(want, T._step_tables([pts], K, adopt), canonical=True)
         ctx.set_option("GEOM_MARGIN", 0)
+        # the small-launch forms (k_block_prepare_small, k_mask_scan's own compaction, the scans inside
+        # k_bucket_finish<true> and k_part_scatter<..., true>) against the separate kernels, and another bucket size
+        ctx.set_option("NO_FUSED_TABLES", 1)
+        T._assert_same_step(want, T._step_tables([pts], K, adopt))
+        ctx.set_option("NO_FUSED_TABLES", 0)
+        ctx.set_option("BUCKET_POINTS", int(rng.choice([640, 2560, 5000])))
+        T._assert_same_step(want, T._step_tables([pts], K, adopt), canonical=True)
+        ctx.set_option("BUCKET_POINTS", 0)
     except Exception as e:  # noqa: BLE001
         bad += 1
         ctx.set_option("NO_SPEC_FINISH", 0)
         ctx.set_option("NO_GEOM_HINT", 0)
         ctx.set_option("GEOM_MARGIN", 0)
+        ctx.set_option("NO_FUSED_TABLES", 0)
+        ctx.set_option("BUCKET_POINTS", 0)
         print("FAILED at", it, n, kind, side, K, repr(e)[:200], flush=True)
     if it % 20 == 19:
         print("iteration", it + 1, "speculative launches held / missed so far:", tuple(a - b for a, b in zip(counters(), (h0, m0))),
