@@ -20,7 +20,7 @@ except OSError:
     fl = {}
 print("| kernel | µs (median of its full launches) | fetch / write MB | counter TB/s (of 8) | waves/SIMD, wait | bound by |")
 print("|---|---|---|---|---|---|")
-for k in ("k_build_begin", "k_part_hist<true,true>", "k_part_hist<false,true>", "k_table_scan", "k_part_scatter<8,false,12>",
+for k in ("k_build_begin", "k_part_hist<true,true>", "k_part_hist<false,true>", "k_table_scan", "k_part_scatter<8,false,12,false>",
           "k_bucket_build", "k_bucket_scan_totals", "k_bucket_finish<false>", "k_block_prepare", "k_block_scatter",
           "k_ransac<64,16,6,true,true>", "k_ransac<128,8,6,true,true>", "k_blk_kept", "k_scan_lookback",
           "k_compact_tiles", "k_blk_compact"):
