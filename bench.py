@@ -212,6 +212,7 @@ class Workload:
         self.info = nat.BuildInfo()
         self.e0 = np.zeros(1, dtype=np.int32)
         self.n_alive = C.c_int64(0)
+        self.async_mask = not os.environ.get("OCTL_BENCH_SYNC_APPLY_MASK")   # (A/B: the round-5 form waits per step)
         self.n_recv = C.c_int64(n_local)
         self.send_counts = np.zeros(max(world, 1), dtype=np.int64)   # points this rank sends to every rank, last routing
         self.slot = C.c_int32(0)
@@ -292,7 +293,16 @@ class Workload:
         self.build()
         ctx.check(lib.octl_forest_ransac_all(self.fh, 10, nat.ptr(self.e0), 1, nat.ptr(self.table), H, KPTS,
                                              THRESHOLD))
-        ctx.check(lib.octl_forest_apply_mask(self.fh, C.byref(self.n_alive)))
+        if self.async_mask:
+            # (the scan loop of the reference's API: map_leaf_points_cuda_ransac returns nothing, grid.py:124-215 -
+            #  the count is booked when somebody asks; the next step's first kernels queue up behind this one's last)
+            ctx.check(lib.octl_forest_apply_mask_async(self.fh))
+        else:
+            ctx.check(lib.octl_forest_apply_mask(self.fh, C.byref(self.n_alive)))
+
+    def settle(self):
+        """Book the last apply_mask's counts (points left: self.n_alive)."""
+        self.ctx.check(self.lib.octl_forest_settle(self.fh, C.byref(self.n_alive)))
 
     def insert(self):
         lib, ctx = self.lib, self.ctx
@@ -899,6 +909,7 @@ def main():
     timings = {k: (v[0] * args.steps / prof_steps, v[1] * args.steps / prof_steps) for k, v in timings.items()}
     if "ransac" in live:
         timings["ransac"] = live["ransac"]   # the live measurement of the timed region
+    wl.settle()
     info, n_alive_after = wl.info, int(wl.n_alive.value)
     leaves, nodes, levels = int(info.n_blocks), int(info.n_nodes), int(info.n_levels)
 

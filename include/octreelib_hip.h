@@ -242,6 +242,16 @@ int octl_forest_get_mask(octl_forest* f, int64_t cap, uint8_t* mask, int64_t* n)
  * host: the compaction kernel may still be running (it reads the forest's own arrays only, never a cloud that
  * was taken in place; work enqueued on the context later runs behind it).  octl_ctx_sync waits for it.        */
 int octl_forest_apply_mask(octl_forest* f, int64_t* n_alive);
+/* The same without waiting for the count (round 6): the kernels are enqueued and the call returns; the surviving
+ * point and block counts are booked by the next call that looks at the forest (every octl_forest_* entry point does
+ * so first; octl_forest_clear / _destroy drop them unread).  Grid.map_leaf_points_cuda_ransac returns nothing
+ * (grid/grid.py:124-215), so a scan loop - insert, subdivide, RANSAC, apply_mask, clear - never waits for this count
+ * at all and the next scan's first kernels queue up behind this one's last.  One compaction per context can be in
+ * flight: a second one (any forest of the context) books the first before it starts.  A RANSAC launch that met a
+ * block larger than it was promised is reported by the next wait of the context, whichever call that is.        */
+int octl_forest_apply_mask_async(octl_forest* f);
+/* Book the counts of an octl_forest_apply_mask_async now (a no-op otherwise); *n_alive (nullable): surviving points. */
+int octl_forest_settle(octl_forest* f, int64_t* n_alive);
 /* OctreeNode.filter (octree/octree.py:102-112) for point-count predicates, on the device: every leaf of
  * the poses with slot_sel[slot] != 0 whose point count is outside [lo, hi] is emptied (its points
  * leave the tree), followed by the same compaction as apply_mask.  A criterion `len(points) >= c` is

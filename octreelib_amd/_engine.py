@@ -33,6 +33,7 @@ class Forest:
         self.has_scheme = False              # a K-driven scheme exists
         self._dirty = True                   # points were added since the last build
         self.info = None
+        self._n_ord_pending = False
         self.n_ord = 0
         self._invalidate()
         # grid bookkeeping that must survive rebuilds: voxels each pose was inserted into and
@@ -589,10 +590,26 @@ class Forest:
         self._invalidate()
 
     def apply_device_mask(self):
-        n = C.c_int64(0)
-        self.ctx.check(self.lib.octl_forest_apply_mask(self.handle, C.byref(n)))
-        self.n_ord = n.value
+        # (octl_forest_apply_mask_async: the compaction is enqueued, its counts are booked when somebody asks -
+        #  the reference's map_leaf_points_cuda_ransac returns nothing, grid.py:124-215)
+        self.ctx.check(self.lib.octl_forest_apply_mask_async(self.handle))
+        self._n_ord_pending = True
         self._invalidate()
+
+    @property
+    def n_ord(self) -> int:
+        """Points in the leaf-ordered arrays (after an apply_mask whose count is still on its way: waits for it)."""
+        if self._n_ord_pending:
+            n = C.c_int64(0)
+            self.ctx.check(self.lib.octl_forest_settle(self.handle, C.byref(n)))
+            self._n_ord = n.value
+            self._n_ord_pending = False
+        return self._n_ord
+
+    @n_ord.setter
+    def n_ord(self, value: int):
+        self._n_ord = int(value)
+        self._n_ord_pending = False
 
     def device_mask(self) -> np.ndarray:
         n = C.c_int64(0)

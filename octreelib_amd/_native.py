@@ -85,6 +85,8 @@ SIGNATURES = {
     "octl_forest_ransac_all": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i32, _f64]),
     "octl_forest_get_mask": (C.c_int, [_p, _i64, _p, _pi64]),
     "octl_forest_apply_mask": (C.c_int, [_p, _pi64]),
+    "octl_forest_apply_mask_async": (C.c_int, [_p]),
+    "octl_forest_settle": (C.c_int, [_p, _pi64]),
     "octl_forest_apply_host_mask": (C.c_int, [_p, _p, _i64, _pi64]),
     "octl_forest_filter_count": (C.c_int, [_p, _p, _i32, _i64, _i64, _pi64]),
     "octl_ransac_evaluate": (

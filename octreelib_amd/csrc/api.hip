@@ -532,6 +532,29 @@ int alive_ensure(octl_forest* f) {
   return OCTL_OK;
 }
 
+int forest_settle(octl_forest* f) {
+  if (!f->totals_pending) return OCTL_OK;
+  octl_ctx* ctx = f->ctx;
+  f->totals_pending = false;
+  if (ctx->pending_mask_forest == f) ctx->pending_mask_forest = nullptr;
+  const int flags[2] = {MIRROR_FLAG_MASK0, MIRROR_FLAG_MASK1};
+  const int64_t n = f->totals_n_before;
+  OCTL_TRY(octl_wait_mirror_flags(ctx, flags, 2, f->totals_seq, 200 + n / 20000));
+  uint32_t res[2];
+  std::memcpy(res, static_cast<uint32_t*>(ctx->small_host) + MIRROR_MASK_TOTALS, 8);
+  f->n_alive -= (n - (int64_t)res[0]);
+  f->n_ord = res[0];
+  f->n_blocks = res[1];
+  return OCTL_OK;
+}
+
+void forest_forget_pending(octl_forest* f) {
+  if (!f->totals_pending) return;
+  f->totals_pending = false;
+  if (f->ctx->pending_mask_forest == f) f->ctx->pending_mask_forest = nullptr;
+}
+
+
 namespace {
 
 // Device sources are consumed in stream order (no synchronisation: the caller keeps the buffer
@@ -612,9 +635,13 @@ int store_take_in_place(octl_forest* f, int64_t n) {
 
 // The block table describes the leaf-ordered arrays exactly (every producer leaves it that way), so both
 // are compacted together: points tile-wise, blocks block-wise.  One synchronisation (kept points, blocks).
-int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
+// (async: return behind the last launch - forest_settle books the counts when somebody looks at the forest again)
+int apply_device_mask(octl_forest* f, int64_t* n_alive_out, bool async = false) {
   octl_ctx* ctx = f->ctx;
   hipStream_t st = ctx->stream;
+  // (the counts travel through two words of the context's mirror: one compaction in flight per context)
+  if (ctx->pending_mask_forest && ctx->pending_mask_forest != f) OCTL_TRY(forest_settle(ctx->pending_mask_forest));
+  OCTL_TRY(forest_settle(f));
   const int64_t n = f->n_ord, nb = f->n_blocks;
   f->mask_valid = false;
   f->fast_order_valid = false;  // block ids change
@@ -688,19 +715,17 @@ int apply_device_mask(octl_forest* f, int64_t* n_alive_out) {
     // (the two totals and their flags are written into the pinned mirror by the kernels themselves: the host polls
     //  for them - the compaction of the points may still be running when this returns, everything behind it is
     //  ordered by the stream)
-    const int flags[2] = {MIRROR_FLAG_MASK0, MIRROR_FLAG_MASK1};
-    OCTL_TRY(octl_wait_mirror_flags(ctx, flags, 2, wait_seq, 200 + n / 20000));
-    uint32_t res[2];
-    std::memcpy(res, static_cast<uint32_t*>(ctx->small_host) + MIRROR_MASK_TOTALS, 8);
     std::swap(f->ord_idx, f->ord_idx2);
     std::swap(f->xyz_ord, f->xyz_ord2);
     std::swap(f->blk_node, f->blk_node2);
     std::swap(f->blk_slot, f->blk_slot2);
     std::swap(f->blk_start, f->blk_start2);
     std::swap(f->blk_size, f->blk_size2);
-    f->n_alive -= (n - (int64_t)res[0]);
-    f->n_ord = res[0];
-    f->n_blocks = res[1];
+    f->totals_pending = true;
+    f->totals_seq = wait_seq;
+    f->totals_n_before = n;
+    ctx->pending_mask_forest = f;
+    if (!async) OCTL_TRY(forest_settle(f));
   }
   if (n_alive_out) *n_alive_out = f->n_ord;
   return OCTL_OK;
@@ -790,6 +815,7 @@ int octl_forest_create(octl_ctx* ctx, int mode, const double corner[3], double e
 
 void octl_forest_destroy(octl_forest* f) {
   if (!f) return;
+  forest_forget_pending(f);
   (void)hipSetDevice(f->ctx->device);
   (void)hipStreamSynchronize(f->ctx->stream);
   nodes_free(f->ctx, f->nodes[0]);
@@ -815,6 +841,7 @@ void octl_forest_destroy(octl_forest* f) {
 
 int octl_forest_clear(octl_forest* f) {
   if (!f) return OCTL_E_INVALID;
+  forest_forget_pending(f);   // (counts of a compaction still in flight: nobody will ask for them)
   f->max_block_hint = INT64_MAX;
   f->bbox_stale = true;   // (nothing is launched: whoever fills the box next resets it first)
   f->alive_stale = false;
@@ -852,6 +879,7 @@ int octl_forest_clear(octl_forest* f) {
 
 int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* slot) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   OCTL_TRY(store_append(f, xyz, n, false));
   if (slot) *slot = (int32_t)f->pose_off.size() - 1;
   f->n_store += n;
@@ -863,6 +891,7 @@ int octl_forest_add_pose(octl_forest* f, const double* xyz, int64_t n, int32_t* 
 
 int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n, int32_t* slot) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   // (the cloud may be the target of an octl_dev_upload_async that is still in flight)
   if (n > 0) OCTL_TRY(ctx_wait_uploads(f->ctx, xyz_dev, (size_t)n * 24));
   OCTL_TRY(store_append(f, xyz_dev, n, true));
@@ -876,6 +905,7 @@ int octl_forest_add_pose_device(octl_forest* f, const double* xyz_dev, int64_t n
 
 int octl_forest_add_pose_adopt(octl_forest* f, const double* xyz_dev, int64_t n, int32_t* slot) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   // only the first pose of an empty forest can be read in place (the store is one contiguous array); the
   // kernels read 16 bytes at a time from the start of the cloud
   if (f->n_store != 0 || n <= 0 || !xyz_dev || (reinterpret_cast<uintptr_t>(xyz_dev) & 15) != 0)
@@ -938,16 +968,19 @@ static int extend_pose_impl(octl_forest* f, int32_t slot, const double* xyz, int
 }
 
 int octl_forest_extend_pose(octl_forest* f, int32_t slot, const double* xyz, int64_t n) {
+  if (f) OCTL_TRY(forest_settle(f));
   return extend_pose_impl(f, slot, xyz, n, false);
 }
 
 int octl_forest_extend_pose_device(octl_forest* f, int32_t slot, const double* xyz_dev, int64_t n) {
+  if (f) OCTL_TRY(forest_settle(f));
   return extend_pose_impl(f, slot, xyz_dev, n, true);
 }
 
 int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int32_t n_mask,
                       int32_t keep_scheme, int32_t max_depth, octl_build_info* info) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   const int rc = forest_build(f, K, scheme_mask, n_mask, keep_scheme, max_depth, info);
   if (rc != OCTL_OK && rc != OCTL_E_INVALID && rc != OCTL_E_STATE) {
     // a build that failed half way has overwritten scratch the previous tables referred to:
@@ -966,6 +999,7 @@ int octl_forest_build(octl_forest* f, int64_t K, const uint8_t* scheme_mask, int
 int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int32_t* epoch,
                            int64_t n_nodes, int32_t new_epoch) {
   if (!f || !first_child || !epoch) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "set_scheme needs a built forest");
   const int64_t V = f->n_voxels;
@@ -1007,6 +1041,7 @@ int octl_forest_set_scheme(octl_forest* f, const int32_t* first_child, const int
 int octl_forest_set_contents(octl_forest* f, int64_t n_blocks, const int32_t* blk_node, const int32_t* blk_slot,
                              const int32_t* blk_size, const double* xyz) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built || f->store_dirty)
     return octl_set_error(ctx, OCTL_E_STATE, "set_contents needs a forest whose tables are up to date (build first)");
@@ -1177,6 +1212,7 @@ int octl_forest_get_nodes(octl_forest* f, int64_t cap, int32_t* voxel, int32_t* 
                           int32_t* parent, int32_t* first_child, double* corner, double* edge,
                           int32_t* epoch, int64_t* n_nodes) {
   if (!f || !n_nodes) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   NodeTable& t = f->nodes[f->cur];
@@ -1200,6 +1236,7 @@ int octl_forest_get_nodes(octl_forest* f, int64_t cap, int32_t* voxel, int32_t* 
 
 int octl_forest_get_voxels(octl_forest* f, int64_t cap, int64_t* coords, int64_t* n_voxels) {
   if (!f || !n_voxels) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   if (!f->built) return octl_set_error(f->ctx, OCTL_E_STATE, "no scheme has been built");
   *n_voxels = f->n_voxels;
   if (!coords) return OCTL_OK;
@@ -1218,6 +1255,7 @@ int octl_forest_get_voxels(octl_forest* f, int64_t cap, int64_t* coords, int64_t
 int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* slot,
                            int64_t* start, int32_t* size, int64_t* n_blocks) {
   if (!f || !n_blocks) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   *n_blocks = f->n_blocks;
@@ -1242,6 +1280,7 @@ int octl_forest_get_blocks(octl_forest* f, int64_t cap, int32_t* node, int32_t* 
 int octl_forest_get_slot_voxels(octl_forest* f, int32_t slot, int64_t cap, int32_t* voxel_ranks,
                                 int64_t* n_out) {
   if (!f || !n_out) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   const int n_poses = (int)f->pose_off.size() - 1;
@@ -1282,6 +1321,7 @@ int octl_forest_get_slot_voxels(octl_forest* f, int32_t slot, int64_t cap, int32
 
 int octl_forest_slot_counts(octl_forest* f, int32_t slot, int64_t* n_points, int64_t* n_leaves) {
   if (!f || !n_points || !n_leaves) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   const int n_poses = (int)f->pose_off.size() - 1;
@@ -1306,6 +1346,7 @@ int octl_forest_slot_counts(octl_forest* f, int32_t slot, int64_t* n_points, int
 
 int octl_forest_internal_per_voxel(octl_forest* f, int64_t cap, int32_t* counts, int64_t* n_voxels) {
   if (!f || !n_voxels) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   *n_voxels = f->n_voxels;
@@ -1326,6 +1367,7 @@ int octl_forest_internal_per_voxel(octl_forest* f, int64_t cap, int32_t* counts,
 
 int octl_forest_get_perm(octl_forest* f, int64_t cap, int64_t* perm, int64_t* n_out) {
   if (!f || !n_out) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   *n_out = f->n_ord;
@@ -1343,6 +1385,7 @@ int octl_forest_get_perm(octl_forest* f, int64_t cap, int64_t* perm, int64_t* n_
 
 int octl_forest_get_points(octl_forest* f, int64_t start, int64_t count, double* xyz) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   if (start < 0 || count < 0 || start + count > f->n_ord)
@@ -1358,6 +1401,7 @@ int octl_forest_get_points(octl_forest* f, int64_t start, int64_t count, double*
 int octl_forest_gather_blocks(octl_forest* f, const int32_t* block_ids, int64_t m, int64_t cap, double* xyz,
                               int64_t* n_points) {
   if (!f || !n_points || m < 0 || (m > 0 && !block_ids)) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   *n_points = 0;
@@ -1398,6 +1442,7 @@ int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
                        const double* hypotheses, int32_t H, int32_t k, double threshold,
                        float* plane, int32_t* best_count, int32_t* best_index) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "ransac before build");
   if (nb < 0 || (nb > 0 && !block_order) || !hypotheses)
@@ -1443,6 +1488,7 @@ int octl_forest_ransac(octl_forest* f, const int32_t* block_order, int64_t nb,
 
 int octl_forest_get_mask(octl_forest* f, int64_t cap, uint8_t* mask, int64_t* n_out) {
   if (!f || !n_out) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   *n_out = f->n_ord;
@@ -1456,14 +1502,31 @@ int octl_forest_get_mask(octl_forest* f, int64_t cap, uint8_t* mask, int64_t* n_
 
 int octl_forest_apply_mask(octl_forest* f, int64_t* n_alive) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   if (!f->built) return octl_set_error(f->ctx, OCTL_E_STATE, "apply_mask before build");
   OCTL_TRY(ensure_mask(f));
   return apply_device_mask(f, n_alive);
 }
 
+int octl_forest_apply_mask_async(octl_forest* f) {
+  if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
+  if (!f->built) return octl_set_error(f->ctx, OCTL_E_STATE, "apply_mask before build");
+  OCTL_TRY(ensure_mask(f));
+  return apply_device_mask(f, nullptr, true);
+}
+
+int octl_forest_settle(octl_forest* f, int64_t* n_alive) {
+  if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
+  if (n_alive) *n_alive = f->n_ord;
+  return OCTL_OK;
+}
+
 int octl_forest_filter_count(octl_forest* f, const uint8_t* slot_sel, int32_t n_sel, int64_t lo,
                              int64_t hi, int64_t* n_alive) {
   if (!f || !slot_sel) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "filter before build");
   const int n_poses = (int)f->pose_off.size() - 1;
@@ -1487,6 +1550,7 @@ int octl_forest_filter_count(octl_forest* f, const uint8_t* slot_sel, int32_t n_
 
 int octl_forest_apply_host_mask(octl_forest* f, const uint8_t* mask, int64_t n, int64_t* n_alive) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "apply_mask before build");
   if (n != f->n_ord || (n > 0 && !mask))

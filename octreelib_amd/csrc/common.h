@@ -146,6 +146,7 @@ struct octl_ctx {
   unsigned char geom_hint[192] = {0};
   bool geom_hint_valid = false;
   bool geom_hint_staged = false;  // forest_build's first launch has put the hint into the scalar block already
+  struct octl_forest* pending_mask_forest = nullptr;  // the forest whose apply_mask totals are still in flight (one per context: they share the mirror's words)
   uint64_t geom_hint_want = 0;
   bool geom_hint_two_pass = false;  // the hint is the geometry of a TWO-pass build (> 4096 buckets, host-side form)
   // the last build found a sparse scene (more than 4096 buckets): the next one skips the single-pass attempt

@@ -110,6 +110,11 @@ struct octl_forest {
   DevBuf mask;       // u8 [n_ord]
   DevBuf blk_eval;   // u8 [n_blocks] block was evaluated since the last apply_mask
   bool mask_valid = false;
+  // octl_forest_apply_mask_async: the kernels are enqueued and the arrays swapped, the surviving point / block counts
+  // are still on their way to the pinned mirror - forest_settle (every entry point's first step) waits for them
+  bool totals_pending = false;
+  uint32_t totals_seq = 0;      // wait sequence number the kernels publish under
+  int64_t totals_n_before = 0;  // ordered points before the compaction
 
   // an upper bound of the points a block can hold, when the host knows one (a count-driven build from all poses
   // leaves at most K points per leaf, and masks / filters only remove points): the RANSAC launch skips the instances
@@ -180,3 +185,9 @@ int forest_fix_origin(octl_forest* f, const int bb[6]);
 // its scheme in O(new points).  *done = 0: not applicable, nothing was changed
 int forest_sync_vcodes(octl_forest* f);
 int forest_insert_incremental(octl_forest* f, int* done, octl_build_info* info);
+
+// api.hip: wait for the counts an asynchronous apply_mask left in flight (octl_forest_apply_mask_async) and book
+// them; a no-op otherwise.  Every entry point that looks at the forest calls it first.
+int forest_settle(octl_forest* f);
+// ... and forget them (clear / destroy: nothing will look at the counts)
+void forest_forget_pending(octl_forest* f);

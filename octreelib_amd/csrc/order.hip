@@ -331,6 +331,7 @@ int forest_reference_order(octl_forest* f, const int32_t* e0_host, std::vector<u
 extern "C" int octl_forest_reference_order(octl_forest* f, const int32_t* e0, int32_t n_e0,
                                            int64_t cap, int32_t* order, int64_t* n_blocks) {
   if (!f || !n_blocks) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   octl_ctx* ctx = f->ctx;
   if (!f->built) return octl_set_error(ctx, OCTL_E_STATE, "no scheme has been built");
   const int n_poses = (int)f->pose_off.size() - 1;
@@ -355,6 +356,7 @@ extern "C" int octl_forest_ransac_all(octl_forest* f, int32_t poses_per_batch, c
                                       int32_t n_e0, const double* hypotheses, int32_t H, int32_t k,
                                       double threshold) {
   if (!f || !hypotheses) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   // A mask buffer that was NOT valid before this call only becomes valid when every batch has been
   // enqueued: a failure half way (reference order, a scratch reservation, a later batch) must not leave
   // uninitialised or partly written bytes marked valid for the next apply_mask / filter.

@@ -555,11 +555,13 @@ static int add_routed(octl_forest* f, octl_ctx* rctx, int32_t* slot) {
 
 int octl_forest_add_pose_routed(octl_forest* f, int32_t* slot) {
   if (!f) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   return add_routed(f, f->ctx, slot);
 }
 
 int octl_forest_add_pose_routed_from(octl_forest* f, octl_ctx* route_ctx, int32_t* slot) {
   if (!f || !route_ctx) return OCTL_E_INVALID;
+  OCTL_TRY(forest_settle(f));
   if (route_ctx->device != f->ctx->device)
     return octl_set_error(f->ctx, OCTL_E_INVALID, "the routing context lives on another device");
   // octl_route_points returns after its stream has drained: the routed cloud is complete; what

@@ -3031,6 +3031,101 @@ def test_one_launch_preparation_of_a_small_ransac_launch(n_blocks, H, k):
     assert np.array_equal(m0[:npts], o_mask[:npts])
 
 
+@pytest.mark.gpu
+def test_asynchronous_apply_mask_books_its_counts_when_somebody_asks():
+    """Round 6: octl_forest_apply_mask_async returns behind its last launch; the surviving point / block counts are
+    booked by the next call that looks at the forest (forest_settle at every entry point), dropped unread by clear /
+    destroy, and a second compaction on the context - this forest or another - books the first before it starts
+    (they share two words of the pinned mirror).  Whatever the order of calls, the tables are those of the waiting
+    form (octl_forest_apply_mask; Octree.apply_mask, octree/octree.py:265-274)."""
+    import ctypes as C
+
+    from octreelib_amd import _native as nat
+    from octreelib_amd import synthetic
+    from octreelib_amd._engine import Forest
+
+    ctx = nat.get_context()
+    lib = ctx.lib
+    a = synthetic.planar_cloud(60_000, (5, 5, 5), seed=9, stream=1)
+    b = synthetic.planar_cloud(45_000, (4, 4, 4), seed=9, stream=2)
+    np.random.seed(0)
+    table = np.random.random((256, 6))
+
+    def prepared(pts):
+        f = Forest(0, np.zeros(3), 1.0)
+        f.add_pose(pts)
+        f.subdivide(32)
+        f.ransac_all(10, table, 0.01)
+        return f
+
+    def after(f):
+        return ({k: v.copy() for k, v in f.blocks.items()}, f.perm.copy(), f.xyz.copy())
+
+    def same(x, y):
+        assert x[0].keys() == y[0].keys()
+        for k in x[0]:
+            assert np.array_equal(x[0][k], y[0][k]), k
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+
+    # the waiting form: the truth
+    want, want_n = {}, {}
+    for name, pts in (("a", a), ("b", b)):
+        f = prepared(pts)
+        n = C.c_int64(0)
+        ctx.check(lib.octl_forest_apply_mask(f.handle, C.byref(n)))
+        f.n_ord = n.value
+        f._invalidate()
+        want[name], want_n[name] = after(f), n.value
+        f.close()
+    assert 0 < want_n["a"] < len(a)
+    # 1. asynchronous, then the explicit settle
+    f = prepared(a)
+    ctx.check(lib.octl_forest_apply_mask_async(f.handle))
+    n = C.c_int64(-1)
+    ctx.check(lib.octl_forest_settle(f.handle, C.byref(n)))
+    assert n.value == want_n["a"]
+    ctx.check(lib.octl_forest_settle(f.handle, C.byref(n)))     # (a no-op the second time)
+    assert n.value == want_n["a"]
+    f.n_ord = n.value
+    f._invalidate()
+    same(want["a"], after(f))
+    f.close()
+    # 2. asynchronous, and the next call that looks at the forest books the counts (the engine's lazy n_ord)
+    f = prepared(a)
+    f.apply_device_mask()
+    same(want["a"], after(f))
+    assert f.n_ord == want_n["a"]
+    # ... a second RANSAC + compaction on what is left, asynchronous again
+    f.ransac_all(10, table, 0.01)
+    f.apply_device_mask()
+    n2 = f.n_ord
+    assert 0 < n2 <= want_n["a"]
+    f.close()
+    # 3. two forests of one context: the second compaction books the first one's counts before it starts
+    fa, fb = prepared(a), prepared(b)
+    fa.apply_device_mask()
+    fb.apply_device_mask()
+    same(want["b"], after(fb))
+    same(want["a"], after(fa))
+    assert (fa.n_ord, fb.n_ord) == (want_n["a"], want_n["b"])
+    # 4. clear with the counts still in flight: dropped, the forest builds the next cloud as a fresh one does
+    fa.ransac_all(10, table, 0.01)
+    fa.apply_device_mask()
+    ctx.check(lib.octl_forest_clear(fa.handle))
+    n = C.c_int64(-1)
+    ctx.check(lib.octl_forest_settle(fa.handle, C.byref(n)))
+    assert n.value == 0
+    fa.close()
+    # 5. destroy with the counts in flight
+    fb.ransac_all(10, table, 0.01)
+    fb.apply_device_mask()
+    fb.close()
+    f = prepared(b)
+    f.apply_device_mask()
+    same(want["b"], after(f))
+    f.close()
+
+
 def _input_forms(pts64):
     """The same cloud as the reference's callers may hand it over (the reference upcasts everything to f64:
     internal/voxel.py:81-83, octree/octree.py:100): values are f32-representable so that every form holds the same
