@@ -539,7 +539,7 @@ int forest_settle(octl_forest* f) {
   if (ctx->pending_mask_forest == f) ctx->pending_mask_forest = nullptr;
   const int flags[2] = {MIRROR_FLAG_MASK0, MIRROR_FLAG_MASK1};
   const int64_t n = f->totals_n_before;
-  OCTL_TRY(octl_wait_mirror_flags(ctx, flags, 2, f->totals_seq, 200 + n / 20000));
+  OCTL_TRY(octl_wait_mirror_flags(ctx, flags, 2, f->totals_seq, 500 + n / 2000));
   uint32_t res[2];
   std::memcpy(res, static_cast<uint32_t*>(ctx->small_host) + MIRROR_MASK_TOTALS, 8);
   f->n_alive -= (n - (int64_t)res[0]);

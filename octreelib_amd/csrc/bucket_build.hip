@@ -2923,7 +2923,10 @@ static int bucket_build_impl(octl_forest* f, const BucketBuildArgs& a, NodeTable
     if (with_spec) OCTL_TRY(spec_finish(own_scan ? wait_seq : 0u));
     // (the totals kernel writes the scalars and then its flag into the pinned mirror)
     const int flag = MIRROR_FLAG_BUILD;
-    OCTL_TRY(octl_wait_mirror_flags(ctx, &flag, 1, wait_seq, 200 + n_alive / 20000));
+    // (polling budget: behind an asynchronous apply_mask the previous scan's RANSAC may still be running in front of
+    //  this build - 2.2 ms at 10 M points; falling back to a stream synchronisation would also wait for the
+    //  speculative finish that was enqueued to run BESIDE this wait)
+    OCTL_TRY(octl_wait_mirror_flags(ctx, &flag, 1, wait_seq, 500 + n_alive / 2000));
     std::memcpy(sm, ctx->small_host, sizeof(sm));
     return (int)OCTL_OK;
   };
