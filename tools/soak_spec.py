@@ -23,6 +23,7 @@ def counters():
 
 
 bad = 0
+numbering_only = 0
 h0, m0 = counters()
 for it in range(iters):
     n = int(10 ** rng.uniform(3.3, 6.2))
@@ -37,29 +38,46 @@ for it in range(iters):
     if rng.integers(0, 4) == 0:
         pts = pts + np.array([float(rng.integers(0, 5)), 0.0, float(rng.integers(0, 3))])   # (another voxel box)
     adopt = ctx if rng.integers(0, 2) else None
+    def leg(name, want, got, canonical):
+        """0 = equal; a difference that is only the numbering of the nodes (benign, see below) is reported apart"""
+        global numbering_only
+        try:
+            T._assert_same_step(want, got, canonical=canonical)
+        except AssertionError as e:
+            if not canonical:
+                try:
+                    T._assert_same_step(want, got, canonical=True)
+                    numbering_only += 1
+                    print("numbering only at", it, name, n, kind, side, K, repr(e)[:80], flush=True)
+                    return
+                except AssertionError:
+                    pass
+            raise AssertionError(name + ": " + repr(e)[:160])
+
     try:
         got = T._step_tables([pts], K, adopt)
         ctx.set_option("NO_SPEC_FINISH", 1)
         want = T._step_tables([pts], K, adopt)
         ctx.set_option("NO_SPEC_FINISH", 0)
-        T._assert_same_step(want, got)
+        # (the two builds may run under different geometry hints - the first under the previous scan's: where the
+        #  buckets are cut elsewhere on a skewed scene, other voxels are left to the level loop, which numbers their
+        #  nodes behind the others - same trees, same leaves, same order, other ids)
+        leg("spec", want, got, False)
         # round 6: the same scan without the geometry hint of the context's previous build (its own box pass), and
         # under another margin of the key geometry - the tables never depend on either
-        # (canonical: another geometry cuts the buckets elsewhere, and on a skewed scene other voxels are then left to
-        #  the level loop, which numbers their nodes behind the others - same trees, same leaves, same order, other ids)
         ctx.set_option("NO_GEOM_HINT", 1)
-        T._assert_same_step(want, T._step_tables([pts], K, adopt), canonical=True)
+        leg("no hint", want, T._step_tables([pts], K, adopt), True)
         ctx.set_option("NO_GEOM_HINT", 0)
         ctx.set_option("GEOM_MARGIN", int(rng.choice([-1, 2, 3])))
-        T._assert_same_step(want, T._step_tables([pts], K, adopt), canonical=True)
+        leg("margin", want, T._step_tables([pts], K, adopt), True)
         ctx.set_option("GEOM_MARGIN", 0)
         # the small-launch forms (k_block_prepare_small, k_mask_scan's own compaction, the scans inside
         # k_bucket_finish<true> and k_part_scatter<..., true>) against the separate kernels, and another bucket size
         ctx.set_option("NO_FUSED_TABLES", 1)
-        T._assert_same_step(want, T._step_tables([pts], K, adopt))
+        leg("unfused", want, T._step_tables([pts], K, adopt), False)
         ctx.set_option("NO_FUSED_TABLES", 0)
         ctx.set_option("BUCKET_POINTS", int(rng.choice([640, 2560, 5000])))
-        T._assert_same_step(want, T._step_tables([pts], K, adopt), canonical=True)
+        leg("bucket size", want, T._step_tables([pts], K, adopt), True)
         ctx.set_option("BUCKET_POINTS", 0)
     except Exception as e:  # noqa: BLE001
         bad += 1
@@ -72,5 +90,5 @@ for it in range(iters):
     if it % 20 == 19:
         print("iteration", it + 1, "speculative launches held / missed so far:", tuple(a - b for a, b in zip(counters(), (h0, m0))),
               flush=True)
-print("failures:", bad)
+print("failures:", bad, "| differences in the numbering of the nodes only:", numbering_only)
 sys.exit(1 if bad else 0)
